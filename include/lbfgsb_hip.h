@@ -1,0 +1,171 @@
+/*
+ * lbfgsb_hip.h -- C ABI of the MI355X-native L-BFGS-B inner iteration.
+ *
+ * This is the drop-in boundary for the hot path of jacobwilliams/lbfgsb: the
+ * n-dimensional work inside `mainlb` (reference src/lbfgsb.f90:312-949) runs as
+ * hand-written HIP kernels on gfx950; the 2m x 2m algebra (bmv, formt, dpofa,
+ * dtrsl, dcsrch) runs on the host inside this library.  The reverse-
+ * communication protocol, the `task` strings and the documented isave/dsave/
+ * lsave slots are the reference's (src/lbfgsb.f90:88-244).
+ *
+ * Plain C: pointers and sizes only, no torch/HIP types in the signatures
+ * (a hipStream_t travels as void*).  There is NO CPU fallback: every entry
+ * point that computes fails with LBFGSB_E_NOGPU when no gfx950 device is
+ * usable.
+ *
+ * The Fortran module `lbfgsb_module` in lbfgsb_amd/fortran/ binds these with
+ * iso_c_binding so that reference test/driver1.f90, driver2.f90, driver3.f90
+ * link unchanged.
+ */
+#ifndef LBFGSB_HIP_H
+#define LBFGSB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lbfgsb_hip_ctx lbfgsb_hip_ctx; /* opaque */
+
+/* status codes */
+enum {
+  LBFGSB_OK = 0,
+  LBFGSB_E_NOGPU = -100,   /* no usable HIP device / kernel launch failed   */
+  LBFGSB_E_ARG = -101,     /* bad argument (n<=0, m<=0, m>LBFGSB_MAX_M ...) */
+  LBFGSB_E_ALLOC = -102,   /* device allocation failed                      */
+  LBFGSB_E_COMM = -103,    /* RCCL / host reducer failure                   */
+  LBFGSB_E_STATE = -104    /* call sequence violates the task protocol      */
+};
+
+#define LBFGSB_MAX_M 32
+
+/* flags for lbfgsb_hip_create */
+enum {
+  LBFGSB_F_REAL32 = 1,       /* REAL32 build of the reference (lbfgsb_kinds_module.F90:29):
+                                fp32 storage + kernels, fp64 partials and host algebra */
+  LBFGSB_F_MIRROR_INDEX = 2  /* keep the reference's Index/Indx2 lists (freev,
+                                src/lbfgsb.f90:2044-2054, 2014-2035) on the device so
+                                that lbfgsb_hip_export_state reproduces `iwa` */
+};
+
+/* -------------------------------------------------------------------------
+ * Context.  Replaces the partition of caller memory done by setulb
+ * (src/lbfgsb.f90:250-265): Ws, Wy (n x m each, column-major, leading
+ * dimension padded to 32 rows), z, r, d, t, xp, iwhere and scratch live in
+ * HBM for the life of the context.
+ *   n_local   rows owned by this rank          n_global  total rows
+ *   row0      global 0-based index of local row 0 (contiguous block sharding)
+ * For one GPU: n_local = n_global = n, row0 = 0.
+ * stream: a hipStream_t (may be NULL = a private stream is created).
+ * ------------------------------------------------------------------------- */
+int lbfgsb_hip_create(int64_t n_local, int64_t n_global, int64_t row0, int m, int flags,
+                      int device, void *stream, lbfgsb_hip_ctx **out);
+void lbfgsb_hip_destroy(lbfgsb_hip_ctx *ctx);
+const char *lbfgsb_hip_last_error(void);
+
+/* -------------------------------------------------------------------------
+ * Multi-GPU: every n-length reduction of the path is completed across ranks.
+ * (a) RCCL on the context's stream (librccl is dlopen'ed on first use):
+ *       id = 128-byte ncclUniqueId made by lbfgsb_hip_rccl_unique_id on rank 0
+ *       and distributed by the caller (e.g. torch.distributed broadcast).
+ * (b) a host callback, for launchers that already own a communicator
+ *     (MPI, gloo): called with the rank-local partials in host memory; must
+ *     return with buf[0..nsum) summed, buf[nsum..nsum+nmin) min-reduced and
+ *     the following nmax entries max-reduced over all ranks.  gather: if
+ *     non-NULL, must all-gather `bytes` bytes from every rank into out
+ *     (rank-major).
+ * ------------------------------------------------------------------------- */
+int lbfgsb_hip_rccl_unique_id(void *id128);
+int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, int nranks);
+typedef int (*lbfgsb_allreduce_fn)(void *user, double *buf, int nsum, int nmin, int nmax);
+typedef int (*lbfgsb_allgather_fn)(void *user, const void *in, void *out, int64_t bytes);
+int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar,
+                              lbfgsb_allgather_fn ag, void *user, int rank, int nranks);
+
+/* -------------------------------------------------------------------------
+ * setulb, device-pointer form.  Mirrors reference setulb (src/lbfgsb.f90:88)
+ * argument for argument except that
+ *   - n, m, wa, iwa are replaced by the context,
+ *   - x, l, u, nbd, g are DEVICE pointers to this rank's rows (real = double,
+ *     or float with LBFGSB_F_REAL32; nbd int32), 16-byte aligned,
+ *   - f, factr, pgtol are double; f is the GLOBAL objective value,
+ *   - task/csave are 60 bytes, blank padded, no terminator (Fortran layout),
+ *   - lsave[4] are int32 0/1, isave[44] int32, dsave[29] double, with the
+ *     reference's meaning slot for slot (src/lbfgsb.f90:188-242).
+ * The caller evaluates f,g on the device whenever task(1:2)=='FG'.
+ * ------------------------------------------------------------------------- */
+int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
+                          const int32_t *nbd, double *f, void *g, double factr, double pgtol,
+                          char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave,
+                          double *dsave);
+
+/* -------------------------------------------------------------------------
+ * setulb, host-pointer form: the exact reference signature (what the Fortran
+ * shim binds).  x,l,u,g are host arrays of the real kind, nbd/iwa/isave
+ * default integers (int32), lsave int32.  The context handle is kept in
+ * isave(17:18) (never touched by the reference, src/lbfgsb.f90:250-284),
+ * created on task='START' and released when a terminal task is returned.
+ * x and g travel over PCIe on every FG return; `wa`'s t-slot
+ * (wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175) and, when
+ * iprint >= 0, nothing else of wa/iwa is written unless mirror != 0, in which
+ * case the full reference layout of wa and iwa is exported on every return.
+ * iteration_file may be NULL (-> 'iterate.dat', src/lbfgsb.f90:483-489).
+ * ------------------------------------------------------------------------- */
+int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
+                           const int32_t *nbd, void *f, void *g, double factr, double pgtol,
+                           void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
+                           int32_t *lsave, int32_t *isave, void *dsave,
+                           const char *iteration_file, int32_t real_bytes, int32_t mirror);
+
+/* -------------------------------------------------------------------------
+ * State exchange with the reference's caller-array layout (checkpoint /
+ * resume; used by the one-step parity tests).
+ * wa: host, length 2mn+5n+11m^2+8m reals; iwa: host int32[3n].
+ * export: fills every slot that has a defined meaning at a setulb return
+ *   (SURVEY.md appendix B).  import: loads Ws, Wy, z, r, d, t, xp, iwhere,
+ *   the free-set membership (from Index(1:nfree)), Sy, Ss, Wt, Wn, Snd, wa8m.
+ * Single-rank contexts only.
+ * ------------------------------------------------------------------------- */
+int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa);
+int lbfgsb_hip_import_state(lbfgsb_hip_ctx *ctx, const void *wa, const int32_t *iwa,
+                            const int32_t *isave);
+
+/* -------------------------------------------------------------------------
+ * Per-kernel entry points (one per row of SURVEY.md 8a), for parity tests
+ * and profiling.  All pointers are DEVICE pointers unless named h_*.
+ * Reduction results come back in host doubles, already complete across
+ * ranks.  Each returns LBFGSB_OK or an error code.
+ * ------------------------------------------------------------------------- */
+
+/* projgr, src/lbfgsb.f90:2594-2622 */
+int lbfgsb_hip_projgr(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u,
+                      const int32_t *nbd, const void *g, double *h_sbgnrm);
+
+/* W'v : out[j] = sum_i Wy(i,col_j) v_i (j < col), out[col+j] = sum_i Ws(i,col_j) v_i,
+ * logical column order (head .. head+col-1 mod m).  The WS/WY correction-pair
+ * matvec of matupd (:2333-2338), cauchy (:1300-1304) and subsm (:2742-2754).
+ * Works on the context's own Ws/Wy. */
+int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double *h_out);
+
+/* load host column-major W (n x m each, leading dimension n) into the context */
+int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy);
+
+/* bare streaming kernels used to time the roofline of the W'v matvec */
+int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head);
+int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx);
+
+/* built-in device objectives: evaluate f, g on the
+ * context's stream.  kind 0 = separable bounded quadratic,
+ * kind 1 = extended Rosenbrock (test/driver1.f90:274-289; single rank only).
+ * *h_f receives the GLOBAL value (reduced over ranks). */
+int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f);
+
+/* counters for bench/profiling: number of kernel launches and host syncs so far */
+int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
+                     int64_t *cauchy_fullsorts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

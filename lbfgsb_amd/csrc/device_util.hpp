@@ -1,0 +1,169 @@
+// device_util.hpp -- wave64 / workgroup building blocks for the streaming kernels.
+//
+// gfx950 (CDNA4): 64-lane wavefronts, 4 waves per 256-thread workgroup.  All
+// kernels here are HBM-bound tall-skinny streams: each lane issues 16-byte
+// loads (dwordx4) straight into VGPRs -- the operands are read once and not
+// shared between waves, so an LDS round trip would be pure overhead (cdna
+// guide, "GEMV / M <= 16" row) -- and LDS is used only for the cross-wave step
+// of reductions and for the row tiles of the formk Gram kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace lbk {
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+  static constexpr int V = 2;  // 2 x f64 = 16 B per lane
+};
+template <>
+struct VecOf<float> {
+  static constexpr int V = 4;  // 4 x f32 = 16 B per lane
+};
+
+template <int W>
+using WTag = std::integral_constant<int, W>;
+
+// ---- W consecutive elements, as doubles ----
+template <int W>
+__device__ __forceinline__ void ld(const double *p, double (&o)[W]) {
+  if constexpr (W == 2) {
+    double2 v = *reinterpret_cast<const double2 *>(p);
+    o[0] = v.x;
+    o[1] = v.y;
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) o[k] = p[k];
+  }
+}
+template <int W>
+__device__ __forceinline__ void ld(const float *p, double (&o)[W]) {
+  if constexpr (W == 4) {
+    float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
+    o[3] = v.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) o[k] = p[k];
+  }
+}
+template <int W>
+__device__ __forceinline__ void st(double *p, const double (&o)[W]) {
+  if constexpr (W == 2) {
+    *reinterpret_cast<double2 *>(p) = make_double2(o[0], o[1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) p[k] = o[k];
+  }
+}
+template <int W>
+__device__ __forceinline__ void st(float *p, const double (&o)[W]) {
+  if constexpr (W == 4) {
+    *reinterpret_cast<float4 *>(p) = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) p[k] = (float)o[k];
+  }
+}
+template <int W>
+__device__ __forceinline__ void ldi(const int32_t *p, int (&o)[W]) {
+  if constexpr (W == 2) {
+    int2 v = *reinterpret_cast<const int2 *>(p);
+    o[0] = v.x;
+    o[1] = v.y;
+  } else if constexpr (W == 4) {
+    int4 v = *reinterpret_cast<const int4 *>(p);
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
+    o[3] = v.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) o[k] = p[k];
+  }
+}
+template <int W>
+__device__ __forceinline__ void sti(int32_t *p, const int (&o)[W]) {
+  if constexpr (W == 2) {
+    *reinterpret_cast<int2 *>(p) = make_int2(o[0], o[1]);
+  } else if constexpr (W == 4) {
+    *reinterpret_cast<int4 *>(p) = make_int4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) p[k] = o[k];
+  }
+}
+
+// Grid-stride over rows in groups of V (16 B per lane per array), scalar tail.
+// f(i, WTag<W>) handles rows i .. i+W-1.
+template <typename T, typename F>
+__device__ __forceinline__ void for_rows(int64_t n, F &&f) {
+  constexpr int V = VecOf<T>::V;
+  const int64_t nv = n / V;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t iv = t0; iv < nv; iv += stride) f(iv * V, WTag<V>{});
+  const int64_t it = nv * V + t0;
+  if (it < n) f(it, WTag<1>{});
+}
+
+// ---- reductions: wave shuffle, then LDS across the 4 waves ----
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+  return v;
+}
+
+// acc[0..nsum) are sums, then nmin minima, then nmax maxima.  One value per
+// slot per workgroup goes to part[slot*pstride + blockIdx.x].  Fixed shape =>
+// deterministic for a fixed (n, grid).
+template <int K>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[K], int nsum, int nmin,
+                                                   int nmax, double *__restrict__ part,
+                                                   int pstride) {
+  __shared__ double sm[4][K];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ntot = nsum + nmin + nmax;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k < ntot) {
+      double v = acc[k];
+      if (k < nsum)
+        v = wave_sum(v);
+      else if (k < nsum + nmin)
+        v = wave_min(v);
+      else
+        v = wave_max(v);
+      if (lane == 0) sm[w][k] = v;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ntot; k += blockDim.x) {
+    double s = sm[0][k];
+    if (k < nsum)
+      s = ((s + sm[1][k]) + sm[2][k]) + sm[3][k];
+    else if (k < nsum + nmin)
+      s = fmin(fmin(s, sm[1][k]), fmin(sm[2][k], sm[3][k]));
+    else
+      s = fmax(fmax(s, sm[1][k]), fmax(sm[2][k], sm[3][k]));
+    part[(size_t)k * pstride + blockIdx.x] = s;
+  }
+}
+
+}  // namespace lbk

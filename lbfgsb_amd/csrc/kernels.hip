@@ -1,0 +1,1334 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels for the n-dimensional work
+// of the L-BFGS-B iteration (reference src/lbfgsb.f90, routines cited per kernel).
+//
+// Shape of every kernel: tall-skinny, HBM-bound, no reuse.  One lane owns V
+// consecutive rows (16 B per array per load, dwordx4), grid-stride over rows,
+// <= 2048 workgroups of 4 wave64.  The correction-pair matrices Ws, Wy are
+// column-major with a 256-byte aligned leading dimension, so lane i of a wave
+// reads 16 B at column_base + 16*i: every wave-instruction is one fully
+// coalesced 1 KiB request per column.  Reductions: per-lane fp64 accumulators
+// -> wave shuffle -> LDS across the 4 waves -> one partial per workgroup ->
+// fixed-order finalize kernel (deterministic; no float atomics).  2m <= 64
+// columns is far too thin for MFMA: the flop/byte ratio is <= 2 (fp64), the
+// machine balance ~10, so the roofline is HBM bandwidth.
+//
+// Column loops are unrolled to a compile-time MAXC; logical columns >= col are
+// redirected to logical column 0 (an L1/L2 hit, no HBM traffic) and their
+// results discarded, which keeps every load unconditional and in flight
+// together.
+#include "kernels.hpp"
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device_util.hpp"
+
+namespace lbk {
+
+#define LB_INF (__builtin_huge_val())
+
+int grid_for(int64_t n, int vec) {
+  int64_t g = (n / vec + BLOCK - 1) / BLOCK;
+  if (g < 1) g = 1;
+  if (g > MAX_BLOCKS) g = MAX_BLOCKS;
+  return (int)g;
+}
+
+int maxc_for(int col) { return col <= 5 ? 5 : (col <= 10 ? 10 : (col <= 20 ? 20 : 32)); }
+
+#define DISPATCH_MAXC(col, ...)       \
+  do {                                \
+    if ((col) <= 5) {                 \
+      constexpr int MC = 5;           \
+      __VA_ARGS__;                    \
+    } else if ((col) <= 10) {         \
+      constexpr int MC = 10;          \
+      __VA_ARGS__;                    \
+    } else if ((col) <= 20) {         \
+      constexpr int MC = 20;          \
+      __VA_ARGS__;                    \
+    } else {                          \
+      constexpr int MC = 32;          \
+      __VA_ARGS__;                    \
+    }                                 \
+  } while (0)
+
+// physical column offset (elements) of logical column j; j >= col -> logical 0
+__device__ __forceinline__ int64_t col_off(int j, int col, int head, int m, int64_t ld) {
+  const int jj = j < col ? j : 0;
+  return (int64_t)((head - 1 + jj) % m) * ld;
+}
+
+// =========================== finalize ======================================
+// One workgroup per output slot: fixed-order sum / min / max of the per-block
+// partials.
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double *__restrict__ part,
+                                                         int pstride, int nblocks,
+                                                         double *__restrict__ res, int nsum,
+                                                         int nmin, int nmax) {
+  __shared__ double sm[BLOCK];
+  const int k = blockIdx.x;
+  const int op = k < nsum ? 0 : (k < nsum + nmin ? 1 : 2);
+  double v = op == 0 ? 0.0 : (op == 1 ? LB_INF : -LB_INF);
+  for (int b = threadIdx.x; b < nblocks; b += BLOCK) {
+    const double p = part[(size_t)k * pstride + b];
+    v = op == 0 ? v + p : (op == 1 ? fmin(v, p) : fmax(v, p));
+  }
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double a = sm[threadIdx.x], b = sm[threadIdx.x + s];
+      sm[threadIdx.x] = op == 0 ? a + b : (op == 1 ? fmin(a, b) : fmax(a, b));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) res[k] = sm[0];
+}
+
+static void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int nsum,
+                          int nmin, int nmax) {
+  const int k = nsum + nmin + nmax;
+  if (k <= 0) return;
+  hipLaunchKernelGGL(finalize_kernel, dim3(k), dim3(BLOCK), 0, q.stream, part, pstride, nblocks,
+                     q.d_res, nsum, nmin, nmax);
+  q.launches++;
+}
+void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax) {
+  finalize_from(q, q.d_part, MAX_BLOCKS, nblocks, nsum, nmin, nmax);
+}
+
+// =========================== active / errclb ================================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void active_kernel(int64_t n, T *x, const T *l, const T *u,
+                                                       const int32_t *nbd, int32_t *iwhere,
+                                                       int8_t *wasfree, double *part) {
+  double acc[4] = {0, 0, 0, 0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W];
+    int nb[W], iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (nb[k] > 0) {
+        if (nb[k] <= 2 && xv[k] <= lv[k]) {
+          if (xv[k] < lv[k]) {
+            acc[0] += 1.0;
+            xv[k] = lv[k];
+          }
+          acc[3] += 1.0;
+        } else if (nb[k] >= 2 && xv[k] >= uv[k]) {
+          if (xv[k] > uv[k]) {
+            acc[0] += 1.0;
+            xv[k] = uv[k];
+          }
+          acc[3] += 1.0;
+        }
+      }
+      if (nb[k] != 2) acc[2] += 1.0;
+      if (nb[k] == 0) {
+        iw[k] = -1;
+      } else {
+        acc[1] += 1.0;
+        iw[k] = (nb[k] == 2 && uv[k] - lv[k] <= 0.0) ? 3 : 0;
+      }
+      wasfree[i + k] = 1;
+    }
+    st<W>(x + i, xv);
+    sti<W>(iwhere + i, iw);
+  });
+  block_reduce_store<4>(acc, 4, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd,
+                   int32_t *iwhere, int8_t *wasfree) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(active_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd,
+                     iwhere, wasfree, q.d_part);
+  q.launches++;
+  launch_finalize(q, g, 4, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void errclb_kernel(int64_t n, int64_t row0, const T *l,
+                                                       const T *u, const int32_t *nbd,
+                                                       double *part) {
+  double acc[2] = {0, 0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double lv[W], uv[W];
+    int nb[W];
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const double gi = (double)(row0 + i + k + 1);
+      if (nb[k] < 0 || nb[k] > 3) acc[0] = fmax(acc[0], gi);
+      if (nb[k] == 2 && lv[k] > uv[k]) acc[1] = fmax(acc[1], gi);
+    }
+  });
+  block_reduce_store<2>(acc, 0, 0, 2, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
+                   const int32_t *nbd) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(errclb_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, row0, l, u, nbd,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, g, 0, 0, 2);
+}
+
+// =========================== projgr (:2594-2622) ============================
+__device__ __forceinline__ double proj_g(double x, double l, double u, int nb, double gi) {
+  if (nb != 0) {
+    if (gi < 0.0) {
+      if (nb >= 2) gi = fmax(x - u, gi);
+    } else {
+      if (nb <= 2) gi = fmin(x - l, gi);
+    }
+  }
+  return fabs(gi);
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void projgr_kernel(int64_t n, const T *x, const T *l,
+                                                       const T *u, const int32_t *nbd,
+                                                       const T *g, double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W];
+    int nb[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[0] = fmax(acc[0], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
+  });
+  block_reduce_store<1>(acc, 0, 0, 1, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
+                   const T *g) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(projgr_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 0, 1);
+}
+
+// =========================== W'v ============================================
+// The WS/WY correction-pair matvec: out[j] = sum_i Wy(i,j) v_i,
+// out[col+j] = sum_i Ws(i,j) v_i.  Algorithmic bytes (2 col + 1) n s.
+// Per lane and trip: 2*MC + 1 independent 16-byte loads in flight.
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restrict__ ws,
+                                                    const T *__restrict__ wy, int64_t ldw, int m,
+                                                    int head, int col, const T *__restrict__ v,
+                                                    double *part) {
+  double acc[2 * MC];
+#pragma unroll
+  for (int k = 0; k < 2 * MC; ++k) acc[k] = 0.0;
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double vv[W], a[MC][W], b[MC][W];
+    ld<W>(v + i, vv);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i;
+      ld<W>(wy + off, a[j]);
+      ld<W>(ws + off, b[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += a[j][k] * vv[k];
+        acc[MC + j] += b[j][k] * vv[k];
+      }
+    }
+  });
+  // slots [0..MC) = Wy' v, [MC..2MC) = Ws' v; entries >= col are discarded by the host
+  block_reduce_store<2 * MC>(acc, 2 * MC, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
+  const int g = grid_for(n, VecOf<T>::V);
+  DISPATCH_MAXC(col, hipLaunchKernelGGL((wtv_kernel<T, MC>), dim3(g), dim3(BLOCK), 0, q.stream, n,
+                                        w.ws, w.wy, w.ld, w.m, head, col, v, q.d_part));
+  q.launches++;
+}
+template <typename T>
+void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
+  launch_wtv_nofinalize(q, n, w, head, col, v);
+  launch_finalize(q, grid_for(n, VecOf<T>::V), 2 * maxc_for(col), 0, 0);
+}
+
+// =========================== cauchy scan (:1270-1330) ========================
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, int32_t *iwhere, T *tbrk,
+    const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
+    double *part) {
+  constexpr int NA = 2 * MC + 5;
+  double acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  acc[2 * MC + 4] = LB_INF;  // bkmin
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W], tb[W], ng[W];
+    int nb[W], iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ldi<W>(nbd + i, nb);
+    ldi<W>(iwhere + i, iw);
+    double a[MC > 0 ? MC : 1][W], b[MC > 0 ? MC : 1][W];
+    if constexpr (MC > 0) {
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+        const int64_t off = col_off(j, col, head, m, ldw) + i;
+        ld<W>(wy + off, a[j]);
+        ld<W>(ws + off, b[j]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const double neggi = -gv[k];
+      double tl = 0.0, tu = 0.0;
+      if (iw[k] != 3 && iw[k] != -1) {
+        if (nb[k] <= 2) tl = xv[k] - lv[k];
+        if (nb[k] >= 2) tu = uv[k] - xv[k];
+        const bool xlower = nb[k] <= 2 && tl <= 0.0;
+        const bool xupper = nb[k] >= 2 && tu <= 0.0;
+        iw[k] = 0;
+        if (xlower) {
+          if (neggi <= 0.0) iw[k] = 1;
+        } else if (xupper) {
+          if (neggi >= 0.0) iw[k] = 2;
+        } else {
+          if (fabs(neggi) <= 0.0) iw[k] = -3;
+        }
+      }
+      if (iw[k] != 0 && iw[k] != -1) {
+        tb[k] = -1.0;
+        ng[k] = 0.0;
+      } else {
+        ng[k] = neggi;
+        acc[2 * MC] = acc[2 * MC] - neggi * neggi;  // f1
+        if (nb[k] <= 2 && nb[k] != 0 && neggi < 0.0) {
+          tb[k] = tl / (-neggi);
+          acc[2 * MC + 1] += 1.0;
+          acc[2 * MC + 4] = fmin(acc[2 * MC + 4], tb[k]);
+        } else if (nb[k] >= 2 && neggi > 0.0) {
+          tb[k] = tu / neggi;
+          acc[2 * MC + 1] += 1.0;
+          acc[2 * MC + 4] = fmin(acc[2 * MC + 4], tb[k]);
+        } else {
+          tb[k] = LB_INF;
+          acc[2 * MC + 2] += 1.0;
+          if (fabs(neggi) > 0.0) acc[2 * MC + 3] += 1.0;
+        }
+      }
+    }
+    if constexpr (MC > 0) {
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          acc[j] += a[j][k] * ng[k];
+          acc[MC + j] += b[j][k] * ng[k];
+        }
+      }
+    }
+    sti<W>(iwhere + i, iw);
+    st<W>(tbrk + i, tb);
+  });
+  // slots [0..MC) Wy'd, [MC..2MC) Ws'd, then f1, nbreak, nunb, nunbnz (sums), bkmin (min)
+  block_reduce_store<NA>(acc, 2 * MC + 4, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                        const int32_t *nbd, const T *g, int32_t *iwhere, T *tbrk, WStore<T> w,
+                        int head, int col) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  if (col == 0) {
+    hipLaunchKernelGGL((cauchy_scan_kernel<T, 0>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
+                       nbd, g, iwhere, tbrk, w.ws, w.wy, w.ld, w.m, head, col, q.d_part);
+  } else {
+    DISPATCH_MAXC(col, hipLaunchKernelGGL((cauchy_scan_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+                                          q.stream, n, x, l, u, nbd, g, iwhere, tbrk, w.ws, w.wy,
+                                          w.ld, w.m, head, col, q.d_part));
+  }
+  q.launches++;
+  launch_finalize(q, gr, 2 * (col == 0 ? 0 : maxc_for(col)) + 4, 1, 0);
+}
+
+// =========================== cauchy breakpoint selection =====================
+__device__ __forceinline__ bool after_cursor(double t, int64_t gi, double lo_t, int64_t lo_i) {
+  return t > lo_t || (t == lo_t && gi > lo_i);
+}
+__device__ __forceinline__ uint64_t key_of(double t) {  // t >= 0: bit pattern is monotone
+  return (uint64_t)__double_as_longlong(t);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_window_kernel(int64_t n, int64_t row0,
+                                                              const T *__restrict__ tbrk,
+                                                              double lo_t, int64_t lo_i,
+                                                              double hi_t, uint64_t *keys,
+                                                              uint32_t *idx, uint32_t cap,
+                                                              uint32_t *count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nround = ((n + stride - 1) / stride) * stride;  // keep waves converged
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+    bool pred = false;
+    double t = 0.0;
+    if (i < n) {
+      t = (double)tbrk[i];
+      pred = t >= 0.0 && t <= hi_t && after_cursor(t, row0 + i, lo_t, lo_i);
+    }
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) continue;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) {
+      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        keys[pos] = key_of(t);
+        idx[pos] = (uint32_t)i;
+      }
+    }
+  }
+}
+template <typename T>
+void launch_cauchy_window(Queue &q, int64_t n, int64_t row0, const T *tbrk, double lo_t,
+                          int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
+                          uint32_t *d_count) {
+  (void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), q.stream);
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(cauchy_window_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, tbrk,
+                     lo_t, lo_i, hi_t, keys, idx, cap, d_count);
+  q.launches++;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_allkeys_kernel(int64_t n, int64_t row0,
+                                                               const T *__restrict__ tbrk,
+                                                               double lo_t, int64_t lo_i,
+                                                               uint64_t *keys, uint32_t *idx) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double t = (double)tbrk[i];
+    const bool pred = t >= 0.0 && t < LB_INF && after_cursor(t, row0 + i, lo_t, lo_i);
+    keys[i] = pred ? key_of(t) : ~0ull;
+    idx[i] = (uint32_t)i;
+  }
+}
+template <typename T>
+void launch_cauchy_allkeys(Queue &q, int64_t n, int64_t row0, const T *tbrk, double lo_t,
+                           int64_t lo_i, uint64_t *keys, uint32_t *idx) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(cauchy_allkeys_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, tbrk,
+                     lo_t, lo_i, keys, idx);
+  q.launches++;
+}
+
+size_t sort_pairs_temp_bytes(size_t count) {
+  size_t b1 = 0, b2 = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, b1, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, count, 0, 64,
+                                  (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (const uint64_t *)nullptr, (uint64_t *)nullptr, count, 0, 32,
+                                  (hipStream_t)0);
+  return b1 > b2 ? b1 : b2;
+}
+void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_t *idx_in,
+                        uint32_t *idx_out, const uint64_t *keys_in, uint64_t *keys_out,
+                        size_t count) {
+  (void)rocprim::radix_sort_pairs(d_temp, temp_bytes, idx_in, idx_out, keys_in, keys_out, count, 0,
+                                  32, q.stream);
+  q.launches++;
+}
+void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t *keys_in,
+                       uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out,
+                       size_t count) {
+  (void)rocprim::radix_sort_pairs(d_temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, count, 0,
+                                  64, q.stream);
+  q.launches++;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
+    const uint32_t *__restrict__ idx, uint32_t cnt, const T *__restrict__ x,
+    const T *__restrict__ l, const T *__restrict__ u, const T *__restrict__ g,
+    const T *__restrict__ tbrk, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
+    int m, int head, int col, double *rec) {
+  const int rl = 2 * col + 3;
+  const int64_t total = (int64_t)cnt * rl;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = (uint32_t)(q / rl);
+    const int f = (int)(q % rl);
+    const int64_t i = idx[k];
+    double v;
+    if (f == 0) {
+      v = (double)tbrk[i];
+    } else if (f == 1) {
+      v = -(double)g[i];
+    } else if (f == 2) {
+      const double d = -(double)g[i];
+      v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
+    } else if (f < 3 + col) {
+      v = (double)wy[(int64_t)((head - 1 + (f - 3)) % m) * ldw + i];
+    } else {
+      v = (double)ws[(int64_t)((head - 1 + (f - 3 - col)) % m) * ldw + i];
+    }
+    rec[q] = v;
+  }
+}
+template <typename T>
+void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, const T *x, const T *l,
+                          const T *u, const T *g, const T *tbrk, WStore<T> w, int head, int col,
+                          double *rec) {
+  if (cnt == 0) return;
+  const int64_t total = (int64_t)cnt * (2 * col + 3);
+  int gr = (int)((total + BLOCK - 1) / BLOCK);
+  if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
+  hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, cnt, x, l,
+                     u, g, tbrk, w.ws, w.wy, w.ld, w.m, head, col, rec);
+  q.launches++;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
+    int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
+    const T *__restrict__ u, const T *__restrict__ g, const T *__restrict__ tbrk,
+    int32_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], tb[W], lv[W], uv[W], out[W];
+    int iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(g + i, gv);
+    ld<W>(tbrk + i, tb);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      out[k] = xv[k];
+      if (tb[k] >= 0.0) {
+        const double d = -gv[k];
+        const bool done =
+            tb[k] < last_t || (tb[k] == last_t && (row0 + i + k) <= last_i);
+        if (done) {
+          if (d > 0.0) {
+            out[k] = uv[k];
+            iw[k] = 2;
+          } else {
+            out[k] = lv[k];
+            iw[k] = 1;
+          }
+        } else if (tsum != 0.0) {
+          out[k] = xv[k] + tsum * d;
+        }
+      }
+    }
+    st<W>(xcp + i, out);
+    sti<W>(iwhere + i, iw);
+  });
+}
+template <typename T>
+void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
+                          const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
+                          double last_t, int64_t last_i) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(cauchy_finish_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, l, u,
+                     g, tbrk, iwhere, xcp, tsum, last_t, last_i);
+  q.launches++;
+}
+
+// =========================== freev (:1980-2059) ==============================
+__global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
+                                                            const int32_t *__restrict__ iwhere,
+                                                            int8_t *wasfree, double *part) {
+  double acc[3] = {0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool fr = iwhere[i] <= 0;
+    const bool was = wasfree[i] != 0;
+    if (fr) acc[0] += 1.0;
+    if (fr && !was) acc[1] += 1.0;
+    if (!fr && was) acc[2] += 1.0;
+    wasfree[i] = fr ? 1 : 0;
+  }
+  block_reduce_store<3>(acc, 3, 0, 0, part, MAX_BLOCKS);
+}
+void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(freev_count_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 3, 0, 0);
+}
+
+// ordered stream compaction reproducing the reference's list orders exactly:
+//   Index : free variables ascending from the front, active ascending from the back
+//   Indx2 : entering in DESCENDING variable order from the front (the reference walks the
+//           old active list, which is stored back to front), leaving ascending from the back.
+constexpr int LIST_ITEMS = 4;
+constexpr int LIST_CHUNK = BLOCK * LIST_ITEMS;
+
+__device__ __forceinline__ void list_flags(int64_t i, int64_t n, const int32_t *iwhere,
+                                           const int8_t *prev, int do_el, int &fr, int &en,
+                                           int &lv) {
+  fr = en = lv = 0;
+  if (i < n) {
+    fr = iwhere[i] <= 0;
+    if (do_el) {
+      const int was = prev[i] != 0;
+      en = fr && !was;
+      lv = !fr && was;
+    }
+  }
+}
+__global__ __launch_bounds__(BLOCK) void list_count_kernel(int64_t n, const int32_t *iwhere,
+                                                           const int8_t *prev, int do_el,
+                                                           int32_t *tmp) {
+  __shared__ int s[3];
+  if (threadIdx.x < 3) s[threadIdx.x] = 0;
+  __syncthreads();
+  int c0 = 0, c1 = 0, c2 = 0;
+  for (int k = 0; k < LIST_ITEMS; ++k) {
+    int fr, en, lv;
+    list_flags((int64_t)blockIdx.x * LIST_CHUNK + threadIdx.x * LIST_ITEMS + k, n, iwhere, prev,
+               do_el, fr, en, lv);
+    c0 += fr;
+    c1 += en;
+    c2 += lv;
+  }
+  atomicAdd(&s[0], c0);
+  atomicAdd(&s[1], c1);
+  atomicAdd(&s[2], c2);
+  __syncthreads();
+  if (threadIdx.x < 3) tmp[3 * blockIdx.x + threadIdx.x] = s[threadIdx.x];
+}
+// exclusive scan of the per-chunk counts (single workgroup); totals in tmp[3*nch ..]
+__global__ __launch_bounds__(BLOCK) void list_scan_kernel(int nch, int32_t *tmp) {
+  __shared__ int tot[3][BLOCK];
+  const int per = (nch + BLOCK - 1) / BLOCK;
+  const int b0 = threadIdx.x * per, b1 = min(nch, b0 + per);
+  int c[3] = {0, 0, 0};
+  for (int b = b0; b < b1; ++b)
+    for (int k = 0; k < 3; ++k) c[k] += tmp[3 * b + k];
+  for (int k = 0; k < 3; ++k) tot[k][threadIdx.x] = c[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) {
+      int run = 0;
+      for (int t = 0; t < BLOCK; ++t) {
+        const int v = tot[k][t];
+        tot[k][t] = run;
+        run += v;
+      }
+      tmp[3 * nch + k] = run;
+    }
+  }
+  __syncthreads();
+  int run[3] = {tot[0][threadIdx.x], tot[1][threadIdx.x], tot[2][threadIdx.x]};
+  for (int b = b0; b < b1; ++b)
+    for (int k = 0; k < 3; ++k) {
+      const int v = tmp[3 * b + k];
+      tmp[3 * b + k] = run[k];
+      run[k] += v;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void list_write_kernel(int64_t n, const int32_t *iwhere,
+                                                           const int8_t *prev, int do_el,
+                                                           const int32_t *tmp, int nch,
+                                                           int32_t *index, int32_t *indx2) {
+  __shared__ int sc[3][BLOCK];
+  int fr[LIST_ITEMS], en[LIST_ITEMS], lv[LIST_ITEMS];
+  int c[3] = {0, 0, 0};
+  const int64_t i0 = (int64_t)blockIdx.x * LIST_CHUNK + threadIdx.x * LIST_ITEMS;
+  for (int k = 0; k < LIST_ITEMS; ++k) {
+    list_flags(i0 + k, n, iwhere, prev, do_el, fr[k], en[k], lv[k]);
+    c[0] += fr[k];
+    c[1] += en[k];
+    c[2] += lv[k];
+  }
+  for (int k = 0; k < 3; ++k) sc[k][threadIdx.x] = c[k];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int run = 0;
+    for (int t = 0; t < BLOCK; ++t) {
+      const int v = sc[threadIdx.x][t];
+      sc[threadIdx.x][t] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  int64_t pf = (int64_t)tmp[3 * blockIdx.x + 0] + sc[0][threadIdx.x];
+  int64_t pe = (int64_t)tmp[3 * blockIdx.x + 1] + sc[1][threadIdx.x];
+  int64_t pl = (int64_t)tmp[3 * blockIdx.x + 2] + sc[2][threadIdx.x];
+  const int64_t nenter = tmp[3 * nch + 1];
+  for (int k = 0; k < LIST_ITEMS; ++k) {
+    const int64_t i = i0 + k;
+    if (i >= n) break;
+    const int32_t var = (int32_t)(i + 1);
+    if (fr[k]) {
+      index[pf] = var;
+      pf++;
+    } else {
+      const int64_t ar = i - pf;  // actives before i
+      index[n - 1 - ar] = var;
+    }
+    if (en[k]) {
+      indx2[nenter - 1 - pe] = var;
+      pe++;
+    }
+    if (lv[k]) {
+      indx2[n - 1 - pl] = var;
+      pl++;
+    }
+  }
+}
+void launch_freev_lists(Queue &q, int64_t n, const int32_t *iwhere, const int8_t *prevfree,
+                        int do_enterleave, int32_t *index, int32_t *indx2, int32_t *scan_tmp) {
+  const int nch = (int)((n + LIST_CHUNK - 1) / LIST_CHUNK);
+  hipLaunchKernelGGL(list_count_kernel, dim3(nch), dim3(BLOCK), 0, q.stream, n, iwhere, prevfree,
+                     do_enterleave, scan_tmp);
+  hipLaunchKernelGGL(list_scan_kernel, dim3(1), dim3(BLOCK), 0, q.stream, nch, scan_tmp);
+  hipLaunchKernelGGL(list_write_kernel, dim3(nch), dim3(BLOCK), 0, q.stream, n, iwhere, prevfree,
+                     do_enterleave, scan_tmp, nch, index, indx2);
+  q.launches += 3;
+}
+
+// =========================== formk inner products ============================
+// From-scratch masked Gram of [Wy Ws] (reference keeps wn1 incrementally,
+// :1735-1851; same sums, same row sets, no cliff when many variables change
+// status).  Row tiles are staged in LDS once and every needed product pair reads
+// them from there; each output entry is owned by exactly one lane of the
+// workgroup, so no cross-lane reduction is needed.
+template <int MC>
+struct GramCfg {
+  static constexpr int R = MC <= 20 ? 128 : 64;     // rows per tile
+  static constexpr int RS = 2 * MC + 1;             // LDS row stride (odd: spreads banks)
+  static constexpr int E = 2 * MC * MC + MC;        // outputs at col == MC
+  static constexpr int NE = (E + BLOCK - 1) / BLOCK;  // outputs per lane
+};
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void formk_gram_kernel(int64_t n, const T *__restrict__ ws,
+                                                           const T *__restrict__ wy, int64_t ldw,
+                                                           int m, int head, int col,
+                                                           const int32_t *__restrict__ iwhere,
+                                                           double *gpart) {
+  using C = GramCfg<MC>;
+  __shared__ double tile[C::R * C::RS];
+  __shared__ int flag[C::R];
+  const int tri = col * (col + 1) / 2;
+  const int E = 2 * col * col + col;
+  // which (column a, column b, row set) this lane owns
+  int ca[C::NE], cb[C::NE], want[C::NE];
+  double acc[C::NE];
+#pragma unroll
+  for (int s = 0; s < C::NE; ++s) {
+    const int e = threadIdx.x + s * BLOCK;
+    acc[s] = 0.0;
+    ca[s] = cb[s] = 0;
+    want[s] = 2;  // matches no row
+    if (e < E) {
+      if (e < 2 * tri) {
+        const int ee = e < tri ? e : e - tri;
+        int i = (int)((sqrt(8.0 * ee + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > ee) --i;
+        while ((i + 1) * (i + 2) / 2 <= ee) ++i;
+        const int j = ee - i * (i + 1) / 2;
+        if (e < tri) {
+          ca[s] = i;
+          cb[s] = j;
+          want[s] = 1;  // free rows: Wy_i . Wy_j
+        } else {
+          ca[s] = col + i;
+          cb[s] = col + j;
+          want[s] = 0;  // active rows: Ws_i . Ws_j
+        }
+      } else {
+        const int ee = e - 2 * tri;
+        const int i = ee / col, j = ee % col;
+        ca[s] = col + i;  // Ws_i
+        cb[s] = j;        // Wy_j
+        want[s] = i > j ? 0 : 1;
+      }
+    }
+  }
+  const int64_t ntiles = (n + C::R - 1) / C::R;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t r0 = t * C::R;
+    __syncthreads();
+    for (int qd = threadIdx.x; qd < 2 * col * C::R; qd += BLOCK) {
+      const int c = qd / C::R, r = qd % C::R;
+      const int64_t row = r0 + r;
+      double v = 0.0;
+      if (row < n) {
+        const int jj = c < col ? c : c - col;
+        const int64_t off = (int64_t)((head - 1 + jj) % m) * ldw + row;
+        v = c < col ? (double)wy[off] : (double)ws[off];
+      }
+      tile[r * C::RS + c] = v;
+    }
+    for (int r = threadIdx.x; r < C::R; r += BLOCK) {
+      const int64_t row = r0 + r;
+      flag[r] = row < n ? (iwhere[row] <= 0 ? 1 : 0) : 3;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < C::R; ++r) {
+      const int f = flag[r];
+#pragma unroll
+      for (int s = 0; s < C::NE; ++s) {
+        const double a = tile[r * C::RS + ca[s]];
+        const double b = tile[r * C::RS + cb[s]];
+        if (f == want[s]) acc[s] += a * b;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < C::NE; ++s) {
+    const int e = threadIdx.x + s * BLOCK;
+    if (e < E) gpart[(size_t)e * GRAM_BLOCKS + blockIdx.x] = acc[s];
+  }
+}
+template <typename T>
+void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
+                       const int32_t *iwhere) {
+  int gr = 0;
+  DISPATCH_MAXC(col, {
+    const int64_t ntiles = (n + GramCfg<MC>::R - 1) / GramCfg<MC>::R;
+    gr = (int)(ntiles < GRAM_BLOCKS ? ntiles : GRAM_BLOCKS);
+    hipLaunchKernelGGL((formk_gram_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
+                       w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
+  });
+  q.launches++;
+  finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
+}
+
+// =========================== cmprlb (:1548-1586) =============================
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void cmprlb_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
+    const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
+    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
+    int iw[W];
+    ld<W>(g + i, gv);
+    if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
+#pragma unroll
+      for (int k = 0; k < W; ++k) rv[k] = -gv[k];
+      st<W>(r + i, rv);
+      return;
+    }
+    ld<W>(x + i, xv);
+    ld<W>(z + i, zv);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i;
+      ld<W>(wy + off, a[j]);
+      ld<W>(ws + off, b[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      double rr = -theta * (zv[k] - xv[k]) - gv[k];
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+        if (j < col) rr = rr + a[j][k] * cf.a[j] + b[j][k] * cf.a[MAXM + j];
+      }
+      rv[k] = iw[k] <= 0 ? rr : 0.0;
+    }
+    st<W>(r + i, rv);
+  });
+}
+template <typename T>
+void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
+                   const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
+                   const Coef &a, int plain) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0, q.stream,
+                                        n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m, head, col,
+                                        theta, a, plain));
+  q.launches++;
+}
+
+// =========================== subsm (:2676-2885) ==============================
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
+    int64_t n, T *z, T *r, T *xp, const T *__restrict__ l, const T *__restrict__ u,
+    const int32_t *__restrict__ nbd, const int32_t *__restrict__ iwhere,
+    const T *__restrict__ xx, const T *__restrict__ gg, const T *__restrict__ ws,
+    const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double theta, Coef wv,
+    double *part) {
+  double acc[2] = {0.0, 0.0};
+  const double rtheta = 1.0 / theta;
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double zv[W], rv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
+    int nb[W], iw[W];
+    ld<W>(z + i, zv);
+    ld<W>(r + i, rv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(xx + i, xv);
+    ld<W>(gg + i, gv);
+    ldi<W>(nbd + i, nb);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i;
+      ld<W>(wy + off, a[j]);
+      ld<W>(ws + off, b[j]);
+    }
+    st<W>(xp + i, zv);  // xp = xcp (:2787)
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (iw[k] <= 0) {
+        double dk = rv[k];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+          if (j < col) dk = dk + a[j][k] * wv.a[j] / theta + b[j][k] * wv.a[MAXM + j];
+        }
+        dk = rtheta * dk;  // dscal (:2780)
+        rv[k] = dk;
+        const double xk = zv[k];
+        if (nb[k] != 0) {
+          if (nb[k] == 1) {
+            zv[k] = fmax(lv[k], xk + dk);
+            if (zv[k] == lv[k]) acc[0] += 1.0;
+          } else if (nb[k] == 2) {
+            const double t1 = fmax(lv[k], xk + dk);
+            zv[k] = fmin(uv[k], t1);
+            if (zv[k] == lv[k] || zv[k] == uv[k]) acc[0] += 1.0;
+          } else if (nb[k] == 3) {
+            zv[k] = fmin(uv[k], xk + dk);
+            if (zv[k] == uv[k]) acc[0] += 1.0;
+          }
+        } else {
+          zv[k] = xk + dk;
+        }
+      }
+      acc[1] = acc[1] + (zv[k] - xv[k]) * gv[k];  // dd_p (:2824-2827)
+    }
+    st<W>(z + i, zv);
+    st<W>(r + i, rv);
+  });
+  block_reduce_store<2>(acc, 2, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, const T *u,
+                         const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
+                         WStore<T> w, int head, int col, double theta, const Coef &wv) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  DISPATCH_MAXC(col, hipLaunchKernelGGL((subsm_update_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+                                        q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
+                                        w.wy, w.ld, w.m, head, col, theta, wv, q.d_part));
+  q.launches++;
+  launch_finalize(q, gr, 2, 0, 0);
+}
+
+// backtracking ratio of one free variable (:2842-2857); 2.0 = no restriction
+__device__ __forceinline__ double bt_ratio(double dk, double x, double l, double u, int nb) {
+  double c = 2.0;
+  if (nb != 0) {
+    if (dk < 0.0 && nb <= 2) {
+      const double t2 = l - x;
+      c = t2 >= 0.0 ? 0.0 : t2 / dk;
+    } else if (dk > 0.0 && nb >= 2) {
+      const double t2 = u - x;
+      c = t2 <= 0.0 ? 0.0 : t2 / dk;
+    }
+  }
+  return c;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void subsm_alpha_kernel(int64_t n, int64_t row0,
+                                                            const T *__restrict__ xp,
+                                                            const T *__restrict__ r,
+                                                            const T *__restrict__ l,
+                                                            const T *__restrict__ u,
+                                                            const int32_t *__restrict__ nbd,
+                                                            const int32_t *__restrict__ iwhere,
+                                                            int pass, double alpha, double *part) {
+  double acc[1] = {pass == 0 ? 1.0 : LB_INF};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (iwhere[i] > 0) continue;
+    const double c = bt_ratio((double)r[i], (double)xp[i], (double)l[i], (double)u[i], nbd[i]);
+    if (pass == 0)
+      acc[0] = fmin(acc[0], c);
+    else if (c == alpha)
+      acc[0] = fmin(acc[0], (double)(row0 + i));
+  }
+  block_reduce_store<1>(acc, 0, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l, const T *u,
+                        const int32_t *nbd, const int32_t *iwhere) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, (int64_t)0, xp,
+                     r, l, u, nbd, iwhere, 0, 0.0, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 1, 0);
+}
+template <typename T>
+void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const T *r, const T *l,
+                           const T *u, const int32_t *nbd, const int32_t *iwhere, double alpha) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, xp, r, l,
+                     u, nbd, iwhere, 1, alpha, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 1, 0);
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void subsm_backtrack_kernel(int64_t n, int64_t row0, T *z,
+                                                                const T *__restrict__ xp, T *r,
+                                                                const T *__restrict__ l,
+                                                                const T *__restrict__ u,
+                                                                const int32_t *__restrict__ iwhere,
+                                                                double alpha, int64_t ibd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double xk = (double)xp[i];
+    if (iwhere[i] <= 0) {
+      double dk = (double)r[i];
+      if (alpha < 1.0 && row0 + i == ibd) {  // :2865-2875
+        if (dk > 0.0) {
+          xk = (double)u[i];
+          dk = 0.0;
+        } else if (dk < 0.0) {
+          xk = (double)l[i];
+          dk = 0.0;
+        }
+        r[i] = (T)dk;
+      }
+      xk = xk + alpha * dk;
+    }
+    z[i] = (T)xk;
+  }
+}
+template <typename T>
+void launch_subsm_backtrack(Queue &q, int64_t n, int64_t row0, T *z, const T *xp, T *r, const T *l,
+                            const T *u, const int32_t *iwhere, double alpha, int64_t ibd) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_backtrack_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, z, xp,
+                     r, l, u, iwhere, alpha, ibd);
+  q.launches++;
+}
+
+// =========================== lnsrlb (:2174-2275) =============================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void lnsrlb_begin_kernel(
+    int64_t n, const T *__restrict__ z, const T *__restrict__ x, const T *__restrict__ g,
+    const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd, T *d, T *t,
+    T *r, int do_stpmx, double *part) {
+  double acc[3] = {0.0, 0.0, 1.0e10};  // dtd, gd, stpmx (big, :2189)
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double zv[W], xv[W], gv[W], dv[W], lv[W], uv[W];
+    int nb[W];
+    ld<W>(z + i, zv);
+    ld<W>(x + i, xv);
+    ld<W>(g + i, gv);
+    if (do_stpmx) {
+      ld<W>(l + i, lv);
+      ld<W>(u + i, uv);
+      ldi<W>(nbd + i, nb);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      dv[k] = zv[k] - xv[k];  // mainlb :720-722
+      acc[0] = acc[0] + dv[k] * dv[k];
+      acc[1] = acc[1] + gv[k] * dv[k];
+      if (do_stpmx && nb[k] != 0) {  // :2206-2225
+        const double a1 = dv[k];
+        if (a1 < 0.0 && nb[k] <= 2) {
+          const double a2 = lv[k] - xv[k];
+          acc[2] = fmin(acc[2], a2 >= 0.0 ? 0.0 : a2 / a1);
+        } else if (a1 > 0.0 && nb[k] >= 2) {
+          const double a2 = uv[k] - xv[k];
+          acc[2] = fmin(acc[2], a2 <= 0.0 ? 0.0 : a2 / a1);
+        }
+      }
+    }
+    st<W>(d + i, dv);
+    st<W>(t + i, xv);
+    st<W>(r + i, gv);
+  });
+  block_reduce_store<3>(acc, 2, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_lnsrlb_begin(Queue &q, int64_t n, const T *z, const T *x, const T *g, const T *l,
+                         const T *u, const int32_t *nbd, T *d, T *t, T *r, int do_stpmx) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(lnsrlb_begin_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, z, x, g, l, u,
+                     nbd, d, t, r, do_stpmx, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 2, 1, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void lnsrlb_step_kernel(int64_t n, T *x,
+                                                            const T *__restrict__ z,
+                                                            const T *__restrict__ d,
+                                                            const T *__restrict__ t, double stp) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double o[W];
+    if (stp == 1.0) {
+      ld<W>(z + i, o);  // bit copy of z keeps exact bound values (:2264-2265)
+    } else {
+      double dv[W], tv[W];
+      ld<W>(d + i, dv);
+      ld<W>(t + i, tv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) o[k] = stp * dv[k] + tv[k];
+    }
+    st<W>(x + i, o);
+  });
+}
+template <typename T>
+void launch_lnsrlb_step(Queue &q, int64_t n, T *x, const T *z, const T *d, const T *t,
+                        double stp) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(lnsrlb_step_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, z, d, t, stp);
+  q.launches++;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void lnsrlb_eval_kernel(int64_t n, const T *__restrict__ x,
+                                                            const T *__restrict__ l,
+                                                            const T *__restrict__ u,
+                                                            const int32_t *__restrict__ nbd,
+                                                            const T *__restrict__ g,
+                                                            const T *__restrict__ d, double *part) {
+  double acc[2] = {0.0, 0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W], dv[W];
+    int nb[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ld<W>(d + i, dv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      acc[0] = acc[0] + gv[k] * dv[k];
+      acc[1] = fmax(acc[1], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
+    }
+  });
+  block_reduce_store<2>(acc, 1, 0, 1, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                        const int32_t *nbd, const T *g, const T *d) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(lnsrlb_eval_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
+                     d, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 1, 0, 1);
+}
+
+// =========================== mainlb :812-824 + matupd (:2291-2346) ===========
+// ncol_old = col - 1 older pairs (logical order from head); new pair goes to
+// physical column itail (1-based).
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
+    int64_t n, const T *__restrict__ g, const T *__restrict__ r, const T *__restrict__ d,
+    double stp, T *ws, T *wy, int64_t ldw, int m, int head, int nold, int itail, double *part) {
+  constexpr int NA = 2 * MC + 1;
+  double acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  const int64_t offn = (int64_t)(itail - 1) * ldw;
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double gv[W], rv[W], dv[W], a[MC][W], b[MC][W];
+    ld<W>(g + i, gv);
+    ld<W>(r + i, rv);
+    ld<W>(d + i, dv);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      // nold may be 0: then logical column 0 is the NEW column; read d's own slot instead
+      const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
+      ld<W>(wy + off, a[j]);
+      ld<W>(ws + off, b[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rv[k] = gv[k] - rv[k];                   // y = g - g_old (:813-815)
+      acc[2 * MC] = acc[2 * MC] + rv[k] * rv[k];  // rr (:816)
+      if (stp != 1.0) dv[k] = stp * dv[k];     // dscal (:822)
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += dv[k] * a[j][k];        // Sy(col,j) = d . Wy(:,j) (:2335)
+        acc[MC + j] += b[j][k] * dv[k];   // Ss(j,col) = Ws(:,j) . d (:2336)
+      }
+    }
+    st<W>(ws + offn + i, dv);  // :2313
+    st<W>(wy + offn + i, rv);  // :2314
+  });
+  // slots [0..MC) d'Wy_j, [MC..2MC) Ws_j'd, [2MC] y'y
+  block_reduce_store<NA>(acc, NA, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d, double stp,
+                         WStore<T> w, int head, int col, int itail) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  const int nold = col - 1;
+  DISPATCH_MAXC(nold, hipLaunchKernelGGL((update_pairs_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+                                         q.stream, n, g, r, d, stp, w.ws, w.wy, w.ld, w.m, head,
+                                         nold, itail, q.d_part));
+  q.launches++;
+  launch_finalize(q, gr, 2 * maxc_for(nold) + 1, 0, 0);
+}
+
+// =========================== built-in objectives =============================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void obj_quadratic_kernel(int64_t n, int64_t row0,
+                                                              const T *__restrict__ x, T *g,
+                                                              double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W];
+    ld<W>(x + i, xv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const int64_t gi = row0 + i + k + 1;
+      const double a = 1.0 + 99.0 * (double)((7919 * gi) % 10007) / 10006.0;
+      const double c = -2.0 + 4.0 * (double)((104729 * gi) % 100003) / 100002.0;
+      const double dx = xv[k] - c;
+      gv[k] = a * dx;
+      acc[0] = acc[0] + a * dx * dx;
+    }
+    st<W>(g + i, gv);
+  });
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(obj_quadratic_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, g,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 1, 0, 0);
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, const T *__restrict__ x,
+                                                               T *g, double *part) {
+  double acc[1] = {0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double xi = (double)x[i];
+    double gi;
+    if (i == 0) {
+      const double t1 = (double)x[1] - xi * xi;
+      gi = 2.0 * (xi - 1.0) - 16.0 * xi * t1;
+      acc[0] = acc[0] + 0.25 * ((xi - 1.0) * (xi - 1.0));
+    } else {
+      const double xm = (double)x[i - 1];
+      const double t2 = xi - xm * xm;
+      acc[0] = acc[0] + t2 * t2;
+      if (i == n - 1) {
+        gi = 8.0 * t2;
+      } else {
+        const double t1 = (double)x[i + 1] - xi * xi;
+        gi = 8.0 * t2 - 16.0 * xi * t1;
+      }
+    }
+    g[i] = (T)gi;
+  }
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 1, 0, 0);
+}
+
+// =========================== explicit instantiations =========================
+#define INSTANTIATE(T)                                                                             \
+  template void launch_active<T>(Queue &, int64_t, T *, const T *, const T *, const int32_t *,     \
+                                 int32_t *, int8_t *);                                             \
+  template void launch_errclb<T>(Queue &, int64_t, int64_t, const T *, const T *,                  \
+                                 const int32_t *);                                                 \
+  template void launch_projgr<T>(Queue &, int64_t, const T *, const T *, const T *,                \
+                                 const int32_t *, const T *);                                      \
+  template void launch_wtv<T>(Queue &, int64_t, WStore<T>, int, int, const T *);                   \
+  template void launch_wtv_nofinalize<T>(Queue &, int64_t, WStore<T>, int, int, const T *);        \
+  template void launch_cauchy_scan<T>(Queue &, int64_t, const T *, const T *, const T *,           \
+                                      const int32_t *, const T *, int32_t *, T *, WStore<T>, int,  \
+                                      int);                                                        \
+  template void launch_cauchy_window<T>(Queue &, int64_t, int64_t, const T *, double, int64_t,     \
+                                        double, uint64_t *, uint32_t *, uint32_t, uint32_t *);     \
+  template void launch_cauchy_allkeys<T>(Queue &, int64_t, int64_t, const T *, double, int64_t,    \
+                                         uint64_t *, uint32_t *);                                  \
+  template void launch_cauchy_gather<T>(Queue &, const uint32_t *, uint32_t, const T *, const T *, \
+                                        const T *, const T *, const T *, WStore<T>, int, int,      \
+                                        double *);                                                 \
+  template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
+                                        const T *, const T *, const T *, int32_t *, T *, double,   \
+                                        double, int64_t);                                          \
+  template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const int32_t *);      \
+  template void launch_cmprlb<T>(Queue &, int64_t, const T *, const T *, const T *, T *,           \
+                                 const int32_t *, WStore<T>, int, int, double, const Coef &, int); \
+  template void launch_subsm_update<T>(Queue &, int64_t, T *, T *, T *, const T *, const T *,      \
+                                       const int32_t *, const int32_t *, const T *, const T *,     \
+                                       WStore<T>, int, int, double, const Coef &);                 \
+  template void launch_subsm_alpha<T>(Queue &, int64_t, const T *, const T *, const T *,           \
+                                      const T *, const int32_t *, const int32_t *);                \
+  template void launch_subsm_argalpha<T>(Queue &, int64_t, int64_t, const T *, const T *,          \
+                                         const T *, const T *, const int32_t *, const int32_t *,   \
+                                         double);                                                  \
+  template void launch_subsm_backtrack<T>(Queue &, int64_t, int64_t, T *, const T *, T *,          \
+                                          const T *, const T *, const int32_t *, double, int64_t); \
+  template void launch_lnsrlb_begin<T>(Queue &, int64_t, const T *, const T *, const T *,          \
+                                       const T *, const T *, const int32_t *, T *, T *, T *, int); \
+  template void launch_lnsrlb_step<T>(Queue &, int64_t, T *, const T *, const T *, const T *,      \
+                                      double);                                                     \
+  template void launch_lnsrlb_eval<T>(Queue &, int64_t, const T *, const T *, const T *,           \
+                                      const int32_t *, const T *, const T *);                      \
+  template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double,  \
+                                       WStore<T>, int, int, int);                                  \
+  template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *);                \
+  template void launch_obj_rosenbrock<T>(Queue &, int64_t, const T *, T *);
+
+INSTANTIATE(double)
+INSTANTIATE(float)
+
+}  // namespace lbk

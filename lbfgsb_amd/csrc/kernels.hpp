@@ -1,0 +1,191 @@
+// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+//
+// Every function enqueues work on `q.stream` and returns immediately; results
+// of reductions land in q.d_res (device) after the finalize kernel and are
+// fetched by the solver (solver.hip) in one D2H copy per phase.  No function
+// here synchronises, allocates or frees (graph-capturable, cdna guide G9).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lbk {
+
+constexpr int BLOCK = 256;        // 4 wave64 per workgroup
+constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 workgroups, grid-stride beyond that
+constexpr int GRAM_BLOCKS = 1024;
+constexpr int MAXM = 32;          // LBFGSB_MAX_M
+constexpr int RES_MAX = 4 * MAXM + 32;
+
+// launch queue + reduction scratch owned by the context
+struct Queue {
+  hipStream_t stream;
+  double *d_part;   // [rows][MAX_BLOCKS] block partials (row = output slot)
+  double *d_res;    // [RES_MAX or gram size] finalized results, device
+  double *d_gpart;  // gram partials [E][GRAM_BLOCKS]
+  int64_t launches;
+};
+
+// the circular correction-pair store: Ws, Wy column-major n x m, leading
+// dimension ld (multiple of 32 rows).  head is 1-based like the reference.
+template <typename T>
+struct WStore {
+  T *ws;
+  T *wy;
+  int64_t ld;
+  int m;
+};
+
+// small coefficient vectors travel as kernel arguments (scalar loads)
+struct Coef {
+  double a[2 * MAXM];
+};
+
+int grid_for(int64_t n, int vec);
+// compile-time column capacity the kernels are unrolled to for `col` pairs (5, 10, 20, 32).
+// Reduction slots that depend on col use MC = maxc_for(col) as their stride.
+int maxc_for(int col);
+
+// ---- one-off (START) ----------------------------------------------------
+// active (ref :965-1040): clip x, init iwhere.  res: [0]=#projected (sum),
+// [1]=#(nbd!=0) (sum), [2]=#(nbd!=2) (sum), [3]=nbdd (sum)
+template <typename T>
+void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd,
+                   int32_t *iwhere, int8_t *wasfree);
+// errclb (ref :1601-1643): res max-slots: [0]=largest 1-based global index with invalid nbd
+// (0 if none), [1]=largest index with l>u and nbd==2.
+template <typename T>
+void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
+                   const int32_t *nbd);
+
+// ---- projgr (ref :2594-2622): res max-slot [0] = sbgnrm -------------------
+template <typename T>
+void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                   const int32_t *nbd, const T *g);
+
+// ---- W'v (the WS/WY correction-pair matvec) -------------------------------
+// res sum-slots [0..col) = Wy' v, [MC..MC+col) = Ws' v (logical column order)
+template <typename T>
+void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v);
+template <typename T>
+void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v);
+
+// ---- cauchy (ref :1157-1532) ----------------------------------------------
+// scan (:1270-1330): updates iwhere, writes tbrk (breakpoint t_i > 0; +inf = moves
+// without bound; -1 = does not move).  With MC = (col ? maxc_for(col) : 0), res sum-slots:
+// [0..col) Wy'd, [MC..MC+col) Ws'd, [2MC] f1, [2MC+1] nbreak, [2MC+2] #moving-without-
+// breakpoint, [2MC+3] #of those with g!=0; min-slot [2MC+4] = bkmin (+inf if none)
+template <typename T>
+void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                        const int32_t *nbd, const T *g, int32_t *iwhere, T *tbrk,
+                        WStore<T> w, int head, int col);
+// candidates with (lo_t, lo_i) < (t, gidx) and t <= hi_t, appended (unordered)
+// to keys/idx (capacity cap); *d_count receives the total number found.
+template <typename T>
+void launch_cauchy_window(Queue &q, int64_t n, int64_t row0, const T *tbrk, double lo_t,
+                          int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx,
+                          uint32_t cap, uint32_t *d_count);
+// keys for a full sort of the remaining breakpoints (non candidates -> UINT64_MAX)
+template <typename T>
+void launch_cauchy_allkeys(Queue &q, int64_t n, int64_t row0, const T *tbrk, double lo_t,
+                           int64_t lo_i, uint64_t *keys, uint32_t *idx);
+// stable LSD radix sort of (key, idx) pairs, count elements; temp storage query
+// when d_temp == nullptr.  Uses both halves of the double buffers; the sorted
+// result is left in keys_out/idx_out.
+size_t sort_pairs_temp_bytes(size_t count);
+void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t *keys_in,
+                       uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out,
+                       size_t count);
+// stable sort of the same pairs by idx (first pass of a (t, idx) lexicographic order)
+void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_t *idx_in,
+                        uint32_t *idx_out, const uint64_t *keys_in, uint64_t *keys_out,
+                        size_t count);
+// records for `cnt` breakpoints listed in idx (local rows): rec[k*(2col+3)+..] =
+// { t, d_i (= -g_i), zibp (= bound - x_i), Wy(i,0..col), Ws(i,0..col) }
+template <typename T>
+void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, const T *x, const T *l,
+                          const T *u, const T *g, const T *tbrk, WStore<T> w, int head, int col,
+                          double *rec);
+// finish (:1425-1433, :1515): fix every processed breakpoint variable at its bound,
+// move the others by tsum*d.  processed = (t, gidx) <= (last_t, last_i).
+template <typename T>
+void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
+                          const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
+                          double last_t, int64_t last_i);
+
+// ---- freev (ref :1980-2059) -------------------------------------------------
+// res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave; updates wasfree.
+void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree);
+// mirror of Index / Indx2 (1-based global numbers, reference ordering).  prev = wasfree
+// BEFORE launch_freev_count of this iteration (copy kept by the solver).
+void launch_freev_lists(Queue &q, int64_t n, const int32_t *iwhere, const int8_t *prevfree,
+                        int do_enterleave, int32_t *index, int32_t *indx2, int32_t *scan_tmp);
+
+// ---- formk inner products (ref :1756-1851, from scratch) --------------------
+// res (in d_res, E = 2col^2+col entries):
+//   [ (i*(i+1)/2 + j) ]             i>=j : sum_free Wy_i Wy_j
+//   [ T + (i*(i+1)/2 + j) ]         i>=j : sum_act  Ws_i Ws_j       (T = col(col+1)/2)
+//   [ 2T + i*col + j ]              all  : sum_{i>j ? act : free} Ws_i Wy_j
+template <typename T>
+void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
+                       const int32_t *iwhere);
+
+// ---- cmprlb (ref :1548-1586): r (full length, 0 on non-free rows) ------------
+template <typename T>
+void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
+                   const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
+                   const Coef &a, int plain);
+
+// ---- subsm (ref :2676-2885) --------------------------------------------------
+// update (:2770-2816 + :2824-2827): d = (r + W wv..)/theta on free rows, xp = xcp,
+// projected step into z.  res sum-slots: [0] = #bound hits (iword), [1] = dd_p
+template <typename T>
+void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, const T *u,
+                         const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
+                         WStore<T> w, int head, int col, double theta, const Coef &wv);
+// backtrack (:2836-2863): res min-slot [0] = alpha; then argmin pass:
+// res min-slot [0] = smallest global index attaining alpha (as double)
+template <typename T>
+void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l, const T *u,
+                        const int32_t *nbd, const int32_t *iwhere);
+template <typename T>
+void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const T *r,
+                           const T *l, const T *u, const int32_t *nbd, const int32_t *iwhere,
+                           double alpha);
+template <typename T>
+void launch_subsm_backtrack(Queue &q, int64_t n, int64_t row0, T *z, const T *xp, T *r,
+                            const T *l, const T *u, const int32_t *iwhere, double alpha,
+                            int64_t ibd);
+
+// ---- lnsrlb (ref :2174-2275) + mainlb d=z-x (:720-722) ------------------------
+// begin: d = z - x, t = x, r = g.  res sum [0]=dtd, [1]=gd ; min [2]=stpmx candidate
+template <typename T>
+void launch_lnsrlb_begin(Queue &q, int64_t n, const T *z, const T *x, const T *g, const T *l,
+                         const T *u, const int32_t *nbd, T *d, T *t, T *r, int do_stpmx);
+// trial point (:2264-2270): x = z (stp == 1) or stp*d + t
+template <typename T>
+void launch_lnsrlb_step(Queue &q, int64_t n, T *x, const T *z, const T *d, const T *t,
+                        double stp);
+// after f,g evaluation: res sum [0] = g.d ; max [1] = |proj g|_inf (speculative projgr)
+template <typename T>
+void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                        const int32_t *nbd, const T *g, const T *d);
+
+// ---- mainlb :812-824 + matupd (ref :2291-2346) --------------------------------
+// y = g - r, s = stp*d stored into column itail (1-based physical); with
+// MC = maxc_for(col-1), res sum: [0..col-1) = s'Wy_j, [MC..MC+col-1) = Ws_j's for the
+// col-1 older columns (logical order from head), [2MC] = y'y
+template <typename T>
+void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d, double stp,
+                         WStore<T> w, int head, int col, int itail);
+
+// ---- built-in objectives -------------------------------------------------------
+// res sum [0] = f contribution of this rank
+template <typename T>
+void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g);
+template <typename T>
+void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g);
+
+// finalize: d_part -> d_res (nsum sums, then nmin mins, then nmax maxes)
+void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax);
+
+}  // namespace lbk

@@ -1,0 +1,1367 @@
+// solver.hip -- host side of the MI355X-native L-BFGS-B inner iteration.
+//
+// Mirrors the reverse-communication state machine of the reference `mainlb`
+// (src/lbfgsb.f90:312-949): same task protocol, same isave/dsave/lsave slots,
+// same failure/refresh branches.  Every n-dimensional operation is a kernel
+// launch from kernels.hip; every 2m x 2m operation is host code from
+// host_dense.hpp.  One host thread per context, one HIP stream per context.
+//
+// Phase -> kernels -> one host sync each:
+//   projgr                      : projgr_kernel
+//   cauchy  (:1157-1532)        : cauchy_scan -> [window/sort/gather]* -> cauchy_finish
+//   freev   (:1980-2059)        : freev_count (+ freev_lists when mirroring Index)
+//   formk   (:1681-1908)        : formk_gram, then assemble + 2 Cholesky on host
+//   cmprlb  (:1548-1586)        : host bmv, cmprlb_kernel
+//   subsm   (:2676-2885)        : wtv_kernel, host 2 dtrsl, subsm_update (+ backtrack)
+//   lnsrlb  (:2174-2275)        : lnsrlb_begin | lnsrlb_eval, host dcsrch, lnsrlb_step
+//   matupd  (:2291-2346)        : update_pairs, host formt
+//
+// There is no CPU fallback anywhere in this file.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/lbfgsb_hip.h"
+#include "host_dense.hpp"
+#include "kernels.hpp"
+#include "report.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                    \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(LBFGSB_E_NOGPU, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+#define CHK(expr)          \
+  do {                     \
+    int rc_ = (expr);      \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------- RCCL (dlopen)
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool load() {
+    if (h) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) return false;
+#define SYM(f, name) f = reinterpret_cast<decltype(f)>(dlsym(h, name))
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+#undef SYM
+    return GetUniqueId && CommInitRank && AllReduce && AllGather && GroupStart && GroupEnd;
+  }
+};
+Rccl g_rccl;
+
+struct Rec {  // one breakpoint as the host walk needs it
+  double t;
+  int64_t gidx;
+};
+
+}  // namespace
+
+// ===================================================================== context
+struct lbfgsb_hip_ctx {
+  virtual ~lbfgsb_hip_ctx() {}
+  virtual int setulb_dev(void *x, const void *l, const void *u, const int32_t *nbd, double *f,
+                         void *g, double factr, double pgtol, char *task, int iprint, char *csave,
+                         int32_t *lsave, int32_t *isave, double *dsave) = 0;
+  virtual int export_state(void *wa, int32_t *iwa) = 0;
+  virtual int import_state(const void *wa, const int32_t *iwa, const int32_t *isave) = 0;
+  virtual int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd,
+                       const void *g, double *out) = 0;
+  virtual int k_wtv(const void *v, int col, int head, double *out, bool launch_only) = 0;
+  virtual int k_set_w(const void *hws, const void *hwy) = 0;
+  virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
+  virtual int sync() = 0;
+
+  // host-entry staging (setulb_host)
+  void *hx = nullptr, *hg = nullptr, *hl = nullptr, *hu = nullptr;
+  int32_t *hnbd = nullptr;
+  std::string itfile_name = "iterate.dat";
+  int64_t n = 0, nglob = 0, row0 = 0;
+  int m = 0, flags = 0, device = 0;
+  int rank = 0, nranks = 1;
+  int64_t nsync = 0, nfullsort = 0;
+  lbk::Queue q{};
+};
+
+namespace {
+
+template <typename T>
+class Solver final : public lbfgsb_hip_ctx {
+ public:
+  // ---- device state ----
+  T *ws = nullptr, *wy = nullptr;
+  int64_t ld = 0;
+  T *z = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *xp = nullptr, *tbrk = nullptr;
+  int32_t *iwhere = nullptr, *index = nullptr, *indx2 = nullptr, *scan_tmp = nullptr;
+  int8_t *wasfree = nullptr, *prevfree = nullptr;
+  // cauchy selection
+  static constexpr uint32_t SEL_CAP = 1u << 18;
+  static constexpr uint32_t CHUNK_MAX = 4096;
+  uint64_t *keys[2] = {nullptr, nullptr};
+  uint32_t *idx[2] = {nullptr, nullptr};
+  size_t sel_alloc = 0;  // elements allocated in keys/idx
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  uint32_t *d_count = nullptr, *h_count = nullptr;
+  double *d_rec = nullptr, *h_rec = nullptr;
+  uint32_t *h_idx = nullptr;
+  // reductions
+  double *h_res = nullptr;
+  size_t res_len = 0;
+  // streams
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // host matrices (reference layouts, column-major)
+  std::vector<double> sy, ss, wt, wn, snd, wa8m;
+  // comm
+  ncclComm_t comm = nullptr;
+  lbfgsb_allreduce_fn cb_ar = nullptr;
+  lbfgsb_allgather_fn cb_ag = nullptr;
+  void *cb_user = nullptr;
+  // report
+  lbr::Report rep;
+  char word[4] = {'-', '-', '-', 0};
+  int64_t err_k = 0;
+  bool quiet = false;  // ranks > 0 never print
+
+  ~Solver() override { release(); }
+
+  void release() {
+    auto F = [](auto *&p) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+    };
+    F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
+        F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
+        F(sort_tmp), F(d_count), F(d_rec), F(q.d_part), F(q.d_res), F(q.d_gpart);
+    F(hx), F(hg), F(hl), F(hu), F(hnbd);
+    auto H = [](auto *&p) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+    };
+    H(h_count), H(h_rec), H(h_idx), H(h_res);
+    if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+    comm = nullptr;
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+    if (rep.itf) std::fclose(rep.itf);
+    rep.itf = nullptr;
+  }
+
+  int init(int64_t n_, int64_t nglob_, int64_t row0_, int m_, int flags_, int device_,
+           void *stream_) {
+    n = n_, nglob = nglob_, row0 = row0_, m = m_, flags = flags_, device = device_;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(LBFGSB_E_NOGPU, "no HIP device visible (this library has no CPU path)");
+    HIPCHK(hipSetDevice(device));
+    if (stream_) {
+      stream = (hipStream_t)stream_;
+    } else {
+      HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      own_stream = true;
+    }
+    q.stream = stream;
+    ld = ((n + 31) / 32) * 32;
+    const size_t wbytes = (size_t)ld * m * sizeof(T);
+    HIPCHK(hipMalloc(&ws, wbytes));
+    HIPCHK(hipMalloc(&wy, wbytes));
+    HIPCHK(hipMemsetAsync(ws, 0, wbytes, stream));
+    HIPCHK(hipMemsetAsync(wy, 0, wbytes, stream));
+    const size_t vb = (size_t)(n + 32) * sizeof(T);
+    for (T **p : {&z, &r, &d, &t, &xp, &tbrk}) {
+      HIPCHK(hipMalloc(p, vb));
+      HIPCHK(hipMemsetAsync(*p, 0, vb, stream));
+    }
+    HIPCHK(hipMalloc(&iwhere, (size_t)(n + 32) * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(iwhere, 0, (size_t)(n + 32) * sizeof(int32_t), stream));
+    HIPCHK(hipMalloc(&wasfree, (size_t)n + 32));
+    HIPCHK(hipMemsetAsync(wasfree, 1, (size_t)n + 32, stream));
+    if (flags & LBFGSB_F_MIRROR_INDEX) {
+      HIPCHK(hipMalloc(&prevfree, (size_t)n + 32));
+      HIPCHK(hipMemsetAsync(prevfree, 1, (size_t)n + 32, stream));
+      HIPCHK(hipMalloc(&index, (size_t)n * sizeof(int32_t)));
+      HIPCHK(hipMalloc(&indx2, (size_t)n * sizeof(int32_t)));
+      HIPCHK(hipMemsetAsync(index, 0, (size_t)n * sizeof(int32_t), stream));
+      HIPCHK(hipMemsetAsync(indx2, 0, (size_t)n * sizeof(int32_t), stream));
+      const size_t nch = (size_t)((n + 1023) / 1024) + 2;
+      HIPCHK(hipMalloc(&scan_tmp, 3 * nch * sizeof(int32_t)));
+    }
+    // reduction scratch
+    const size_t E = (size_t)2 * m * m + m;
+    res_len = std::max<size_t>(lbk::RES_MAX, E) + 8;
+    HIPCHK(hipMalloc(&q.d_part, (size_t)lbk::RES_MAX * lbk::MAX_BLOCKS * sizeof(double)));
+    HIPCHK(hipMalloc(&q.d_res, res_len * sizeof(double)));
+    HIPCHK(hipMalloc(&q.d_gpart, E * lbk::GRAM_BLOCKS * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_res, res_len * sizeof(double)));
+    // cauchy selection scratch (window mode); the full-sort buffers grow on demand
+    CHK(ensure_sel(SEL_CAP));
+    HIPCHK(hipMalloc(&d_count, sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc(&h_count, sizeof(uint32_t)));
+    const size_t recl = (size_t)2 * m + 3;
+    HIPCHK(hipMalloc(&d_rec, CHUNK_MAX * recl * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_rec, CHUNK_MAX * recl * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_idx, CHUNK_MAX * sizeof(uint32_t)));
+    sy.assign((size_t)m * m, 0.0);
+    ss.assign((size_t)m * m, 0.0);
+    wt.assign((size_t)m * m, 0.0);
+    wn.assign((size_t)4 * m * m, 0.0);
+    snd.assign((size_t)4 * m * m, 0.0);
+    wa8m.assign((size_t)8 * m, 0.0);
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  int ensure_sel(size_t count) {
+    if (count <= sel_alloc) return 0;
+    auto F = [](auto *&p) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+    };
+    F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]), F(sort_tmp);
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipMalloc(&keys[k], count * sizeof(uint64_t)));
+      HIPCHK(hipMalloc(&idx[k], count * sizeof(uint32_t)));
+    }
+    sort_tmp_bytes = lbk::sort_pairs_temp_bytes(count) + 256;
+    HIPCHK(hipMalloc(&sort_tmp, sort_tmp_bytes));
+    sel_alloc = count;
+    return 0;
+  }
+
+  // ---- complete a reduction across ranks and bring it to the host ----
+  int fetch(int nsum, int nmin, int nmax) {
+    const int k = nsum + nmin + nmax;
+    if (nranks > 1 && comm) {
+      if (g_rccl.GroupStart() != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclGroupStart");
+      ncclResult_t rc = ncclSuccess;
+      if (nsum)
+        rc = g_rccl.AllReduce(q.d_res, q.d_res, nsum, ncclDouble, ncclSum, comm, stream);
+      if (rc == ncclSuccess && nmin)
+        rc = g_rccl.AllReduce(q.d_res + nsum, q.d_res + nsum, nmin, ncclDouble, ncclMin, comm,
+                              stream);
+      if (rc == ncclSuccess && nmax)
+        rc = g_rccl.AllReduce(q.d_res + nsum + nmin, q.d_res + nsum + nmin, nmax, ncclDouble,
+                              ncclMax, comm, stream);
+      if (g_rccl.GroupEnd() != ncclSuccess || rc != ncclSuccess)
+        return fail(LBFGSB_E_COMM, "ncclAllReduce failed");
+    }
+    HIPCHK(hipMemcpyAsync(h_res, q.d_res, (size_t)k * sizeof(double), hipMemcpyDeviceToHost,
+                          stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    nsync++;
+    if (nranks > 1 && !comm) {
+      if (!cb_ar) return fail(LBFGSB_E_COMM, "multi-rank context without a reducer");
+      if (cb_ar(cb_user, h_res, nsum, nmin, nmax) != 0)
+        return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
+    }
+    return 0;
+  }
+
+  lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m}; }
+
+  // =================================================================== cauchy
+  // Breakpoint provider: hands the host walk the breakpoints in ascending
+  // (t, global index) order, a chunk at a time (SURVEY.md 7.3-1 option (a)).
+  struct Provider {
+    bool have = false;   // a candidate list exists on the device
+    bool full = false;   // list = ALL remaining breakpoints (full sort)
+    double win_hi = -1;  // list covers every breakpoint after the fetch cursor with t <= win_hi
+    uint32_t C = 0;      // list length (valid candidates)
+    int cur = 0;         // which keys/idx buffer holds the sorted list
+    uint32_t pos = 0;    // next list position to hand out
+    uint32_t cb = 0, ce = 0;  // host chunk holds list positions [cb, ce)
+    uint32_t next_chunk = 64;
+    int grow = 0;
+  };
+
+  int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, int64_t nleft) {
+    if (nranks > 1) return fail(LBFGSB_E_STATE, "multi-rank Cauchy walk not available");
+    lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
+                                 d_count);
+    HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    nsync++;
+    const uint32_t cnt = *h_count;
+    pv.have = true;
+    pv.pos = pv.cb = pv.ce = 0;
+    pv.next_chunk = 64;
+    if (cnt <= SEL_CAP) {
+      pv.full = false;
+      pv.win_hi = hi;
+      pv.C = cnt;
+      pv.cur = 0;
+      if (cnt > 1) {
+        // (t, idx) lexicographic order: stable sort by idx, then stable sort by t
+        lbk::launch_sort_by_idx(q, sort_tmp, sort_tmp_bytes, idx[0], idx[1], keys[0], keys[1], cnt);
+        lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[1], keys[0], idx[1], idx[0], cnt);
+      }
+    } else {
+      // too many candidates in the window: order ALL remaining breakpoints once
+      nfullsort++;
+      CHK(ensure_sel((size_t)n));
+      lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, lo_t, lo_i, keys[0], idx[0]);
+      lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1],
+                             (size_t)n);
+      pv.full = true;
+      pv.win_hi = std::numeric_limits<double>::infinity();
+      pv.C = (uint32_t)std::min<int64_t>(nleft, 0xFFFFFFFFll);  // the rest are non-candidates
+      pv.cur = 1;
+    }
+    return 0;
+  }
+
+  // bring list positions [pv.pos, pv.pos+len) to the host (records + indices)
+  int chunk_load(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
+    uint32_t len = std::min<uint32_t>(pv.next_chunk, pv.C - pv.pos);
+    pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, CHUNK_MAX);
+    const int recl = 2 * col + 3;
+    lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pos, len, x, l, u, g, tbrk, W(), head, col,
+                                 d_rec);
+    HIPCHK(hipMemcpyAsync(h_rec, d_rec, (size_t)len * recl * sizeof(double),
+                          hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_idx, idx[pv.cur] + pv.pos, (size_t)len * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    nsync++;
+    pv.cb = pv.pos;
+    pv.ce = pv.pos + len;
+    return 0;
+  }
+
+  // Generalized Cauchy point, reference :1157-1532.  p,c,wbp,v = wa8m slots.
+  int cauchy(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
+             int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
+    double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
+    if (sbgnrm <= 0.0) {  // :1245-1249
+      HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      return 0;
+    }
+    const int col2 = 2 * col;
+    const int MC = col ? lbk::maxc_for(col) : 0;
+    lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
+    CHK(fetch(2 * MC + 4, 1, 0));
+    for (int j = 0; j < col; ++j) {
+      p[j] = h_res[j];
+      p[col + j] = h_res[MC + j];
+    }
+    double f1 = h_res[2 * MC];
+    const int64_t nbreak = (int64_t)h_res[2 * MC + 1];
+    const int64_t nunb = (int64_t)h_res[2 * MC + 2];
+    const bool bnded = h_res[2 * MC + 3] == 0.0;
+    const double bkmin = h_res[2 * MC + 4];
+    if (theta != 1.0)
+      for (int j = 0; j < col; ++j) p[col + j] = theta * p[col + j];  // :1337
+
+    double last_t = -1.0;
+    int64_t last_i = -1;
+    if (nbreak == 0 && nunb == 0) {  // d = 0: xcp = x (:1343-1347)
+      lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, 0.0, last_t, last_i);
+      return 0;
+    }
+    for (int j = 0; j < col2; ++j) c[j] = 0.0;
+    double f2 = -theta * f1;  // :1357-1363
+    const double f2_org = f2;
+    if (col > 0) {
+      info = lbh::bmv(m, sy.data(), wt.data(), col, p, v);
+      if (info != 0) return 0;
+      f2 = f2 - lbh::dot_seq(col2, v, p);
+    }
+    double dtm = -f1 / f2;
+    double tsum = 0.0;
+    nseg = 1;
+
+    if (nbreak != 0) {
+      int64_t nleft = nbreak;
+      int64_t iter = 1;
+      double tj = 0.0;
+      Provider pv;
+      const int recl = 2 * col + 3;
+      const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
+      for (;;) {
+        const double tj0 = tj;
+        if (iter == 1) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
+          if (dtm < bkmin - tj0) break;
+        }
+        // ---- next breakpoint after (last_t, last_i), if it can matter: t <= tj0 + dtm ----
+        const double hi_need = (tj0 + dtm) * INFL;
+        const double *rec = nullptr;
+        int64_t rec_gi = -1;
+        for (;;) {
+          if (pv.have && pv.pos < pv.C) {
+            if (pv.pos >= pv.ce) CHK(chunk_load(pv, x, l, u, g, head, col));
+            const double *rr = &h_rec[(size_t)(pv.pos - pv.cb) * recl];
+            if (rr[0] <= hi_need && rr[0] < std::numeric_limits<double>::infinity()) {
+              rec = rr;
+              rec_gi = row0 + (int64_t)h_idx[pv.pos - pv.cb];
+            }
+            break;
+          }
+          if (pv.have && (pv.full || pv.win_hi >= hi_need)) break;  // nothing left in reach
+          // (re)fetch: ask further ahead each time so long walks need few round trips
+          double hi = hi_need;
+          if (pv.grow > 0 && std::isfinite(hi_need)) {
+            const double base = last_t > 0 ? last_t : 0.0;
+            hi = base + (hi_need - base) * std::ldexp(1.0, std::min(pv.grow, 40));
+          }
+          pv.grow++;
+          CHK(window_fetch(pv, last_t, last_i, hi, nleft));
+        }
+        if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
+        tj = rec[0];
+        const double dt = tj - tj0;
+        if (dtm < dt) break;  // :1416
+
+        // fix this variable (:1421-1434)
+        pv.pos++;
+        tsum = tsum + dt;
+        nleft = nleft - 1;
+        iter = iter + 1;
+        const double dibp = rec[1];
+        const double zibp = rec[2];
+        last_t = tj;
+        last_i = rec_gi;
+        if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
+          dtm = dt;
+          if (col > 0)
+            for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];
+          lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, 0.0, last_t,
+                                       last_i);
+          return 0;
+        }
+        nseg = nseg + 1;
+        const double dibp2 = dibp * dibp;
+        f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;  // :1452-1453
+        f2 = f2 - theta * dibp2;
+        if (col > 0) {
+          if (dt != 0.0)
+            for (int j = 0; j < col2; ++j) c[j] = c[j] + dt * p[j];
+          for (int j = 0; j < col; ++j) {
+            wbp[j] = rec[3 + j];
+            wbp[col + j] = theta * rec[3 + col + j];
+          }
+          info = lbh::bmv(m, sy.data(), wt.data(), col, wbp, v);
+          if (info != 0) return 0;
+          const double wmc = lbh::dot_seq(col2, c, v);
+          const double wmp = lbh::dot_seq(col2, p, v);
+          const double wmw = lbh::dot_seq(col2, wbp, v);
+          if (-dibp != 0.0)
+            for (int j = 0; j < col2; ++j) p[j] = p[j] + (-dibp) * wbp[j];
+          f1 = f1 + dibp * wmc;
+          f2 = f2 + 2.0 * dibp * wmp - dibp2 * wmw;
+        }
+        f2 = std::max(epsmch * f2_org, f2);  // :1483
+        if (nleft > 0) {
+          dtm = -f1 / f2;
+        } else if (bnded) {
+          f1 = 0.0;
+          f2 = 0.0;
+          dtm = 0.0;
+          break;
+        } else {
+          dtm = -f1 / f2;
+          break;
+        }
+      }
+    }
+    if (dtm <= 0.0) dtm = 0.0;  // :1509
+    tsum = tsum + dtm;
+    lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tsum, last_t, last_i);
+    if (col > 0 && dtm != 0.0)
+      for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
+    return 0;
+  }
+
+  // ==================================================================== formk
+  int formk(int col, int head, double theta, int &info) {
+    lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
+    const int E = 2 * col * col + col;
+    CHK(fetch(E, 0, 0));
+    const int m2 = 2 * m;
+    lbh::Mat WN{wn.data(), m2}, WN1{snd.data(), m2}, SY{sy.data(), m};
+    const int tri = col * (col + 1) / 2;
+    for (int i = 0; i < col; ++i)
+      for (int j = 0; j <= i; ++j) {
+        WN1(i, j) = h_res[i * (i + 1) / 2 + j];                  // Y'ZZ'Y
+        WN1(m + i, m + j) = h_res[tri + i * (i + 1) / 2 + j];    // S'AA'S
+      }
+    for (int i = 0; i < col; ++i)
+      for (int j = 0; j < col; ++j) WN1(m + i, j) = h_res[2 * tri + i * col + j];  // L_a + R_z
+    // upper triangle of WN (:1856-1873)
+    for (int iy = 0; iy < col; ++iy) {
+      const int is = col + iy, is1 = m + iy;
+      for (int jy = 0; jy <= iy; ++jy) {
+        const int js = col + jy, js1 = m + jy;
+        WN(jy, iy) = WN1(iy, jy) / theta;
+        WN(js, is) = WN1(is1, js1) * theta;
+      }
+      for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
+      for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
+      WN(iy, iy) = WN(iy, iy) + SY(iy, iy);
+    }
+    if (lbh::dpofa(WN, col) != 0) {  // :1880-1884
+      info = -1;
+      return 0;
+    }
+    const int col2 = 2 * col;
+    for (int js = col; js < col2; ++js) (void)lbh::dtrsl(WN, col, &WN(0, js), 11);
+    for (int is = col; is < col2; ++is)
+      for (int js = is; js < col2; ++js)
+        WN(is, js) = WN(is, js) + lbh::dot_seq(col, &WN(0, is), &WN(0, js));
+    lbh::Mat WN22{&WN(col, col), m2};
+    if (lbh::dpofa(WN22, col) != 0) {  // :1902-1906
+      info = -2;
+      return 0;
+    }
+    info = 0;
+    return 0;
+  }
+
+  // ========================================================== cmprlb + subsm
+  int subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
+               int col, int head, bool cnstnd, int &iword, int &info) {
+    // cmprlb :1548-1586
+    lbk::Coef cf;
+    std::memset(&cf, 0, sizeof cf);
+    const bool plain = !cnstnd && col > 0;
+    if (!plain) {
+      int rc = lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]);
+      if (rc != 0) {
+        info = -8;
+        return 0;
+      }
+      for (int j = 0; j < col; ++j) {
+        cf.a[j] = wa8m[j];
+        cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
+      }
+    }
+    lbk::launch_cmprlb<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0);
+    // subsm :2742-2766
+    const int MC = lbk::maxc_for(col);
+    lbk::launch_wtv<T>(q, n, W(), head, col, r);
+    CHK(fetch(2 * MC, 0, 0));
+    double *wv = &wa8m[0];
+    for (int i = 0; i < col; ++i) {
+      wv[i] = h_res[i];
+      wv[col + i] = theta * h_res[MC + i];
+    }
+    lbh::Mat WN{wn.data(), 2 * m};
+    const int col2 = 2 * col;
+    info = lbh::dtrsl(WN, col2, wv, 11);
+    if (info != 0) return 0;
+    for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+    info = lbh::dtrsl(WN, col2, wv, 1);
+    if (info != 0) return 0;
+    lbk::Coef cw;
+    std::memset(&cw, 0, sizeof cw);
+    for (int j = 0; j < col; ++j) {
+      cw.a[j] = wv[j];
+      cw.a[lbk::MAXM + j] = wv[col + j];
+    }
+    lbk::launch_subsm_update<T>(q, n, z, r, xp, l, u, nbd, iwhere, x, g, W(), head, col, theta,
+                                cw);
+    CHK(fetch(2, 0, 0));
+    iword = h_res[0] > 0.0 ? 1 : 0;
+    const double dd_p = h_res[1];
+    if (iword == 0 || dd_p <= 0.0) return 0;  // :2820, :2828
+    if (rep.out && !quiet && print_level >= 0) {
+      std::fprintf(rep.out, " Positive dir derivative in projection \n");
+      std::fprintf(rep.out, " Using the backtracking step \n");
+    }
+    lbk::launch_subsm_alpha<T>(q, n, xp, r, l, u, nbd, iwhere);
+    CHK(fetch(0, 1, 0));
+    const double alpha = std::min(1.0, h_res[0]);
+    int64_t ibd = -1;
+    if (alpha < 1.0) {
+      lbk::launch_subsm_argalpha<T>(q, n, row0, xp, r, l, u, nbd, iwhere, alpha);
+      CHK(fetch(0, 1, 0));
+      ibd = (int64_t)h_res[0];
+    }
+    lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, r, l, u, iwhere, alpha, ibd);
+    return 0;
+  }
+
+  int print_level = -1;
+
+  // =================================================================== mainlb
+  int setulb_dev(void *x_, const void *l_, const void *u_, const int32_t *nbd, double *f,
+                 void *g_, double factr, double pgtol, char *task, int iprint, char *csave,
+                 int32_t *lsave, int32_t *isave_user, double *dsave) override {
+    T *x = (T *)x_;
+    T *g = (T *)g_;
+    const T *l = (const T *)l_;
+    const T *u = (const T *)u_;
+    int32_t *isave = isave_user + 21;  // mainlb's Isave(1:23) = user isave(22:44)
+    HIPCHK(hipSetDevice(device));
+    print_level = iprint;
+    quiet = rank != 0;
+    const int ipr = quiet ? -1 : iprint;
+    for (const void *p : {(const void *)x, (const void *)l, (const void *)u, (const void *)g})
+      if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
+
+    bool prjctd, cnstnd, boxed, updatd, wrk = false;
+    int nintol, iback, nskip, head, col, iter, itail, iupdat, nseg, nfgv, info, ifun, iword,
+        nfree, nact, ileave, nenter;
+    double theta, fold, tol, dnorm, epsmch, cpu1, cachyt, sbtime, lnscht, time1, gd, stpmx,
+        sbgnrm, stp, gdold, dtd, xstep = 0.0;
+
+    auto save_locals = [&]() {  // :904-947
+      lsave[0] = prjctd, lsave[1] = cnstnd, lsave[2] = boxed, lsave[3] = updatd;
+      isave[0] = nintol, isave[2] = 0, isave[3] = iback, isave[4] = nskip, isave[5] = head;
+      isave[6] = col, isave[7] = itail, isave[8] = iter, isave[9] = iupdat, isave[11] = nseg;
+      isave[12] = nfgv, isave[13] = info, isave[14] = ifun, isave[15] = iword;
+      isave[16] = (int32_t)std::min<int64_t>(nfree_g, INT32_MAX);
+      isave[17] = (int32_t)std::min<int64_t>(nglob - nfree_g, INT32_MAX);
+      isave[18] = (int32_t)std::min<int64_t>(ileave_g, INT32_MAX);
+      isave[19] = (int32_t)std::min<int64_t>(nenter_g, INT32_MAX);
+      dsave[0] = theta, dsave[1] = fold, dsave[2] = tol, dsave[3] = dnorm, dsave[4] = epsmch;
+      dsave[5] = cpu1, dsave[6] = cachyt, dsave[7] = sbtime, dsave[8] = lnscht, dsave[9] = time1;
+      dsave[10] = gd, dsave[11] = stpmx, dsave[12] = sbgnrm, dsave[13] = stp, dsave[14] = gdold;
+      dsave[15] = dtd;
+    };
+    auto finish = [&]() {  // :892-902
+      const double time = now_s() - time1;
+      if (!quiet)
+        rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip,
+                   (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm, time, nseg, word,
+                   iback, stp, xstep, err_k, cachyt, sbtime, lnscht);
+      save_locals();
+    };
+    auto refresh = [&]() {
+      info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
+    };
+
+    if (lbh::str60_eq(task, "START")) {  // :430-507
+      epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
+                              : std::numeric_limits<double>::epsilon();
+      time1 = now_s();
+      col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false, iback = 0, itail = 0;
+      iword = 0, nact = 0, ileave = 0, nenter = 0, fold = 0, dnorm = 0, cpu1 = 0, gd = 0;
+      stpmx = 0, sbgnrm = 0, stp = 0, gdold = 0, dtd = 0, iter = 0, nfgv = 0, nseg = 0;
+      nintol = 0, nskip = 0, ifun = 0, cachyt = 0, sbtime = 0, lnscht = 0, info = 0;
+      nfree_g = nglob, nenter_g = 0, ileave_g = 0;
+      tol = factr * epsmch;
+      std::memcpy(word, "---", 4);
+      prjctd = cnstnd = false, boxed = true;
+      if (ipr >= 1 && !rep.itf) rep.itf = std::fopen(itfile_name.c_str(), "w");
+      // errclb :1601-1643
+      err_k = 0;
+      if (nglob <= 0) lbh::str60_set(task, "ERROR: N <= 0");
+      if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
+      if (factr < 0.0) lbh::str60_set(task, "ERROR: FACTR < 0");
+      lbk::launch_errclb<T>(q, n, row0, l, u, nbd);
+      CHK(fetch(0, 0, 2));
+      {
+        const int64_t k6 = (int64_t)h_res[0], k7 = (int64_t)h_res[1];
+        if (k6 > 0 || k7 > 0) {
+          if (k6 > k7) {
+            lbh::str60_set(task, "ERROR: INVALID NBD");
+            info = -6, err_k = k6;
+          } else {
+            lbh::str60_set(task, "ERROR: NO FEASIBLE SOLUTION");
+            info = -7, err_k = k7;
+          }
+        }
+      }
+      if (lbh::str60_pre(task, "ERROR")) {
+        if (!quiet)
+          rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip, nact, sbgnrm, 0.0,
+                     nseg, word, iback, stp, xstep, err_k, cachyt, sbtime, lnscht);
+        return 0;
+      }
+      if (!quiet) rep.prn1lb(nglob, m, ipr, epsmch);
+      lbk::launch_active<T>(q, n, x, l, u, nbd, iwhere, wasfree);  // :965-1040
+      CHK(fetch(4, 0, 0));
+      prjctd = h_res[0] > 0.0;
+      cnstnd = h_res[1] > 0.0;
+      boxed = h_res[2] == 0.0;
+      if (!quiet) rep.active_msgs(ipr, prjctd, cnstnd, (long long)h_res[3]);
+      if (prevfree) HIPCHK(hipMemsetAsync(prevfree, 1, (size_t)n, stream));
+      lbh::str60_set(task, "FG_START");
+      save_locals();
+      return 0;
+    }
+
+    // restore :511-550
+    prjctd = lsave[0], cnstnd = lsave[1], boxed = lsave[2], updatd = lsave[3];
+    nintol = isave[0], iback = isave[3], nskip = isave[4], head = isave[5], col = isave[6];
+    itail = isave[7], iter = isave[8], iupdat = isave[9], nseg = isave[11], nfgv = isave[12];
+    info = isave[13], ifun = isave[14], iword = isave[15];
+    nfree = isave[16], nact = isave[17], ileave = isave[18], nenter = isave[19];
+    (void)nfree, (void)nact, (void)ileave, (void)nenter;
+    theta = dsave[0], fold = dsave[1], tol = dsave[2], dnorm = dsave[3], epsmch = dsave[4];
+    cpu1 = dsave[5], cachyt = dsave[6], sbtime = dsave[7], lnscht = dsave[8], time1 = dsave[9];
+    gd = dsave[10], stpmx = dsave[11], sbgnrm = dsave[12], stp = dsave[13], gdold = dsave[14];
+    dtd = dsave[15];
+
+    bool compute_pg = true, prelims = true, linesearch = true;
+    double spec_sbgnrm = 0.0;
+    if (lbh::str60_pre(task, "FG_LN")) {
+      compute_pg = false, prelims = false;
+      // g.d for the line search and, speculatively, |proj g| for the NEW_X return
+      lbk::launch_lnsrlb_eval<T>(q, n, x, l, u, nbd, g, d);
+      CHK(fetch(1, 0, 1));
+      gd = h_res[0];
+      spec_sbgnrm = h_res[1];
+    } else if (lbh::str60_pre(task, "NEW_X")) {
+      compute_pg = false, prelims = false, linesearch = false;
+    } else if (!lbh::str60_pre(task, "FG_ST")) {
+      if (lbh::str60_pre(task, "STOP")) {
+        if (std::strncmp(task + 6, "CPU", 3) == 0) {  // :566-571
+          HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+          HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+          HIPCHK(hipStreamSynchronize(stream));
+          *f = fold;
+        }
+        finish();
+      } else {
+        lbh::str60_set(task, "FG_START");
+        save_locals();
+      }
+      return 0;
+    }
+
+    if (compute_pg) {  // :579-596
+      nfgv = 1;
+      lbk::launch_projgr<T>(q, n, x, l, u, nbd, g);
+      CHK(fetch(0, 0, 1));
+      sbgnrm = h_res[0];
+      if (!quiet) rep.iterate0(ipr, iter, nfgv, *f, sbgnrm);
+      if (sbgnrm <= pgtol) {
+        lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
+        finish();
+        return 0;
+      }
+    }
+
+    for (;;) {  // main_loop :599
+      if (prelims) {
+        if (ipr >= 99) std::fprintf(rep.out, "\n\nITERATION %5d\n", iter + 1);
+        iword = -1;
+        if (!cnstnd && col > 0) {  // :607-611
+          HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+          wrk = updatd;
+          nseg = 0;
+        } else {
+          cpu1 = now_s();
+          CHK(cauchy(x, l, u, nbd, g, theta, col, head, sbgnrm, epsmch, nseg, info));
+          if (info != 0) {  // :620-635
+            if (ipr >= 1)
+              std::fprintf(rep.out,
+                           "\n Singular triangular system detected;\n   refresh the lbfgs "
+                           "memory and restart the iteration.\n");
+            refresh();
+            cachyt += now_s() - cpu1;
+            continue;
+          }
+          // freev :1980-2059 (counts; the lists only when mirroring Index)
+          if (prevfree)
+            HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
+          lbk::launch_freev_count(q, n, iwhere, wasfree);
+          CHK(fetch(3, 0, 0));
+          cachyt += now_s() - cpu1;
+          nintol += nseg;
+          nfree_g = (int64_t)h_res[0];
+          if (iter > 0 && cnstnd) {
+            nenter_g = (int64_t)h_res[1];
+            ileave_g = nglob + 1 - (int64_t)h_res[2];
+          } else {
+            nenter_g = 0;
+            ileave_g = nglob + 1;
+          }
+          wrk = (ileave_g < nglob + 1) || (nenter_g > 0) || updatd;
+          if (index)
+            lbk::launch_freev_lists(q, n, iwhere, prevfree, (iter > 0 && cnstnd) ? 1 : 0, index,
+                                    indx2, scan_tmp);
+        }
+
+        if (nfree_g == 0 || col == 0) {
+          // skip the subspace minimization :648-651
+        } else {
+          cpu1 = now_s();
+          if (wrk) CHK(formk(col, head, theta, info));
+          if (info != 0) {  // :666-682
+            if (ipr >= 1)
+              std::fprintf(rep.out,
+                           "\n Nonpositive definiteness in Cholesky factorization in formk;\n   "
+                           "refresh the lbfgs memory and restart the iteration.\n");
+            refresh();
+            sbtime += now_s() - cpu1;
+            continue;
+          }
+          CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info));
+          if (info != 0) {  // :694-710
+            if (ipr >= 1)
+              std::fprintf(rep.out,
+                           "\n Singular triangular system detected;\n   refresh the lbfgs "
+                           "memory and restart the iteration.\n");
+            refresh();
+            sbtime += now_s() - cpu1;
+            continue;
+          }
+          sbtime += now_s() - cpu1;
+        }
+        cpu1 = now_s();
+      }
+
+      if (linesearch) {  // lnsrlb :2174-2275
+        const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
+        bool ls_abort = false;
+        if (!lbh::str60_pre(task, "FG_LN")) {
+          const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
+          lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, t, r, do_stpmx);
+          CHK(fetch(2, 1, 0));
+          dtd = h_res[0];
+          gd = h_res[1];
+          dnorm = std::sqrt(dtd);
+          stpmx = big;
+          if (cnstnd) stpmx = iter == 0 ? 1.0 : std::min(big, h_res[2]);
+          stp = (iter == 0 && !boxed) ? std::min(1.0 / dnorm, stpmx) : 1.0;
+          fold = *f;
+          ifun = 0;
+          iback = 0;
+          lbh::str60_set(csave, "START");
+        }
+        if (ifun == 0) {
+          gdold = gd;
+          if (gd >= 0.0) {  // :2247-2253
+            std::fprintf(rep.out, "  ascent direction in projection gd = %s\n",
+                         lbr::flist(gd).c_str());
+            info = -4;
+            ls_abort = true;
+          }
+        }
+        if (!ls_abort) {
+          lbh::dcsrch(*f, gd, stp, ftol, gtol, xtol, 0.0, stpmx, csave, isave + 21, dsave + 16);
+          xstep = stp * dnorm;
+          if (!lbh::str60_pre(csave, "CONV") && !lbh::str60_pre(csave, "WARN")) {
+            lbh::str60_set(task, "FG_LNSRCH");
+            ifun++;
+            nfgv++;
+            iback = ifun - 1;
+            lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
+          } else {
+            lbh::str60_set(task, "NEW_X");
+          }
+        }
+
+        if (info != 0 || iback >= 20) {  // :734-769
+          HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+          HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+          *f = fold;
+          if (col == 0) {
+            if (info == 0) {
+              info = -9;
+              nfgv--, ifun--, iback--;
+            }
+            lbh::str60_set(task, "ABNORMAL_TERMINATION_IN_LNSRCH");
+            iter++;
+            HIPCHK(hipStreamSynchronize(stream));
+            finish();
+            return 0;
+          }
+          if (ipr >= 1)
+            std::fprintf(rep.out,
+                         "\n Bad direction in the line search;\n   refresh the lbfgs memory and "
+                         "restart the iteration.\n");
+          if (info == 0) nfgv--;
+          refresh();
+          lbh::str60_set(task, "RESTART_FROM_LNSRCH");
+          lnscht += now_s() - cpu1;
+          prelims = linesearch = true;
+          continue;
+        } else if (lbh::str60_pre(task, "FG_LN")) {
+          save_locals();
+          HIPCHK(hipStreamSynchronize(stream));  // x is ready for the caller's f,g evaluation
+          nsync++;
+          return 0;
+        } else {
+          lnscht += now_s() - cpu1;
+          iter++;
+          sbgnrm = spec_sbgnrm;  // projgr (:781) was evaluated with g.d: x, g unchanged since
+          switch (iword) {       // prn2lb :2438-2443
+            case 0: std::memcpy(word, "con", 4); break;
+            case 1: std::memcpy(word, "bnd", 4); break;
+            case 5: std::memcpy(word, "TNT", 4); break;
+            default: std::memcpy(word, "---", 4);
+          }
+          if (!quiet)
+            rep.prn2lb(ipr, iter, nfgv, (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm,
+                       nseg, word, iback, stp, xstep, *f);
+          save_locals();
+          return 0;
+        }
+      }
+
+      // ---- NEW_X re-entry: termination tests :794-810 ----
+      if (sbgnrm <= pgtol) {
+        lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
+        finish();
+        return 0;
+      }
+      double ddum = std::max(std::max(std::fabs(fold), std::fabs(*f)), 1.0);
+      if ((fold - *f) <= tol * ddum) {
+        lbh::str60_set(task, "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH");
+        if (iback >= 10) info = -5;
+        finish();
+        return 0;
+      }
+
+      // ---- :812-834 ----
+      double dr;
+      if (stp == 1.0) {
+        dr = gd - gdold;
+        ddum = -gdold;
+      } else {
+        dr = (gd - gdold) * stp;
+        ddum = -gdold * stp;
+      }
+      if (dr <= epsmch * ddum) {
+        nskip++;
+        updatd = false;
+        if (ipr >= 1)
+          std::fprintf(rep.out, "  ys=%s  -gs=%s BFGS update SKIPPED\n", lbr::fE(dr, 10, 3).c_str(),
+                       lbr::fE(ddum, 10, 3).c_str());
+        prelims = linesearch = true;
+        continue;
+      }
+
+      // ---- matupd :2291-2346 (pointer bookkeeping on the host) ----
+      updatd = true;
+      iupdat++;
+      if (iupdat <= m) {
+        col = iupdat;
+        itail = (head + iupdat - 2) % m + 1;
+      } else {
+        itail = itail % m + 1;
+        head = head % m + 1;
+      }
+      lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
+      const int MCo = lbk::maxc_for(col - 1);
+      CHK(fetch(2 * MCo + 1, 0, 0));
+      const double rr = h_res[2 * MCo];
+      theta = rr / dr;
+      lbh::Mat SY{sy.data(), m}, SS{ss.data(), m};
+      if (iupdat > m) {  // :2324-2330
+        for (int j = 0; j < col - 1; ++j) {
+          for (int i = 0; i <= j; ++i) SS(i, j) = SS(i + 1, j + 1);
+          for (int i = j; i < col - 1; ++i) SY(i, j) = SY(i + 1, j + 1);
+        }
+      }
+      for (int j = 0; j < col - 1; ++j) {
+        SY(col - 1, j) = h_res[j];
+        SS(j, col - 1) = h_res[MCo + j];
+      }
+      SS(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
+      SY(col - 1, col - 1) = dr;
+      info = lbh::formt(m, wt.data(), sy.data(), ss.data(), col, theta);  // :849
+      if (info != 0) {
+        if (ipr >= 1)
+          std::fprintf(rep.out,
+                       "\n Nonpositive definiteness in Cholesky factorization in formt;\n   "
+                       "refresh the lbfgs memory and restart the iteration.\n");
+        refresh();
+      }
+      prelims = linesearch = true;
+    }
+  }
+
+  int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
+
+  // ============================================================ state exchange
+  int export_state(void *wa_, int32_t *iwa) override {
+    if (nranks != 1) return fail(LBFGSB_E_STATE, "export_state: single-rank contexts only");
+    T *wa = (T *)wa_;
+    const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
+    HIPCHK(hipMemcpy2DAsync(wa, (size_t)n * sizeof(T), ws, (size_t)ld * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpy2DAsync(wa + mn, (size_t)n * sizeof(T), wy, (size_t)ld * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, stream));
+    T *ps = wa + 2 * mn;
+    auto put = [&](const std::vector<double> &v) {
+      for (double e : v) *ps++ = (T)e;
+    };
+    put(sy), put(ss), put(wt), put(wn), put(snd);
+    (void)mm;
+    for (T *src : {z, r, d, t, xp}) {
+      HIPCHK(hipMemcpyAsync(ps, src, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
+      ps += n;
+    }
+    put(wa8m);
+    if (iwa) {
+      if (index) {
+        HIPCHK(hipMemcpyAsync(iwa, index, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(iwa + 2 * n, indx2, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+      }
+      HIPCHK(hipMemcpyAsync(iwa + n, iwhere, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  int import_state(const void *wa_, const int32_t *iwa, const int32_t *isave_user) override {
+    if (nranks != 1) return fail(LBFGSB_E_STATE, "import_state: single-rank contexts only");
+    const T *wa = (const T *)wa_;
+    const int64_t mn = (int64_t)m * n;
+    HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), wa + mn, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    const T *ps = wa + 2 * mn;
+    auto get = [&](std::vector<double> &v) {
+      for (double &e : v) e = (double)*ps++;
+    };
+    get(sy), get(ss), get(wt), get(wn), get(snd);
+    for (T *dst : {z, r, d, t, xp}) {
+      HIPCHK(hipMemcpyAsync(dst, ps, (size_t)n * sizeof(T), hipMemcpyHostToDevice, stream));
+      ps += n;
+    }
+    get(wa8m);
+    HIPCHK(hipMemcpyAsync(iwhere, iwa + n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    // free-set membership as of the last freev: Index(1:nfree)
+    std::vector<int8_t> wf((size_t)n, 0);
+    const int iter = isave_user[29];
+    const int64_t nfree = isave_user[37];
+    bool have_index = false;
+    for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
+    if (!have_index) {
+      std::fill(wf.begin(), wf.end(), (int8_t)1);
+    } else {
+      for (int64_t i = 0; i < nfree; ++i) wf[iwa[i] - 1] = 1;
+    }
+    (void)iter;
+    HIPCHK(hipMemcpyAsync(wasfree, wf.data(), (size_t)n, hipMemcpyHostToDevice, stream));
+    if (index) {
+      HIPCHK(hipMemcpyAsync(index, iwa, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(indx2, iwa + 2 * n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    nfree_g = nfree;
+    nenter_g = isave_user[40];
+    ileave_g = isave_user[39];
+    return 0;
+  }
+
+  // ======================================================= per-kernel entries
+  int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd, const void *g,
+               double *out) override {
+    HIPCHK(hipSetDevice(device));
+    lbk::launch_projgr<T>(q, n, (const T *)x, (const T *)l, (const T *)u, nbd, (const T *)g);
+    CHK(fetch(0, 0, 1));
+    *out = h_res[0];
+    return 0;
+  }
+  int k_wtv(const void *v, int col, int head, double *out, bool launch_only) override {
+    HIPCHK(hipSetDevice(device));
+    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "wtv: bad col/head");
+    if (launch_only) {
+      lbk::launch_wtv_nofinalize<T>(q, n, W(), head, col, (const T *)v);
+      return 0;
+    }
+    lbk::launch_wtv<T>(q, n, W(), head, col, (const T *)v);
+    const int MC = lbk::maxc_for(col);
+    CHK(fetch(2 * MC, 0, 0));
+    for (int j = 0; j < col; ++j) {
+      out[j] = h_res[j];
+      out[col + j] = h_res[MC + j];
+    }
+    return 0;
+  }
+  int k_set_w(const void *hws, const void *hwy) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), hws, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), hwy, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int k_objective(int kind, const void *x, void *g, double *f) override {
+    HIPCHK(hipSetDevice(device));
+    if (kind == 0) {
+      lbk::launch_obj_quadratic<T>(q, n, row0, (const T *)x, (T *)g);
+    } else if (kind == 1) {
+      if (nranks != 1) return fail(LBFGSB_E_ARG, "rosenbrock objective: single rank only");
+      lbk::launch_obj_rosenbrock<T>(q, n, (const T *)x, (T *)g);
+    } else {
+      return fail(LBFGSB_E_ARG, "unknown objective kind");
+    }
+    CHK(fetch(1, 0, 0));
+    *f = kind == 0 ? 0.5 * h_res[0] : 4.0 * h_res[0];
+    return 0;
+  }
+  int sync() override {
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+};
+
+template <typename T>
+Solver<T> *as(lbfgsb_hip_ctx *c) {
+  return static_cast<Solver<T> *>(c);
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char *lbfgsb_hip_last_error(void) { return g_err.c_str(); }
+
+int lbfgsb_hip_create(int64_t n_local, int64_t n_global, int64_t row0, int m, int flags,
+                      int device, void *stream, lbfgsb_hip_ctx **out) {
+  if (!out) return fail(LBFGSB_E_ARG, "out == NULL");
+  *out = nullptr;
+  if (n_local <= 0 || n_global < n_local || row0 < 0 || row0 + n_local > n_global)
+    return fail(LBFGSB_E_ARG, "bad n_local / n_global / row0");
+  if (m <= 0 || m > LBFGSB_MAX_M) return fail(LBFGSB_E_ARG, "m must be in 1..LBFGSB_MAX_M");
+  if (n_local > 0xFFFFFFF0ll) return fail(LBFGSB_E_ARG, "n_local must fit 32 bits");
+  int rc;
+  if (flags & LBFGSB_F_REAL32) {
+    auto *s = new Solver<float>();
+    rc = s->init(n_local, n_global, row0, m, flags, device, stream);
+    if (rc) {
+      delete s;
+      return rc;
+    }
+    *out = s;
+  } else {
+    auto *s = new Solver<double>();
+    rc = s->init(n_local, n_global, row0, m, flags, device, stream);
+    if (rc) {
+      delete s;
+      return rc;
+    }
+    *out = s;
+  }
+  return LBFGSB_OK;
+}
+
+void lbfgsb_hip_destroy(lbfgsb_hip_ctx *ctx) { delete ctx; }
+
+int lbfgsb_hip_rccl_unique_id(void *id128) {
+  if (!g_rccl.load()) return fail(LBFGSB_E_COMM, "cannot load librccl");
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclGetUniqueId");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, 128);
+  return 0;
+}
+
+int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, int nranks) {
+  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return fail(LBFGSB_E_ARG, "bad rank");
+  if (!g_rccl.load()) return fail(LBFGSB_E_COMM, "cannot load librccl");
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  if (g_rccl.CommInitRank(&comm, nranks, id, rank) != ncclSuccess)
+    return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  if (ctx->flags & LBFGSB_F_REAL32)
+    as<float>(ctx)->comm = comm;
+  else
+    as<double>(ctx)->comm = comm;
+  return 0;
+}
+
+int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag,
+                              void *user, int rank, int nranks) {
+  if (!ctx || !ar || nranks < 1 || rank < 0 || rank >= nranks)
+    return fail(LBFGSB_E_ARG, "bad host reducer arguments");
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  if (ctx->flags & LBFGSB_F_REAL32) {
+    auto *s = as<float>(ctx);
+    s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
+  } else {
+    auto *s = as<double>(ctx);
+    s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
+  }
+  return 0;
+}
+
+int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
+                          const int32_t *nbd, double *f, void *g, double factr, double pgtol,
+                          char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave,
+                          double *dsave) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->setulb_dev(x, l, u, nbd, f, g, factr, pgtol, task, iprint, csave, lsave, isave,
+                         dsave);
+}
+
+int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->export_state(wa, iwa);
+}
+int lbfgsb_hip_import_state(lbfgsb_hip_ctx *ctx, const void *wa, const int32_t *iwa,
+                            const int32_t *isave) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->import_state(wa, iwa, isave);
+}
+
+int lbfgsb_hip_projgr(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u,
+                      const int32_t *nbd, const void *g, double *h_sbgnrm) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->k_projgr(x, l, u, nbd, g, h_sbgnrm);
+}
+int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double *h_out) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->k_wtv(v, col, head, h_out, false);
+}
+int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->k_wtv(v, col, head, nullptr, true);
+}
+int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->k_set_w(h_ws, h_wy);
+}
+int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->sync();
+}
+int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->k_objective(kind, x, g, h_f);
+}
+int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
+                     int64_t *cauchy_fullsorts) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (launches) *launches = ctx->q.launches;
+  if (syncs) *syncs = ctx->nsync;
+  if (cauchy_fullsorts) *cauchy_fullsorts = ctx->nfullsort;
+  return 0;
+}
+
+// ----------------------------------------------------------- host-pointer form
+// The exact reference signature (src/lbfgsb.f90:88-89) plus real_bytes/mirror.
+int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
+                           const int32_t *nbd, void *f, void *g, double factr, double pgtol,
+                           void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
+                           int32_t *lsave, int32_t *isave, void *dsave, const char *iteration_file,
+                           int32_t real_bytes, int32_t mirror) {
+  const bool r32 = real_bytes == 4;
+  if (real_bytes != 4 && real_bytes != 8) return fail(LBFGSB_E_ARG, "real_bytes must be 4 or 8");
+  const size_t rb = (size_t)real_bytes;
+  lbfgsb_hip_ctx *ctx = nullptr;
+  const bool start = lbh::str60_eq(task, "START");
+  if (start) {
+    // the reference's own argument checks that do not need a context (:1618-1620)
+    if (n <= 0 || m <= 0) {
+      if (n <= 0) lbh::str60_set(task, "ERROR: N <= 0");
+      if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
+      return 0;
+    }
+    int fl = (r32 ? LBFGSB_F_REAL32 : 0) | (mirror ? LBFGSB_F_MIRROR_INDEX : 0);
+    int rc = lbfgsb_hip_create(n, n, 0, m, fl, 0, nullptr, &ctx);
+    if (rc) return rc;
+    if (iteration_file && iteration_file[0]) ctx->itfile_name = iteration_file;
+    const size_t vb = ((size_t)n + 32) * rb;
+    HIPCHK(hipMalloc(&ctx->hx, vb));
+    HIPCHK(hipMalloc(&ctx->hg, vb));
+    HIPCHK(hipMalloc(&ctx->hl, vb));
+    HIPCHK(hipMalloc(&ctx->hu, vb));
+    HIPCHK(hipMalloc(&ctx->hnbd, ((size_t)n + 32) * 4));
+    HIPCHK(hipMemset(ctx->hg, 0, vb));
+    HIPCHK(hipMemcpy(ctx->hx, x, (size_t)n * rb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->hl, l, (size_t)n * rb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->hu, u, (size_t)n * rb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->hnbd, nbd, (size_t)n * 4, hipMemcpyHostToDevice));
+    std::memset(isave, 0, 44 * sizeof(int32_t));
+    uint64_t hbits = (uint64_t)(uintptr_t)ctx;
+    std::memcpy(&isave[16], &hbits, 8);  // isave(17:18): never written by the reference
+    // offsets the reference documents in isave(1:16) (:250-265), saturated instead of wrapped
+    const int64_t off[16] = {(int64_t)m * n, (int64_t)m * m, 4ll * m * m};
+    (void)off;
+  } else {
+    uint64_t hbits = 0;
+    std::memcpy(&hbits, &isave[16], 8);
+    ctx = (lbfgsb_hip_ctx *)(uintptr_t)hbits;
+    if (!ctx || ctx->n != n || ctx->m != m)
+      return fail(LBFGSB_E_STATE, "setulb called without a live context (task must be START first)");
+    if (lbh::str60_pre(task, "FG"))
+      HIPCHK(hipMemcpy(ctx->hg, g, (size_t)n * rb, hipMemcpyHostToDevice));
+  }
+  double fd = r32 ? (double)*(float *)f : *(double *)f;
+  double ds[29];
+  for (int i = 0; i < 29; ++i) ds[i] = r32 ? (double)((float *)dsave)[i] : ((double *)dsave)[i];
+  int rc = ctx->setulb_dev(ctx->hx, ctx->hl, ctx->hu, ctx->hnbd, &fd, ctx->hg, factr, pgtol, task,
+                           iprint, csave, lsave, isave, ds);
+  if (rc) return rc;
+  for (int i = 0; i < 29; ++i) {
+    if (r32)
+      ((float *)dsave)[i] = (float)ds[i];
+    else
+      ((double *)dsave)[i] = ds[i];
+  }
+  if (r32)
+    *(float *)f = (float)fd;
+  else
+    *(double *)f = fd;
+  HIPCHK(hipMemcpy(x, ctx->hx, (size_t)n * rb, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(g, ctx->hg, (size_t)n * rb, hipMemcpyDeviceToHost));
+  if (mirror) {
+    rc = ctx->export_state(wa, iwa);
+    if (rc) return rc;
+  } else if (wa) {
+    // previous iterate: wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175
+    const int64_t off_t = 2ll * m * n + 11ll * m * m + 3ll * n;
+    void *src = r32 ? (void *)as<float>(ctx)->t : (void *)as<double>(ctx)->t;
+    HIPCHK(hipMemcpy((char *)wa + (size_t)off_t * rb, src, (size_t)n * rb, hipMemcpyDeviceToHost));
+  }
+  if (!lbh::str60_pre(task, "FG") && !lbh::str60_pre(task, "NEW_X")) {
+    lbfgsb_hip_destroy(ctx);  // terminal task: CONVERGENCE / ABNORMAL / ERROR / STOP
+    isave[16] = isave[17] = 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+"""Host-side mirror of the reference interface for the hot path.
+
+`setulb(...)` has the reference's argument list (src/lbfgsb.f90:88-89) with numpy
+arrays standing in for the Fortran arrays; it calls the C ABI's host-pointer form
+exactly as the Fortran shim does.  `DeviceSolver` is the device-resident form used
+by bench.py and the parity tests: x, l, u, nbd, g are torch tensors on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import capi
+from .capi import LbfgsbError, check, load_library
+
+TASK_LEN = 60
+
+
+def wa_length(n: int, m: int) -> int:
+    """reference src/lbfgsb.f90:146"""
+    return 2 * m * n + 5 * n + 11 * m * m + 8 * m
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a.data_ptr()))  # torch tensor
+
+
+def pad60(s: str) -> np.ndarray:
+    b = s.encode()[:TASK_LEN]
+    return np.frombuffer(b + b" " * (TASK_LEN - len(b)), dtype=np.uint8).copy()
+
+
+def task_str(a) -> str:
+    return bytes(np.asarray(a).tobytes()).decode("ascii", "replace").rstrip()
+
+
+def setulb(n, m, x, l, u, nbd, f, g, factr, pgtol, wa, iwa, task, iprint, csave, lsave, isave,
+           dsave, iteration_file: Optional[str] = None, mirror: bool = False):
+    """Reference `setulb` (src/lbfgsb.f90:88).  All arrays are numpy and are updated in
+    place: x, g, wa (real kind), f (1 element), iwa/isave/lsave (int32), task/csave
+    (60 uint8, blank padded), dsave (real kind).  mirror=True exports the complete
+    reference layout of wa/iwa after every return (parity tests)."""
+    lib = load_library()
+    real_bytes = x.dtype.itemsize
+    check(lib.lbfgsb_hip_setulb_host(
+        n, m, _p(x), _p(l), _p(u), _p(nbd), _p(f), _p(g), float(factr), float(pgtol), _p(wa),
+        _p(iwa), _p(task), int(iprint), _p(csave), _p(lsave), _p(isave), _p(dsave),
+        iteration_file.encode() if iteration_file else None, real_bytes, 1 if mirror else 0))
+
+
+class DeviceSolver:
+    """One rank of the device-resident solver.  Tensors stay on the GPU; only the
+    60-byte task, f and the isave/dsave scalars cross PCIe."""
+
+    def __init__(self, n_local: int, m: int, n_global: Optional[int] = None, row0: int = 0,
+                 real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None):
+        self.lib = load_library()
+        self.n, self.m = int(n_local), int(m)
+        self.n_global = int(n_global if n_global is not None else n_local)
+        self.row0 = int(row0)
+        self.real = np.float32 if real32 else np.float64
+        flags = (capi.F_REAL32 if real32 else 0) | (capi.F_MIRROR_INDEX if mirror_index else 0)
+        h = C.c_void_p()
+        sp = C.c_void_p(int(stream)) if stream else None
+        check(self.lib.lbfgsb_hip_create(self.n, self.n_global, self.row0, self.m, flags, device,
+                                         sp, C.byref(h)))
+        self.h = h
+        self.task = pad60("START")
+        self.csave = pad60("")
+        self.lsave = np.zeros(4, np.int32)
+        self.isave = np.zeros(44, np.int32)
+        self.dsave = np.zeros(29, np.float64)
+        self.f = np.zeros(1, np.float64)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lbfgsb_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- multi-GPU ----
+    def init_rccl(self, unique_id: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(unique_id, 128)
+        check(self.lib.lbfgsb_hip_comm_init_rccl(self.h, buf, rank, nranks))
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        check(lib.lbfgsb_hip_rccl_unique_id(buf))
+        return buf.raw
+
+    def init_host_reducer(self, allreduce, rank: int, nranks: int):
+        """allreduce(np_view, nsum, nmin, nmax) must reduce the view in place over ranks."""
+        def _cb(user, buf, nsum, nmin, nmax):
+            try:
+                k = nsum + nmin + nmax
+                view = np.ctypeslib.as_array(buf, shape=(k,))
+                allreduce(view, nsum, nmin, nmax)
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+        cb = capi.ALLREDUCE_FN(_cb)
+        self._keep.append(cb)
+        check(self.lib.lbfgsb_hip_comm_init_host(self.h, cb, None, None, rank, nranks))
+
+    # ---- setulb, device-pointer form ----
+    @property
+    def task_s(self) -> str:
+        return task_str(self.task)
+
+    def set_task(self, s: str):
+        self.task[:] = pad60(s)
+
+    def setulb(self, x, l, u, nbd, g, factr: float, pgtol: float, iprint: int = -1) -> str:
+        check(self.lib.lbfgsb_hip_setulb_dev(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(self.f),
+                                             _p(g), float(factr), float(pgtol), _p(self.task),
+                                             int(iprint), _p(self.csave), _p(self.lsave),
+                                             _p(self.isave), _p(self.dsave)))
+        return self.task_s
+
+    # ---- state exchange / kernels ----
+    def export_state(self):
+        wa = np.zeros(wa_length(self.n, self.m), self.real)
+        iwa = np.zeros(3 * self.n, np.int32)
+        check(self.lib.lbfgsb_hip_export_state(self.h, _p(wa), _p(iwa)))
+        return wa, iwa
+
+    def import_state(self, wa, iwa, isave):
+        wa = np.ascontiguousarray(wa, self.real)
+        iwa = np.ascontiguousarray(iwa, np.int32)
+        isave = np.ascontiguousarray(isave, np.int32)
+        check(self.lib.lbfgsb_hip_import_state(self.h, _p(wa), _p(iwa), _p(isave)))
+
+    def projgr(self, x, l, u, nbd, g) -> float:
+        out = np.zeros(1)
+        check(self.lib.lbfgsb_hip_projgr(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g), _p(out)))
+        return float(out[0])
+
+    def set_w(self, ws: np.ndarray, wy: np.ndarray):
+        """ws, wy: host arrays of shape (m, n) C-order == Fortran (n, m) column-major."""
+        ws = np.ascontiguousarray(ws, self.real)
+        wy = np.ascontiguousarray(wy, self.real)
+        assert ws.shape == (self.m, self.n) and wy.shape == (self.m, self.n)
+        check(self.lib.lbfgsb_hip_set_w(self.h, _p(ws), _p(wy)))
+
+    def wtv(self, v, col: int, head: int = 1) -> np.ndarray:
+        out = np.zeros(2 * col)
+        check(self.lib.lbfgsb_hip_wtv(self.h, _p(v), col, head, _p(out)))
+        return out
+
+    def wtv_launch(self, v, col: int, head: int = 1):
+        check(self.lib.lbfgsb_hip_wtv_launch_only(self.h, _p(v), col, head))
+
+    def sync(self):
+        check(self.lib.lbfgsb_hip_sync(self.h))
+
+    def objective(self, kind: int, x, g) -> float:
+        out = np.zeros(1)
+        check(self.lib.lbfgsb_hip_objective(self.h, kind, _p(x), _p(g), _p(out)))
+        return float(out[0])
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.lbfgsb_hip_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value)

@@ -1,0 +1,394 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): bit-exact for active-set / index / counter work;
+<= 1e-10 relative on fp64 f, g and the n-vectors at IDENTICAL iterates (one call made
+from the same caller state on both sides).  Whole-trajectory tests use integer columns
+exactly and floats with a drift allowance, because reductions are summed in a different
+order on the GPU (cross-compiler drift is already ~1e-11 after 23 iterations).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIME_D = [5, 6, 7, 8, 9]      # dsave(6:10): wall-clock slots
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def env(oracle_built):
+    import torch
+    import lbfgsb_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    lbfgsb_amd.load_library()
+    return dict(po=oracle_built, torch=torch, la=lbfgsb_amd)
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def nrm_close(a, b, rtol, what, floor=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(float(np.max(np.abs(b))) if b.size else 0.0, floor)
+    err = float(np.max(np.abs(a - b))) if b.size else 0.0
+    assert err <= rtol * scale + 1e-300, "%s: max|diff| %.3e > %.1e * %.3e" % (what, err, rtol, scale)
+
+
+def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True):
+    """got / exp: pyoracle.State after the same call from the same input state."""
+    assert got.task_s == exp.task_s
+    assert bytes(got.csave.tobytes()).rstrip() == bytes(exp.csave.tobytes()).rstrip()
+    gi, ei = got.isave[21:44].copy(), exp.isave[21:44].copy()
+    gi[2] = ei[2] = 0                     # isave(24): iteration-file unit
+    assert np.array_equal(gi, ei), "counters differ: %s vs %s" % (gi, ei)
+    assert np.array_equal(got.lsave != 0, exp.lsave != 0)
+    gd, ed = got.dsave.copy(), exp.dsave.copy()
+    gd[TIME_D] = ed[TIME_D] = 0
+    for k in range(29):
+        s = max(abs(ed[k]), 1e-300)
+        assert abs(gd[k] - ed[k]) <= 1e-9 * s + 1e-12 * max(1.0, abs(float(exp.f[0]))), \
+            "dsave(%d): %r vs %r" % (k + 1, gd[k], ed[k])
+    nrm_close(got.x, exp.x, rtol, "x")
+    nrm_close(got.g, exp.g, rtol, "g")
+    nrm_close(got.f, exp.f, rtol, "f")
+    off = po.wa_offsets(n, m)
+    col = int(exp.isave[27])
+
+    def seg(s, name):
+        o, ln = off[name]
+        return s.wa[o:o + ln]
+    for name in ("z", "r", "d", "t", "xp"):
+        fl = float(np.max(np.abs(exp.x))) * 1e-3
+        nrm_close(seg(got, name), seg(exp, name), rtol, name, floor=fl)
+    nrm_close(seg(got, "ws"), seg(exp, "ws"), rtol, "ws")
+    nrm_close(seg(got, "wy"), seg(exp, "wy"), rtol, "wy")
+    if col > 0:
+        for name in ("sy", "ss"):
+            a = seg(got, name).reshape(m, m, order="F")[:col, :col]
+            b = seg(exp, name).reshape(m, m, order="F")[:col, :col]
+            a, b = (np.tril(a), np.tril(b)) if name == "sy" else (np.triu(a), np.triu(b))
+            nrm_close(a, b, 1e-9, name)
+        a = np.triu(seg(got, "wt").reshape(m, m, order="F")[:col, :col])
+        b = np.triu(seg(exp, "wt").reshape(m, m, order="F")[:col, :col])
+        nrm_close(a, b, 1e-7, "wt")
+    iw_g = got.iwa[n:2 * n]
+    iw_e = exp.iwa[n:2 * n]
+    assert np.array_equal(iw_g, iw_e), "iwhere differs at %s" % np.nonzero(iw_g != iw_e)[0][:8]
+    if check_lists:
+        assert np.array_equal(got.iwa[:n], exp.iwa[:n]), "Index differs"
+        nenter, ileave = int(exp.isave[40]), int(exp.isave[39])
+        if ileave >= 1:                   # freev has run
+            assert np.array_equal(got.iwa[2 * n:2 * n + nenter], exp.iwa[2 * n:2 * n + nenter])
+            assert np.array_equal(got.iwa[2 * n + ileave - 1:], exp.iwa[2 * n + ileave - 1:])
+
+
+def oracle_snapshots(po, p, max_calls, on_new_x=None):
+    snaps = []
+    po.run(po.Engine("oracle"), p, max_calls=max_calls, snapshot=lambda k, s: snaps.append(s.copy()),
+           on_new_x=on_new_x)
+    return snaps
+
+
+def gpu_one_call(env, p, s_in):
+    """Load caller state s_in into a fresh device context, make ONE setulb call through the
+    C ABI (device-pointer form) and return the resulting caller state."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    s = s_in.copy()
+    t = s.task_s
+    if t.startswith("FG"):
+        s.f[0] = p.fg(s.x, s.g)
+    sol = la.DeviceSolver(p.n, p.m, mirror_index=True)
+    try:
+        x, g = _dev(torch, s.x), _dev(torch, s.g)
+        l, u, nbd = _dev(torch, p.l), _dev(torch, p.u), _dev(torch, p.nbd.astype(np.int32))
+        if not t.startswith("START"):
+            sol.import_state(s.wa, s.iwa, s.isave)
+        sol.task[:] = s.task
+        sol.csave[:] = s.csave
+        sol.lsave[:] = s.lsave
+        sol.isave[:] = s.isave
+        sol.dsave[:] = s.dsave
+        sol.f[0] = s.f[0]
+        sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+        torch.cuda.synchronize()
+        wa, iwa = sol.export_state()
+        out = po.State(p.n, p.m, x.cpu().numpy(), g.cpu().numpy(), sol.f.copy(), wa, iwa,
+                       sol.task.copy(), sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(),
+                       sol.dsave.copy())
+    finally:
+        sol.close()
+    return s, out
+
+
+ONE_STEP_CASES = [
+    ("rosenbrock25", dict(kind="ros", n=25, m=5, factr=1e7, pgtol=1e-5), 52, 1),
+    ("rosenbrock1000", dict(kind="ros", n=1000, m=10, factr=0.0, pgtol=0.0), 60, 1),
+    ("quad1000", dict(kind="quad", n=1000, m=10), 70, 1),
+    ("quadmix4099", dict(kind="quadmix", n=4099, m=10), 60, 1),
+    ("quadmix777_m3", dict(kind="quadmix", n=777, m=3), 40, 1),
+    ("quad20000_m17", dict(kind="quad", n=20000, m=17), 44, 2),
+]
+
+
+def make_problem(po, spec):
+    if spec["kind"] == "ros":
+        return po.problem_rosenbrock(spec["n"], spec["m"], spec["factr"], spec["pgtol"])
+    return po.problem_quadratic(spec["n"], spec["m"], mixed_nbd=spec["kind"] == "quadmix")
+
+
+@pytest.mark.parametrize("name,spec,ncalls,stride", ONE_STEP_CASES, ids=[c[0] for c in ONE_STEP_CASES])
+def test_one_step_parity_from_identical_state(env, name, spec, ncalls, stride):
+    """Every setulb return of the oracle trajectory is used as the INPUT state of one GPU call;
+    the GPU output must equal the oracle's next state: integers exactly, floats to 1e-10."""
+    po = env["po"]
+    p = make_problem(po, spec)
+    snaps = oracle_snapshots(po, p, ncalls)
+    # call 0 is START itself
+    fresh = po.State.fresh(p)
+    _, out0 = gpu_one_call(env, p, fresh)
+    compare_states(out0, snaps[0], p.n, p.m, po, check_lists=False)
+    tested = 0
+    for k in range(0, len(snaps) - 1, stride):
+        t = snaps[k].task_s
+        if not (t.startswith("FG") or t.startswith("NEW_X")):
+            continue
+        _, out = gpu_one_call(env, p, snaps[k])
+        compare_states(out, snaps[k + 1], p.n, p.m, po)
+        tested += 1
+    assert tested >= min(10, (len(snaps) - 1) // stride)
+
+
+def run_host_api(env, p, max_calls, on_new_x=None, iprint=-1, iteration_file=None, mirror=True):
+    """The drop-in form: reference argument list, host arrays (lbfgsb_amd.setulb)."""
+    po, la = env["po"], env["la"]
+    s = po.State.fresh(p)
+    nbd = p.nbd.astype(np.int32)
+    snaps = []
+    for _ in range(max_calls):
+        la.setulb(p.n, p.m, s.x, p.l, p.u, nbd, s.f, s.g, p.factr, p.pgtol, s.wa, s.iwa, s.task,
+                  iprint, s.csave, s.lsave, s.isave, s.dsave, iteration_file=iteration_file,
+                  mirror=mirror)
+        snaps.append(s.copy())
+        t = s.task_s
+        if t.startswith("FG"):
+            s.f[0] = p.fg(s.x, s.g)
+        elif t.startswith("NEW_X"):
+            if on_new_x is not None:
+                stop = on_new_x(s)
+                if stop:
+                    s.task[:] = po.pad60(stop)
+        else:
+            break
+    return snaps
+
+
+def driver_stop(lim):
+    def rule(s):
+        if s.isave[33] >= lim:
+            return "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT"
+        if s.dsave[12] <= 1.0e-10 * (1.0 + abs(float(s.f[0]))):
+            return "STOP: THE PROJECTED GRADIENT IS SUFFICIENTLY SMALL"
+        return None
+    return rule
+
+
+def test_driver1_trajectory_drop_in(env, tmp_path):
+    """reference test/driver1.f90 through the host-pointer ABI: the integer columns of
+    test/OUTPUTS/iterate.dat (it nf nseg nact itls) exactly, 23 iterations / 28 evaluations /
+    47 segments, floats to 6 digits, and the iteration file written by the library."""
+    po = env["po"]
+    p = po.problem_rosenbrock(25, 5, 1e7, 1e-5)
+    itf = str(tmp_path / "driver1_output.txt")
+    snaps = run_host_api(env, p, 200, iprint=1, iteration_file=itf)
+    last = snaps[-1]
+    assert last.task_s == "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"
+    assert (last.isave[29], last.isave[33], last.isave[21], last.isave[25]) == (23, 28, 47, 0)
+    assert float(last.f[0]) == pytest.approx(1.0834900834300614e-09, rel=1e-6)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_outputs",
+                        "iterate.dat")
+
+    def rows(path):
+        out = []
+        with open(path) as fh:
+            for line in fh:
+                tk = line.split()
+                if len(tk) == 10 and tk[0].isdigit() and tk[2].isdigit():
+                    out.append(tk)
+        return out
+    a, b = rows(itf), rows(gold)
+    assert len(a) == len(b) == 23
+    for ra, rb in zip(a, b):
+        assert ra[:6] == rb[:6], (ra, rb)          # it nf nseg nact sub itls
+        for ca, cb in zip(ra[6:], rb[6:]):
+            assert float(ca.replace("D", "E")) == pytest.approx(float(cb.replace("D", "E")), rel=2e-3)
+
+
+@pytest.mark.parametrize("case,lim", [("driver2", 99), ("driver3", 900)])
+def test_driver23_trajectory_drop_in(env, case, lim):
+    """driver2 (n=25) / driver3 (n=1000) settings with their user stops: per-iteration integer
+    state equal to the reference's golden trajectory while f is far above its noise floor."""
+    po = env["po"]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case + "_traj.npz"))
+    p = po.problem_rosenbrock(int(z["n"]), int(z["m"]), 0.0, 0.0)
+    snaps = run_host_api(env, p, 400, on_new_x=driver_stop(lim), mirror=False)
+    gold_new_x = [k for k in range(z["f"].shape[0]) if bytes(z["task"][k].tobytes()).startswith(b"NEW_X")]
+    mine_new_x = [k for k, s in enumerate(snaps) if s.task_s.startswith("NEW_X")]
+    checked = 0
+    for ka, kb in zip(mine_new_x, gold_new_x):
+        fa, fb = float(snaps[ka].f[0]), float(z["f"][kb])
+        if fb < 1e-9:
+            break
+        ia, ib = snaps[ka].isave, z["isave"][kb]
+        for slot in (29, 33, 32, 38, 35):           # iter nfgv nseg nact ifun
+            assert ia[slot] == ib[slot], (slot, ia[slot], ib[slot])
+        assert fa == pytest.approx(fb, rel=1e-6)
+        checked += 1
+    assert checked >= 25
+    assert snaps[-1].task_s.startswith("STOP: THE PROJECTED GRADIENT IS SUFFICIENTLY SMALL")
+
+
+def test_kernel_projgr_bit_exact(env):
+    po, torch, la = env["po"], env["torch"], env["la"]
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 255, 4097, 100003):
+        x = rng.standard_normal(n)
+        g = rng.standard_normal(n) * 3
+        l = x - rng.random(n) * (rng.random(n) > 0.3)
+        u = x + rng.random(n) * (rng.random(n) > 0.3)
+        nbd = rng.integers(0, 4, n).astype(np.int32)
+        eo = po.Engine("oracle")
+        eo.lib.lbo_projgr.restype = __import__("ctypes").c_double
+        import ctypes as C
+        eo.lib.lbo_projgr.argtypes = [C.c_int] + [C.c_void_p] * 5
+        want = eo.lib.lbo_projgr(n, l.ctypes.data, u.ctypes.data, nbd.ctypes.data, x.ctypes.data, g.ctypes.data)
+        sol = la.DeviceSolver(n, 3)
+        got = sol.projgr(_dev(torch, x), _dev(torch, l), _dev(torch, u), _dev(torch, nbd), _dev(torch, g))
+        sol.close()
+        assert got == want            # a max-reduction is exact in any order
+
+
+def test_kernel_wtv_against_float128(env):
+    """The WS/WY matvec for every column count 1..m, circular head, ragged n."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    rng = np.random.default_rng(11)
+    for n, m in ((5, 3), (1000, 5), (4099, 10), (30001, 20), (2049, 32)):
+        ws = rng.standard_normal((m, n))
+        wy = rng.standard_normal((m, n))
+        v = rng.standard_normal(n)
+        sol = la.DeviceSolver(n, m)
+        sol.set_w(ws, wy)
+        vd = _dev(torch, v)
+        for col in sorted({1, 2, m // 2 + 1, m}):
+            for head in (1, m):
+                got = sol.wtv(vd, col, head)
+                cols = [(head - 1 + j) % m for j in range(col)]
+                want = np.concatenate([wy[cols].astype(np.longdouble) @ v.astype(np.longdouble),
+                                       ws[cols].astype(np.longdouble) @ v.astype(np.longdouble)])
+                bound = np.concatenate([np.abs(wy[cols]) @ np.abs(v), np.abs(ws[cols]) @ np.abs(v)])
+                assert np.all(np.abs(got - want.astype(np.float64)) <= 1e-13 * bound + 1e-300)
+        # linearity (size-independent property): W'(a v1 + v2) = a W'v1 + W'v2
+        v2 = rng.standard_normal(n)
+        a = 0.37
+        lhs = sol.wtv(_dev(torch, a * v + v2), m, 1)
+        rhs = a * sol.wtv(vd, m, 1) + sol.wtv(_dev(torch, v2), m, 1)
+        assert np.allclose(lhs, rhs, rtol=1e-11, atol=1e-11 * np.sqrt(n))
+        sol.close()
+
+
+def test_edge_cases(env):
+    """n=1, unconstrained (cauchy skipped after the first update), all variables fixed,
+    zero gradient at start, invalid nbd and l>u."""
+    po = env["po"]
+    # unconstrained quadratic: nbd = 0 everywhere
+    p = po.problem_quadratic(513, 4)
+    p.nbd[:] = 0
+    a = oracle_snapshots(po, p, 40)
+    b = run_host_api(env, p, 40)
+    assert len(a) == len(b)
+    for sa, sb in zip(a, b):
+        assert sa.task_s == sb.task_s
+        assert np.array_equal(sa.isave[21:44][[6, 8, 12, 11, 16]], sb.isave[21:44][[6, 8, 12, 11, 16]])
+        nrm_close(sb.x, sa.x, 1e-7, "x (trajectory)")
+    # n = 1
+    p1 = po.problem_quadratic(1, 3)
+    a = oracle_snapshots(po, p1, 30)
+    b = run_host_api(env, p1, 30)
+    assert [s.task_s for s in a] == [s.task_s for s in b]
+    nrm_close(b[-1].x, a[-1].x, 1e-9, "x n=1")
+    # every variable fixed: l = u = x0
+    pf = po.problem_quadratic(300, 5)
+    pf.l[:] = 0.25
+    pf.u[:] = 0.25
+    a = oracle_snapshots(po, pf, 10)
+    b = run_host_api(env, pf, 10)
+    assert [s.task_s for s in a] == [s.task_s for s in b]
+    assert np.array_equal(b[-1].x, a[-1].x)
+    # errors detected by errclb (reference :1601-1643)
+    pe = po.problem_quadratic(100, 5)
+    pe.nbd[17] = 7
+    b = run_host_api(env, pe, 3)
+    assert b[-1].task_s == "ERROR: INVALID NBD" and b[-1].isave[21 + 13] == 0
+    pe = po.problem_quadratic(100, 5)
+    pe.l[40] = 2.0
+    b = run_host_api(env, pe, 3)
+    assert b[-1].task_s == "ERROR: NO FEASIBLE SOLUTION"
+
+
+def test_device_objectives_match_oracle(env):
+    po, torch, la = env["po"], env["torch"], env["la"]
+    rng = np.random.default_rng(3)
+    for n in (7, 1001, 65537):
+        x = rng.standard_normal(n)
+        g = np.zeros(n)
+        sol = la.DeviceSolver(n, 3)
+        xd, gd = _dev(torch, x), _dev(torch, g)
+        for kind, fn in ((0, po.quadratic_fg), (1, po.rosenbrock_fg)):
+            f_dev = sol.objective(kind, xd, gd)
+            f_cpu = fn(x, g)
+            assert f_dev == pytest.approx(f_cpu, rel=1e-12)
+            assert np.array_equal(gd.cpu().numpy(), g)      # elementwise: bit-exact
+        sol.close()
+
+
+def test_full_size_quadratic_n1e6_against_oracle(env):
+    """BASELINE.json configs[1]: separable bounded quadratic, n = 1e6, m = 10, on-device
+    objective.  Iteration 1 walks ~976,721 Cauchy segments (full breakpoint sort); integer
+    state must equal the oracle's, f to 1e-9.  Anchors pinned by the reference itself
+    (BASELINE.md section 2): nseg(it1) = 976721, nfree(it1) = 23280, f(it1) = 8.2541454907951783E+06."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 1_000_000, 10, 4
+    p = po.problem_quadratic(n, m)
+    rows_o = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                int(s.isave[37]), float(s.f[0]))) if s.task_s.startswith("NEW_X") else None)
+    sol = la.DeviceSolver(n, m)
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    g = torch.zeros_like(x)
+    l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+    nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    rows_g = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(0, x, g)
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
+                           int(sol.isave[37]), float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    st = sol.stats()
+    sol.close()
+    assert rows_o[0][2] == 976721 and rows_o[0][3] == 23280
+    assert rows_o[0][4] == pytest.approx(8.2541454907951783e06, rel=1e-13)
+    assert len(rows_g) == len(rows_o) == iters
+    for a, b in zip(rows_g, rows_o):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
+    assert st["cauchy_fullsorts"] >= 1
