@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- setulb iterations/sec on the MI355X-native L-BFGS-B inner iteration.
+
+Workload (BASELINE.json metric): separable bounded quadratic, n = 1e8, m = 10, fp64,
+l = -1, u = +1, x0 = 0, factr = pgtol = 0, on-device objective.  A "step"
+is one L-BFGS-B iteration (one NEW_X return): every kernel of the hot path runs, plus the
+f/g evaluations the line search asks for.  With --gpus N the n rows are sharded over N
+ranks (STRONG scaling: n stays 1e8) and every reduction is completed with RCCL all-reduces
+on the <= 4m+5 partials.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n ROWS] [--m M]
+
+Prints ONE JSON line (rank 0).  `value` = K / wall time of the K timed iterations
+(objective evaluations included; `iters_per_sec_setulb_only` excludes them).
+`roofline` is measured live on the WS/WY matvec kernel (wtv_kernel) with HIP events on the
+stream it runs on.  `cpu_baseline` times the real reference (oracle/_ref) on host cores,
+rank 0 at N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=4_000_000)
+    ap.add_argument("--roofline-reps", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(m, n_full, n_sample):
+    """The untouched reference (oracle/_ref, amdflang -O2) on one host core -- it is single
+    threaded by construction -- on the same problem at n_sample rows; steady-state (col = m)
+    iterations timed inside setulb only; value scaled linearly to n_full rows."""
+    from oracle import pyoracle as po
+    kind = "reference"
+    try:
+        eng = po.Engine("ref")
+    except (FileNotFoundError, OSError):
+        eng = po.Engine("oracle")
+        kind = "port"
+    p = po.problem_quadratic(n_sample, m)
+    s = po.State.fresh(p, eng.int)
+    t_in, marks = 0.0, []
+    total_iters = m + 5
+    t_start = time.time()
+    while True:
+        t0 = time.perf_counter()
+        po.call(eng, p, s)
+        t_in += time.perf_counter() - t0
+        t = s.task_s
+        if t.startswith("FG"):
+            s.f[0] = p.fg(s.x, s.g)
+        elif t.startswith("NEW_X"):
+            marks.append(t_in)
+            if s.isave[29] >= total_iters or time.time() - t_start > 60:
+                break
+        else:
+            break
+    k = min(4, len(marks) - 1)
+    per_iter = (marks[-1] - marks[-1 - k]) / k
+    ips_sample = 1.0 / per_iter
+    return {
+        "value": ips_sample * n_sample / n_full,
+        "unit": "iters/sec",
+        "cores": 1,
+        "kind": kind,
+        "sample": "n=%d rows (1/%g of the workload), m=%d, last %d of %d iterations (col=m), "
+                  "time inside setulb only: %.4f s/iter at the sample size; value scaled "
+                  "linearly in n to n=%d; first iteration (nseg~0.977n) took %.2f s"
+                  % (n_sample, n_full / n_sample, m, k, len(marks), per_iter, n_full, marks[0]),
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import lbfgsb_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, m = a.n, a.m
+    # contiguous block sharding of the rows
+    base, rem = divmod(n, world)
+    n_loc = base + (1 if rank < rem else 0)
+    row0 = rank * base + min(rank, rem)
+
+    sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank)
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            raw = lbfgsb_amd.DeviceSolver.rccl_unique_id()
+            idt.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        sol.init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, world)
+
+    x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+    g = torch.zeros_like(x)
+    l = torch.full_like(x, -1.0)
+    u = torch.full_like(x, 1.0)
+    nbd = torch.full((n_loc,), 2, dtype=torch.int32, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_setulb = 0.0
+    iter_marks = []          # (wall, t_setulb) at each NEW_X
+
+    def advance(iters):
+        nonlocal t_setulb
+        done = 0
+        while done < iters:
+            t0 = time.perf_counter()
+            task = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            t_setulb += time.perf_counter() - t0
+            if task.startswith("FG"):
+                sol.f[0] = sol.objective(0, x, g)
+            elif task.startswith("NEW_X"):
+                done += 1
+                iter_marks.append((time.perf_counter(), t_setulb))
+            else:
+                raise SystemExit("solver stopped: " + task)
+
+    barrier()
+    tw0 = time.perf_counter()
+    advance(1)
+    barrier()
+    first_iter_s = time.perf_counter() - tw0
+    nseg_first = int(sol.isave[32])
+    if a.warmup > 1:
+        advance(a.warmup - 1)
+    barrier()
+    ts0 = t_setulb
+    t0 = time.perf_counter()
+    advance(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt_setulb = t_setulb - ts0
+    if world > 1:
+        tt = torch.tensor([dt, dt_setulb], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, dt_setulb = float(tt[0]), float(tt[1])
+    stats = sol.stats()
+    f_final = float(sol.f[0])
+    col = int(sol.isave[27])
+    nfree = int(sol.isave[37])
+
+    # ---- roofline of the WS/WY matvec (wtv_kernel), live, HIP events on its stream ----
+    v = g  # any n-vector
+    head = int(sol.isave[26])
+    ms_kernel = sol.wtv_time(v, col, head, a.roofline_reps)
+    alg_bytes = (2 * col + 1) * n_loc * 8
+    achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "wtv_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "wtv_kernel<double,%d>" % (5 if col <= 5 else 10 if col <= 10 else 20 if col <= 20 else 32),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_kernel,
+                "rows_per_launch": n_loc, "col": col}
+
+    out = {
+        "metric": "setulb iters/sec + achieved HBM GB/s on WS/WY matvec, n=1e8 m=10",
+        "value": a.steps / dt,
+        "unit": "iters/sec",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "separable bounded quadratic (SURVEY.md 8d), n=%d, m=%d, fp64, "
+                               "l=-1,u=1,x0=0, on-device objective" % (n, m),
+                   "n": n, "m": m, "rows_per_gpu": n_loc, "parallelism": "rows/%d" % world,
+                   "collective": "RCCL all-reduce of <=4m+5 fp64 partials per phase" if world > 1 else "none"},
+        "iters_per_sec_setulb_only": a.steps / dt_setulb,
+        "first_iteration_s": first_iter_s,
+        "first_iteration_nseg": nseg_first,
+        "f_final": f_final,
+        "col": col,
+        "nfree": nfree,
+        "launches_per_iter": None,
+        "host_syncs_total": stats["syncs"],
+        "cauchy_fullsorts": stats["cauchy_fullsorts"],
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(m, n, min(a.cpu_n, n))
+        except Exception as e:  # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "iters/sec", "cores": 1, "kind": "reference",
+                                   "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(out))
+    sol.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

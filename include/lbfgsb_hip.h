@@ -151,8 +151,11 @@ int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double
 /* load host column-major W (n x m each, leading dimension n) into the context */
 int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy);
 
-/* bare streaming kernels used to time the roofline of the W'v matvec */
+/* bare streaming kernel launches, and the same bracketed by hipEvents on the
+ * context's stream: *h_ms_per_launch = average duration of `reps` launches. */
 int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head);
+int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, int reps,
+                        double *h_ms_per_launch);
 int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx);
 
 /* built-in device objectives: evaluate f, g on the

@@ -475,11 +475,11 @@ void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
-    const uint32_t *__restrict__ idx, uint32_t cnt, const T *__restrict__ x,
+    const uint32_t *__restrict__ idx, uint32_t cnt, int64_t row0, const T *__restrict__ x,
     const T *__restrict__ l, const T *__restrict__ u, const T *__restrict__ g,
     const T *__restrict__ tbrk, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
     int m, int head, int col, double *rec) {
-  const int rl = 2 * col + 3;
+  const int rl = 2 * col + 4;
   const int64_t total = (int64_t)cnt * rl;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (int64_t)gridDim.x * blockDim.x) {
@@ -490,28 +490,30 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
     if (f == 0) {
       v = (double)tbrk[i];
     } else if (f == 1) {
-      v = -(double)g[i];
+      v = (double)(row0 + i);
     } else if (f == 2) {
+      v = -(double)g[i];
+    } else if (f == 3) {
       const double d = -(double)g[i];
       v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
-    } else if (f < 3 + col) {
-      v = (double)wy[(int64_t)((head - 1 + (f - 3)) % m) * ldw + i];
+    } else if (f < 4 + col) {
+      v = (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
     } else {
-      v = (double)ws[(int64_t)((head - 1 + (f - 3 - col)) % m) * ldw + i];
+      v = (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
     }
     rec[q] = v;
   }
 }
 template <typename T>
-void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, const T *x, const T *l,
-                          const T *u, const T *g, const T *tbrk, WStore<T> w, int head, int col,
-                          double *rec) {
+void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t row0, const T *x,
+                          const T *l, const T *u, const T *g, const T *tbrk, WStore<T> w, int head,
+                          int col, double *rec) {
   if (cnt == 0) return;
-  const int64_t total = (int64_t)cnt * (2 * col + 3);
+  const int64_t total = (int64_t)cnt * (2 * col + 4);
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
-  hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, cnt, x, l,
-                     u, g, tbrk, w.ws, w.wy, w.ld, w.m, head, col, rec);
+  hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, cnt, row0, x,
+                     l, u, g, tbrk, w.ws, w.wy, w.ld, w.m, head, col, rec);
   q.launches++;
 }
 
@@ -1298,9 +1300,9 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
                                         double, uint64_t *, uint32_t *, uint32_t, uint32_t *);     \
   template void launch_cauchy_allkeys<T>(Queue &, int64_t, int64_t, const T *, double, int64_t,    \
                                          uint64_t *, uint32_t *);                                  \
-  template void launch_cauchy_gather<T>(Queue &, const uint32_t *, uint32_t, const T *, const T *, \
-                                        const T *, const T *, const T *, WStore<T>, int, int,      \
-                                        double *);                                                 \
+  template void launch_cauchy_gather<T>(Queue &, const uint32_t *, uint32_t, int64_t, const T *,  \
+                                        const T *, const T *, const T *, const T *, WStore<T>,    \
+                                        int, int, double *);                                                 \
   template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
                                         const T *, const T *, const T *, int32_t *, T *, double,   \
                                         double, int64_t);                                          \

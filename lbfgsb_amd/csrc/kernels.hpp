@@ -99,12 +99,12 @@ void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t
 void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_t *idx_in,
                         uint32_t *idx_out, const uint64_t *keys_in, uint64_t *keys_out,
                         size_t count);
-// records for `cnt` breakpoints listed in idx (local rows): rec[k*(2col+3)+..] =
-// { t, d_i (= -g_i), zibp (= bound - x_i), Wy(i,0..col), Ws(i,0..col) }
+// records for `cnt` breakpoints listed in idx (local rows): rec[k*(2col+4)+..] =
+// { t, global index, d_i (= -g_i), zibp (= bound - x_i), Wy(i,0..col), Ws(i,0..col) }
 template <typename T>
-void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, const T *x, const T *l,
-                          const T *u, const T *g, const T *tbrk, WStore<T> w, int head, int col,
-                          double *rec);
+void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t row0, const T *x,
+                          const T *l, const T *u, const T *g, const T *tbrk, WStore<T> w, int head,
+                          int col, double *rec);
 // finish (:1425-1433, :1515): fix every processed breakpoint variable at its bound,
 // move the others by tsum*d.  processed = (t, gidx) <= (last_t, last_i).
 template <typename T>

@@ -142,15 +142,16 @@ class Solver final : public lbfgsb_hip_ctx {
   int8_t *wasfree = nullptr, *prevfree = nullptr;
   // cauchy selection
   static constexpr uint32_t SEL_CAP = 1u << 18;
-  static constexpr uint32_t CHUNK_MAX = 4096;
+  static constexpr uint32_t CHUNK_MAX = 16384;
   uint64_t *keys[2] = {nullptr, nullptr};
   uint32_t *idx[2] = {nullptr, nullptr};
   size_t sel_alloc = 0;  // elements allocated in keys/idx
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   uint32_t *d_count = nullptr, *h_count = nullptr;
-  double *d_rec = nullptr, *h_rec = nullptr;
-  uint32_t *h_idx = nullptr;
+  double *d_msg = nullptr, *d_msg_all = nullptr, *h_msg_all = nullptr, *h_msg_loc = nullptr;
+  double *h_hdr = nullptr;
+  size_t msg_len = 0;  // doubles per rank message
   // reductions
   double *h_res = nullptr;
   size_t res_len = 0;
@@ -179,13 +180,13 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
-        F(sort_tmp), F(d_count), F(d_rec), F(q.d_part), F(q.d_res), F(q.d_gpart);
+        F(sort_tmp), F(d_count), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
       p = nullptr;
     };
-    H(h_count), H(h_rec), H(h_idx), H(h_res);
+    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res);
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -244,10 +245,10 @@ class Solver final : public lbfgsb_hip_ctx {
     CHK(ensure_sel(SEL_CAP));
     HIPCHK(hipMalloc(&d_count, sizeof(uint32_t)));
     HIPCHK(hipHostMalloc(&h_count, sizeof(uint32_t)));
-    const size_t recl = (size_t)2 * m + 3;
-    HIPCHK(hipMalloc(&d_rec, CHUNK_MAX * recl * sizeof(double)));
-    HIPCHK(hipHostMalloc(&h_rec, CHUNK_MAX * recl * sizeof(double)));
-    HIPCHK(hipHostMalloc(&h_idx, CHUNK_MAX * sizeof(uint32_t)));
+    msg_len = 2 + (size_t)CHUNK_MAX * (2 * m + 4);
+    HIPCHK(hipMalloc(&d_msg, msg_len * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_hdr, 2 * sizeof(double)));
+    CHK(set_ranks(0, 1));
     sy.assign((size_t)m * m, 0.0);
     ss.assign((size_t)m * m, 0.0);
     wt.assign((size_t)m * m, 0.0);
@@ -255,6 +256,19 @@ class Solver final : public lbfgsb_hip_ctx {
     snd.assign((size_t)4 * m * m, 0.0);
     wa8m.assign((size_t)8 * m, 0.0);
     HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // (re)size the all-gather landing buffers for `nr` ranks
+  int set_ranks(int rk, int nr) {
+    rank = rk, nranks = nr;
+    if (d_msg_all) (void)hipFree(d_msg_all);
+    if (h_msg_all) (void)hipHostFree(h_msg_all);
+    if (h_msg_loc) (void)hipHostFree(h_msg_loc);
+    d_msg_all = h_msg_all = h_msg_loc = nullptr;
+    HIPCHK(hipMalloc(&d_msg_all, (size_t)nr * msg_len * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_msg_all, (size_t)nr * msg_len * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_msg_loc, msg_len * sizeof(double)));
     return 0;
   }
 
@@ -307,35 +321,86 @@ class Solver final : public lbfgsb_hip_ctx {
   lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m}; }
 
   // =================================================================== cauchy
-  // Breakpoint provider: hands the host walk the breakpoints in ascending
-  // (t, global index) order, a chunk at a time (SURVEY.md 7.3-1 option (a)).
+  // Breakpoint provider: hands the replicated host walk the breakpoints of ALL ranks in
+  // ascending (t, global index) order (SURVEY.md 7.3-1 option (a)).  Each rank keeps its own
+  // candidates sorted on the device; chunks of records are all-gathered and merged on the
+  // host.  A merged record is "safe" to consume once no rank can still hold an earlier one.
+  struct MRec {
+    double t;
+    int64_t gidx;
+    int rank;
+    const double *rec;
+  };
   struct Provider {
-    bool have = false;   // a candidate list exists on the device
-    bool full = false;   // list = ALL remaining breakpoints (full sort)
-    double win_hi = -1;  // list covers every breakpoint after the fetch cursor with t <= win_hi
-    uint32_t C = 0;      // list length (valid candidates)
-    int cur = 0;         // which keys/idx buffer holds the sorted list
-    uint32_t pos = 0;    // next list position to hand out
-    uint32_t cb = 0, ce = 0;  // host chunk holds list positions [cb, ce)
+    bool have = false;   // candidate lists exist on the devices
+    bool full = false;   // lists = ALL remaining breakpoints (full sort)
+    double win_hi = -1;  // lists cover every breakpoint after the fetch cursor with t <= win_hi
+    uint32_t Cl = 0;     // local list length
+    uint32_t pl = 0;     // local list position of the first record not yet consumed
+    int cur = 0;         // which keys/idx buffer holds the sorted local list
+    std::vector<MRec> M; // merged chunk, all ranks
+    size_t mpos = 0, safe_end = 0;
+    bool more_anywhere = false;
+    std::vector<uint32_t> taken;
     uint32_t next_chunk = 64;
     int grow = 0;
   };
 
-  int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, int64_t nleft) {
-    if (nranks > 1) return fail(LBFGSB_E_STATE, "multi-rank Cauchy walk not available");
-    lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
-                                 d_count);
+  // every rank contributes d_msg[0..count) (device); all of it lands in h_msg_all (rank-major)
+  int exchange(size_t count) {
+    if (nranks == 1) {
+      HIPCHK(hipMemcpyAsync(h_msg_all, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
+                            stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    } else if (comm) {
+      if (g_rccl.AllGather(d_msg, d_msg_all, count, ncclDouble, comm, stream) != ncclSuccess)
+        return fail(LBFGSB_E_COMM, "ncclAllGather failed");
+      HIPCHK(hipMemcpyAsync(h_msg_all, d_msg_all, (size_t)nranks * count * sizeof(double),
+                            hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    } else {
+      if (!cb_ag) return fail(LBFGSB_E_COMM, "multi-rank context without an all-gather");
+      HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
+                            stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      if (cb_ag(cb_user, h_msg_loc, h_msg_all, (int64_t)(count * sizeof(double))) != 0)
+        return fail(LBFGSB_E_COMM, "host all-gather callback failed");
+    }
+    nsync++;
+    return 0;
+  }
+  int put_header(double a, double b) {
+    h_hdr[0] = a, h_hdr[1] = b;
+    HIPCHK(hipMemcpyAsync(d_msg, h_hdr, 2 * sizeof(double), hipMemcpyHostToDevice, stream));
+    return 0;
+  }
+  int local_count(double lo_t, int64_t lo_i, double hi, uint32_t cap, uint32_t &cnt) {
+    lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], cap, d_count);
     HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     nsync++;
-    const uint32_t cnt = *h_count;
+    cnt = *h_count;
+    return 0;
+  }
+
+  int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi) {
+    uint32_t cnt = 0;
+    CHK(local_count(lo_t, lo_i, hi, SEL_CAP, cnt));
+    CHK(put_header((double)cnt, 0.0));
+    CHK(exchange(2));
+    double gsum = 0.0;
+    for (int rk = 0; rk < nranks; ++rk) gsum += h_msg_all[(size_t)rk * 2];
     pv.have = true;
-    pv.pos = pv.cb = pv.ce = 0;
+    pv.pl = 0;
+    pv.taken.clear();
+    pv.M.clear();
+    pv.mpos = pv.safe_end = 0;
+    pv.more_anywhere = true;  // forces a refill
     pv.next_chunk = 64;
-    if (cnt <= SEL_CAP) {
+    if (gsum <= (double)SEL_CAP) {
       pv.full = false;
       pv.win_hi = hi;
-      pv.C = cnt;
+      pv.Cl = cnt;
       pv.cur = 0;
       if (cnt > 1) {
         // (t, idx) lexicographic order: stable sort by idx, then stable sort by t
@@ -346,32 +411,65 @@ class Solver final : public lbfgsb_hip_ctx {
       // too many candidates in the window: order ALL remaining breakpoints once
       nfullsort++;
       CHK(ensure_sel((size_t)n));
+      CHK(local_count(lo_t, lo_i, std::numeric_limits<double>::max(), 0, cnt));
       lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, lo_t, lo_i, keys[0], idx[0]);
       lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1],
                              (size_t)n);
       pv.full = true;
       pv.win_hi = std::numeric_limits<double>::infinity();
-      pv.C = (uint32_t)std::min<int64_t>(nleft, 0xFFFFFFFFll);  // the rest are non-candidates
+      pv.Cl = cnt;  // the rest of the sorted array are non-candidates (key = ~0)
       pv.cur = 1;
     }
     return 0;
   }
 
-  // bring list positions [pv.pos, pv.pos+len) to the host (records + indices)
-  int chunk_load(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
-    uint32_t len = std::min<uint32_t>(pv.next_chunk, pv.C - pv.pos);
+  // all-gather the next chunk of every rank's local list and merge
+  int refill(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
+    const int recl = 2 * col + 4;
+    const uint32_t chunk = pv.next_chunk;
     pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, CHUNK_MAX);
-    const int recl = 2 * col + 3;
-    lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pos, len, x, l, u, g, tbrk, W(), head, col,
-                                 d_rec);
-    HIPCHK(hipMemcpyAsync(h_rec, d_rec, (size_t)len * recl * sizeof(double),
-                          hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(h_idx, idx[pv.cur] + pv.pos, (size_t)len * sizeof(uint32_t),
-                          hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    nsync++;
-    pv.cb = pv.pos;
-    pv.ce = pv.pos + len;
+    const uint32_t len = std::min<uint32_t>(chunk, pv.Cl - pv.pl);
+    lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, len, row0, x, l, u, g, tbrk, W(), head,
+                                 col, d_msg + 2);
+    CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
+    const size_t count = 2 + (size_t)chunk * recl;
+    CHK(exchange(count));
+    pv.M.clear();
+    pv.more_anywhere = false;
+    double bt = std::numeric_limits<double>::infinity();
+    int64_t bi = std::numeric_limits<int64_t>::max();
+    for (int rk = 0; rk < nranks; ++rk) {
+      const double *base = h_msg_all + (size_t)rk * count;
+      const uint32_t lr = (uint32_t)base[0];
+      for (uint32_t k = 0; k < lr; ++k) {
+        const double *rec = base + 2 + (size_t)k * recl;
+        pv.M.push_back(MRec{rec[0], (int64_t)rec[1], rk, rec});
+      }
+      if (base[1] > 0.0) {  // this rank holds later records: nothing beyond its last one is safe
+        pv.more_anywhere = true;
+        const double *last = base + 2 + (size_t)(lr - 1) * recl;
+        if (last[0] < bt || (last[0] == bt && (int64_t)last[1] < bi)) bt = last[0], bi = (int64_t)last[1];
+      }
+    }
+    auto less = [](const MRec &a, const MRec &b) {
+      return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
+    };
+    if (nranks > 1) std::sort(pv.M.begin(), pv.M.end(), less);
+    pv.safe_end = pv.M.size();
+    if (pv.more_anywhere) {
+      size_t k = 0;
+      while (k < pv.M.size() && (pv.M[k].t < bt || (pv.M[k].t == bt && pv.M[k].gidx <= bi))) ++k;
+      pv.safe_end = k;
+    }
+    pv.mpos = 0;
+    pv.taken.assign(nranks, 0);
+    if (std::getenv("LBFGSB_DEBUG")) {
+      std::fprintf(stderr, "[refill] chunk=%u len=%u Cl=%u pl=%u cur=%d M=%zu safe=%zu more=%d\n", chunk,
+                   len, pv.Cl, pv.pl, pv.cur, pv.M.size(), pv.safe_end, (int)pv.more_anywhere);
+      for (size_t k = 0; k < pv.M.size() && k < 30; ++k)
+        std::fprintf(stderr, "   rec %zu: t=%.17g gidx=%lld d=%g z=%g\n", k, pv.M[k].t,
+                     (long long)pv.M[k].gidx, pv.M[k].rec[2], pv.M[k].rec[3]);
+    }
     return 0;
   }
 
@@ -422,7 +520,6 @@ class Solver final : public lbfgsb_hip_ctx {
       int64_t iter = 1;
       double tj = 0.0;
       Provider pv;
-      const int recl = 2 * col + 3;
       const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
       for (;;) {
         const double tj0 = tj;
@@ -434,14 +531,18 @@ class Solver final : public lbfgsb_hip_ctx {
         const double *rec = nullptr;
         int64_t rec_gi = -1;
         for (;;) {
-          if (pv.have && pv.pos < pv.C) {
-            if (pv.pos >= pv.ce) CHK(chunk_load(pv, x, l, u, g, head, col));
-            const double *rr = &h_rec[(size_t)(pv.pos - pv.cb) * recl];
-            if (rr[0] <= hi_need && rr[0] < std::numeric_limits<double>::infinity()) {
-              rec = rr;
-              rec_gi = row0 + (int64_t)h_idx[pv.pos - pv.cb];
+          if (pv.have && pv.mpos < pv.safe_end) {
+            const MRec &mr = pv.M[pv.mpos];
+            if (mr.t <= hi_need && mr.t < std::numeric_limits<double>::infinity()) {
+              rec = mr.rec;
+              rec_gi = mr.gidx;
             }
             break;
+          }
+          if (pv.have && (pv.mpos < pv.M.size() || pv.more_anywhere)) {
+            pv.pl += pv.taken.empty() ? 0 : pv.taken[rank];
+            CHK(refill(pv, x, l, u, g, head, col));
+            continue;
           }
           if (pv.have && (pv.full || pv.win_hi >= hi_need)) break;  // nothing left in reach
           // (re)fetch: ask further ahead each time so long walks need few round trips
@@ -451,7 +552,7 @@ class Solver final : public lbfgsb_hip_ctx {
             hi = base + (hi_need - base) * std::ldexp(1.0, std::min(pv.grow, 40));
           }
           pv.grow++;
-          CHK(window_fetch(pv, last_t, last_i, hi, nleft));
+          CHK(window_fetch(pv, last_t, last_i, hi));
         }
         if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
         tj = rec[0];
@@ -459,12 +560,13 @@ class Solver final : public lbfgsb_hip_ctx {
         if (dtm < dt) break;  // :1416
 
         // fix this variable (:1421-1434)
-        pv.pos++;
+        pv.taken[pv.M[pv.mpos].rank]++;
+        pv.mpos++;
         tsum = tsum + dt;
         nleft = nleft - 1;
         iter = iter + 1;
-        const double dibp = rec[1];
-        const double zibp = rec[2];
+        const double dibp = rec[2];
+        const double zibp = rec[3];
         last_t = tj;
         last_i = rec_gi;
         if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
@@ -483,8 +585,8 @@ class Solver final : public lbfgsb_hip_ctx {
           if (dt != 0.0)
             for (int j = 0; j < col2; ++j) c[j] = c[j] + dt * p[j];
           for (int j = 0; j < col; ++j) {
-            wbp[j] = rec[3 + j];
-            wbp[col + j] = theta * rec[3 + col + j];
+            wbp[j] = rec[4 + j];
+            wbp[col + j] = theta * rec[4 + col + j];
           }
           info = lbh::bmv(m, sy.data(), wt.data(), col, wbp, v);
           if (info != 0) return 0;
@@ -510,6 +612,9 @@ class Solver final : public lbfgsb_hip_ctx {
         }
       }
     }
+    if (std::getenv("LBFGSB_DEBUG"))
+      std::fprintf(stderr, "[cauchy] nseg=%d tsum=%g dtm=%g last=(%.17g,%lld)\n", nseg, tsum, dtm,
+                   last_t, (long long)last_i);
     if (dtm <= 0.0) dtm = 0.0;  // :1509
     tsum = tsum + dtm;
     lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tsum, last_t, last_i);
@@ -1203,29 +1308,26 @@ int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, 
   ncclComm_t comm = nullptr;
   if (g_rccl.CommInitRank(&comm, nranks, id, rank) != ncclSuccess)
     return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
-  ctx->rank = rank;
-  ctx->nranks = nranks;
-  if (ctx->flags & LBFGSB_F_REAL32)
+  if (ctx->flags & LBFGSB_F_REAL32) {
     as<float>(ctx)->comm = comm;
-  else
-    as<double>(ctx)->comm = comm;
-  return 0;
+    return as<float>(ctx)->set_ranks(rank, nranks);
+  }
+  as<double>(ctx)->comm = comm;
+  return as<double>(ctx)->set_ranks(rank, nranks);
 }
 
 int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag,
                               void *user, int rank, int nranks) {
   if (!ctx || !ar || nranks < 1 || rank < 0 || rank >= nranks)
     return fail(LBFGSB_E_ARG, "bad host reducer arguments");
-  ctx->rank = rank;
-  ctx->nranks = nranks;
   if (ctx->flags & LBFGSB_F_REAL32) {
     auto *s = as<float>(ctx);
     s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
-  } else {
-    auto *s = as<double>(ctx);
-    s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
+    return s->set_ranks(rank, nranks);
   }
-  return 0;
+  auto *s = as<double>(ctx);
+  s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
+  return s->set_ranks(rank, nranks);
 }
 
 int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
@@ -1259,6 +1361,25 @@ int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double
 int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   return ctx->k_wtv(v, col, head, nullptr, true);
+}
+int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, int reps,
+                        double *h_ms_per_launch) {
+  if (!ctx || reps < 1) return fail(LBFGSB_E_ARG, "wtv_time: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int k = 0; k < 3; ++k) CHK(ctx->k_wtv(v, col, head, nullptr, true));
+  HIPCHK(hipEventRecord(e0, ctx->q.stream));
+  for (int k = 0; k < reps; ++k) CHK(ctx->k_wtv(v, col, head, nullptr, true));
+  HIPCHK(hipEventRecord(e1, ctx->q.stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *h_ms_per_launch = (double)ms / reps;
+  return 0;
 }
 int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");

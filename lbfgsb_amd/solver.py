@@ -125,6 +125,10 @@ class DeviceSolver:
         self.task[:] = pad60(s)
 
     def setulb(self, x, l, u, nbd, g, factr: float, pgtol: float, iprint: int = -1) -> str:
+        if self.task_s == "START" and not isinstance(x, np.ndarray):
+            # the solver runs on its own stream: make sure the caller's tensors are materialised
+            import torch
+            torch.cuda.synchronize()
         check(self.lib.lbfgsb_hip_setulb_dev(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(self.f),
                                              _p(g), float(factr), float(pgtol), _p(self.task),
                                              int(iprint), _p(self.csave), _p(self.lsave),
@@ -163,6 +167,12 @@ class DeviceSolver:
 
     def wtv_launch(self, v, col: int, head: int = 1):
         check(self.lib.lbfgsb_hip_wtv_launch_only(self.h, _p(v), col, head))
+
+    def wtv_time(self, v, col: int, head: int = 1, reps: int = 20) -> float:
+        """average milliseconds of one W'v kernel launch (hipEvents on the solver's stream)"""
+        out = np.zeros(1)
+        check(self.lib.lbfgsb_hip_wtv_time(self.h, _p(v), col, head, reps, _p(out)))
+        return float(out[0])
 
     def sync(self):
         check(self.lib.lbfgsb_hip_sync(self.h))
