@@ -106,18 +106,10 @@ def main():
 
     n, m = a.n, a.m
     # contiguous block sharding of the rows
-    base, rem = divmod(n, world)
-    n_loc = base + (1 if rank < rem else 0)
-    row0 = rank * base + min(rank, rem)
-
+    row0, n_loc = lbfgsb_amd.block_partition(n, world, rank)
     sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank)
     if world > 1:
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            raw = lbfgsb_amd.DeviceSolver.rccl_unique_id()
-            idt.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        sol.init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        lbfgsb_amd.attach_rccl(sol, rank, world, dev)
 
     x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
     g = torch.zeros_like(x)

@@ -8,6 +8,7 @@ a gfx950 device is missing.
 """
 from .capi import LbfgsbError, lib_path, load_library, build_library  # noqa: F401
 from .solver import DeviceSolver, setulb, wa_length, TASK_LEN  # noqa: F401
+from .distributed import block_partition, attach_rccl, attach_host_group  # noqa: F401
 
 __all__ = ["LbfgsbError", "DeviceSolver", "setulb", "wa_length", "load_library",
            "build_library", "lib_path", "TASK_LEN"]

@@ -19,7 +19,7 @@ PROTOTYPES = {
     "lbfgsb_hip_last_error": (C.c_char_p, []),
     "lbfgsb_hip_rccl_unique_id": (C.c_int, [_vp]),
     "lbfgsb_hip_comm_init_rccl": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
-    "lbfgsb_hip_comm_init_host": (C.c_int, [_vp, ALLREDUCE_FN, _vp, _vp, C.c_int, C.c_int]),
+    "lbfgsb_hip_comm_init_host": (C.c_int, [_vp, ALLREDUCE_FN, ALLGATHER_FN, _vp, C.c_int, C.c_int]),
     "lbfgsb_hip_setulb_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
                                         _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_setulb_host": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -390,27 +390,57 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_kernel(int64_t n, int64_t
                                                               double hi_t, uint64_t *keys,
                                                               uint32_t *idx, uint32_t cap,
                                                               uint32_t *count) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t nround = ((n + stride - 1) / stride) * stride;  // keep waves converged
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
-    bool pred = false;
-    double t = 0.0;
-    if (i < n) {
-      t = (double)tbrk[i];
-      pred = t >= 0.0 && t <= hi_t && after_cursor(t, row0 + i, lo_t, lo_i);
+  // 4 independent 16-byte loads per lane and trip (8 rows for fp64); candidates are rare, so
+  // the common trip is: loads, 8 compares, one ballot.
+  constexpr int V = VecOf<T>::V, U = 4, RPT = V * U;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ngroups = (n + V - 1) / V;  // groups of V rows; the last may be partial
+  const int64_t ntrips = (ngroups + nthreads * U - 1) / (nthreads * U);
+  const int lane = threadIdx.x & 63;
+  for (int64_t trip = 0; trip < ntrips; ++trip) {
+    double tv[RPT];
+    int64_t ri[RPT];
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+      const int64_t gq = (trip * U + uu) * nthreads + t0;
+      const int64_t r = gq * V;
+      double tmp[V];
+      if (r + V <= n) {
+        ld<V>(tbrk + r, tmp);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) tmp[k] = r + k < n ? (double)tbrk[r + k] : -1.0;
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        tv[uu * V + k] = tmp[k];
+        ri[uu * V + k] = r + k;
+      }
     }
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) continue;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (pred) {
-      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < cap) {
-        keys[pos] = key_of(t);
-        idx[pos] = (uint32_t)i;
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      const double t = tv[e];
+      const bool pred = t >= 0.0 && t <= hi_t && after_cursor(t, row0 + ri[e], lo_t, lo_i);
+      bits |= pred ? (1u << e) : 0u;
+    }
+    if (__ballot(bits != 0) == 0ull) continue;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      const bool pred = (bits >> e) & 1u;
+      const unsigned long long mask = __ballot(pred);
+      if (mask == 0ull) continue;
+      const int leader = __ffsll((long long)mask) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+      base = __shfl(base, leader);
+      if (pred) {
+        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < cap) {
+          keys[pos] = key_of(tv[e]);
+          idx[pos] = (uint32_t)ri[e];
+        }
       }
     }
   }
@@ -420,7 +450,7 @@ void launch_cauchy_window(Queue &q, int64_t n, int64_t row0, const T *tbrk, doub
                           int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
                           uint32_t *d_count) {
   (void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), q.stream);
-  const int gr = grid_for(n, 1);
+  const int gr = grid_for(n, VecOf<T>::V * 4);
   hipLaunchKernelGGL(cauchy_window_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, tbrk,
                      lo_t, lo_i, hi_t, keys, idx, cap, d_count);
   q.launches++;
@@ -817,10 +847,155 @@ __global__ __launch_bounds__(BLOCK) void formk_gram_kernel(int64_t n, const T *_
     if (e < E) gpart[(size_t)e * GRAM_BLOCKS + blockIdx.x] = acc[s];
   }
 }
+// Row-parallel variant for col <= 10 (the benchmark's m = 10): a workgroup's 4 waves
+// each load a quarter of the 2*MC columns of a 128-row slab once (16 B per lane,
+// coalesced), share them through a double-buffered LDS slab (conflict-free 16-byte
+// slots, one barrier per slab), and each wave owns one quarter of the outputs in
+// registers: wave 0 Y'ZZ'Y, wave 1 S'AA'S, wave 2 R_z (free rows, i<=j), wave 3 L_a
+// (active rows, i>j).  HBM traffic is exactly one pass over W plus iwhere.
+template <int MC>
+struct GramRows {
+  static constexpr int NACC = MC * (MC + 1) / 2;
+  static constexpr int ROWS = 128;  // 64 lanes x 2 rows
+};
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void formk_gram_rows_kernel(
+    int64_t n, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head,
+    int col, const int32_t *__restrict__ iwhere, double *gpart) {
+  using G = GramRows<MC>;
+  constexpr int NC = 2 * MC;             // columns: [0,MC) = Wy, [MC,2MC) = Ws
+  constexpr int PER = (NC + 3) / 4;      // columns loaded per wave
+  __shared__ double2 slab[2][NC][64];
+  __shared__ int2 fl[2][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double acc[G::NACC];
+#pragma unroll
+  for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0;
+
+  const int64_t nslab = (n + G::ROWS - 1) / G::ROWS;
+  double2 stage[PER];
+  int2 fstage = make_int2(3, 3);
+  auto issue = [&](int64_t sl) {
+    const int64_t r0 = sl * G::ROWS + 2 * lane;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int c = w + 4 * q;
+      double2 v = make_double2(0.0, 0.0);
+      if (c < NC && r0 < n) {
+        const int j = c < MC ? c : c - MC;
+        const T *base = (c < MC ? wy : ws) + col_off(j, col, head, m, ldw) + r0;
+        if (r0 + 1 < n) {
+          double t2[2];
+          ld<2>(base, t2);
+          v = make_double2(t2[0], t2[1]);
+        } else {
+          v.x = (double)base[0];
+        }
+      }
+      stage[q] = v;
+    }
+    if (w == 0) {
+      fstage = make_int2(3, 3);
+      if (r0 < n) fstage.x = iwhere[r0] <= 0 ? 1 : 0;
+      if (r0 + 1 < n) fstage.y = iwhere[r0 + 1] <= 0 ? 1 : 0;
+    }
+  };
+  int buf = 0;
+  if ((int64_t)blockIdx.x < nslab) issue(blockIdx.x);
+  for (int64_t sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int c = w + 4 * q;
+      if (c < NC) slab[buf][c][lane] = stage[q];
+    }
+    if (w == 0) fl[buf][lane] = fstage;
+    __syncthreads();
+    if (sl + gridDim.x < nslab) issue(sl + gridDim.x);  // next slab's loads fly during the math
+    const int2 f = fl[buf][lane];
+    // masks: free rows for waves 0 and 2, active rows for waves 1 and 3
+    const int want = (w == 0 || w == 2) ? 1 : 0;
+    const double m0 = f.x == want ? 1.0 : 0.0, m1 = f.y == want ? 1.0 : 0.0;
+    if (w == 0 || w == 1) {
+      // symmetric block of one matrix: Y (w=0, columns [0,MC)) or S (w=1, columns [MC,2MC))
+      double2 a[MC];
+#pragma unroll
+      for (int j = 0; j < MC; ++j) a[j] = slab[buf][(w == 0 ? 0 : MC) + j][lane];
+#pragma unroll
+      for (int i = 0; i < MC; ++i) {
+        const double ax = a[i].x * m0, ay = a[i].y * m1;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) acc[i * (i + 1) / 2 + j] += ax * a[j].x + ay * a[j].y;
+      }
+    } else {
+      double2 y[MC], sv[MC];
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+        y[j] = slab[buf][j][lane];
+        sv[j] = slab[buf][MC + j][lane];
+      }
+      if (w == 2) {  // R_z: Ws_i . Wy_j over free rows, i <= j
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+          const double yx = y[j].x * m0, yy = y[j].y * m1;
+#pragma unroll
+          for (int i = 0; i <= j; ++i) acc[j * (j + 1) / 2 + i] += sv[i].x * yx + sv[i].y * yy;
+        }
+      } else {  // L_a: Ws_i . Wy_j over active rows, i > j
+#pragma unroll
+        for (int i = 1; i < MC; ++i) {
+          const double sx = sv[i].x * m0, sy = sv[i].y * m1;
+#pragma unroll
+          for (int j = 0; j < i; ++j) acc[(i - 1) * i / 2 + j] += sx * y[j].x + sy * y[j].y;
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  // per-wave reduction; lane 0 of each wave owns its outputs
+  const int tri = col * (col + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      // (i,j) with i >= j enumerates: w0/w1 element (i,j); w2 element (row j.. see below)
+      int e = -1;
+      double v = 0.0;
+      if (w == 0 || w == 1) {
+        v = wave_sum(acc[i * (i + 1) / 2 + j]);
+        if (i < col) e = (w == 0 ? 0 : tri) + i * (i + 1) / 2 + j;
+      } else if (w == 2) {
+        // stored at acc[J*(J+1)/2 + I] with I <= J: here J = i, I = j  -> Ws_I . Wy_J
+        v = wave_sum(acc[i * (i + 1) / 2 + j]);
+        if (i < col) e = 2 * tri + j * col + i;
+      } else {
+        // w == 3: acc[(I-1)*I/2 + Jc], I > Jc; enumerate I = i+1 (<MC), Jc = j
+        if (i + 1 < MC) {
+          v = wave_sum(acc[i * (i + 1) / 2 + j]);
+          if (i + 1 < col) e = 2 * tri + (i + 1) * col + j;
+        }
+      }
+      if (lane == 0 && e >= 0) gpart[(size_t)e * GRAM_BLOCKS + blockIdx.x] = v;
+    }
+  }
+}
+
 template <typename T>
 void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
                        const int32_t *iwhere) {
   int gr = 0;
+  if (col <= 10) {
+    const int64_t nslab = (n + 127) / 128;
+    gr = (int)(nslab < GRAM_BLOCKS ? nslab : GRAM_BLOCKS);
+    if (col <= 5)
+      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 5>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
+                         w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
+    else
+      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 10>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
+                         w.ws, w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
+    q.launches++;
+    finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
+    return;
+  }
   DISPATCH_MAXC(col, {
     const int64_t ntiles = (n + GramCfg<MC>::R - 1) / GramCfg<MC>::R;
     gr = (int)(ntiles < GRAM_BLOCKS ? ntiles : GRAM_BLOCKS);

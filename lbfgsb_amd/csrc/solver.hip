@@ -292,7 +292,7 @@ class Solver final : public lbfgsb_hip_ctx {
   // ---- complete a reduction across ranks and bring it to the host ----
   int fetch(int nsum, int nmin, int nmax) {
     const int k = nsum + nmin + nmax;
-    if (nranks > 1 && comm) {
+    if (comm) {
       if (g_rccl.GroupStart() != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclGroupStart");
       ncclResult_t rc = ncclSuccess;
       if (nsum)
@@ -348,7 +348,7 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // every rank contributes d_msg[0..count) (device); all of it lands in h_msg_all (rank-major)
   int exchange(size_t count) {
-    if (nranks == 1) {
+    if (nranks == 1 && !comm) {
       HIPCHK(hipMemcpyAsync(h_msg_all, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
                             stream));
       HIPCHK(hipStreamSynchronize(stream));

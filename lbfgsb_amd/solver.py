@@ -102,19 +102,36 @@ class DeviceSolver:
         check(lib.lbfgsb_hip_rccl_unique_id(buf))
         return buf.raw
 
-    def init_host_reducer(self, allreduce, rank: int, nranks: int):
-        """allreduce(np_view, nsum, nmin, nmax) must reduce the view in place over ranks."""
-        def _cb(user, buf, nsum, nmin, nmax):
+    def init_host_reducer(self, allreduce, rank: int, nranks: int, allgather=None):
+        """allreduce(np_view, nsum, nmin, nmax) reduces the fp64 view in place over ranks
+        (sums | mins | maxes).  allgather(np_uint8_local) -> rank-major concatenation."""
+        def _ar(user, buf, nsum, nmin, nmax):
             try:
                 k = nsum + nmin + nmax
                 view = np.ctypeslib.as_array(buf, shape=(k,))
                 allreduce(view, nsum, nmin, nmax)
                 return 0
             except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
                 return 1
-        cb = capi.ALLREDUCE_FN(_cb)
-        self._keep.append(cb)
-        check(self.lib.lbfgsb_hip_comm_init_host(self.h, cb, None, None, rank, nranks))
+
+        def _ag(user, inp, out, nbytes):
+            try:
+                world = nranks
+                src = np.ctypeslib.as_array(C.cast(inp, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)),
+                                            shape=(nbytes * world,))
+                dst[:] = allgather(src)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb_ar = capi.ALLREDUCE_FN(_ar)
+        cb_ag = capi.ALLGATHER_FN(_ag) if allgather is not None else C.cast(None, capi.ALLGATHER_FN)
+        self._keep += [cb_ar, cb_ag]
+        check(self.lib.lbfgsb_hip_comm_init_host(self.h, cb_ar, cb_ag, None, rank, nranks))
 
     # ---- setulb, device-pointer form ----
     @property
