@@ -1335,8 +1335,10 @@ int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const voi
                           char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave,
                           double *dsave) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->setulb_dev(x, l, u, nbd, f, g, factr, pgtol, task, iprint, csave, lsave, isave,
-                         dsave);
+  const int rc = ctx->setulb_dev(x, l, u, nbd, f, g, factr, pgtol, task, iprint, csave, lsave,
+                                 isave, dsave);
+  if (iprint >= 0) std::fflush(stdout);
+  return rc;
 }
 
 int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa) {
@@ -1456,6 +1458,7 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
   for (int i = 0; i < 29; ++i) ds[i] = r32 ? (double)((float *)dsave)[i] : ((double *)dsave)[i];
   int rc = ctx->setulb_dev(ctx->hx, ctx->hl, ctx->hu, ctx->hnbd, &fd, ctx->hg, factr, pgtol, task,
                            iprint, csave, lsave, isave, ds);
+  if (iprint >= 0) std::fflush(stdout);
   if (rc) return rc;
   for (int i = 0; i < 29; ++i) {
     if (r32)
