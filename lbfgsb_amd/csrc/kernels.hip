@@ -847,41 +847,132 @@ __global__ __launch_bounds__(BLOCK) void formk_gram_kernel(int64_t n, const T *_
     if (e < E) gpart[(size_t)e * GRAM_BLOCKS + blockIdx.x] = acc[s];
   }
 }
-// Row-parallel variant for col <= 10 (the benchmark's m = 10): a workgroup's 4 waves
-// each load a quarter of the 2*MC columns of a 128-row slab once (16 B per lane,
-// coalesced), share them through a double-buffered LDS slab (conflict-free 16-byte
-// slots, one barrier per slab), and each wave owns one quarter of the outputs in
-// registers: wave 0 Y'ZZ'Y, wave 1 S'AA'S, wave 2 R_z (free rows, i<=j), wave 3 L_a
-// (active rows, i>j).  HBM traffic is exactly one pass over W plus iwhere.
+// Row-parallel variant for col <= 10 (the benchmark's m = 10).  A 512-thread workgroup
+// (8 waves) takes a 128-row slab: each wave loads 1/8 of the 2*MC columns once (16 B per
+// lane, coalesced) into a double-buffered LDS slab (conflict-free 16-byte slots, ONE barrier
+// per slab, the next slab's global loads in flight during the math), and each wave owns one
+// eighth of the outputs in registers -- matrix = wave/2: Y'ZZ'Y (free rows), S'AA'S (active
+// rows), R_z (free, i<=j), L_a (active, i>j); half = wave%2 splits the outer index at H.
+// <= 28 accumulators per lane keep it under 128 VGPRs: two workgroups (16 waves) per CU.
+// HBM traffic is exactly one pass over W plus iwhere.
 template <int MC>
 struct GramRows {
-  static constexpr int NACC = MC * (MC + 1) / 2;
+  static constexpr int H = MC == 10 ? 7 : (MC + 1) / 2 + 1;  // outer-index split
+  static constexpr int NACC = H * (H + 1) / 2 > (MC - H) * (MC + H + 1) / 2
+                                  ? H * (H + 1) / 2
+                                  : (MC - H) * (MC + H + 1) / 2;
   static constexpr int ROWS = 128;  // 64 lanes x 2 rows
+  static constexpr int NW = 8;
 };
+
+// accumulate one slab for role (MT, HALF); a = pointer to the slab [2*MC][64] of double2
+template <int MC, int MT, int HALF>
+__device__ __forceinline__ void gram_role(const double2 (*__restrict__ sl)[64], int lane, double m0,
+                                          double m1, double (&acc)[GramRows<MC>::NACC]) {
+  constexpr int H = GramRows<MC>::H;
+  constexpr int LO = HALF == 0 ? 0 : H, HI = HALF == 0 ? H : MC;
+  // inner operands are re-read from LDS (cheap: the LDS pipe is otherwise idle)
+  if constexpr (MT == 0 || MT == 1) {
+    constexpr int C0 = MT == 0 ? 0 : MC;  // Y block or S block
+    int k = 0;
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+      const double2 ai = sl[C0 + i][lane];
+      const double ax = ai.x * m0, ay = ai.y * m1;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const double2 aj = sl[C0 + j][lane];
+        acc[k++] += ax * aj.x + ay * aj.y;
+      }
+    }
+  } else if constexpr (MT == 2) {  // R_z: Ws_i . Wy_j, free rows, i <= j, outer j in [LO,HI)
+    int k = 0;
+#pragma unroll
+    for (int j = LO; j < HI; ++j) {
+      const double2 y = sl[j][lane];
+      const double yx = y.x * m0, yy = y.y * m1;
+#pragma unroll
+      for (int i = 0; i <= j; ++i) {
+        const double2 sv = sl[MC + i][lane];
+        acc[k++] += sv.x * yx + sv.y * yy;
+      }
+    }
+  } else {  // L_a: Ws_i . Wy_j, active rows, i > j, outer i in [max(LO,1),HI)
+    int k = 0;
+#pragma unroll
+    for (int i = (LO < 1 ? 1 : LO); i < HI; ++i) {
+      const double2 sv = sl[MC + i][lane];
+      const double sx = sv.x * m0, sy = sv.y * m1;
+#pragma unroll
+      for (int j = 0; j < i; ++j) {
+        const double2 y = sl[j][lane];
+        acc[k++] += sx * y.x + sy * y.y;
+      }
+    }
+  }
+}
+// write one role's outputs (same enumeration order as gram_role)
+template <int MC, int MT, int HALF>
+__device__ __forceinline__ void gram_store(const double (&acc)[GramRows<MC>::NACC], int lane, int col,
+                                           double *gpart) {
+  constexpr int H = GramRows<MC>::H;
+  constexpr int LO = HALF == 0 ? 0 : H, HI = HALF == 0 ? H : MC;
+  const int tri = col * (col + 1) / 2;
+  int k = 0;
+  if constexpr (MT == 0 || MT == 1) {
+#pragma unroll
+    for (int i = LO; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const double v = wave_sum(acc[k++]);
+        if (lane == 0 && i < col)
+          gpart[(size_t)((MT == 0 ? 0 : tri) + i * (i + 1) / 2 + j) * GRAM_BLOCKS + blockIdx.x] = v;
+      }
+  } else if constexpr (MT == 2) {
+#pragma unroll
+    for (int j = LO; j < HI; ++j)
+#pragma unroll
+      for (int i = 0; i <= j; ++i) {
+        const double v = wave_sum(acc[k++]);
+        if (lane == 0 && j < col) gpart[(size_t)(2 * tri + i * col + j) * GRAM_BLOCKS + blockIdx.x] = v;
+      }
+  } else {
+#pragma unroll
+    for (int i = (LO < 1 ? 1 : LO); i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) {
+        const double v = wave_sum(acc[k++]);
+        if (lane == 0 && i < col) gpart[(size_t)(2 * tri + i * col + j) * GRAM_BLOCKS + blockIdx.x] = v;
+      }
+  }
+}
+
 template <typename T, int MC>
-__global__ __launch_bounds__(BLOCK) void formk_gram_rows_kernel(
+__global__ __launch_bounds__(512) void formk_gram_rows_kernel(
     int64_t n, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head,
     int col, const int32_t *__restrict__ iwhere, double *gpart) {
   using G = GramRows<MC>;
-  constexpr int NC = 2 * MC;             // columns: [0,MC) = Wy, [MC,2MC) = Ws
-  constexpr int PER = (NC + 3) / 4;      // columns loaded per wave
+  constexpr int NC = 2 * MC;                      // columns: [0,MC) = Wy, [MC,2MC) = Ws
+  constexpr int PER = (NC + G::NW - 1) / G::NW;   // columns loaded per wave
   __shared__ double2 slab[2][NC][64];
   __shared__ int2 fl[2][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform role
   double acc[G::NACC];
 #pragma unroll
   for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0;
 
   const int64_t nslab = (n + G::ROWS - 1) / G::ROWS;
-  double2 stage[PER];
-  int2 fstage = make_int2(3, 3);
-  auto issue = [&](int64_t sl) {
+  // two register stages: while slab t is computed from LDS, slabs t+1 and t+2 are in flight
+  double2 stA[PER], stB[PER];
+  int2 fA = make_int2(3, 3), fB = make_int2(3, 3);
+  auto issue = [&](int64_t sl, double2(&stage)[PER], int2 &fstage) {
     const int64_t r0 = sl * G::ROWS + 2 * lane;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int c = w + 4 * q;
+      const int c = w + G::NW * q;
       double2 v = make_double2(0.0, 0.0);
-      if (c < NC && r0 < n) {
+      if (sl < nslab && c < NC && r0 < n) {
         const int j = c < MC ? c : c - MC;
         const T *base = (c < MC ? wy : ws) + col_off(j, col, head, m, ldw) + r0;
         if (r0 + 1 < n) {
@@ -894,88 +985,60 @@ __global__ __launch_bounds__(BLOCK) void formk_gram_rows_kernel(
       }
       stage[q] = v;
     }
-    if (w == 0) {
+    if (w == G::NW - 1) {
       fstage = make_int2(3, 3);
-      if (r0 < n) fstage.x = iwhere[r0] <= 0 ? 1 : 0;
-      if (r0 + 1 < n) fstage.y = iwhere[r0 + 1] <= 0 ? 1 : 0;
+      if (sl < nslab && r0 < n) fstage.x = iwhere[r0] <= 0 ? 1 : 0;
+      if (sl < nslab && r0 + 1 < n) fstage.y = iwhere[r0 + 1] <= 0 ? 1 : 0;
     }
   };
-  int buf = 0;
-  if ((int64_t)blockIdx.x < nslab) issue(blockIdx.x);
-  for (int64_t sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+  auto put = [&](int buf, const double2(&stage)[PER], const int2 &fstage) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int c = w + 4 * q;
+      const int c = w + G::NW * q;
       if (c < NC) slab[buf][c][lane] = stage[q];
     }
-    if (w == 0) fl[buf][lane] = fstage;
-    __syncthreads();
-    if (sl + gridDim.x < nslab) issue(sl + gridDim.x);  // next slab's loads fly during the math
+    if (w == G::NW - 1) fl[buf][lane] = fstage;
+  };
+  auto math = [&](int buf) {
     const int2 f = fl[buf][lane];
-    // masks: free rows for waves 0 and 2, active rows for waves 1 and 3
-    const int want = (w == 0 || w == 2) ? 1 : 0;
+    const int mt = w >> 1;
+    const int want = (mt == 0 || mt == 2) ? 1 : 0;  // free rows for Y'ZZ'Y and R_z
     const double m0 = f.x == want ? 1.0 : 0.0, m1 = f.y == want ? 1.0 : 0.0;
-    if (w == 0 || w == 1) {
-      // symmetric block of one matrix: Y (w=0, columns [0,MC)) or S (w=1, columns [MC,2MC))
-      double2 a[MC];
-#pragma unroll
-      for (int j = 0; j < MC; ++j) a[j] = slab[buf][(w == 0 ? 0 : MC) + j][lane];
-#pragma unroll
-      for (int i = 0; i < MC; ++i) {
-        const double ax = a[i].x * m0, ay = a[i].y * m1;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) acc[i * (i + 1) / 2 + j] += ax * a[j].x + ay * a[j].y;
-      }
-    } else {
-      double2 y[MC], sv[MC];
-#pragma unroll
-      for (int j = 0; j < MC; ++j) {
-        y[j] = slab[buf][j][lane];
-        sv[j] = slab[buf][MC + j][lane];
-      }
-      if (w == 2) {  // R_z: Ws_i . Wy_j over free rows, i <= j
-#pragma unroll
-        for (int j = 0; j < MC; ++j) {
-          const double yx = y[j].x * m0, yy = y[j].y * m1;
-#pragma unroll
-          for (int i = 0; i <= j; ++i) acc[j * (j + 1) / 2 + i] += sv[i].x * yx + sv[i].y * yy;
-        }
-      } else {  // L_a: Ws_i . Wy_j over active rows, i > j
-#pragma unroll
-        for (int i = 1; i < MC; ++i) {
-          const double sx = sv[i].x * m0, sy = sv[i].y * m1;
-#pragma unroll
-          for (int j = 0; j < i; ++j) acc[(i - 1) * i / 2 + j] += sx * y[j].x + sy * y[j].y;
-        }
-      }
+    switch (w) {
+      case 0: gram_role<MC, 0, 0>(slab[buf], lane, m0, m1, acc); break;
+      case 1: gram_role<MC, 0, 1>(slab[buf], lane, m0, m1, acc); break;
+      case 2: gram_role<MC, 1, 0>(slab[buf], lane, m0, m1, acc); break;
+      case 3: gram_role<MC, 1, 1>(slab[buf], lane, m0, m1, acc); break;
+      case 4: gram_role<MC, 2, 0>(slab[buf], lane, m0, m1, acc); break;
+      case 5: gram_role<MC, 2, 1>(slab[buf], lane, m0, m1, acc); break;
+      case 6: gram_role<MC, 3, 0>(slab[buf], lane, m0, m1, acc); break;
+      default: gram_role<MC, 3, 1>(slab[buf], lane, m0, m1, acc); break;
     }
-    buf ^= 1;
+  };
+  const int64_t g = gridDim.x;
+  issue(blockIdx.x, stA, fA);
+  issue(blockIdx.x + g, stB, fB);
+  for (int64_t sl = blockIdx.x; sl < nslab; sl += 2 * g) {
+    put(0, stA, fA);
+    __syncthreads();
+    issue(sl + 2 * g, stA, fA);
+    math(0);
+    if (sl + g < nslab) {  // uniform over the workgroup
+      put(1, stB, fB);
+      __syncthreads();
+      issue(sl + 3 * g, stB, fB);
+      math(1);
+    }
   }
-  // per-wave reduction; lane 0 of each wave owns its outputs
-  const int tri = col * (col + 1) / 2;
-#pragma unroll
-  for (int i = 0; i < MC; ++i) {
-#pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      // (i,j) with i >= j enumerates: w0/w1 element (i,j); w2 element (row j.. see below)
-      int e = -1;
-      double v = 0.0;
-      if (w == 0 || w == 1) {
-        v = wave_sum(acc[i * (i + 1) / 2 + j]);
-        if (i < col) e = (w == 0 ? 0 : tri) + i * (i + 1) / 2 + j;
-      } else if (w == 2) {
-        // stored at acc[J*(J+1)/2 + I] with I <= J: here J = i, I = j  -> Ws_I . Wy_J
-        v = wave_sum(acc[i * (i + 1) / 2 + j]);
-        if (i < col) e = 2 * tri + j * col + i;
-      } else {
-        // w == 3: acc[(I-1)*I/2 + Jc], I > Jc; enumerate I = i+1 (<MC), Jc = j
-        if (i + 1 < MC) {
-          v = wave_sum(acc[i * (i + 1) / 2 + j]);
-          if (i + 1 < col) e = 2 * tri + (i + 1) * col + j;
-        }
-      }
-      if (lane == 0 && e >= 0) gpart[(size_t)e * GRAM_BLOCKS + blockIdx.x] = v;
-    }
+  switch (w) {
+    case 0: gram_store<MC, 0, 0>(acc, lane, col, gpart); break;
+    case 1: gram_store<MC, 0, 1>(acc, lane, col, gpart); break;
+    case 2: gram_store<MC, 1, 0>(acc, lane, col, gpart); break;
+    case 3: gram_store<MC, 1, 1>(acc, lane, col, gpart); break;
+    case 4: gram_store<MC, 2, 0>(acc, lane, col, gpart); break;
+    case 5: gram_store<MC, 2, 1>(acc, lane, col, gpart); break;
+    case 6: gram_store<MC, 3, 0>(acc, lane, col, gpart); break;
+    default: gram_store<MC, 3, 1>(acc, lane, col, gpart); break;
   }
 }
 
@@ -987,10 +1050,10 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
     const int64_t nslab = (n + 127) / 128;
     gr = (int)(nslab < GRAM_BLOCKS ? nslab : GRAM_BLOCKS);
     if (col <= 5)
-      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 5>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
+      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 5>), dim3(gr), dim3(512), 0, q.stream, n, w.ws,
                          w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
     else
-      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 10>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
+      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 10>), dim3(gr), dim3(512), 0, q.stream, n,
                          w.ws, w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
     q.launches++;
     finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
