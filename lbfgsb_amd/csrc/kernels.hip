@@ -1454,6 +1454,119 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
   launch_finalize(q, gr, 2 * maxc_for(nold) + 1, 0, 0);
 }
 
+// =========================== matupd + cauchy scan, fused ======================
+// On a NEW_X re-entry the reference runs matupd (:842) and, at the top of the next loop
+// trip, the n-loop of cauchy (:1270-1330).  Both stream every stored column of W; fused,
+// the old columns are read ONCE for s'Wy_j, Ws_j's (matupd) and for p = W'd (cauchy), and
+// the new pair (s, y) is used from registers.  Per element the arithmetic is exactly that
+// of update_pairs_kernel and cauchy_scan_kernel.
+// slots: [0,MC) s'Wy_j | [MC,2MC) Ws_j's | [2MC] y'y | [2MC+1,3MC+1) Wy_j'd | [3MC+1] y'd |
+//        [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | f1, nbreak, nunb, nunbnz | min: bkmin
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void update_scan_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
+    const T *__restrict__ d, double stp, int32_t *iwhere, T *tbrk, T *ws, T *wy, int64_t ldw,
+    int m, int head, int nold, int itail, double *part) {
+  constexpr int NA = 4 * MC + 8;
+  double acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  acc[4 * MC + 7] = LB_INF;
+  const int64_t offn = (int64_t)(itail - 1) * ldw;
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W], a[MC][W], b[MC][W];
+    int nb[W], iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ld<W>(r + i, rv);
+    ld<W>(d + i, dv);
+    ldi<W>(nbd + i, nb);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
+      ld<W>(wy + off, a[j]);
+      ld<W>(ws + off, b[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rv[k] = gv[k] - rv[k];                              // y (:813-815)
+      acc[2 * MC] = acc[2 * MC] + rv[k] * rv[k];          // rr (:816)
+      if (stp != 1.0) dv[k] = stp * dv[k];                // s (:822)
+      // ---- cauchy n-loop (:1270-1330) ----
+      const double neggi = -gv[k];
+      double tl = 0.0, tu = 0.0;
+      if (iw[k] != 3 && iw[k] != -1) {
+        if (nb[k] <= 2) tl = xv[k] - lv[k];
+        if (nb[k] >= 2) tu = uv[k] - xv[k];
+        const bool xlower = nb[k] <= 2 && tl <= 0.0;
+        const bool xupper = nb[k] >= 2 && tu <= 0.0;
+        iw[k] = 0;
+        if (xlower) {
+          if (neggi <= 0.0) iw[k] = 1;
+        } else if (xupper) {
+          if (neggi >= 0.0) iw[k] = 2;
+        } else {
+          if (fabs(neggi) <= 0.0) iw[k] = -3;
+        }
+      }
+      if (iw[k] != 0 && iw[k] != -1) {
+        tb[k] = -1.0;
+        ng[k] = 0.0;
+      } else {
+        ng[k] = neggi;
+        acc[4 * MC + 3] = acc[4 * MC + 3] - neggi * neggi;
+        if (nb[k] <= 2 && nb[k] != 0 && neggi < 0.0) {
+          tb[k] = tl / (-neggi);
+          acc[4 * MC + 4] += 1.0;
+          acc[4 * MC + 7] = fmin(acc[4 * MC + 7], tb[k]);
+        } else if (nb[k] >= 2 && neggi > 0.0) {
+          tb[k] = tu / neggi;
+          acc[4 * MC + 4] += 1.0;
+          acc[4 * MC + 7] = fmin(acc[4 * MC + 7], tb[k]);
+        } else {
+          tb[k] = LB_INF;
+          acc[4 * MC + 5] += 1.0;
+          if (fabs(neggi) > 0.0) acc[4 * MC + 6] += 1.0;
+        }
+      }
+      acc[3 * MC + 1] += rv[k] * ng[k];  // new Wy column . d
+      acc[4 * MC + 2] += dv[k] * ng[k];  // new Ws column . d
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += dv[k] * a[j][k];               // Sy(col,j) (:2335)
+        acc[MC + j] += b[j][k] * dv[k];          // Ss(j,col) (:2336)
+        acc[2 * MC + 1 + j] += a[j][k] * ng[k];  // p_j        (:1301)
+        acc[3 * MC + 2 + j] += b[j][k] * ng[k];  // p_{col+j}  (:1302)
+      }
+    }
+    st<W>(ws + offn + i, dv);
+    st<W>(wy + offn + i, rv);
+    sti<W>(iwhere + i, iw);
+    st<W>(tbrk + i, tb);
+  });
+  block_reduce_store<NA>(acc, 4 * MC + 7, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
+                        const T *g, const T *r, const T *d, double stp, int32_t *iwhere, T *tbrk,
+                        WStore<T> w, int head, int col, int itail) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  const int nold = col - 1;
+  DISPATCH_MAXC(nold, hipLaunchKernelGGL((update_scan_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+                                         q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,
+                                         w.wy, w.ld, w.m, head, nold, itail, q.d_part));
+  q.launches++;
+  launch_finalize(q, gr, 4 * maxc_for(nold) + 7, 1, 0);
+}
+
 // =========================== built-in objectives =============================
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void obj_quadratic_kernel(int64_t n, int64_t row0,
@@ -1565,6 +1678,9 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
                                       const int32_t *, const T *, const T *);                      \
   template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double,  \
                                        WStore<T>, int, int, int);                                  \
+  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *,           \
+                                      const int32_t *, const T *, const T *, const T *, double,    \
+                                      int32_t *, T *, WStore<T>, int, int, int);                   \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *);                \
   template void launch_obj_rosenbrock<T>(Queue &, int64_t, const T *, T *);
 

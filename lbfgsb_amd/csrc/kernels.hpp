@@ -14,7 +14,7 @@ constexpr int BLOCK = 256;        // 4 wave64 per workgroup
 constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 workgroups, grid-stride beyond that
 constexpr int GRAM_BLOCKS = 1024;
 constexpr int MAXM = 32;          // LBFGSB_MAX_M
-constexpr int RES_MAX = 4 * MAXM + 32;
+constexpr int RES_MAX = 4 * MAXM + 32;  // >= 4*MC + 8 slots of the fused update+scan
 
 // launch queue + reduction scratch owned by the context
 struct Queue {
@@ -177,6 +177,14 @@ void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 template <typename T>
 void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d, double stp,
                          WStore<T> w, int head, int col, int itail);
+
+// the two above fused (one pass over the old columns); slots, MC = maxc_for(col-1):
+// [0,MC) s'Wy_j | [MC,2MC) Ws_j's | [2MC] y'y | [2MC+1,3MC+1) Wy_j'd | [3MC+1] y'd |
+// [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | [4MC+3] f1, nbreak, nunb, nunbnz | min [4MC+7] bkmin
+template <typename T>
+void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                        const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
+                        int32_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail);
 
 // ---- built-in objectives -------------------------------------------------------
 // res sum [0] = f contribution of this rank

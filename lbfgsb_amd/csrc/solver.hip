@@ -474,26 +474,40 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   // Generalized Cauchy point, reference :1157-1532.  p,c,wbp,v = wa8m slots.
+  // results of the n-loop of cauchy when it was fused into the matupd pass
+  struct ScanOut {
+    bool ready = false;
+    double p[2 * lbk::MAXM];
+    double f1 = 0, nbreak = 0, nunb = 0, nunbnz = 0, bkmin = 0;
+  } scan;
+
   int cauchy(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
              int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
     double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
     if (sbgnrm <= 0.0) {  // :1245-1249
+      scan.ready = false;
       HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
       return 0;
     }
     const int col2 = 2 * col;
     const int MC = col ? lbk::maxc_for(col) : 0;
-    lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
-    CHK(fetch(2 * MC + 4, 1, 0));
-    for (int j = 0; j < col; ++j) {
-      p[j] = h_res[j];
-      p[col + j] = h_res[MC + j];
+    if (!scan.ready) {
+      lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
+      CHK(fetch(2 * MC + 4, 1, 0));
+      for (int j = 0; j < col; ++j) {
+        scan.p[j] = h_res[j];
+        scan.p[col + j] = h_res[MC + j];
+      }
+      scan.f1 = h_res[2 * MC], scan.nbreak = h_res[2 * MC + 1], scan.nunb = h_res[2 * MC + 2];
+      scan.nunbnz = h_res[2 * MC + 3], scan.bkmin = h_res[2 * MC + 4];
     }
-    double f1 = h_res[2 * MC];
-    const int64_t nbreak = (int64_t)h_res[2 * MC + 1];
-    const int64_t nunb = (int64_t)h_res[2 * MC + 2];
-    const bool bnded = h_res[2 * MC + 3] == 0.0;
-    const double bkmin = h_res[2 * MC + 4];
+    scan.ready = false;
+    for (int j = 0; j < col2; ++j) p[j] = scan.p[j];
+    double f1 = scan.f1;
+    const int64_t nbreak = (int64_t)scan.nbreak;
+    const int64_t nunb = (int64_t)scan.nunb;
+    const bool bnded = scan.nunbnz == 0.0;
+    const double bkmin = scan.bkmin;
     if (theta != 1.0)
       for (int j = 0; j < col; ++j) p[col + j] = theta * p[col + j];  // :1337
 
@@ -1087,10 +1101,30 @@ class Solver final : public lbfgsb_hip_ctx {
         itail = itail % m + 1;
         head = head % m + 1;
       }
-      lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
       const int MCo = lbk::maxc_for(col - 1);
-      CHK(fetch(2 * MCo + 1, 0, 0));
-      const double rr = h_res[2 * MCo];
+      double rr;
+      if (cnstnd) {
+        // the next loop trip starts with cauchy: do its n-loop in the same pass over W
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, W(), head, col,
+                                   itail);
+        CHK(fetch(4 * MCo + 7, 1, 0));
+        rr = h_res[2 * MCo];
+        const int nold = col - 1;
+        for (int j = 0; j < nold; ++j) {
+          scan.p[j] = h_res[2 * MCo + 1 + j];
+          scan.p[col + j] = h_res[3 * MCo + 2 + j];
+        }
+        scan.p[col - 1] = h_res[3 * MCo + 1];
+        scan.p[2 * col - 1] = h_res[4 * MCo + 2];
+        scan.f1 = h_res[4 * MCo + 3], scan.nbreak = h_res[4 * MCo + 4];
+        scan.nunb = h_res[4 * MCo + 5], scan.nunbnz = h_res[4 * MCo + 6];
+        scan.bkmin = h_res[4 * MCo + 7];
+        scan.ready = true;
+      } else {
+        lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
+        CHK(fetch(2 * MCo + 1, 0, 0));
+        rr = h_res[2 * MCo];
+      }
       theta = rr / dr;
       lbh::Mat SY{sy.data(), m}, SS{ss.data(), m};
       if (iupdat > m) {  // :2324-2330
