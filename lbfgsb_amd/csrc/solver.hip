@@ -454,7 +454,25 @@ class Solver final : public lbfgsb_hip_ctx {
     auto less = [](const MRec &a, const MRec &b) {
       return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
     };
-    if (nranks > 1) std::sort(pv.M.begin(), pv.M.end(), less);
+    if (nranks > 1) {
+      // every rank's run is already sorted: merge the runs pairwise (O(N log ranks))
+      std::vector<size_t> cut;
+      cut.push_back(0);
+      for (size_t k = 1; k < pv.M.size(); ++k)
+        if (pv.M[k].rank != pv.M[k - 1].rank) cut.push_back(k);
+      cut.push_back(pv.M.size());
+      while (cut.size() > 2) {
+        std::vector<size_t> nxt;
+        for (size_t k = 0; k + 2 < cut.size(); k += 2) {
+          std::inplace_merge(pv.M.begin() + cut[k], pv.M.begin() + cut[k + 1],
+                             pv.M.begin() + cut[k + 2], less);
+          nxt.push_back(cut[k]);
+        }
+        if (cut.size() % 2 == 0) nxt.push_back(cut[cut.size() - 2]);
+        nxt.push_back(pv.M.size());
+        cut.swap(nxt);
+      }
+    }
     pv.safe_end = pv.M.size();
     if (pv.more_anywhere) {
       size_t k = 0;
