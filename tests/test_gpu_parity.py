@@ -392,3 +392,45 @@ def test_full_size_quadratic_n1e6_against_oracle(env):
         assert a[:4] == b[:4], (a, b)
         assert a[4] == pytest.approx(b[4], rel=1e-9)
     assert st["cauchy_fullsorts"] >= 1
+
+
+def test_full_size_rosenbrock_n1e6_against_oracle(env):
+    """BASELINE.json configs[2] shape (extended Rosenbrock with box bounds, driver3 formulas) at
+    n = 1e6, m = 10, on-device objective.  Iteration 1 fixes 999,999 variables in two massive
+    TIE groups of breakpoints (x0 is uniform): nseg = 1,000,000, nfree = 1.  Anchors measured on
+    the reference: it1 f = 9.9898699732555956E+07 (nfg 5),
+    it2 f = 6.0004592590896189E+06, it10 f = 2.8578393725511319E+01."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 1_000_000, 10, 14
+    p = po.problem_rosenbrock(n, m, 0.0, 0.0)
+    rows_o = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                int(s.isave[37]), float(s.f[0]))) if s.task_s.startswith("NEW_X") else None)
+    assert rows_o[0][:4] == (1, 5, 1000000, 1)
+    assert rows_o[0][4] == pytest.approx(9.9898699732555956e07, rel=1e-13)
+    assert rows_o[1][4] == pytest.approx(6.0004592590896189e06, rel=1e-13)
+    assert rows_o[9][4] == pytest.approx(2.8578393725511319e01, rel=1e-12)
+    sol = la.DeviceSolver(n, m)
+    x = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+    g = torch.zeros_like(x)
+    l = torch.from_numpy(p.l).cuda()
+    u = torch.from_numpy(p.u).cuda()
+    nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    rows_g = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(1, x, g)
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
+                           int(sol.isave[37]), float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    sol.close()
+    assert len(rows_g) == iters
+    for a, b in zip(rows_g, rows_o):
+        assert a[:4] == b[:4], (a, b)                 # iter, nfg, nseg, nfree
+        assert a[4] == pytest.approx(b[4], rel=1e-8)
