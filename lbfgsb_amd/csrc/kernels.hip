@@ -1118,6 +1118,71 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
   q.launches++;
 }
 
+// cmprlb fused with the first matvec of subsm (:2742-2754): r_k depends only on row k, so
+// W'r is accumulated in the same pass that computes and stores r (one pass over W instead
+// of two).  Per element the arithmetic is exactly cmprlb_kernel's.
+// slots: [0,MC) Wy'r, [MC,2MC) Ws'r
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
+    const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
+    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, double *part) {
+  double acc[2 * MC];
+#pragma unroll
+  for (int k = 0; k < 2 * MC; ++k) acc[k] = 0.0;
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
+    int iw[W];
+    ld<W>(g + i, gv);
+    if (!plain) {
+      ld<W>(x + i, xv);
+      ld<W>(z + i, zv);
+      ldi<W>(iwhere + i, iw);
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i;
+      ld<W>(wy + off, a[j]);
+      ld<W>(ws + off, b[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
+        rv[k] = -gv[k];
+      } else {
+        double rr = -theta * (zv[k] - xv[k]) - gv[k];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+          if (j < col) rr = rr + a[j][k] * cf.a[j] + b[j][k] * cf.a[MAXM + j];
+        }
+        rv[k] = iw[k] <= 0 ? rr : 0.0;
+      }
+    }
+    st<W>(r + i, rv);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += a[j][k] * rv[k];
+        acc[MC + j] += b[j][k] * rv[k];
+      }
+    }
+  });
+  block_reduce_store<2 * MC>(acc, 2 * MC, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
+                       const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
+                       const Coef &a, int plain) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+                                        q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m, head,
+                                        col, theta, a, plain, q.d_part));
+  q.launches++;
+  launch_finalize(q, gr, 2 * maxc_for(col), 0, 0);
+}
+
 // =========================== subsm (:2676-2885) ==============================
 template <typename T, int MC>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
@@ -1660,6 +1725,9 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
   template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const int32_t *);      \
   template void launch_cmprlb<T>(Queue &, int64_t, const T *, const T *, const T *, T *,           \
                                  const int32_t *, WStore<T>, int, int, double, const Coef &, int); \
+  template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, const T *, T *,       \
+                                     const int32_t *, WStore<T>, int, int, double, const Coef &,  \
+                                     int);                                                          \
   template void launch_subsm_update<T>(Queue &, int64_t, T *, T *, T *, const T *, const T *,      \
                                        const int32_t *, const int32_t *, const T *, const T *,     \
                                        WStore<T>, int, int, double, const Coef &);                 \

@@ -135,6 +135,13 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
                    const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
                    const Coef &a, int plain);
 
+// cmprlb + the first matvec of subsm (W'r, :2742-2754) in one pass over W.
+// res sum-slots (MC = maxc_for(col)): [0..col) Wy'r, [MC..MC+col) Ws'r
+template <typename T>
+void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
+                       const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
+                       const Coef &a, int plain);
+
 // ---- subsm (ref :2676-2885) --------------------------------------------------
 // update (:2770-2816 + :2824-2827): d = (r + W wv..)/theta on free rows, xp = xcp,
 // projected step into z.  res sum-slots: [0] = #bound hits (iword), [1] = dd_p

@@ -718,10 +718,9 @@ class Solver final : public lbfgsb_hip_ctx {
         cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
       }
     }
-    lbk::launch_cmprlb<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0);
-    // subsm :2742-2766
+    // r of cmprlb and wv = W'Zr of subsm (:2742-2754) in one pass over W
     const int MC = lbk::maxc_for(col);
-    lbk::launch_wtv<T>(q, n, W(), head, col, r);
+    lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0);
     CHK(fetch(2 * MC, 0, 0));
     double *wv = &wa8m[0];
     for (int i = 0; i < col; ++i) {
