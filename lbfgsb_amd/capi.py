@@ -32,6 +32,7 @@ PROTOTYPES = {
     "lbfgsb_hip_set_w": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_wtv_launch_only": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "lbfgsb_hip_wtv_time": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "lbfgsb_hip_kernel_time": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "lbfgsb_hip_sync": (C.c_int, [_vp]),
     "lbfgsb_hip_objective": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lbfgsb_hip_stats": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -115,6 +115,7 @@ struct lbfgsb_hip_ctx {
                        const void *g, double *out) = 0;
   virtual int k_wtv(const void *v, int col, int head, double *out, bool launch_only) = 0;
   virtual int k_set_w(const void *hws, const void *hwy) = 0;
+  virtual int k_launch(int which, const void *x, const void *g, int col, int head) = 0;
   virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
   virtual int sync() = 0;
 
@@ -1269,6 +1270,19 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     return 0;
   }
+  int k_launch(int which, const void *x, const void *g, int col, int head) override {
+    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "bad col/head");
+    lbk::Coef cf;
+    std::memset(&cf, 0, sizeof cf);
+    if (which == 0)
+      lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, z, r, iwhere, W(), head, col, 1.0,
+                                cf, 0);
+    else if (which == 1)
+      lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
+    else
+      return fail(LBFGSB_E_ARG, "unknown kernel");
+    return 0;
+  }
   int k_set_w(const void *hws, const void *hwy) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), hws, (size_t)n * sizeof(T),
@@ -1425,6 +1439,25 @@ int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, i
   for (int k = 0; k < 3; ++k) CHK(ctx->k_wtv(v, col, head, nullptr, true));
   HIPCHK(hipEventRecord(e0, ctx->q.stream));
   for (int k = 0; k < reps; ++k) CHK(ctx->k_wtv(v, col, head, nullptr, true));
+  HIPCHK(hipEventRecord(e1, ctx->q.stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *h_ms_per_launch = (double)ms / reps;
+  return 0;
+}
+int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const void *g, int col,
+                           int head, int reps, double *h_ms_per_launch) {
+  if (!ctx || reps < 1) return fail(LBFGSB_E_ARG, "kernel_time: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int k = 0; k < 2; ++k) CHK(ctx->k_launch(which, x, g, col, head));
+  HIPCHK(hipEventRecord(e0, ctx->q.stream));
+  for (int k = 0; k < reps; ++k) CHK(ctx->k_launch(which, x, g, col, head));
   HIPCHK(hipEventRecord(e1, ctx->q.stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -191,6 +191,12 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_wtv_time(self.h, _p(v), col, head, reps, _p(out)))
         return float(out[0])
 
+    def kernel_time(self, which: int, x, g, col: int, head: int = 1, reps: int = 20) -> float:
+        """average ms per launch of an in-iteration kernel: 0 = cmprlb_wtv, 1 = formk gram"""
+        out = np.zeros(1)
+        check(self.lib.lbfgsb_hip_kernel_time(self.h, which, _p(x), _p(g), col, head, reps, _p(out)))
+        return float(out[0])
+
     def sync(self):
         check(self.lib.lbfgsb_hip_sync(self.h))
 
