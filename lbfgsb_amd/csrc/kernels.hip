@@ -599,23 +599,56 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
 // =========================== freev (:1980-2059) ==============================
 __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
                                                             const int32_t *__restrict__ iwhere,
-                                                            int8_t *wasfree, double *part) {
+                                                            int8_t *wasfree, double *part,
+                                                            uint32_t *chg, uint32_t chg_cap,
+                                                            uint32_t *chg_count) {
+  // rows whose status changed are collected per workgroup in LDS and appended to the global
+  // list with ONE global atomic per flush (a same-address atomic per row would serialise:
+  // 1e5 changes x ~12 ns)
+  constexpr int LCAP = 2048;
+  __shared__ uint32_t lbuf[LCAP];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
   double acc[3] = {0, 0, 0};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const bool fr = iwhere[i] <= 0;
-    const bool was = wasfree[i] != 0;
-    if (fr) acc[0] += 1.0;
-    if (fr && !was) acc[1] += 1.0;
-    if (!fr && was) acc[2] += 1.0;
-    wasfree[i] = fr ? 1 : 0;
+  const int64_t ntrip = (n + stride - 1) / stride;  // uniform trip count (barriers inside)
+  for (int64_t trip = 0; trip < ntrip; ++trip) {
+    const int64_t i = trip * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+      const bool fr = iwhere[i] <= 0;
+      const bool was = wasfree[i] != 0;
+      if (fr) acc[0] += 1.0;
+      if (fr && !was) acc[1] += 1.0;
+      if (!fr && was) acc[2] += 1.0;
+      if (chg && fr != was) {
+        const uint32_t pos = atomicAdd(&lcount, 1u);  // LDS atomic; pos < LCAP by the flush rule
+        lbuf[pos] = (uint32_t)i | (fr ? 0u : 0x80000000u);
+      }
+      wasfree[i] = fr ? 1 : 0;
+    }
+    if (chg) {
+      __syncthreads();
+      const uint32_t cnt = lcount;
+      if (cnt > LCAP - BLOCK || trip == ntrip - 1) {  // uniform: flush
+        if (threadIdx.x == 0) gbase = cnt ? atomicAdd(chg_count, cnt) : 0u;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cnt; k += BLOCK)
+          if (gbase + k < chg_cap) chg[gbase + k] = lbuf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) lcount = 0;
+        __syncthreads();
+      }
+    }
   }
   block_reduce_store<3>(acc, 3, 0, 0, part, MAX_BLOCKS);
 }
-void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree) {
+void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree, uint32_t *chg,
+                        uint32_t chg_cap, uint32_t *chg_count) {
   const int gr = grid_for(n, 1);
+  if (chg) (void)hipMemsetAsync(chg_count, 0, sizeof(uint32_t), q.stream);
   hipLaunchKernelGGL(freev_count_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
-                     q.d_part);
+                     q.d_part, chg, chg_cap, chg_count);
   q.launches++;
   launch_finalize(q, gr, 3, 0, 0);
 }
@@ -1121,15 +1154,19 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
 // cmprlb fused with the first matvec of subsm (:2742-2754): r_k depends only on row k, so
 // W'r is accumulated in the same pass that computes and stores r (one pass over W instead
 // of two).  Per element the arithmetic is exactly cmprlb_kernel's.
-// slots: [0,MC) Wy'r, [MC,2MC) Ws'r
-template <typename T, int MC>
+// NEWROW: the same pass also yields the new row/column of formk's WN1 (:1756-1793) for the
+// pair just stored (logical column col-1): with y = Wy_new, s = Ws_new,
+//   t1_j = sum_free y Wy_j, t2_j = sum_act s Ws_j, t3_j = sum_act s Wy_j, t4_j = sum_free Ws_j y.
+// slots: [0,MC) Wy'r | [MC,2MC) Ws'r | NEWROW: [2MC,3MC) t1 | [3MC,4MC) t2 | [4MC,5MC) t3 | [5MC,6MC) t4
+template <typename T, int MC, bool NEWROW>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
     const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
     int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, double *part) {
-  double acc[2 * MC];
+  constexpr int NA = NEWROW ? 6 * MC : 2 * MC;
+  double acc[NA];
 #pragma unroll
-  for (int k = 0; k < 2 * MC; ++k) acc[k] = 0.0;
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
@@ -1139,6 +1176,9 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
       ld<W>(x + i, xv);
       ld<W>(z + i, zv);
       ldi<W>(iwhere + i, iw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
@@ -1168,19 +1208,133 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
         acc[MC + j] += b[j][k] * rv[k];
       }
     }
+    if constexpr (NEWROW) {
+      double yf[W], sa[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        double yn = 0.0, sn = 0.0;
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+          if (j == col - 1) {
+            yn = a[j][k];
+            sn = b[j][k];
+          }
+        yf[k] = iw[k] <= 0 ? yn : 0.0;  // free rows
+        sa[k] = iw[k] <= 0 ? 0.0 : sn;  // active rows
+      }
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          acc[2 * MC + j] += yf[k] * a[j][k];  // temp1 (:1764)
+          acc[3 * MC + j] += sa[k] * b[j][k];  // temp2 (:1769)
+          acc[4 * MC + j] += sa[k] * a[j][k];  // temp3 (:1770)
+          acc[5 * MC + j] += b[j][k] * yf[k];  // temp3 of the new column (:1789)
+        }
+      }
+    }
   });
-  block_reduce_store<2 * MC>(acc, 2 * MC, 0, 0, part, MAX_BLOCKS);
+  block_reduce_store<NA>(acc, NA, 0, 0, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
                        const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
-                       const Coef &a, int plain) {
+                       const Coef &a, int plain, int newrow) {
   const int gr = grid_for(n, VecOf<T>::V);
-  DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
-                                        q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m, head,
-                                        col, theta, a, plain, q.d_part));
+  if (newrow) {
+    DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true>), dim3(gr), dim3(BLOCK), 0,
+                                          q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m,
+                                          head, col, theta, a, plain, q.d_part));
+  } else {
+    DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false>), dim3(gr), dim3(BLOCK), 0,
+                                          q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m,
+                                          head, col, theta, a, plain, q.d_part));
+  }
   q.launches++;
-  launch_finalize(q, gr, 2 * maxc_for(col), 0, 0);
+  launch_finalize(q, gr, (newrow ? 6 : 2) * maxc_for(col), 0, 0);
+}
+
+// formk's patches for variables that changed status (:1801-1851): signed Gram over the
+// listed rows only, sign +1 for rows that entered the free set, -1 for rows that left it.
+// chg[k] = local row | (left ? 0x80000000 : 0).  Output layout = the Gram's (E entries for
+// `upcl` columns): P_yy (i>=j), P_ss (i>=j), P_sy (all i,j).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void formk_patch_kernel(const uint32_t *__restrict__ chg,
+                                                            uint32_t cnt,
+                                                            const T *__restrict__ ws,
+                                                            const T *__restrict__ wy, int64_t ldw,
+                                                            int m, int head, int upcl,
+                                                            double *gpart) {
+  constexpr int R = 64, RS = 2 * MAXM + 1;
+  __shared__ double tile[R * RS];
+  __shared__ double sgn[R];
+  const int tri = upcl * (upcl + 1) / 2;
+  const int E = 2 * upcl * upcl + upcl;
+  constexpr int NE = (2 * MAXM * MAXM + MAXM + BLOCK - 1) / BLOCK;
+  int ca[NE], cb[NE];
+  double acc[NE];
+#pragma unroll
+  for (int s = 0; s < NE; ++s) {
+    const int e = threadIdx.x + s * BLOCK;
+    acc[s] = 0.0;
+    ca[s] = cb[s] = 0;
+    if (e < E) {
+      if (e < 2 * tri) {
+        const int ee = e < tri ? e : e - tri;
+        int i = (int)((sqrt(8.0 * ee + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > ee) --i;
+        while ((i + 1) * (i + 2) / 2 <= ee) ++i;
+        const int j = ee - i * (i + 1) / 2;
+        ca[s] = (e < tri ? 0 : upcl) + i;
+        cb[s] = (e < tri ? 0 : upcl) + j;
+      } else {
+        const int ee = e - 2 * tri;
+        ca[s] = upcl + ee / upcl;  // Ws_i
+        cb[s] = ee % upcl;         // Wy_j
+      }
+    }
+  }
+  const uint32_t ntile = (cnt + R - 1) / R;
+  for (uint32_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+    __syncthreads();
+    for (int qd = threadIdx.x; qd < 2 * upcl * R; qd += BLOCK) {
+      const int c = qd / R, rr = qd % R;
+      const uint32_t k = t * R + rr;
+      double v = 0.0;
+      if (k < cnt) {
+        const int64_t row = chg[k] & 0x7FFFFFFFu;
+        const int jj = c < upcl ? c : c - upcl;
+        const int64_t off = (int64_t)((head - 1 + jj) % m) * ldw + row;
+        v = c < upcl ? (double)wy[off] : (double)ws[off];
+      }
+      tile[rr * RS + c] = v;
+    }
+    for (int rr = threadIdx.x; rr < R; rr += BLOCK) {
+      const uint32_t k = t * R + rr;
+      sgn[rr] = k < cnt ? ((chg[k] & 0x80000000u) ? -1.0 : 1.0) : 0.0;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < R; ++rr) {
+      const double sg = sgn[rr];
+#pragma unroll
+      for (int s = 0; s < NE; ++s) acc[s] += sg * tile[rr * RS + ca[s]] * tile[rr * RS + cb[s]];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NE; ++s) {
+    const int e = threadIdx.x + s * BLOCK;
+    if (e < E) gpart[(size_t)e * GRAM_BLOCKS + blockIdx.x] = acc[s];
+  }
+}
+template <typename T>
+void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w, int head, int upcl) {
+  int gr = (int)((cnt + 63) / 64);
+  if (gr < 1) gr = 1;
+  if (gr > 256) gr = 256;
+  hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cnt, w.ws, w.wy,
+                     w.ld, w.m, head, upcl, q.d_gpart);
+  q.launches++;
+  finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * upcl * upcl + upcl, 0, 0);
 }
 
 // =========================== subsm (:2676-2885) ==============================
@@ -1727,7 +1881,8 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
                                  const int32_t *, WStore<T>, int, int, double, const Coef &, int); \
   template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, const T *, T *,       \
                                      const int32_t *, WStore<T>, int, int, double, const Coef &,  \
-                                     int);                                                          \
+                                     int, int);                                                     \
+  template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int);    \
   template void launch_subsm_update<T>(Queue &, int64_t, T *, T *, T *, const T *, const T *,      \
                                        const int32_t *, const int32_t *, const T *, const T *,     \
                                        WStore<T>, int, int, double, const Coef &);                 \

@@ -14,7 +14,7 @@ constexpr int BLOCK = 256;        // 4 wave64 per workgroup
 constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 workgroups, grid-stride beyond that
 constexpr int GRAM_BLOCKS = 1024;
 constexpr int MAXM = 32;          // LBFGSB_MAX_M
-constexpr int RES_MAX = 4 * MAXM + 32;  // >= 4*MC + 8 slots of the fused update+scan
+constexpr int RES_MAX = 6 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 4*MC+8 of update_scan
 
 // launch queue + reduction scratch owned by the context
 struct Queue {
@@ -114,7 +114,10 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
 
 // ---- freev (ref :1980-2059) -------------------------------------------------
 // res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave; updates wasfree.
-void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree);
+// chg (optional): rows whose free/active status changed are appended (unordered) as
+// row | 0x80000000 if it LEFT the free set; *chg_count = number found (may exceed chg_cap).
+void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree,
+                        uint32_t *chg, uint32_t chg_cap, uint32_t *chg_count);
 // mirror of Index / Indx2 (1-based global numbers, reference ordering).  prev = wasfree
 // BEFORE launch_freev_count of this iteration (copy kept by the solver).
 void launch_freev_lists(Queue &q, int64_t n, const int32_t *iwhere, const int8_t *prevfree,
@@ -136,11 +139,18 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
                    const Coef &a, int plain);
 
 // cmprlb + the first matvec of subsm (W'r, :2742-2754) in one pass over W.
-// res sum-slots (MC = maxc_for(col)): [0..col) Wy'r, [MC..MC+col) Ws'r
+// res sum-slots (MC = maxc_for(col)): [0..col) Wy'r, [MC..MC+col) Ws'r; with newrow also the
+// new row/column of formk's WN1 for the pair in logical column col-1 (ref :1756-1793):
+// [2MC..) sum_free Wy_new Wy_j, [3MC..) sum_act Ws_new Ws_j, [4MC..) sum_act Ws_new Wy_j,
+// [5MC..) sum_free Ws_j Wy_new
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
                        const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
-                       const Coef &a, int plain);
+                       const Coef &a, int plain, int newrow);
+// formk patches (ref :1801-1851): signed Gram over the listed rows (+ entered, - left the free
+// set) for the first upcl logical columns; res layout as launch_formk_gram with col = upcl.
+template <typename T>
+void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w, int head, int upcl);
 
 // ---- subsm (ref :2676-2885) --------------------------------------------------
 // update (:2770-2816 + :2824-2827): d = (r + W wv..)/theta on free rows, xp = xcp,

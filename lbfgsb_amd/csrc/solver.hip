@@ -150,6 +150,10 @@ class Solver final : public lbfgsb_hip_ctx {
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   uint32_t *d_count = nullptr, *h_count = nullptr;
+  // rows whose free/active status changed in the last freev (formk patches)
+  static constexpr uint32_t CHG_CAP = 1u << 18;
+  uint32_t *d_chg = nullptr;
+  uint32_t chg_local = 0;
   double *d_msg = nullptr, *d_msg_all = nullptr, *h_msg_all = nullptr, *h_msg_loc = nullptr;
   double *h_hdr = nullptr;
   size_t msg_len = 0;  // doubles per rank message
@@ -181,7 +185,7 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
-        F(sort_tmp), F(d_count), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart);
+        F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
@@ -245,6 +249,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // cauchy selection scratch (window mode); the full-sort buffers grow on demand
     CHK(ensure_sel(SEL_CAP));
     HIPCHK(hipMalloc(&d_count, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_chg, (size_t)CHG_CAP * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc(&h_count, sizeof(uint32_t)));
     msg_len = 2 + (size_t)CHUNK_MAX * (2 * m + 4);
     HIPCHK(hipMalloc(&d_msg, msg_len * sizeof(double)));
@@ -657,12 +662,13 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   // ==================================================================== formk
-  int formk(int col, int head, double theta, int &info) {
+  // WN1 from scratch: one masked Gram pass over W (any col; also the fallback when too many
+  // variables changed status for the sparse patches)
+  int formk_scratch(int col, int head) {
     lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     const int E = 2 * col * col + col;
     CHK(fetch(E, 0, 0));
-    const int m2 = 2 * m;
-    lbh::Mat WN{wn.data(), m2}, WN1{snd.data(), m2}, SY{sy.data(), m};
+    lbh::Mat WN1{snd.data(), 2 * m};
     const int tri = col * (col + 1) / 2;
     for (int i = 0; i < col; ++i)
       for (int j = 0; j <= i; ++j) {
@@ -671,7 +677,69 @@ class Solver final : public lbfgsb_hip_ctx {
       }
     for (int i = 0; i < col; ++i)
       for (int j = 0; j < col; ++j) WN1(m + i, j) = h_res[2 * tri + i * col + j];  // L_a + R_z
-    // upper triangle of WN (:1856-1873)
+    return 0;
+  }
+
+  // WN1 kept incrementally exactly as the reference does (:1735-1851): shift, new row and
+  // column from `nr` (the four sum vectors that rode along in the cmprlb_wtv pass), and
+  // patches for the variables that entered / left the free set (sparse signed Gram).
+  int formk_incremental(int col, int head, bool updatd, int iupdat, const double *nr, int MCnr) {
+    const int m2 = 2 * m;
+    lbh::Mat WN1{snd.data(), m2};
+    const int upcl = updatd ? col - 1 : col;
+    const int64_t nchg = nenter_g + (nglob + 1 - ileave_g);
+    bool patched = false;
+    std::vector<double> P;
+    if (nchg > 0 && upcl > 0) {
+      if (nchg > (int64_t)CHG_CAP) return formk_scratch(col, head);  // whole Gram is cheaper
+      lbk::launch_formk_patch<T>(q, d_chg, std::min<uint32_t>(chg_local, CHG_CAP), W(), head, upcl);
+      const int E = 2 * upcl * upcl + upcl;
+      CHK(fetch(E, 0, 0));
+      P.assign(h_res, h_res + E);
+      patched = true;
+    }
+    if (updatd) {
+      if (iupdat > m) {  // shift old part of WN1 (:1736-1744)
+        for (int jy = 0; jy < m - 1; ++jy) {
+          const int js = m + jy;
+          for (int i = 0; i < m - 1 - jy; ++i) {
+            WN1(jy + i, jy) = WN1(jy + 1 + i, jy + 1);
+            WN1(js + i, js) = WN1(js + 1 + i, js + 1);
+          }
+          for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
+        }
+      }
+      const int nw = col - 1;  // new pair = logical column col-1 (:1746-1793)
+      for (int jy = 0; jy < col; ++jy) {
+        WN1(nw, jy) = nr[0 * MCnr + jy];          // Y'ZZ'Y row
+        WN1(m + nw, m + jy) = nr[1 * MCnr + jy];  // S'AA'S row
+        WN1(m + nw, jy) = nr[2 * MCnr + jy];      // L_a row
+      }
+      for (int i = 0; i < col; ++i) WN1(m + i, nw) = nr[3 * MCnr + i];  // R_z column
+    }
+    if (patched) {  // :1801-1851 (P = sums over entering rows - sums over leaving rows)
+      const int tri = upcl * (upcl + 1) / 2;
+      for (int iy = 0; iy < upcl; ++iy)
+        for (int jy = 0; jy <= iy; ++jy) {
+          WN1(iy, jy) = WN1(iy, jy) + P[iy * (iy + 1) / 2 + jy];
+          WN1(m + iy, m + jy) = WN1(m + iy, m + jy) - P[tri + iy * (iy + 1) / 2 + jy];
+        }
+      for (int is = 0; is < upcl; ++is)
+        for (int jy = 0; jy < upcl; ++jy) {
+          const double psy = P[2 * tri + is * upcl + jy];
+          if (is <= jy)
+            WN1(m + is, jy) = WN1(m + is, jy) + psy;
+          else
+            WN1(m + is, jy) = WN1(m + is, jy) - psy;
+        }
+    }
+    return 0;
+  }
+
+  // upper triangle of WN from WN1 and the two Cholesky factorisations (:1856-1906)
+  void formk_factor(int col, double theta, int &info) {
+    const int m2 = 2 * m;
+    lbh::Mat WN{wn.data(), m2}, WN1{snd.data(), m2}, SY{sy.data(), m};
     for (int iy = 0; iy < col; ++iy) {
       const int is = col + iy, is1 = m + iy;
       for (int jy = 0; jy <= iy; ++jy) {
@@ -685,7 +753,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     if (lbh::dpofa(WN, col) != 0) {  // :1880-1884
       info = -1;
-      return 0;
+      return;
     }
     const int col2 = 2 * col;
     for (int js = col; js < col2; ++js) (void)lbh::dtrsl(WN, col, &WN(0, js), 11);
@@ -695,15 +763,23 @@ class Solver final : public lbfgsb_hip_ctx {
     lbh::Mat WN22{&WN(col, col), m2};
     if (lbh::dpofa(WN22, col) != 0) {  // :1902-1906
       info = -2;
-      return 0;
+      return;
     }
     info = 0;
+  }
+
+  int formk(int col, int head, double theta, int &info) {
+    CHK(formk_scratch(col, head));
+    formk_factor(col, theta, info);
     return 0;
   }
 
   // ========================================================== cmprlb + subsm
+  // do_formk: formk is pending for this iteration and col <= 10: its new row/column sums ride
+  // along in the cmprlb_wtv pass and the status changes are patched sparsely.
   int subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
-               int col, int head, bool cnstnd, int &iword, int &info) {
+               int col, int head, bool cnstnd, int &iword, int &info, bool do_formk, bool updatd,
+               int iupdat) {
     // cmprlb :1548-1586
     lbk::Coef cf;
     std::memset(&cf, 0, sizeof cf);
@@ -711,6 +787,8 @@ class Solver final : public lbfgsb_hip_ctx {
     if (!plain) {
       int rc = lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]);
       if (rc != 0) {
+        // (the reference would run formk first, :663; either failure refreshes the memory,
+        //  after which WN1 is rebuilt from new rows only)
         info = -8;
         return 0;
       }
@@ -721,12 +799,21 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     // r of cmprlb and wv = W'Zr of subsm (:2742-2754) in one pass over W
     const int MC = lbk::maxc_for(col);
-    lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0);
-    CHK(fetch(2 * MC, 0, 0));
+    const bool newrow = do_formk && updatd;
+    lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0,
+                              newrow ? 1 : 0);
+    CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
     double *wv = &wa8m[0];
     for (int i = 0; i < col; ++i) {
       wv[i] = h_res[i];
       wv[col + i] = theta * h_res[MC + i];
+    }
+    if (do_formk) {
+      double nr[4 * lbk::MAXM];
+      if (newrow) std::memcpy(nr, h_res + 2 * MC, sizeof(double) * 4 * MC);
+      CHK(formk_incremental(col, head, updatd, iupdat, nr, MC));
+      formk_factor(col, theta, info);
+      if (info != 0) return 0;
     }
     lbh::Mat WN{wn.data(), 2 * m};
     const int col2 = 2 * col;
@@ -940,8 +1027,12 @@ class Solver final : public lbfgsb_hip_ctx {
           // freev :1980-2059 (counts; the lists only when mirroring Index)
           if (prevfree)
             HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
-          lbk::launch_freev_count(q, n, iwhere, wasfree);
+          const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
+          lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
+          if (track)
+            HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
           CHK(fetch(3, 0, 0));
+          chg_local = track ? *h_count : 0;
           cachyt += now_s() - cpu1;
           nintol += nseg;
           nfree_g = (int64_t)h_res[0];
@@ -962,7 +1053,8 @@ class Solver final : public lbfgsb_hip_ctx {
           // skip the subspace minimization :648-651
         } else {
           cpu1 = now_s();
-          if (wrk) CHK(formk(col, head, theta, info));
+          const bool incr = wrk && col <= 10;  // incremental WN1, fused into the cmprlb pass
+          if (wrk && !incr) CHK(formk(col, head, theta, info));
           if (info != 0) {  // :666-682
             if (ipr >= 1)
               std::fprintf(rep.out,
@@ -972,7 +1064,16 @@ class Solver final : public lbfgsb_hip_ctx {
             sbtime += now_s() - cpu1;
             continue;
           }
-          CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info));
+          CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat));
+          if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
+            if (ipr >= 1)
+              std::fprintf(rep.out,
+                           "\n Nonpositive definiteness in Cholesky factorization in formk;\n   "
+                           "refresh the lbfgs memory and restart the iteration.\n");
+            refresh();
+            sbtime += now_s() - cpu1;
+            continue;
+          }
           if (info != 0) {  // :694-710
             if (ipr >= 1)
               std::fprintf(rep.out,
@@ -1274,9 +1375,9 @@ class Solver final : public lbfgsb_hip_ctx {
     if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "bad col/head");
     lbk::Coef cf;
     std::memset(&cf, 0, sizeof cf);
-    if (which == 0)
+    if (which == 0 || which == 2)
       lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, z, r, iwhere, W(), head, col, 1.0,
-                                cf, 0);
+                                cf, 0, which == 2 ? 1 : 0);
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     else

@@ -75,6 +75,17 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True):
         a = np.triu(seg(got, "wt").reshape(m, m, order="F")[:col, :col])
         b = np.triu(seg(exp, "wt").reshape(m, m, order="F")[:col, :col])
         nrm_close(a, b, 1e-7, "wt")
+        # formk state: WN1 (kept incrementally, reference :1735-1851) and the factored WN
+        ga = seg(got, "snd").reshape(2 * m, 2 * m, order="F")
+        ea = seg(exp, "snd").reshape(2 * m, 2 * m, order="F")
+        scale = float(np.max(np.abs(ea))) * 1e-6
+        nrm_close(np.tril(ga[:col, :col]), np.tril(ea[:col, :col]), 1e-8, "wn1 Y'ZZ'Y", floor=scale)
+        nrm_close(np.tril(ga[m:m + col, m:m + col]), np.tril(ea[m:m + col, m:m + col]), 1e-8,
+                  "wn1 S'AA'S", floor=scale)
+        nrm_close(ga[m:m + col, :col], ea[m:m + col, :col], 1e-8, "wn1 L_a+R_z", floor=scale)
+        gw = seg(got, "wn").reshape(2 * m, 2 * m, order="F")[:2 * col, :2 * col]
+        ew = seg(exp, "wn").reshape(2 * m, 2 * m, order="F")[:2 * col, :2 * col]
+        nrm_close(np.triu(gw), np.triu(ew), 1e-6, "wn")
     iw_g = got.iwa[n:2 * n]
     iw_e = exp.iwa[n:2 * n]
     assert np.array_equal(iw_g, iw_e), "iwhere differs at %s" % np.nonzero(iw_g != iw_e)[0][:8]
