@@ -1338,14 +1338,19 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 }
 
 // =========================== subsm (:2676-2885) ==============================
-template <typename T, int MC>
+// LS (fused line-search set-up): the projected point z is final unless the rare backtracking
+// branch (:2830-2879) is taken, so the same pass also does what mainlb :720-722 and the first
+// call of lnsrlb (:2196-2236) do next: d = z - x, t = x, r = g, dtd = d'd, the stpmx ratios;
+// g'd is dd_p itself.  The Newton direction then goes to `ndir` (scratch) instead of r.
+// res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
+template <typename T, int MC, bool LS>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, T *z, T *r, T *xp, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const int32_t *__restrict__ iwhere,
     const T *__restrict__ xx, const T *__restrict__ gg, const T *__restrict__ ws,
     const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double theta, Coef wv,
-    double *part) {
-  double acc[2] = {0.0, 0.0};
+    T *ndir, T *dvec, T *tvec, int do_stpmx, double *part) {
+  double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -1393,23 +1398,55 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
           zv[k] = xk + dk;
         }
       }
-      acc[1] = acc[1] + (zv[k] - xv[k]) * gv[k];  // dd_p (:2824-2827)
+      acc[1] = acc[1] + (zv[k] - xv[k]) * gv[k];  // dd_p (:2824-2827) == g'd (:2244)
     }
     st<W>(z + i, zv);
-    st<W>(r + i, rv);
+    if constexpr (!LS) {
+      st<W>(r + i, rv);
+    } else {
+      double dv[W];
+      st<W>(ndir + i, rv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        dv[k] = zv[k] - xv[k];            // mainlb :720-722
+        acc[2] = acc[2] + dv[k] * dv[k];  // dtd (:2196)
+        if (do_stpmx && nb[k] != 0) {     // :2206-2225
+          const double a1 = dv[k];
+          if (a1 < 0.0 && nb[k] <= 2) {
+            const double a2 = lv[k] - xv[k];
+            acc[3] = fmin(acc[3], a2 >= 0.0 ? 0.0 : a2 / a1);
+          } else if (a1 > 0.0 && nb[k] >= 2) {
+            const double a2 = uv[k] - xv[k];
+            acc[3] = fmin(acc[3], a2 <= 0.0 ? 0.0 : a2 / a1);
+          }
+        }
+      }
+      st<W>(dvec + i, dv);
+      st<W>(tvec + i, xv);  // t = x (:2235)
+      st<W>(r + i, gv);     // r = g (:2236)
+    }
   });
-  block_reduce_store<2>(acc, 2, 0, 0, part, MAX_BLOCKS);
+  block_reduce_store<4>(acc, 3, 1, 0, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
-                         WStore<T> w, int head, int col, double theta, const Coef &wv) {
+                         WStore<T> w, int head, int col, double theta, const Coef &wv, T *ndir,
+                         T *dvec, T *tvec, int do_stpmx) {
   const int gr = grid_for(n, VecOf<T>::V);
-  DISPATCH_MAXC(col, hipLaunchKernelGGL((subsm_update_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
-                                        q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
-                                        w.wy, w.ld, w.m, head, col, theta, wv, q.d_part));
+  if (ndir) {
+    DISPATCH_MAXC(col, hipLaunchKernelGGL((subsm_update_kernel<T, MC, true>), dim3(gr), dim3(BLOCK),
+                                          0, q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
+                                          w.wy, w.ld, w.m, head, col, theta, wv, ndir, dvec, tvec,
+                                          do_stpmx, q.d_part));
+  } else {
+    DISPATCH_MAXC(col, hipLaunchKernelGGL((subsm_update_kernel<T, MC, false>), dim3(gr), dim3(BLOCK),
+                                          0, q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
+                                          w.wy, w.ld, w.m, head, col, theta, wv, ndir, dvec, tvec,
+                                          do_stpmx, q.d_part));
+  }
   q.launches++;
-  launch_finalize(q, gr, 2, 0, 0);
+  launch_finalize(q, gr, 3, 1, 0);
 }
 
 // backtracking ratio of one free variable (:2842-2857); 2.0 = no restriction
@@ -1885,7 +1922,8 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
   template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int);    \
   template void launch_subsm_update<T>(Queue &, int64_t, T *, T *, T *, const T *, const T *,      \
                                        const int32_t *, const int32_t *, const T *, const T *,     \
-                                       WStore<T>, int, int, double, const Coef &);                 \
+                                       WStore<T>, int, int, double, const Coef &, T *, T *, T *,   \
+                                       int);                                                       \
   template void launch_subsm_alpha<T>(Queue &, int64_t, const T *, const T *, const T *,           \
                                       const T *, const int32_t *, const int32_t *);                \
   template void launch_subsm_argalpha<T>(Queue &, int64_t, int64_t, const T *, const T *,          \

@@ -154,11 +154,15 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 
 // ---- subsm (ref :2676-2885) --------------------------------------------------
 // update (:2770-2816 + :2824-2827): d = (r + W wv..)/theta on free rows, xp = xcp,
-// projected step into z.  res sum-slots: [0] = #bound hits (iword), [1] = dd_p
+// projected step into z.  res sum-slots: [0] = #bound hits (iword), [1] = dd_p (= g'(z-x)),
+// [2] = dtd ; min-slot [3] = stpmx candidate (the last two only with ndir != nullptr).
+// ndir != nullptr: the Newton direction goes to ndir instead of r and the pass also does the
+// line-search set-up of mainlb :720-722 / lnsrlb :2196-2236: dvec = z - x, tvec = x, r = g.
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
-                         WStore<T> w, int head, int col, double theta, const Coef &wv);
+                         WStore<T> w, int head, int col, double theta, const Coef &wv, T *ndir,
+                         T *dvec, T *tvec, int do_stpmx);
 // backtrack (:2836-2863): res min-slot [0] = alpha; then argmin pass:
 // res min-slot [0] = smallest global index attaining alpha (as double)
 template <typename T>

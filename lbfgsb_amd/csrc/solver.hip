@@ -828,28 +828,42 @@ class Solver final : public lbfgsb_hip_ctx {
       cw.a[j] = wv[j];
       cw.a[lbk::MAXM + j] = wv[col + j];
     }
+    // the Newton direction lives in tbrk (free since cauchy_finish); d, t, r get their
+    // line-search values in the same pass (see subsm_update_kernel)
     lbk::launch_subsm_update<T>(q, n, z, r, xp, l, u, nbd, iwhere, x, g, W(), head, col, theta,
-                                cw);
-    CHK(fetch(2, 0, 0));
+                                cw, tbrk, d, t, ls_do_stpmx ? 1 : 0);
+    CHK(fetch(3, 1, 0));
     iword = h_res[0] > 0.0 ? 1 : 0;
     const double dd_p = h_res[1];
+    ls.ready = true;
+    ls.gd = dd_p;
+    ls.dtd = h_res[2];
+    ls.stpmx = h_res[3];
     if (iword == 0 || dd_p <= 0.0) return 0;  // :2820, :2828
+    ls.ready = false;  // z changes below: lnsrlb_begin redoes d, t, r
     if (rep.out && !quiet && print_level >= 0) {
       std::fprintf(rep.out, " Positive dir derivative in projection \n");
       std::fprintf(rep.out, " Using the backtracking step \n");
     }
-    lbk::launch_subsm_alpha<T>(q, n, xp, r, l, u, nbd, iwhere);
+    lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
     CHK(fetch(0, 1, 0));
     const double alpha = std::min(1.0, h_res[0]);
     int64_t ibd = -1;
     if (alpha < 1.0) {
-      lbk::launch_subsm_argalpha<T>(q, n, row0, xp, r, l, u, nbd, iwhere, alpha);
+      lbk::launch_subsm_argalpha<T>(q, n, row0, xp, tbrk, l, u, nbd, iwhere, alpha);
       CHK(fetch(0, 1, 0));
       ibd = (int64_t)h_res[0];
     }
-    lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, r, l, u, iwhere, alpha, ibd);
+    lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, tbrk, l, u, iwhere, alpha, ibd);
     return 0;
   }
+
+  // line-search set-up values when they were produced by the subsm pass
+  struct LsOut {
+    bool ready = false;
+    double gd = 0, dtd = 0, stpmx = 0;
+  } ls;
+  bool ls_do_stpmx = false;
 
   int print_level = -1;
 
@@ -1008,6 +1022,8 @@ class Solver final : public lbfgsb_hip_ctx {
       if (prelims) {
         if (ipr >= 99) std::fprintf(rep.out, "\n\nITERATION %5d\n", iter + 1);
         iword = -1;
+        ls.ready = false;
+        ls_do_stpmx = cnstnd && iter != 0;
         if (!cnstnd && col > 0) {  // :607-611
           HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
           wrk = updatd;
@@ -1093,13 +1109,18 @@ class Solver final : public lbfgsb_hip_ctx {
         bool ls_abort = false;
         if (!lbh::str60_pre(task, "FG_LN")) {
           const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
-          lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, t, r, do_stpmx);
-          CHK(fetch(2, 1, 0));
-          dtd = h_res[0];
-          gd = h_res[1];
+          double stpmx_cand;
+          if (ls.ready) {  // d, t, r, dtd, g'd came out of the subsm pass
+            dtd = ls.dtd, gd = ls.gd, stpmx_cand = ls.stpmx;
+          } else {
+            lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, t, r, do_stpmx);
+            CHK(fetch(2, 1, 0));
+            dtd = h_res[0], gd = h_res[1], stpmx_cand = h_res[2];
+          }
+          ls.ready = false;
           dnorm = std::sqrt(dtd);
           stpmx = big;
-          if (cnstnd) stpmx = iter == 0 ? 1.0 : std::min(big, h_res[2]);
+          if (cnstnd) stpmx = iter == 0 ? 1.0 : std::min(big, stpmx_cand);
           stp = (iter == 0 && !boxed) ? std::min(1.0 / dnorm, stpmx) : 1.0;
           fold = *f;
           ifun = 0;
