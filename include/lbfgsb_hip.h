@@ -44,9 +44,11 @@ enum {
 enum {
   LBFGSB_F_REAL32 = 1,       /* REAL32 build of the reference (lbfgsb_kinds_module.F90:29):
                                 fp32 storage + kernels, fp64 partials and host algebra */
-  LBFGSB_F_MIRROR_INDEX = 2  /* keep the reference's Index/Indx2 lists (freev,
+  LBFGSB_F_MIRROR_INDEX = 2, /* keep the reference's Index/Indx2 lists (freev,
                                 src/lbfgsb.f90:2044-2054, 2014-2035) on the device so
                                 that lbfgsb_hip_export_state reproduces `iwa` */
+  LBFGSB_F_NO_RETURN_SYNC = 4 /* the caller evaluates f,g on the SAME stream: do not block the
+                                host when returning task='FG_LNSRCH' (x is ordered by the stream) */
 };
 
 /* -------------------------------------------------------------------------
@@ -170,9 +172,10 @@ int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx);
  * *h_f receives the GLOBAL value (reduced over ranks). */
 int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f);
 
-/* counters for bench/profiling: number of kernel launches and host syncs so far */
+/* counters for bench/profiling: kernel launches, host syncs, full breakpoint sorts so far,
+ * and the seconds the host spent blocked waiting for the stream */
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
-                     int64_t *cauchy_fullsorts);
+                     int64_t *cauchy_fullsorts, double *wait_seconds);
 
 #ifdef __cplusplus
 }

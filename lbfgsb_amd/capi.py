@@ -35,11 +35,12 @@ PROTOTYPES = {
     "lbfgsb_hip_kernel_time": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "lbfgsb_hip_sync": (C.c_int, [_vp]),
     "lbfgsb_hip_objective": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
-    "lbfgsb_hip_stats": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }
 
 F_REAL32 = 1
 F_MIRROR_INDEX = 2
+F_NO_RETURN_SYNC = 4
 
 
 class LbfgsbError(RuntimeError):

@@ -127,6 +127,7 @@ struct lbfgsb_hip_ctx {
   int m = 0, flags = 0, device = 0;
   int rank = 0, nranks = 1;
   int64_t nsync = 0, nfullsort = 0;
+  double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
   lbk::Queue q{};
 };
 
@@ -314,7 +315,11 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     HIPCHK(hipMemcpyAsync(h_res, q.d_res, (size_t)k * sizeof(double), hipMemcpyDeviceToHost,
                           stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    {
+      const double t0 = now_s();
+      HIPCHK(hipStreamSynchronize(stream));
+      t_wait += now_s() - t0;
+    }
     nsync++;
     if (nranks > 1 && !comm) {
       if (!cb_ar) return fail(LBFGSB_E_COMM, "multi-rank context without a reducer");
@@ -1177,8 +1182,12 @@ class Solver final : public lbfgsb_hip_ctx {
           continue;
         } else if (lbh::str60_pre(task, "FG_LN")) {
           save_locals();
-          HIPCHK(hipStreamSynchronize(stream));  // x is ready for the caller's f,g evaluation
-          nsync++;
+          if (!(flags & LBFGSB_F_NO_RETURN_SYNC)) {
+            const double t0 = now_s();
+            HIPCHK(hipStreamSynchronize(stream));  // x is ready for the caller's f,g evaluation
+            t_wait += now_s() - t0;
+            nsync++;
+          }
           return 0;
         } else {
           lnscht += now_s() - cpu1;
@@ -1602,11 +1611,12 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
   return ctx->k_objective(kind, x, g, h_f);
 }
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
-                     int64_t *cauchy_fullsorts) {
+                     int64_t *cauchy_fullsorts, double *wait_seconds) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   if (launches) *launches = ctx->q.launches;
   if (syncs) *syncs = ctx->nsync;
   if (cauchy_fullsorts) *cauchy_fullsorts = ctx->nfullsort;
+  if (wait_seconds) *wait_seconds = ctx->t_wait;
   return 0;
 }
 

@@ -59,13 +59,15 @@ class DeviceSolver:
     60-byte task, f and the isave/dsave scalars cross PCIe."""
 
     def __init__(self, n_local: int, m: int, n_global: Optional[int] = None, row0: int = 0,
-                 real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None):
+                 real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None,
+                 same_stream_objective: bool = False):
         self.lib = load_library()
         self.n, self.m = int(n_local), int(m)
         self.n_global = int(n_global if n_global is not None else n_local)
         self.row0 = int(row0)
         self.real = np.float32 if real32 else np.float64
         flags = (capi.F_REAL32 if real32 else 0) | (capi.F_MIRROR_INDEX if mirror_index else 0)
+        flags |= capi.F_NO_RETURN_SYNC if same_stream_objective else 0
         h = C.c_void_p()
         sp = C.c_void_p(int(stream)) if stream else None
         check(self.lib.lbfgsb_hip_create(self.n, self.n_global, self.row0, self.m, flags, device,
@@ -206,6 +208,6 @@ class DeviceSolver:
         return float(out[0])
 
     def stats(self):
-        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
-        check(self.lib.lbfgsb_hip_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value)
+        a, b, c, w = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        check(self.lib.lbfgsb_hip_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(w)))
+        return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value, wait_seconds=w.value)
