@@ -171,8 +171,8 @@ def main():
 
     # ---- roofline, live, hipEvents on the solver's stream ----
     # (1) the kernel that carries the WS/WY matvec INSIDE the iteration: cmprlb_wtv_kernel
-    #     (r of cmprlb + W'r of subsm in one pass); algorithmic bytes per row = 2col reads of W +
-    #     x, z, g reads + r write (fp64) + iwhere (int32)
+    #     (r of cmprlb + W'r of subsm + formk's new row sums in one pass); algorithmic bytes per
+    #     row = 2col reads of W + x, z, g reads + r write (fp64) + iwhere (int32)
     # (2) the bare W'v kernel (wtv_kernel), (2col+1) n s bytes -- BASELINE.md's definition
     head = int(sol.isave[26])
     mc = 5 if col <= 5 else 10 if col <= 10 else 20 if col <= 20 else 32
@@ -186,10 +186,10 @@ def main():
                 return None
         return None
 
-    ms_fused = sol.kernel_time(0, x, g, col, head, a.roofline_reps)
+    ms_fused = sol.kernel_time(2, x, g, col, head, a.roofline_reps)  # the variant the iteration runs
     alg_fused = ((2 * col + 4) * 8 + 4) * n_loc
     ach_fused = alg_fused / (ms_fused * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<double,%d>" % mc,
+    roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<double,%d,true>" % mc,
                 "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_fused / HBM_PEAK_GBS, "traffic": traffic_of("cmprlb_wtv_traffic.json", n_loc),
                 "algorithmic_bytes_per_launch": alg_fused, "avg_launch_ms": ms_fused,

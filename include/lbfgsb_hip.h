@@ -160,7 +160,9 @@ int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, i
                         double *h_ms_per_launch);
 /* the same for the kernels that carry the matvec inside the iteration: which = 0
  * cmprlb_wtv_kernel (r of cmprlb + W'r of subsm, src/lbfgsb.f90:1565-1583 + :2742-2754),
- * which = 1 formk_gram kernel (:1756-1851).  Uses the context's current W, z, iwhere;
+ * which = 2 the same with formk's new row/column sums riding along (:1756-1793; the variant
+ * the iteration runs after a BFGS update), which = 1 the from-scratch formk Gram kernel
+ * (:1756-1851).  Uses the context's current W, z, iwhere;
  * x, g are device pointers; r is overwritten. */
 int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const void *g, int col,
                            int head, int reps, double *h_ms_per_launch);
