@@ -92,7 +92,7 @@ static void finalize_from(Queue &q, const double *part, int pstride, int nblocks
   const int k = nsum + nmin + nmax;
   if (k <= 0) return;
   hipLaunchKernelGGL(finalize_kernel, dim3(k), dim3(BLOCK), 0, q.stream, part, pstride, nblocks,
-                     q.d_res, nsum, nmin, nmax);
+                     q.d_res + q.res_off, nsum, nmin, nmax);
   q.launches++;
 }
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax) {
@@ -534,6 +534,60 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
     rec[q] = v;
   }
 }
+// Fast path of the window fetch: the candidate count stays on the device.  Gathers the
+// records of the first min(*d_count, cap) candidates (unordered, as the window kernel appended
+// them) and writes the header {count, 0} in front, so ONE host sync delivers everything a
+// short walk needs; the host orders the few records itself.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
+    const uint32_t *__restrict__ idx, const uint32_t *__restrict__ d_count, uint32_t cap,
+    int64_t row0, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const T *__restrict__ g, const T *__restrict__ tbrk, const T *__restrict__ ws,
+    const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double *msg) {
+  const uint32_t total_cnt = *d_count;
+  const uint32_t cnt = total_cnt < cap ? total_cnt : cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    msg[0] = (double)total_cnt;
+    msg[1] = 0.0;
+  }
+  double *rec = msg + 2;
+  const int rl = 2 * col + 4;
+  const int64_t total = (int64_t)cnt * rl;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = (uint32_t)(q / rl);
+    const int f = (int)(q % rl);
+    const int64_t i = idx[k];
+    double v;
+    if (f == 0) {
+      v = (double)tbrk[i];
+    } else if (f == 1) {
+      v = (double)(row0 + i);
+    } else if (f == 2) {
+      v = -(double)g[i];
+    } else if (f == 3) {
+      const double d = -(double)g[i];
+      v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
+    } else if (f < 4 + col) {
+      v = (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
+    } else {
+      v = (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
+    }
+    rec[q] = v;
+  }
+}
+template <typename T>
+void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint32_t *d_count, uint32_t cap,
+                              int64_t row0, const T *x, const T *l, const T *u, const T *g,
+                              const T *tbrk, WStore<T> w, int head, int col, double *msg) {
+  const int64_t total = (int64_t)cap * (2 * col + 4);
+  int gr = (int)((total + BLOCK - 1) / BLOCK);
+  if (gr > 64) gr = 64;
+  hipLaunchKernelGGL(cauchy_gather_dyn_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, d_count,
+                     cap, row0, x, l, u, g, tbrk, w.ws, w.wy, w.ld, w.m, head, col, msg);
+  q.launches++;
+}
+
 template <typename T>
 void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t row0, const T *x,
                           const T *l, const T *u, const T *g, const T *tbrk, WStore<T> w, int head,
@@ -1910,6 +1964,9 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, uint32_t, int64_t, const T *,  \
                                         const T *, const T *, const T *, const T *, WStore<T>,    \
                                         int, int, double *);                                                 \
+  template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint32_t *, uint32_t, \
+                                            int64_t, const T *, const T *, const T *, const T *,   \
+                                            const T *, WStore<T>, int, int, double *);            \
   template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
                                         const T *, const T *, const T *, int32_t *, T *, double,   \
                                         double, int64_t);                                          \

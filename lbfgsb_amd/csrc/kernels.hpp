@@ -23,6 +23,7 @@ struct Queue {
   double *d_res;    // [RES_MAX or gram size] finalized results, device
   double *d_gpart;  // gram partials [E][GRAM_BLOCKS]
   int64_t launches;
+  int res_off = 0;  // finalize writes d_res[res_off + slot] (lets two phases share one fetch)
 };
 
 // the circular correction-pair store: Ws, Wy column-major n x m, leading
@@ -105,6 +106,11 @@ template <typename T>
 void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t row0, const T *x,
                           const T *l, const T *u, const T *g, const T *tbrk, WStore<T> w, int head,
                           int col, double *rec);
+// one-sync fast path: msg = { *d_count, 0, records of the first min(*d_count, cap) candidates }
+template <typename T>
+void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint32_t *d_count, uint32_t cap,
+                              int64_t row0, const T *x, const T *l, const T *u, const T *g,
+                              const T *tbrk, WStore<T> w, int head, int col, double *msg);
 // finish (:1425-1433, :1515): fix every processed breakpoint variable at its bound,
 // move the others by tsum*d.  processed = (t, gidx) <= (last_t, last_i).
 template <typename T>

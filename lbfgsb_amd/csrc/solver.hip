@@ -394,13 +394,52 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
-  int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi) {
-    uint32_t cnt = 0;
-    CHK(local_count(lo_t, lo_i, hi, SEL_CAP, cnt));
-    CHK(put_header((double)cnt, 0.0));
-    CHK(exchange(2));
+  static constexpr uint32_t FAST_CAP = 256;  // candidates delivered by the one-sync fast path
+
+  int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, const T *x, const T *l,
+                   const T *u, const T *g, int head, int col) {
+    // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
+    const int recl = 2 * col + 4;
+    lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
+                                 d_count);
+    lbk::launch_cauchy_gather_dyn<T>(q, idx[0], d_count, FAST_CAP, row0, x, l, u, g, tbrk, W(), head,
+                                     col, d_msg);
+    const size_t fcount = 2 + (size_t)FAST_CAP * recl;
+    CHK(exchange(fcount));
     double gsum = 0.0;
-    for (int rk = 0; rk < nranks; ++rk) gsum += h_msg_all[(size_t)rk * 2];
+    bool all_small = true;
+    for (int rk = 0; rk < nranks; ++rk) {
+      const double c = h_msg_all[(size_t)rk * fcount];
+      gsum += c;
+      if (c > (double)FAST_CAP) all_small = false;
+    }
+    uint32_t cnt = (uint32_t)h_msg_all[(size_t)rank * fcount];
+    if (all_small) {
+      pv.have = true;
+      pv.full = false;
+      pv.win_hi = hi;
+      pv.Cl = cnt;
+      pv.pl = cnt;  // everything is already on the host
+      pv.cur = 0;
+      pv.M.clear();
+      for (int rk = 0; rk < nranks; ++rk) {
+        const double *base = h_msg_all + (size_t)rk * fcount;
+        const uint32_t lr = (uint32_t)base[0];
+        for (uint32_t k = 0; k < lr; ++k) {
+          const double *rec = base + 2 + (size_t)k * recl;
+          pv.M.push_back(MRec{rec[0], (int64_t)rec[1], rk, rec});
+        }
+      }
+      std::sort(pv.M.begin(), pv.M.end(), [](const MRec &a, const MRec &b) {
+        return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
+      });
+      pv.mpos = 0;
+      pv.safe_end = pv.M.size();
+      pv.more_anywhere = false;
+      pv.taken.assign(nranks, 0);
+      pv.next_chunk = 64;
+      return 0;
+    }
     pv.have = true;
     pv.pl = 0;
     pv.taken.clear();
@@ -595,7 +634,7 @@ class Solver final : public lbfgsb_hip_ctx {
             hi = base + (hi_need - base) * std::ldexp(1.0, std::min(pv.grow, 40));
           }
           pv.grow++;
-          CHK(window_fetch(pv, last_t, last_i, hi));
+          CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col));
         }
         if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
         tj = rec[0];
@@ -780,42 +819,51 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   // ========================================================== cmprlb + subsm
+  // coefficients of cmprlb: wa(1:2m) = M c (bmv, :1569) -> a1_j, a2_j = theta * (.) (:1576-1577)
+  bool cmprlb_coef(int col, double theta, bool cnstnd, lbk::Coef &cf, bool &plain) {
+    std::memset(&cf, 0, sizeof cf);
+    plain = !cnstnd && col > 0;
+    if (plain) return true;
+    if (lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]) != 0) return false;
+    for (int j = 0; j < col; ++j) {
+      cf.a[j] = wa8m[j];
+      cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
+    }
+    return true;
+  }
+
   // do_formk: formk is pending for this iteration and col <= 10: its new row/column sums ride
   // along in the cmprlb_wtv pass and the status changes are patched sparsely.
   int subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
                int col, int head, bool cnstnd, int &iword, int &info, bool do_formk, bool updatd,
-               int iupdat) {
-    // cmprlb :1548-1586
-    lbk::Coef cf;
-    std::memset(&cf, 0, sizeof cf);
-    const bool plain = !cnstnd && col > 0;
-    if (!plain) {
-      int rc = lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]);
-      if (rc != 0) {
+               int iupdat, const double *pre) {
+    // cmprlb :1548-1586 (+ W'r of subsm).  `pre` != nullptr: the pass was already launched
+    // together with freev's counts (one fetch for both) and its sums are in pre[].
+    const int MC = lbk::maxc_for(col);
+    const bool newrow = do_formk && updatd;
+    const double *res = pre;
+    if (!pre) {
+      lbk::Coef cf;
+      bool plain;
+      if (!cmprlb_coef(col, theta, cnstnd, cf, plain)) {
         // (the reference would run formk first, :663; either failure refreshes the memory,
         //  after which WN1 is rebuilt from new rows only)
         info = -8;
         return 0;
       }
-      for (int j = 0; j < col; ++j) {
-        cf.a[j] = wa8m[j];
-        cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
-      }
+      lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0,
+                                newrow ? 1 : 0);
+      CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
+      res = h_res;
     }
-    // r of cmprlb and wv = W'Zr of subsm (:2742-2754) in one pass over W
-    const int MC = lbk::maxc_for(col);
-    const bool newrow = do_formk && updatd;
-    lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0,
-                              newrow ? 1 : 0);
-    CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
     double *wv = &wa8m[0];
     for (int i = 0; i < col; ++i) {
-      wv[i] = h_res[i];
-      wv[col + i] = theta * h_res[MC + i];
+      wv[i] = res[i];
+      wv[col + i] = theta * res[MC + i];
     }
     if (do_formk) {
       double nr[4 * lbk::MAXM];
-      if (newrow) std::memcpy(nr, h_res + 2 * MC, sizeof(double) * 4 * MC);
+      if (newrow) std::memcpy(nr, res + 2 * MC, sizeof(double) * 4 * MC);
       CHK(formk_incremental(col, head, updatd, iupdat, nr, MC));
       formk_factor(col, theta, info);
       if (info != 0) return 0;
@@ -869,6 +917,9 @@ class Solver final : public lbfgsb_hip_ctx {
     double gd = 0, dtd = 0, stpmx = 0;
   } ls;
   bool ls_do_stpmx = false;
+  // sums of a cmprlb_wtv pass that was launched together with freev's counts
+  double pre_res[6 * lbk::MAXM];
+  bool pre_valid = false;
 
   int print_level = -1;
 
@@ -1033,6 +1084,7 @@ class Solver final : public lbfgsb_hip_ctx {
           HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
           wrk = updatd;
           nseg = 0;
+          pre_valid = false;
         } else {
           cpu1 = now_s();
           CHK(cauchy(x, l, u, nbd, g, theta, col, head, sbgnrm, epsmch, nseg, info));
@@ -1052,7 +1104,27 @@ class Solver final : public lbfgsb_hip_ctx {
           lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
           if (track)
             HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-          CHK(fetch(3, 0, 0));
+          // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
+          // sets of sums with ONE host sync (it is wasted only if no variable is free)
+          pre_valid = false;
+          int npre = 0;
+          if (col > 0) {
+            lbk::Coef cf;
+            bool plain;
+            if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
+              const bool newrow = updatd && col <= 10;  // updatd implies wrk
+              q.res_off = 3;
+              lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf,
+                                        plain ? 1 : 0, newrow ? 1 : 0);
+              q.res_off = 0;
+              npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
+            }
+          }
+          CHK(fetch(3 + npre, 0, 0));
+          if (npre) {
+            std::memcpy(pre_res, h_res + 3, sizeof(double) * npre);
+            pre_valid = true;
+          }
           chg_local = track ? *h_count : 0;
           cachyt += now_s() - cpu1;
           nintol += nseg;
@@ -1085,7 +1157,9 @@ class Solver final : public lbfgsb_hip_ctx {
             sbtime += now_s() - cpu1;
             continue;
           }
-          CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat));
+          CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
+                       pre_valid ? pre_res : nullptr));
+          pre_valid = false;
           if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
             if (ipr >= 1)
               std::fprintf(rep.out,
