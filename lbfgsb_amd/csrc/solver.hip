@@ -477,7 +477,10 @@ class Solver final : public lbfgsb_hip_ctx {
   int refill(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
     const int recl = 2 * col + 4;
     const uint32_t chunk = pv.next_chunk;
-    pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, CHUNK_MAX);
+    // the message buffer holds CHUNK_MAX records of the widest kind (col = m); narrower records
+    // (col = 0 on the first iteration: 4 doubles) travel in proportionally longer chunks
+    const uint32_t chunk_cap = (uint32_t)((msg_len - 2) / (size_t)recl);
+    pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, chunk_cap);
     const uint32_t len = std::min<uint32_t>(chunk, pv.Cl - pv.pl);
     lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, len, row0, x, l, u, g, tbrk, W(), head,
                                  col, d_msg + 2);
