@@ -42,7 +42,11 @@ __device__ __forceinline__ void ld(const double *p, double (&o)[W]) {
 }
 template <int W>
 __device__ __forceinline__ void ld(const float *p, double (&o)[W]) {
-  if constexpr (W == 4) {
+  if constexpr (W == 2) {
+    float2 v = *reinterpret_cast<const float2 *>(p);
+    o[0] = v.x;
+    o[1] = v.y;
+  } else if constexpr (W == 4) {
     float4 v = *reinterpret_cast<const float4 *>(p);
     o[0] = v.x;
     o[1] = v.y;
@@ -64,7 +68,9 @@ __device__ __forceinline__ void st(double *p, const double (&o)[W]) {
 }
 template <int W>
 __device__ __forceinline__ void st(float *p, const double (&o)[W]) {
-  if constexpr (W == 4) {
+  if constexpr (W == 2) {
+    *reinterpret_cast<float2 *>(p) = make_float2((float)o[0], (float)o[1]);
+  } else if constexpr (W == 4) {
     *reinterpret_cast<float4 *>(p) = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
   } else {
 #pragma unroll
@@ -100,11 +106,17 @@ __device__ __forceinline__ void sti(int32_t *p, const int (&o)[W]) {
   }
 }
 
-// Grid-stride over rows in groups of V (16 B per lane per array), scalar tail.
+// rows per lane for kernels unrolled to MC column pairs: 16 B per lane per array, halved
+// for MC >= 20 so that the 2*MC operand values of a row group still fit the register file
+template <typename T, int MC>
+struct RowsPer {
+  static constexpr int V = MC >= 20 ? VecOf<T>::V / 2 : VecOf<T>::V;
+};
+
+// Grid-stride over rows in groups of V (16 B per lane per array by default), scalar tail.
 // f(i, WTag<W>) handles rows i .. i+W-1.
-template <typename T, typename F>
+template <typename T, int V = VecOf<T>::V, typename F>
 __device__ __forceinline__ void for_rows(int64_t n, F &&f) {
-  constexpr int V = VecOf<T>::V;
   const int64_t nv = n / V;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
   double acc[2 * MC];
 #pragma unroll
   for (int k = 0; k < 2 * MC; ++k) acc[k] = 0.0;
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double vv[W], a[MC][W], b[MC][W];
     ld<W>(v + i, vv);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   acc[2 * MC + 4] = LB_INF;  // bkmin
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], tb[W], ng[W];
     int nb[W], iw[W];
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
     const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
     int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain) {
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
     int iw[W];
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
     int iw[W];
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     T *ndir, T *dvec, T *tvec, int do_stpmx, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double zv[W], rv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double gv[W], rv[W], dv[W], a[MC][W], b[MC][W];
     ld<W>(g + i, gv);
@@ -1784,7 +1784,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   acc[4 * MC + 7] = LB_INF;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
-  for_rows<T>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];

@@ -1115,7 +1115,7 @@ class Solver final : public lbfgsb_hip_ctx {
             lbk::Coef cf;
             bool plain;
             if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
-              const bool newrow = updatd && col <= 10;  // updatd implies wrk
+              const bool newrow = updatd && col <= 20;  // updatd implies wrk
               q.res_off = 3;
               lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf,
                                         plain ? 1 : 0, newrow ? 1 : 0);
@@ -1149,7 +1149,7 @@ class Solver final : public lbfgsb_hip_ctx {
           // skip the subspace minimization :648-651
         } else {
           cpu1 = now_s();
-          const bool incr = wrk && col <= 10;  // incremental WN1, fused into the cmprlb pass
+          const bool incr = wrk && col <= 20;  // incremental WN1, fused into the cmprlb pass
           if (wrk && !incr) CHK(formk(col, head, theta, info));
           if (info != 0) {  // :666-682
             if (ipr >= 1)
