@@ -1212,8 +1212,9 @@ class Solver final : public lbfgsb_hip_ctx {
         if (ifun == 0) {
           gdold = gd;
           if (gd >= 0.0) {  // :2247-2253
-            std::fprintf(rep.out, "  ascent direction in projection gd = %s\n",
-                         lbr::flist(gd).c_str());
+            if (!quiet)  // the reference prints this regardless of iprint (:2250)
+              std::fprintf(rep.out, "  ascent direction in projection gd = %s\n",
+                           lbr::flist(gd).c_str());
             info = -4;
             ls_abort = true;
           }

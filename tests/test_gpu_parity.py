@@ -142,6 +142,7 @@ ONE_STEP_CASES = [
     ("quadmix4099", dict(kind="quadmix", n=4099, m=10), 60, 1),
     ("quadmix777_m3", dict(kind="quadmix", n=777, m=3), 40, 1),
     ("quad20000_m17", dict(kind="quad", n=20000, m=17), 44, 2),
+    ("quadmix3001_m25", dict(kind="quadmix", n=3001, m=25), 70, 3),   # col > 20: from-scratch formk path
 ]
 
 
