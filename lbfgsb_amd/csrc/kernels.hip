@@ -608,22 +608,34 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
     int32_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i) {
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
-    double xv[W], gv[W], tb[W], lv[W], uv[W], out[W];
-    int iw[W];
+    double xv[W], gv[W], tb[W], out[W];
     ld<W>(x + i, xv);
     ld<W>(g + i, gv);
     ld<W>(tbrk + i, tb);
-    ld<W>(l + i, lv);
-    ld<W>(u + i, uv);
-    ldi<W>(iwhere + i, iw);
+    // which rows were fixed by the walk?  Usually none or few: the bounds and iwhere are only
+    // touched by the waves that need them (wave-uniform branch)
+    bool done[W];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      done[k] = tb[k] >= 0.0 &&
+                (tb[k] < last_t || (tb[k] == last_t && (row0 + i + k) <= last_i));
+      any = any || done[k];
+    }
+    const bool wave_any = __ballot(any) != 0ull;
+    double lv[W], uv[W];
+    int iw[W];
+    if (wave_any) {
+      ld<W>(l + i, lv);
+      ld<W>(u + i, uv);
+      ldi<W>(iwhere + i, iw);
+    }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       out[k] = xv[k];
       if (tb[k] >= 0.0) {
         const double d = -gv[k];
-        const bool done =
-            tb[k] < last_t || (tb[k] == last_t && (row0 + i + k) <= last_i);
-        if (done) {
+        if (done[k]) {
           if (d > 0.0) {
             out[k] = uv[k];
             iw[k] = 2;
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
       }
     }
     st<W>(xcp + i, out);
-    sti<W>(iwhere + i, iw);
+    if (wave_any) sti<W>(iwhere + i, iw);
   });
 }
 template <typename T>

@@ -16,5 +16,6 @@ sol = lbfgsb_amd.DeviceSolver(n, m)
 x = torch.randn(n, dtype=torch.float64, device="cuda")
 g = torch.randn(n, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
-print("avg ms per launch (hipEvents):", sol.kernel_time(0, x, g, m, 1, reps))
+# which = 2: the variant the iteration runs (formk new-row sums riding along)
+print("avg ms per launch (hipEvents):", sol.kernel_time(2, x, g, m, 1, reps))
 sol.close()
