@@ -10,6 +10,8 @@
 #pragma once
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 
 namespace lbr {
