@@ -20,6 +20,10 @@
 
 typedef lbo_real real;
 
+/* test instrumentation: how often rare branches were taken (read by tests to pick cases that
+ * exercise them); [0] = subsm backtracking branch (:2830-2879), [1] = memory refreshes in mainlb */
+long lbo_branch_count[4] = {0, 0, 0, 0};
+
 #ifdef LBO_REAL32
 #define RSQRT(x) sqrtf(x)
 #define RABS(x) fabsf(x)
@@ -862,6 +866,7 @@ void lbo_subsm(int n, int m, int nsub, const int *ind, const real *l, const real
   if (dd_p <= ZERO) return;
 
   dcopy(n, xp, x); /* :2830-2879 */
+  lbo_branch_count[0]++;
   alpha = ONE;
   temp1 = alpha;
   ibd = 0;
@@ -1266,6 +1271,7 @@ static void mainlb(int n, int m, real *x, const real *l, const real *u, const in
 
 #define REFRESH_MEMORY()                                                                        \
   do {                                                                                          \
+    lbo_branch_count[1]++;                                                                      \
     info = 0;                                                                                   \
     col = 0;                                                                                    \
     head = 1;                                                                                   \

@@ -446,3 +446,51 @@ def test_full_size_rosenbrock_n1e6_against_oracle(env):
     for a, b in zip(rows_g, rows_o):
         assert a[:4] == b[:4], (a, b)                 # iter, nfg, nseg, nfree
         assert a[4] == pytest.approx(b[4], rel=1e-8)
+
+
+def _random_box_rosenbrock(po, seed):
+    """Extended Rosenbrock with a random start, random boxes around it and all four bound
+    types: small problems that reach the rarely taken branches of the reference."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(10, 120))
+    m = int(rng.integers(2, 8))
+    p = po.problem_rosenbrock(n, m, 0.0, 0.0)
+    x0 = rng.uniform(-2.5, 2.5, n)
+    w = rng.uniform(0.05, 3.0, n)
+    p.x0[:] = x0
+    p.l[:] = x0 - w * rng.random(n)
+    p.u[:] = x0 + w * rng.random(n)
+    p.nbd[:] = rng.integers(0, 4, n)
+    return p
+
+
+@pytest.mark.parametrize("seed", [5003, 5021, 5028, 5006, 5007])
+def test_rare_branches_one_step(env, seed):
+    """The subsm backtracking branch ('Positive dir derivative in projection', reference
+    :2830-2879: alpha with arg-min, snap to the bound) and the 'refresh the lbfgs memory'
+    branches of mainlb: the oracle's branch counters locate the calls that take them; those
+    calls (and their neighbours) are replayed on the GPU from the identical state."""
+    import ctypes as C
+    po = env["po"]
+    p = _random_box_rosenbrock(po, seed)
+    eng = po.Engine("oracle")
+    cnt = (C.c_long * 4).in_dll(eng.lib, "lbo_branch_count")
+    cnt[0] = cnt[1] = 0
+    snaps, marks = [], []
+
+    def snap(k, s):
+        snaps.append(s.copy())
+        marks.append((cnt[0], cnt[1]))
+    po.run(eng, p, max_iter=150, snapshot=snap)
+    hits = [k for k in range(1, len(marks)) if marks[k] != marks[k - 1]]
+    assert hits, "this seed is expected to reach a rare branch"
+    tested = 0
+    for kb in hits[:2]:
+        for k in range(max(1, kb - 1), min(len(snaps), kb + 2)):
+            t = snaps[k - 1].task_s
+            if not (t.startswith("FG") or t.startswith("NEW_X")):
+                continue
+            _, out = gpu_one_call(env, p, snaps[k - 1])
+            compare_states(out, snaps[k], p.n, p.m, po, rtol=1e-9)
+            tested += 1
+    assert tested >= 2
