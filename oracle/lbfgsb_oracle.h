@@ -120,6 +120,10 @@ void lbo_dtrsl(const lbo_real *t, int ldt, int n, lbo_real *b, int job, int *inf
 /* lbfgsb_blas_module.F90:165-222 */
 lbo_real lbo_ddot(int64_t n, const lbo_real *dx, const lbo_real *dy);
 
+/* test instrumentation: [0] = times the subsm backtracking branch (:2830-2879) ran,
+ * [1] = memory refreshes in mainlb.  Lets tests locate calls that take rare branches. */
+extern long lbo_branch_count[4];
+
 /* Synthetic objectives used by bench/tests (these are
  * definitions from SURVEY.md section 8d, not reference code).  i0 = 0-based
  * global index of element 0 (for sharded evaluation).  Returns f. */
