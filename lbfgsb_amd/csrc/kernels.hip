@@ -37,6 +37,18 @@ int grid_for(int64_t n, int vec) {
 
 int maxc_for(int col) { return col <= 5 ? 5 : (col <= 10 ? 10 : (col <= 20 ? 20 : 32)); }
 
+// the same, also selecting the load policy at run time (q.nt)
+#define DISPATCH_MAXC_NT(col, ntflag, ...)   \
+  do {                                        \
+    if (ntflag) {                             \
+      constexpr bool NTV = true;              \
+      DISPATCH_MAXC(col, __VA_ARGS__);        \
+    } else {                                  \
+      constexpr bool NTV = false;             \
+      DISPATCH_MAXC(col, __VA_ARGS__);        \
+    }                                         \
+  } while (0)
+
 #define DISPATCH_MAXC(col, ...)       \
   do {                                \
     if ((col) <= 5) {                 \
@@ -229,7 +241,7 @@ void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, cons
 // The WS/WY correction-pair matvec: out[j] = sum_i Wy(i,j) v_i,
 // out[col+j] = sum_i Ws(i,j) v_i.  Algorithmic bytes (2 col + 1) n s.
 // Per lane and trip: 2*MC + 1 independent 16-byte loads in flight.
-template <typename T, int MC>
+template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restrict__ ws,
                                                     const T *__restrict__ wy, int64_t ldw, int m,
                                                     int head, int col, const T *__restrict__ v,
@@ -240,12 +252,12 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double vv[W], a[MC][W], b[MC][W];
-    ld<W>(v + i, vv);
+    ldx<W, NT>(v + i, vv);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld<W>(wy + off, a[j]);
-      ld<W>(ws + off, b[j]);
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
 template <typename T>
 void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
   const int g = grid_for(n, VecOf<T>::V);
-  DISPATCH_MAXC(col, hipLaunchKernelGGL((wtv_kernel<T, MC>), dim3(g), dim3(BLOCK), 0, q.stream, n,
+  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((wtv_kernel<T, MC, NTV>), dim3(g), dim3(BLOCK), 0, q.stream, n,
                                         w.ws, w.wy, w.ld, w.m, head, col, v, q.d_part));
   q.launches++;
 }
@@ -273,7 +285,7 @@ void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v)
 }
 
 // =========================== cauchy scan (:1270-1330) ========================
-template <typename T, int MC>
+template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, int32_t *iwhere, T *tbrk,
@@ -288,10 +300,10 @@ __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], tb[W], ng[W];
     int nb[W], iw[W];
-    ld<W>(x + i, xv);
-    ld<W>(l + i, lv);
-    ld<W>(u + i, uv);
-    ld<W>(g + i, gv);
+    ldx<W, NT>(x + i, xv);
+    ldx<W, NT>(l + i, lv);
+    ldx<W, NT>(u + i, uv);
+    ldx<W, NT>(g + i, gv);
     ldi<W>(nbd + i, nb);
     ldi<W>(iwhere + i, iw);
     double a[MC > 0 ? MC : 1][W], b[MC > 0 ? MC : 1][W];
@@ -299,8 +311,8 @@ __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
 #pragma unroll
       for (int j = 0; j < MC; ++j) {
         const int64_t off = col_off(j, col, head, m, ldw) + i;
-        ld<W>(wy + off, a[j]);
-        ld<W>(ws + off, b[j]);
+        ldx<W, NT>(wy + off, a[j]);
+        ldx<W, NT>(ws + off, b[j]);
       }
     }
 #pragma unroll
@@ -364,10 +376,10 @@ void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         int head, int col) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (col == 0) {
-    hipLaunchKernelGGL((cauchy_scan_kernel<T, 0>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
+    hipLaunchKernelGGL((cauchy_scan_kernel<T, 0, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
                        nbd, g, iwhere, tbrk, w.ws, w.wy, w.ld, w.m, head, col, q.d_part);
   } else {
-    DISPATCH_MAXC(col, hipLaunchKernelGGL((cauchy_scan_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cauchy_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, l, u, nbd, g, iwhere, tbrk, w.ws, w.wy,
                                           w.ld, w.m, head, col, q.d_part));
   }
@@ -1169,7 +1181,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
 }
 
 // =========================== cmprlb (:1548-1586) =============================
-template <typename T, int MC>
+template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
     const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
@@ -1178,21 +1190,21 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_kernel(
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
     int iw[W];
-    ld<W>(g + i, gv);
+    ldx<W, NT>(g + i, gv);
     if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
 #pragma unroll
       for (int k = 0; k < W; ++k) rv[k] = -gv[k];
       st<W>(r + i, rv);
       return;
     }
-    ld<W>(x + i, xv);
-    ld<W>(z + i, zv);
+    ldx<W, NT>(x + i, xv);
+    ldx<W, NT>(z + i, zv);
     ldi<W>(iwhere + i, iw);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld<W>(wy + off, a[j]);
-      ld<W>(ws + off, b[j]);
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -1211,7 +1223,7 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
                    const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
                    const Coef &a, int plain) {
   const int gr = grid_for(n, VecOf<T>::V);
-  DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0, q.stream,
+  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0, q.stream,
                                         n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m, head, col,
                                         theta, a, plain));
   q.launches++;
@@ -1224,7 +1236,7 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
 // pair just stored (logical column col-1): with y = Wy_new, s = Ws_new,
 //   t1_j = sum_free y Wy_j, t2_j = sum_act s Ws_j, t3_j = sum_act s Wy_j, t4_j = sum_free Ws_j y.
 // slots: [0,MC) Wy'r | [MC,2MC) Ws'r | NEWROW: [2MC,3MC) t1 | [3MC,4MC) t2 | [4MC,5MC) t3 | [5MC,6MC) t4
-template <typename T, int MC, bool NEWROW>
+template <typename T, int MC, bool NEWROW, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
     const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
@@ -1237,10 +1249,10 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
     int iw[W];
-    ld<W>(g + i, gv);
+    ldx<W, NT>(g + i, gv);
     if (!plain) {
-      ld<W>(x + i, xv);
-      ld<W>(z + i, zv);
+      ldx<W, NT>(x + i, xv);
+      ldx<W, NT>(z + i, zv);
       ldi<W>(iwhere + i, iw);
     } else {
 #pragma unroll
@@ -1249,8 +1261,8 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld<W>(wy + off, a[j]);
-      ld<W>(ws + off, b[j]);
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -1308,11 +1320,11 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, 
                        const Coef &a, int plain, int newrow) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (newrow) {
-    DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true>), dim3(gr), dim3(BLOCK), 0,
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m,
                                           head, col, theta, a, plain, q.d_part));
   } else {
-    DISPATCH_MAXC(col, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false>), dim3(gr), dim3(BLOCK), 0,
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m,
                                           head, col, theta, a, plain, q.d_part));
   }
@@ -1409,7 +1421,7 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 // call of lnsrlb (:2196-2236) do next: d = z - x, t = x, r = g, dtd = d'd, the stpmx ratios;
 // g'd is dd_p itself.  The Newton direction then goes to `ndir` (scratch) instead of r.
 // res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
-template <typename T, int MC, bool LS>
+template <typename T, int MC, bool LS, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, T *z, T *r, T *xp, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const int32_t *__restrict__ iwhere,
@@ -1422,19 +1434,19 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     constexpr int W = decltype(wt)::value;
     double zv[W], rv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
-    ld<W>(z + i, zv);
-    ld<W>(r + i, rv);
-    ld<W>(l + i, lv);
-    ld<W>(u + i, uv);
-    ld<W>(xx + i, xv);
-    ld<W>(gg + i, gv);
+    ldx<W, NT>(z + i, zv);
+    ldx<W, NT>(r + i, rv);
+    ldx<W, NT>(l + i, lv);
+    ldx<W, NT>(u + i, uv);
+    ldx<W, NT>(xx + i, xv);
+    ldx<W, NT>(gg + i, gv);
     ldi<W>(nbd + i, nb);
     ldi<W>(iwhere + i, iw);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld<W>(wy + off, a[j]);
-      ld<W>(ws + off, b[j]);
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
     }
     st<W>(xp + i, zv);  // xp = xcp (:2787)
 #pragma unroll
@@ -1501,12 +1513,12 @@ void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, con
                          T *dvec, T *tvec, int do_stpmx) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (ndir) {
-    DISPATCH_MAXC(col, hipLaunchKernelGGL((subsm_update_kernel<T, MC, true>), dim3(gr), dim3(BLOCK),
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK),
                                           0, q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
                                           w.wy, w.ld, w.m, head, col, theta, wv, ndir, dvec, tvec,
                                           do_stpmx, q.d_part));
   } else {
-    DISPATCH_MAXC(col, hipLaunchKernelGGL((subsm_update_kernel<T, MC, false>), dim3(gr), dim3(BLOCK),
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK),
                                           0, q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
                                           w.wy, w.ld, w.m, head, col, theta, wv, ndir, dvec, tvec,
                                           do_stpmx, q.d_part));
@@ -1722,7 +1734,7 @@ void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // =========================== mainlb :812-824 + matupd (:2291-2346) ===========
 // ncol_old = col - 1 older pairs (logical order from head); new pair goes to
 // physical column itail (1-based).
-template <typename T, int MC>
+template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
     int64_t n, const T *__restrict__ g, const T *__restrict__ r, const T *__restrict__ d,
     double stp, T *ws, T *wy, int64_t ldw, int m, int head, int nold, int itail, double *part) {
@@ -1734,15 +1746,15 @@ __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double gv[W], rv[W], dv[W], a[MC][W], b[MC][W];
-    ld<W>(g + i, gv);
-    ld<W>(r + i, rv);
-    ld<W>(d + i, dv);
+    ldx<W, NT>(g + i, gv);
+    ldx<W, NT>(r + i, rv);
+    ldx<W, NT>(d + i, dv);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       // nold may be 0: then logical column 0 is the NEW column; read d's own slot instead
       const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
-      ld<W>(wy + off, a[j]);
-      ld<W>(ws + off, b[j]);
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -1769,7 +1781,7 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
                          WStore<T> w, int head, int col, int itail) {
   const int gr = grid_for(n, VecOf<T>::V);
   const int nold = col - 1;
-  DISPATCH_MAXC(nold, hipLaunchKernelGGL((update_pairs_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+  DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_pairs_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, g, r, d, stp, w.ws, w.wy, w.ld, w.m, head,
                                          nold, itail, q.d_part));
   q.launches++;
@@ -1784,7 +1796,7 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // of update_pairs_kernel and cauchy_scan_kernel.
 // slots: [0,MC) s'Wy_j | [MC,2MC) Ws_j's | [2MC] y'y | [2MC+1,3MC+1) Wy_j'd | [3MC+1] y'd |
 //        [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | f1, nbreak, nunb, nunbnz | min: bkmin
-template <typename T, int MC>
+template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
@@ -1800,19 +1812,19 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
-    ld<W>(x + i, xv);
-    ld<W>(l + i, lv);
-    ld<W>(u + i, uv);
-    ld<W>(g + i, gv);
-    ld<W>(r + i, rv);
-    ld<W>(d + i, dv);
+    ldx<W, NT>(x + i, xv);
+    ldx<W, NT>(l + i, lv);
+    ldx<W, NT>(u + i, uv);
+    ldx<W, NT>(g + i, gv);
+    ldx<W, NT>(r + i, rv);
+    ldx<W, NT>(d + i, dv);
     ldi<W>(nbd + i, nb);
     ldi<W>(iwhere + i, iw);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
-      ld<W>(wy + off, a[j]);
-      ld<W>(ws + off, b[j]);
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -1882,7 +1894,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         WStore<T> w, int head, int col, int itail) {
   const int gr = grid_for(n, VecOf<T>::V);
   const int nold = col - 1;
-  DISPATCH_MAXC(nold, hipLaunchKernelGGL((update_scan_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0,
+  DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,
                                          w.wy, w.ld, w.m, head, nold, itail, q.d_part));
   q.launches++;

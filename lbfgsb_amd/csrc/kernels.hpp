@@ -24,6 +24,7 @@ struct Queue {
   double *d_gpart;  // gram partials [E][GRAM_BLOCKS]
   int64_t launches;
   int res_off = 0;  // finalize writes d_res[res_off + slot] (lets two phases share one fetch)
+  bool nt = false;  // nontemporal loads in the W-pass kernels (W much larger than the Infinity Cache)
 };
 
 // the circular correction-pair store: Ws, Wy column-major n x m, leading

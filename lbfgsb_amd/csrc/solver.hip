@@ -216,6 +216,9 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     q.stream = stream;
     ld = ((n + 31) / 32) * 32;
+    // streamed-once data: nontemporal loads unless W fits the 256 MiB Infinity Cache
+    q.nt = (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
+    if (const char *e = std::getenv("LBFGSB_NT")) q.nt = e[0] == '1';
     const size_t wbytes = (size_t)ld * m * sizeof(T);
     HIPCHK(hipMalloc(&ws, wbytes));
     HIPCHK(hipMalloc(&wy, wbytes));
