@@ -179,6 +179,12 @@ def main():
     # (2) the bare W'v kernel (wtv_kernel), (2col+1) n s bytes -- BASELINE.md's definition
     head = int(sol.isave[26])
     mc = 5 if col <= 5 else 10 if col <= 10 else 20 if col <= 20 else 32
+    # load policy the library picked (solver.hip init): nontemporal when W >> Infinity Cache
+    ld_rows = (n_loc + 31) // 32 * 32
+    nt = 2 * ld_rows * m * rbytes > (192 << 20)
+    if os.environ.get("LBFGSB_NT") in ("0", "1"):
+        nt = os.environ["LBFGSB_NT"] == "1"
+    nts = "true" if nt else "false"
 
     def traffic_of(name, rows):
         tf = os.path.join(ROOT, "profiles", name)
@@ -192,7 +198,7 @@ def main():
     ms_fused = sol.kernel_time(2, x, g, col, head, a.roofline_reps)  # the variant the iteration runs
     alg_fused = ((2 * col + 4) * rbytes + 4) * n_loc
     ach_fused = alg_fused / (ms_fused * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s,%d,true>" % ("float" if a.real32 else "double", mc),
+    roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s, %d, true, %s>" % ("float" if a.real32 else "double", mc, nts),
                 "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_fused / HBM_PEAK_GBS, "traffic": traffic_of("cmprlb_wtv_traffic.json", n_loc),
                 "algorithmic_bytes_per_launch": alg_fused, "avg_launch_ms": ms_fused,
@@ -200,7 +206,7 @@ def main():
     ms_kernel = sol.wtv_time(g, col, head, a.roofline_reps)
     alg_bytes = (2 * col + 1) * n_loc * rbytes
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
-    roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s,%d>" % ("float" if a.real32 else "double", mc),
+    roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s, %d, %s>" % ("float" if a.real32 else "double", mc, nts),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of("wtv_traffic.json", n_loc),
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_kernel,
