@@ -121,6 +121,21 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
                            const char *iteration_file, int32_t real_bytes, int32_t mirror);
 
 /* -------------------------------------------------------------------------
+ * Convenience driver around lbfgsb_hip_setulb_dev -- the "high-level wrapper so the user
+ * doesn't have to call the reverse communication routine directly" that the reference lists
+ * as @todo (src/lbfgsb.f90:36-37).  Runs the loop of test/driver2.f90: evaluates f,g whenever
+ * task(1:2)=='FG' -- through `fg` (device pointers in, GLOBAL f out), or, when fg == NULL, the
+ * built-in objective `builtin_kind` of lbfgsb_hip_objective -- and stops on a terminal task or
+ * when max_iter iterations / max_fg evaluations are reached ('STOP: ...' as the drivers do).
+ * On return *f, x, g hold the final point; task/isave/dsave/lsave as after the last setulb.
+ * ------------------------------------------------------------------------- */
+typedef double (*lbfgsb_fg_fn)(void *user, const void *x_dev, void *g_dev);
+int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
+                        const int32_t *nbd, void *g, double factr, double pgtol, int max_iter,
+                        int max_fg, int iprint, lbfgsb_fg_fn fg, void *user, int builtin_kind,
+                        double *f, char *task, int32_t *lsave, int32_t *isave, double *dsave);
+
+/* -------------------------------------------------------------------------
  * State exchange with the reference's caller-array layout (checkpoint /
  * resume; used by the one-step parity tests).
  * wa: host, length 2mn+5n+11m^2+8m reals; iwa: host int32[3n].

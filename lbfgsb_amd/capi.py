@@ -12,6 +12,7 @@ _LIB = None
 _vp, _i32p, _dp, _cp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_char_p
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+FG_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_void_p)
 PROTOTYPES = {
     "lbfgsb_hip_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     _vp, C.POINTER(_vp)]),
@@ -25,6 +26,8 @@ PROTOTYPES = {
     "lbfgsb_hip_setulb_host": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
                                          C.c_double, C.c_double, _vp, _vp, _vp, C.c_int32, _vp,
                                          _vp, _vp, _vp, _cp, C.c_int32, C.c_int32]),
+    "lbfgsb_hip_minimize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
+                                      C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_export_state": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_import_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lbfgsb_hip_projgr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1618,6 +1618,41 @@ int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const voi
   return rc;
 }
 
+int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
+                        const int32_t *nbd, void *g, double factr, double pgtol, int max_iter,
+                        int max_fg, int iprint, lbfgsb_fg_fn fg, void *user, int builtin_kind,
+                        double *f, char *task, int32_t *lsave, int32_t *isave, double *dsave) {
+  if (!ctx || !f || !task || !lsave || !isave || !dsave)
+    return fail(LBFGSB_E_ARG, "minimize: NULL argument");
+  char csave[60];
+  std::memset(csave, ' ', 60);
+  lbh::str60_set(task, "START");
+  for (;;) {
+    int rc = ctx->setulb_dev(x, l, u, nbd, f, g, factr, pgtol, task, iprint, csave, lsave, isave,
+                             dsave);
+    if (rc) return rc;
+    if (lbh::str60_pre(task, "FG")) {
+      if (fg) {
+        rc = ctx->sync();  // a callback may run on any stream
+        if (rc) return rc;
+        *f = fg(user, x, g);
+      } else {
+        rc = ctx->k_objective(builtin_kind, x, g, f);
+        if (rc) return rc;
+      }
+    } else if (lbh::str60_pre(task, "NEW_X")) {
+      if (max_iter > 0 && isave[29] >= max_iter)
+        lbh::str60_set(task, "STOP: MAXIMUM NUMBER OF ITERATIONS REACHED");
+      else if (max_fg > 0 && isave[33] >= max_fg)
+        lbh::str60_set(task, "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT");
+    } else {
+      break;
+    }
+  }
+  if (iprint >= 0) std::fflush(stdout);
+  return ctx->sync();
+}
+
 int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   return ctx->export_state(wa, iwa);

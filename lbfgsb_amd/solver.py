@@ -154,6 +154,25 @@ class DeviceSolver:
                                              _p(self.isave), _p(self.dsave)))
         return self.task_s
 
+    def minimize(self, x, l, u, nbd, g, fg=None, builtin: int = 0, factr: float = 1e7,
+                 pgtol: float = 1e-5, max_iter: int = 0, max_fg: int = 0, iprint: int = -1) -> str:
+        """The reference's @todo wrapper (src/lbfgsb.f90:36-37): run the reverse-communication
+        loop inside the library.  fg(x_ptr, g_ptr) -> global f evaluates the objective on the
+        device (raw device pointers as ints); fg=None uses the built-in objective `builtin`."""
+        if not isinstance(x, np.ndarray):
+            import torch
+            torch.cuda.synchronize()
+        cb = C.cast(None, capi.FG_FN)
+        if fg is not None:
+            cb = capi.FG_FN(lambda user, xp, gp: float(fg(xp, gp)))
+            self._keep.append(cb)
+        check(self.lib.lbfgsb_hip_minimize(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g),
+                                           float(factr), float(pgtol), int(max_iter), int(max_fg),
+                                           int(iprint), cb, None, int(builtin), _p(self.f),
+                                           _p(self.task), _p(self.lsave), _p(self.isave),
+                                           _p(self.dsave)))
+        return self.task_s
+
     # ---- state exchange / kernels ----
     def export_state(self):
         wa = np.zeros(wa_length(self.n, self.m), self.real)

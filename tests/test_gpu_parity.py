@@ -494,3 +494,40 @@ def test_rare_branches_one_step(env, seed):
             compare_states(out, snaps[k], p.n, p.m, po, rtol=1e-9)
             tested += 1
     assert tested >= 2
+
+
+def test_minimize_wrapper_matches_reverse_communication(env):
+    """lbfgsb_hip_minimize (the wrapper the reference lists as @todo, src/lbfgsb.f90:36-37) runs
+    the same loop as driver2: same final state as driving setulb by hand; built-in objective and
+    a Python callback; the iteration cap ends with a 'STOP' task like the drivers do."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m = 5003, 6
+    p = po.problem_quadratic(n, m, mixed_nbd=True)
+    ref = po.run(po.Engine("oracle"), p)
+    assert ref.task_s.startswith("CONVERGENCE")
+
+    def tensors():
+        return (torch.from_numpy(p.x0.copy()).cuda(), torch.from_numpy(p.l).cuda(),
+                torch.from_numpy(p.u).cuda(), torch.from_numpy(p.nbd.astype(np.int32)).cuda(),
+                torch.zeros(n, dtype=torch.float64, device="cuda"))
+    sol = la.DeviceSolver(n, m)
+    x, l, u, nbd, g = tensors()
+    t = sol.minimize(x, l, u, nbd, g, builtin=0, factr=0.0, pgtol=0.0)
+    assert t == ref.task_s
+    assert int(sol.isave[29]) == int(ref.isave[29]) and int(sol.isave[33]) == int(ref.isave[33])
+    assert float(sol.f[0]) == pytest.approx(float(ref.f[0]), rel=1e-10)
+    assert np.max(np.abs(x.cpu().numpy() - ref.x)) <= 1e-7
+    sol.close()
+    # Python callback objective (device pointers) + iteration cap
+    sol = la.DeviceSolver(n, m)
+    x, l, u, nbd, g = tensors()
+    calls = []
+
+    def fg(xp, gp):
+        assert xp == x.data_ptr() and gp == g.data_ptr()
+        calls.append(1)
+        return sol.objective(0, x, g)
+    t = sol.minimize(x, l, u, nbd, g, fg=fg, factr=0.0, pgtol=0.0, max_iter=7)
+    assert t.startswith("STOP: MAXIMUM NUMBER OF ITERATIONS") and int(sol.isave[29]) == 7
+    assert len(calls) == int(sol.isave[33])
+    sol.close()
