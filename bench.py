@@ -243,6 +243,31 @@ def main():
         "roofline": roofline,
         "roofline_wtv": roofline_wtv,
     }
+    sol.close()
+    # the opt-in closed-form GCP (LBFGSB_F_PARALLEL_GCP): only the first iteration differs
+    # (col = 0, nseg ~ 0.977 n); timed on a fresh context, outside the timed region above
+    try:
+        if world > 1:      # single-GPU leg only: no second communicator inside the scaling runs
+            raise RuntimeError("skipped for n_gpus > 1")
+        sol2 = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,
+                                       same_stream_objective=True, real32=a.real32,
+                                       parallel_gcp=True)
+        x.zero_()
+        barrier()
+        tp0 = time.perf_counter()
+        while True:
+            task = sol2.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if task.startswith("FG"):
+                sol2.f[0] = sol2.objective(0, x, g)
+            else:
+                break
+        barrier()
+        out["first_iteration_parallel_gcp_s"] = time.perf_counter() - tp0
+        out["first_iteration_parallel_gcp_nseg"] = int(sol2.isave[32])
+        sol2.close()
+    except Exception as e:
+        out["first_iteration_parallel_gcp_s"] = None
+        out["first_iteration_parallel_gcp_error"] = repr(e)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(m, n, min(a.cpu_n, n))
@@ -251,7 +276,6 @@ def main():
                                    "sample": "failed: %r" % (e,)}
     if rank == 0:
         print(json.dumps(out))
-    sol.close()
     if world > 1:
         dist.destroy_process_group()
 

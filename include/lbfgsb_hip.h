@@ -47,8 +47,20 @@ enum {
   LBFGSB_F_MIRROR_INDEX = 2, /* keep the reference's Index/Indx2 lists (freev,
                                 src/lbfgsb.f90:2044-2054, 2014-2035) on the device so
                                 that lbfgsb_hip_export_state reproduces `iwa` */
-  LBFGSB_F_NO_RETURN_SYNC = 4 /* the caller evaluates f,g on the SAME stream: do not block the
+  LBFGSB_F_NO_RETURN_SYNC = 4, /* the caller evaluates f,g on the SAME stream: do not block the
                                 host when returning task='FG_LNSRCH' (x is ordered by the stream) */
+  LBFGSB_F_PARALLEL_GCP = 8  /* OPT-IN deviation from the reference's arithmetic: when no pair is
+                                stored (col = 0: first iteration, after every memory refresh -- the
+                                calls where nseg ~ n) the model Hessian is theta*I, the derivative
+                                along the projected path is -(1 - theta t) * sum_{t_j >= t} d_j^2,
+                                and the generalized Cauchy point is t* = 1/theta in closed form: one
+                                elementwise kernel instead of the ordered walk of
+                                src/lbfgsb.f90:1378-1497.  Equal to the reference in exact arithmetic;
+                                in floating point the reference's f1/f2 recurrence carries its own
+                                rounding noise, so tsum (and nseg by a few units) may differ.  Also
+                                ignores the clamp f2 >= epsmch*f2_org (:1483), which only acts once
+                                the remaining gradient mass is below epsmch of the total.
+                                Calls with col > 0 always replay the walk exactly. */
 };
 
 /* -------------------------------------------------------------------------

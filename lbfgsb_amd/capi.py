@@ -44,6 +44,7 @@ PROTOTYPES = {
 F_REAL32 = 1
 F_MIRROR_INDEX = 2
 F_NO_RETURN_SYNC = 4
+F_PARALLEL_GCP = 8
 
 
 class LbfgsbError(RuntimeError):

@@ -613,11 +613,13 @@ void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t r
   q.launches++;
 }
 
-template <typename T>
+// COUNT: also return the number of rows fixed (closed-form GCP, where no walk counted them)
+template <typename T, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
     int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
     const T *__restrict__ u, const T *__restrict__ g, const T *__restrict__ tbrk,
-    int32_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i) {
+    int32_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i, double *part) {
+  double acc[1] = {0.0};
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], tb[W], out[W];
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
       done[k] = tb[k] >= 0.0 &&
                 (tb[k] < last_t || (tb[k] == last_t && (row0 + i + k) <= last_i));
       any = any || done[k];
+      if (COUNT && done[k]) acc[0] += 1.0;
     }
     const bool wave_any = __ballot(any) != 0ull;
     double lv[W], uv[W];
@@ -663,15 +666,23 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
     st<W>(xcp + i, out);
     if (wave_any) sti<W>(iwhere + i, iw);
   });
+  if constexpr (COUNT) block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
                           const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
-                          double last_t, int64_t last_i) {
+                          double last_t, int64_t last_i, int count) {
   const int gr = grid_for(n, VecOf<T>::V);
-  hipLaunchKernelGGL(cauchy_finish_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, l, u,
-                     g, tbrk, iwhere, xcp, tsum, last_t, last_i);
-  q.launches++;
+  if (count) {
+    hipLaunchKernelGGL((cauchy_finish_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, row0,
+                       x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.d_part);
+    q.launches++;
+    launch_finalize(q, gr, 1, 0, 0);
+  } else {
+    hipLaunchKernelGGL((cauchy_finish_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, row0,
+                       x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.d_part);
+    q.launches++;
+  }
 }
 
 // =========================== freev (:1980-2059) ==============================
@@ -1993,7 +2004,7 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
                                             const T *, WStore<T>, int, int, double *);            \
   template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
                                         const T *, const T *, const T *, int32_t *, T *, double,   \
-                                        double, int64_t);                                          \
+                                        double, int64_t, int);                                     \
   template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const int32_t *);      \
   template void launch_cmprlb<T>(Queue &, int64_t, const T *, const T *, const T *, T *,           \
                                  const int32_t *, WStore<T>, int, int, double, const Coef &, int); \

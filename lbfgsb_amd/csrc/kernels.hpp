@@ -114,10 +114,11 @@ void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint32_t *d_c
                               const T *tbrk, WStore<T> w, int head, int col, double *msg);
 // finish (:1425-1433, :1515): fix every processed breakpoint variable at its bound,
 // move the others by tsum*d.  processed = (t, gidx) <= (last_t, last_i).
+// count != 0: res[0] = number of rows fixed (finalize launched).
 template <typename T>
 void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
                           const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
-                          double last_t, int64_t last_i);
+                          double last_t, int64_t last_i, int count = 0);
 
 // ---- freev (ref :1980-2059) -------------------------------------------------
 // res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave; updates wasfree.

@@ -603,6 +603,20 @@ class Solver final : public lbfgsb_hip_ctx {
     double tsum = 0.0;
     nseg = 1;
 
+    if (col == 0 && nbreak != 0 && (flags & LBFGSB_F_PARALLEL_GCP) && dtm >= bkmin) {
+      // B = theta*I: phi'(t) = -(1 - theta t) * (remaining d'd), so the walk stops at t = 1/theta
+      // having fixed exactly the breakpoints t_j <= 1/theta (see include/lbfgsb_hip.h).
+      const double tstar = 1.0 / theta;
+      lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tstar, tstar,
+                                   std::numeric_limits<int64_t>::max(), 1);
+      CHK(fetch(1, 0, 0));
+      const int64_t done = (int64_t)h_res[0];
+      // the walk counts a segment per fixed variable except a last one that fixes all n (:1436)
+      const int64_t ns = 1 + done - ((done == nbreak && nbreak == nglob) ? 1 : 0);
+      nseg = (int)std::min<int64_t>(ns, std::numeric_limits<int>::max());
+      return 0;
+    }
+
     if (nbreak != 0) {
       int64_t nleft = nbreak;
       int64_t iter = 1;

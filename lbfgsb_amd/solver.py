@@ -60,7 +60,7 @@ class DeviceSolver:
 
     def __init__(self, n_local: int, m: int, n_global: Optional[int] = None, row0: int = 0,
                  real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None,
-                 same_stream_objective: bool = False):
+                 same_stream_objective: bool = False, parallel_gcp: bool = False):
         self.lib = load_library()
         self.n, self.m = int(n_local), int(m)
         self.n_global = int(n_global if n_global is not None else n_local)
@@ -68,6 +68,7 @@ class DeviceSolver:
         self.real = np.float32 if real32 else np.float64
         flags = (capi.F_REAL32 if real32 else 0) | (capi.F_MIRROR_INDEX if mirror_index else 0)
         flags |= capi.F_NO_RETURN_SYNC if same_stream_objective else 0
+        flags |= capi.F_PARALLEL_GCP if parallel_gcp else 0  # opt-in, see include/lbfgsb_hip.h
         h = C.c_void_p()
         sp = C.c_void_p(int(stream)) if stream else None
         check(self.lib.lbfgsb_hip_create(self.n, self.n_global, self.row0, self.m, flags, device,

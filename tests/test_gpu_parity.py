@@ -531,3 +531,52 @@ def test_minimize_wrapper_matches_reverse_communication(env):
     assert t.startswith("STOP: MAXIMUM NUMBER OF ITERATIONS") and int(sol.isave[29]) == 7
     assert len(calls) == int(sol.isave[33])
     sol.close()
+
+
+@pytest.mark.parametrize("kind", ["quadratic", "quadmix", "rosenbrock"])
+def test_parallel_gcp_opt_in(env, kind):
+    """LBFGSB_F_PARALLEL_GCP (col = 0 case): the closed-form GCP
+    t* = 1/theta replaces the ordered walk of src/lbfgsb.f90:1378-1497 when no pair is stored.
+    Equal in exact arithmetic; the reference's f1/f2 recurrence has its own rounding noise, so
+    the tolerance here is the opt-in mode's documented one: nseg within 2 of the oracle's,
+    f to 1e-9, and no host sorting/walking at all (no full sort, a handful of syncs)."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 200_000, 10, 3
+    if kind == "rosenbrock":
+        p = po.problem_rosenbrock(n, m, factr=0.0, pgtol=0.0)
+    else:
+        p = po.problem_quadratic(n, m, mixed_nbd=(kind == "quadmix"))
+    rows_o = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                int(s.isave[37]), float(s.f[0]))) if s.task_s.startswith("NEW_X") else None)
+    sol = la.DeviceSolver(n, m, parallel_gcp=True)
+    x = torch.from_numpy(p.x0.copy()).cuda()
+    g = torch.zeros_like(x)
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+    rows_g = []
+    st1 = None
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(0 if kind != "rosenbrock" else 1, x, g)
+            if st1 is None:
+                pass
+        elif t.startswith("NEW_X"):
+            if st1 is None:
+                st1 = sol.stats()
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
+                           int(sol.isave[37]), float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    sol.close()
+    assert rows_o[0][2] > n // 4            # iteration 1 really is the nseg ~ n case
+    assert st1["cauchy_fullsorts"] == 0      # and it was done without sorting or walking
+    assert len(rows_g) == len(rows_o) == iters
+    for a, b in zip(rows_g, rows_o):
+        assert a[:2] == b[:2], (a, b)
+        assert abs(a[2] - b[2]) <= 2 and abs(a[3] - b[3]) <= 2, (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
