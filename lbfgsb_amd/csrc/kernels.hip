@@ -1943,26 +1943,33 @@ void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
   q.launches++;
   launch_finalize(q, gr, 1, 0, 0);
 }
+// rows [row0, row0+n) of the chain; xl / xr = the neighbours' boundary elements x(row0-1),
+// x(row0+n) (1-element halo, exchanged by the caller; unused at the global ends)
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, const T *__restrict__ x,
-                                                               T *g, double *part) {
+__global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, int64_t row0,
+                                                               int64_t nglob,
+                                                               const T *__restrict__ x, T *g,
+                                                               double xl, double xr, double *part) {
   double acc[1] = {0.0};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double xi = (double)x[i];
+    const int64_t gi_ = row0 + i;
     double gi;
-    if (i == 0) {
-      const double t1 = (double)x[1] - xi * xi;
+    if (gi_ == 0) {
+      const double xp1 = i + 1 < n ? (double)x[i + 1] : xr;
+      const double t1 = xp1 - xi * xi;
       gi = 2.0 * (xi - 1.0) - 16.0 * xi * t1;
       acc[0] = acc[0] + 0.25 * ((xi - 1.0) * (xi - 1.0));
     } else {
-      const double xm = (double)x[i - 1];
+      const double xm = i > 0 ? (double)x[i - 1] : xl;
       const double t2 = xi - xm * xm;
       acc[0] = acc[0] + t2 * t2;
-      if (i == n - 1) {
+      if (gi_ == nglob - 1) {
         gi = 8.0 * t2;
       } else {
-        const double t1 = (double)x[i + 1] - xi * xi;
+        const double xp1 = i + 1 < n ? (double)x[i + 1] : xr;
+        const double t1 = xp1 - xi * xi;
         gi = 8.0 * t2 - 16.0 * xi * t1;
       }
     }
@@ -1971,12 +1978,26 @@ __global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, const 
   block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
 }
 template <typename T>
-void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
+void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, const T *x, T *g,
+                           double xl, double xr) {
   const int gr = grid_for(n, 1);
-  hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g,
-                     q.d_part);
+  hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, nglob,
+                     x, g, xl, xr, q.d_part);
   q.launches++;
   launch_finalize(q, gr, 1, 0, 0);
+}
+// first and last local element, as doubles, into out[0..1] (halo message)
+template <typename T>
+__global__ void halo_pack_kernel(int64_t n, const T *__restrict__ x, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = (double)x[0];
+    out[1] = (double)x[n - 1];
+  }
+}
+template <typename T>
+void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
+  hipLaunchKernelGGL(halo_pack_kernel<T>, dim3(1), dim3(64), 0, q.stream, n, x, out);
+  q.launches++;
 }
 
 // =========================== explicit instantiations =========================
@@ -2035,7 +2056,9 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g) {
                                       const int32_t *, const T *, const T *, const T *, double,    \
                                       int32_t *, T *, WStore<T>, int, int, int);                   \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *);                \
-  template void launch_obj_rosenbrock<T>(Queue &, int64_t, const T *, T *);
+  template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *,       \
+                                         double, double);                                          \
+  template void launch_halo_pack<T>(Queue &, int64_t, const T *, double *);
 
 INSTANTIATE(double)
 INSTANTIATE(float)

@@ -220,7 +220,10 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 template <typename T>
 void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g);
 template <typename T>
-void launch_obj_rosenbrock(Queue &q, int64_t n, const T *x, T *g);
+void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, const T *x, T *g,
+                           double xl, double xr);
+template <typename T>
+void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out);
 
 // finalize: d_part -> d_res (nsum sums, then nmin mins, then nmax maxes)
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax);

@@ -1523,8 +1523,15 @@ class Solver final : public lbfgsb_hip_ctx {
     if (kind == 0) {
       lbk::launch_obj_quadratic<T>(q, n, row0, (const T *)x, (T *)g);
     } else if (kind == 1) {
-      if (nranks != 1) return fail(LBFGSB_E_ARG, "rosenbrock objective: single rank only");
-      lbk::launch_obj_rosenbrock<T>(q, n, (const T *)x, (T *)g);
+      if (nglob < 2) return fail(LBFGSB_E_ARG, "rosenbrock objective needs n >= 2");
+      double xl = 0.0, xr = 0.0;
+      if (nranks > 1) {  // 1-element halo: every rank's first and last x, all-gathered
+        lbk::launch_halo_pack<T>(q, n, (const T *)x, d_msg);
+        CHK(exchange(2));
+        if (rank > 0) xl = h_msg_all[2 * (rank - 1) + 1];
+        if (rank < nranks - 1) xr = h_msg_all[2 * (rank + 1)];
+      }
+      lbk::launch_obj_rosenbrock<T>(q, n, row0, nglob, (const T *)x, (T *)g, xl, xr);
     } else {
       return fail(LBFGSB_E_ARG, "unknown objective kind");
     }
