@@ -175,7 +175,8 @@ def main():
     # ---- roofline, live, hipEvents on the solver's stream ----
     # (1) the kernel that carries the WS/WY matvec INSIDE the iteration: cmprlb_wtv_kernel
     #     (r of cmprlb + W'r of subsm + formk's new row sums in one pass); algorithmic bytes per
-    #     row = 2col reads of W + x, z, g reads + r write (fp64) + iwhere (int32)
+    #     row = 2col reads of W + x, g reads (fp64) + iwhere (int32); xcp and r stay in registers
+    #     (subsm_update_kernel recomputes it), so the pass writes nothing but its partials
     # (2) the bare W'v kernel (wtv_kernel), (2col+1) n s bytes -- BASELINE.md's definition
     head = int(sol.isave[26])
     mc = 5 if col <= 5 else 10 if col <= 10 else 20 if col <= 20 else 32
@@ -196,7 +197,7 @@ def main():
         return None
 
     ms_fused = sol.kernel_time(2, x, g, col, head, a.roofline_reps)  # the variant the iteration runs
-    alg_fused = ((2 * col + 4) * rbytes + 4) * n_loc
+    alg_fused = ((2 * col + 2) * rbytes + 4) * n_loc
     ach_fused = alg_fused / (ms_fused * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s, %d, true, %s>" % ("float" if a.real32 else "double", mc, nts),
                 "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -52,7 +52,8 @@ class LbfgsbError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "liblbfgsb_hip.so")
+    # LBFGSB_HIP_LIBRARY: another build of the same ABI (A/B timing of two builds on one box)
+    return os.environ.get("LBFGSB_HIP_LIBRARY") or os.path.join(HERE, "liblbfgsb_hip.so")
 
 
 def build_library() -> str:

@@ -685,6 +685,21 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
   }
 }
 
+// rows fixed by a short walk, as a list: entry = global row * 2 + (1 if fixed at the upper bound)
+__global__ void cauchy_fix_kernel(const int64_t *__restrict__ list, int count, int64_t row0,
+                                  int64_t n, int32_t *iwhere) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int64_t gi = list[k] >> 1;
+  if (gi >= row0 && gi < row0 + n) iwhere[gi - row0] = (list[k] & 1) ? 2 : 1;
+}
+void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, int64_t n,
+                       int32_t *iwhere) {
+  hipLaunchKernelGGL(cauchy_fix_kernel, dim3((count + 255) / 256), dim3(256), 0, q.stream, list, count,
+                     row0, n, iwhere);
+  q.launches++;
+}
+
 // =========================== freev (:1980-2059) ==============================
 __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
                                                             const int32_t *__restrict__ iwhere,
@@ -1240,6 +1255,27 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
   q.launches++;
 }
 
+// The generalized Cauchy point is not stored as a vector on the main path: after the walk,
+// xcp(k) is a function of row k's own x, g, bounds and iwhere (cauchy :1341, :1425-1433, :1515):
+//   iwhere in {0,-1} (the row moves with d = -g and was not fixed):  x + tsum*d
+//   iwhere == 1 / 2 (at its lower/upper bound, before or by this walk): that bound
+//   otherwise (always fixed, or free with zero gradient): x
+// Every consumer evaluates exactly the expression cauchy_finish_kernel stores (incl. the
+// rounding to T), so results do not depend on whether z was materialised.
+template <typename T>
+__device__ __forceinline__ double xcp_free(double xk, double gk, int iw, double tsum) {
+  if ((iw == 0 || iw == -1) && tsum != 0.0) return (double)(T)(xk + tsum * (-gk));
+  return xk;
+}
+template <typename T>
+__device__ __forceinline__ double xcp_row(double xk, double gk, int iw, double lk, double uk,
+                                          double tsum) {
+  if (tsum == 0.0) return xk;  // a walk that fixed a row has tsum >= its breakpoint > 0
+  if (iw == 1) return xk == lk ? xk : lk;
+  if (iw == 2) return xk == uk ? xk : uk;
+  return xcp_free<T>(xk, gk, iw, tsum);
+}
+
 // cmprlb fused with the first matvec of subsm (:2742-2754): r_k depends only on row k, so
 // W'r is accumulated in the same pass that computes and stores r (one pass over W instead
 // of two).  Per element the arithmetic is exactly cmprlb_kernel's.
@@ -1247,9 +1283,12 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
 // pair just stored (logical column col-1): with y = Wy_new, s = Ws_new,
 //   t1_j = sum_free y Wy_j, t2_j = sum_act s Ws_j, t3_j = sum_act s Wy_j, t4_j = sum_free Ws_j y.
 // slots: [0,MC) Wy'r | [MC,2MC) Ws'r | NEWROW: [2MC,3MC) t1 | [3MC,4MC) t2 | [4MC,5MC) t3 | [5MC,6MC) t4
+// r itself is NOT stored: its only consumer, subsm_update_kernel, streams the same operands
+// anyway and recomputes it bit for bit (a store stream costs this HBM-bound pass more than it
+// moves: +0.8 GB written = +0.45 ms at n = 1e8, profiles/scripts/cmprlb_wtv_variants.hip).
 template <typename T, int MC, bool NEWROW, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
-    int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
     const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
     int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, double *part) {
   constexpr int NA = NEWROW ? 6 * MC : 2 * MC;
@@ -1258,12 +1297,11 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
-    double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
+    double xv[W], gv[W], rv[W], a[MC][W], b[MC][W];
     int iw[W];
     ldx<W, NT>(g + i, gv);
     if (!plain) {
       ldx<W, NT>(x + i, xv);
-      ldx<W, NT>(z + i, zv);
       ldi<W>(iwhere + i, iw);
     } else {
 #pragma unroll
@@ -1280,7 +1318,8 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
       if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
         rv[k] = -gv[k];
       } else {
-        double rr = -theta * (zv[k] - xv[k]) - gv[k];
+        const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);  // only free rows are used
+        double rr = -theta * (zk - xv[k]) - gv[k];
 #pragma unroll
         for (int j = 0; j < MC; ++j) {
           if (j < col) rr = rr + a[j][k] * cf.a[j] + b[j][k] * cf.a[MAXM + j];
@@ -1288,7 +1327,6 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
         rv[k] = iw[k] <= 0 ? rr : 0.0;
       }
     }
-    st<W>(r + i, rv);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
 #pragma unroll
@@ -1326,17 +1364,17 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
   block_reduce_store<NA>(acc, NA, 0, 0, part, MAX_BLOCKS);
 }
 template <typename T>
-void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
+void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
                        const Coef &a, int plain, int newrow) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (newrow) {
     DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                          q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m,
+                                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
                                           head, col, theta, a, plain, q.d_part));
   } else {
     DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                          q.stream, n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m,
+                                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
                                           head, col, theta, a, plain, q.d_part));
   }
   q.launches++;
@@ -1427,49 +1465,76 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 }
 
 // =========================== subsm (:2676-2885) ==============================
-// LS (fused line-search set-up): the projected point z is final unless the rare backtracking
-// branch (:2830-2879) is taken, so the same pass also does what mainlb :720-722 and the first
-// call of lnsrlb (:2196-2236) do next: d = z - x, t = x, r = g, dtd = d'd, the stpmx ratios;
-// g'd is dd_p itself.  The Newton direction then goes to `ndir` (scratch) instead of r.
+// Newton direction of one free row (cmprlb :1560-1583 then subsm :2770-2780): the reduced
+// gradient r is recomputed here exactly as cmprlb_wtv_kernel computed it for W'r.
+template <int MC>
+__device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, const double (&a)[MC],
+                                            const double (&b)[MC], int col, double theta,
+                                            double rtheta, const Coef &cf, int plain,
+                                            const Coef &wv) {
+  double dk;
+  if (plain) {
+    dk = -gk;
+  } else {
+    dk = -theta * (zk - xk) - gk;
+#pragma unroll
+    for (int j = 0; j < MC; ++j)
+      if (j < col) dk = dk + a[j] * cf.a[j] + b[j] * cf.a[MAXM + j];
+  }
+#pragma unroll
+  for (int j = 0; j < MC; ++j)
+    if (j < col) dk = dk + a[j] * wv.a[j] / theta + b[j] * wv.a[MAXM + j];
+  return rtheta * dk;  // dscal (:2780)
+}
+
+// One pass: Newton direction, projected step (:2789-2816), dd_p (:2824-2827) and -- because the
+// projected point is final unless the rare backtracking branch (:2830-2879) is taken -- what
+// mainlb :720-722 and the first call of lnsrlb (:2196-2236) do next: d = z - x, t = x, r = g,
+// dtd = d'd, the stpmx ratios; g'd is dd_p itself.  The Cauchy point is evaluated per row
+// (xcp_row), the subspace minimiser written to `zout`; neither xp (:2787) nor the direction is
+// stored (the backtracking branch regenerates both: cauchy_finish_kernel, subsm_dir_kernel).
 // res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
-template <typename T, int MC, bool LS, bool NT>
+template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
-    int64_t n, T *z, T *r, T *xp, const T *__restrict__ l, const T *__restrict__ u,
-    const int32_t *__restrict__ nbd, const int32_t *__restrict__ iwhere,
-    const T *__restrict__ xx, const T *__restrict__ gg, const T *__restrict__ ws,
-    const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double theta, Coef wv,
-    T *ndir, T *dvec, T *tvec, int do_stpmx, double *part) {
+    int64_t n, double tsum, T *__restrict__ zout, T *__restrict__ r,
+    const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
+    const int32_t *__restrict__ iwhere, const T *__restrict__ xx, const T *__restrict__ gg,
+    const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
+    double theta, Coef cf, int plain, Coef wv, T *__restrict__ dvec, T *__restrict__ tvec,
+    int do_stpmx, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
-    double zv[W], rv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
+    double zv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
-    ldx<W, NT>(z + i, zv);
-    ldx<W, NT>(r + i, rv);
     ldx<W, NT>(l + i, lv);
     ldx<W, NT>(u + i, uv);
     ldx<W, NT>(xx + i, xv);
     ldx<W, NT>(gg + i, gv);
     ldi<W>(nbd + i, nb);
-    ldi<W>(iwhere + i, iw);
+    if (!plain) {
+      ldi<W>(iwhere + i, iw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
+    }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
       ldx<W, NT>(wy + off, a[j]);
       ldx<W, NT>(ws + off, b[j]);
     }
-    st<W>(xp + i, zv);  // xp = xcp (:2787)
+#pragma unroll
+    for (int k = 0; k < W; ++k) zv[k] = xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], tsum);
+    double dv[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       if (iw[k] <= 0) {
-        double dk = rv[k];
+        double ak[MC], bk[MC];
 #pragma unroll
-        for (int j = 0; j < MC; ++j) {
-          if (j < col) dk = dk + a[j][k] * wv.a[j] / theta + b[j][k] * wv.a[MAXM + j];
-        }
-        dk = rtheta * dk;  // dscal (:2780)
-        rv[k] = dk;
+        for (int j = 0; j < MC; ++j) ak[j] = a[j][k], bk[j] = b[j][k];
+        const double dk = subsm_dir<MC>(xv[k], zv[k], gv[k], ak, bk, col, theta, rtheta, cf, plain, wv);
         const double xk = zv[k];
         if (nb[k] != 0) {
           if (nb[k] == 1) {
@@ -1487,55 +1552,90 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
           zv[k] = xk + dk;
         }
       }
-      acc[1] = acc[1] + (zv[k] - xv[k]) * gv[k];  // dd_p (:2824-2827) == g'd (:2244)
-    }
-    st<W>(z + i, zv);
-    if constexpr (!LS) {
-      st<W>(r + i, rv);
-    } else {
-      double dv[W];
-      st<W>(ndir + i, rv);
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        dv[k] = zv[k] - xv[k];            // mainlb :720-722
-        acc[2] = acc[2] + dv[k] * dv[k];  // dtd (:2196)
-        if (do_stpmx && nb[k] != 0) {     // :2206-2225
-          const double a1 = dv[k];
-          if (a1 < 0.0 && nb[k] <= 2) {
-            const double a2 = lv[k] - xv[k];
-            acc[3] = fmin(acc[3], a2 >= 0.0 ? 0.0 : a2 / a1);
-          } else if (a1 > 0.0 && nb[k] >= 2) {
-            const double a2 = uv[k] - xv[k];
-            acc[3] = fmin(acc[3], a2 <= 0.0 ? 0.0 : a2 / a1);
-          }
+      dv[k] = zv[k] - xv[k];            // mainlb :720-722
+      acc[1] = acc[1] + dv[k] * gv[k];  // dd_p (:2824-2827) == g'd (:2244)
+      acc[2] = acc[2] + dv[k] * dv[k];  // dtd (:2196)
+      if (do_stpmx && nb[k] != 0) {     // :2206-2225
+        const double a1 = dv[k];
+        if (a1 < 0.0 && nb[k] <= 2) {
+          const double a2 = lv[k] - xv[k];
+          acc[3] = fmin(acc[3], a2 >= 0.0 ? 0.0 : a2 / a1);
+        } else if (a1 > 0.0 && nb[k] >= 2) {
+          const double a2 = uv[k] - xv[k];
+          acc[3] = fmin(acc[3], a2 <= 0.0 ? 0.0 : a2 / a1);
         }
       }
-      st<W>(dvec + i, dv);
-      st<W>(tvec + i, xv);  // t = x (:2235)
-      st<W>(r + i, gv);     // r = g (:2236)
     }
+    st<W>(zout + i, zv);
+    st<W>(dvec + i, dv);
+    st<W>(tvec + i, xv);  // t = x (:2235)
+    st<W>(r + i, gv);     // r = g (:2236)
   });
   block_reduce_store<4>(acc, 3, 1, 0, part, MAX_BLOCKS);
 }
 template <typename T>
-void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, const T *u,
+void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
-                         WStore<T> w, int head, int col, double theta, const Coef &wv, T *ndir,
-                         T *dvec, T *tvec, int do_stpmx) {
+                         WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
+                         const Coef &wv, T *dvec, T *tvec, int do_stpmx) {
   const int gr = grid_for(n, VecOf<T>::V);
-  if (ndir) {
-    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK),
-                                          0, q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
-                                          w.wy, w.ld, w.m, head, col, theta, wv, ndir, dvec, tvec,
-                                          do_stpmx, q.d_part));
-  } else {
-    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK),
-                                          0, q.stream, n, z, r, xp, l, u, nbd, iwhere, xx, gg, w.ws,
-                                          w.wy, w.ld, w.m, head, col, theta, wv, ndir, dvec, tvec,
-                                          do_stpmx, q.d_part));
-  }
+  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
+                                        q.stream, n, tsum, zout, r, l, u, nbd, iwhere, xx, gg, w.ws,
+                                        w.wy, w.ld, w.m, head, col, theta, cf, plain, wv, dvec, tvec,
+                                        do_stpmx, q.d_part));
   q.launches++;
   launch_finalize(q, gr, 3, 1, 0);
+}
+
+// The Newton direction as a vector (free rows; 0 elsewhere), for the backtracking branch only.
+template <typename T, int MC, bool NT>
+__global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
+    int64_t n, const T *__restrict__ xcp, const int32_t *__restrict__ iwhere,
+    const T *__restrict__ xx, const T *__restrict__ gg, const T *__restrict__ ws,
+    const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double theta, Coef cf,
+    int plain, Coef wv, T *__restrict__ ndir) {
+  const double rtheta = 1.0 / theta;
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double zv[W], xv[W], gv[W], a[MC][W], b[MC][W], out[W];
+    int iw[W];
+    ldx<W, NT>(xcp + i, zv);
+    ldx<W, NT>(xx + i, xv);
+    ldx<W, NT>(gg + i, gv);
+    if (!plain) {
+      ldi<W>(iwhere + i, iw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) iw[k] = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i;
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      out[k] = 0.0;
+      if (iw[k] <= 0) {
+        double ak[MC], bk[MC];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) ak[j] = a[j][k], bk[j] = b[j][k];
+        out[k] = subsm_dir<MC>(xv[k], zv[k], gv[k], ak, bk, col, theta, rtheta, cf, plain, wv);
+      }
+    }
+    st<W>(ndir + i, out);
+  });
+}
+template <typename T>
+void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const int32_t *iwhere, const T *xx,
+                      const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
+                      int plain, const Coef &wv, T *ndir) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_dir_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
+                                        q.stream, n, xcp, iwhere, xx, gg, w.ws, w.wy, w.ld, w.m, head,
+                                        col, theta, cf, plain, wv, ndir));
+  q.launches++;
 }
 
 // backtracking ratio of one free variable (:2842-2857); 2.0 = no restriction
@@ -2029,14 +2129,17 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
   template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const int32_t *);      \
   template void launch_cmprlb<T>(Queue &, int64_t, const T *, const T *, const T *, T *,           \
                                  const int32_t *, WStore<T>, int, int, double, const Coef &, int); \
-  template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, const T *, T *,       \
+  template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double,               \
                                      const int32_t *, WStore<T>, int, int, double, const Coef &,  \
                                      int, int);                                                     \
   template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int);    \
-  template void launch_subsm_update<T>(Queue &, int64_t, T *, T *, T *, const T *, const T *,      \
-                                       const int32_t *, const int32_t *, const T *, const T *,     \
-                                       WStore<T>, int, int, double, const Coef &, T *, T *, T *,   \
-                                       int);                                                       \
+  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *,              \
+                                       const T *, const int32_t *, const int32_t *, const T *,     \
+                                       const T *, WStore<T>, int, int, double, const Coef &, int,  \
+                                       const Coef &, T *, T *, int);                               \
+  template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const int32_t *, const T *,       \
+                                    const T *, WStore<T>, int, int, double, const Coef &, int,     \
+                                    const Coef &, T *);                                            \
   template void launch_subsm_alpha<T>(Queue &, int64_t, const T *, const T *, const T *,           \
                                       const T *, const int32_t *, const int32_t *);                \
   template void launch_subsm_argalpha<T>(Queue &, int64_t, int64_t, const T *, const T *,          \

@@ -120,6 +120,10 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
                           const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
                           double last_t, int64_t last_i, int count = 0);
 
+// rows fixed by a short walk (list entry = global row * 2 + upper?): iwhere = 1 / 2
+void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, int64_t n,
+                       int32_t *iwhere);
+
 // ---- freev (ref :1980-2059) -------------------------------------------------
 // res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave; updates wasfree.
 // chg (optional): rows whose free/active status changed are appended (unordered) as
@@ -150,9 +154,10 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
 // res sum-slots (MC = maxc_for(col)): [0..col) Wy'r, [MC..MC+col) Ws'r; with newrow also the
 // new row/column of formk's WN1 for the pair in logical column col-1 (ref :1756-1793):
 // [2MC..) sum_free Wy_new Wy_j, [3MC..) sum_act Ws_new Ws_j, [4MC..) sum_act Ws_new Wy_j,
-// [5MC..) sum_free Ws_j Wy_new
+// [5MC..) sum_free Ws_j Wy_new.  r itself is not stored: launch_subsm_update recomputes it.
+// The Cauchy point is evaluated per row from (x, g, iwhere, tsum), see xcp_free in kernels.hip.
 template <typename T>
-void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
+void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
                        const Coef &a, int plain, int newrow);
 // formk patches (ref :1801-1851): signed Gram over the listed rows (+ entered, - left the free
@@ -161,16 +166,22 @@ template <typename T>
 void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w, int head, int upcl);
 
 // ---- subsm (ref :2676-2885) --------------------------------------------------
-// update (:2770-2816 + :2824-2827): d = (r + W wv..)/theta on free rows, xp = xcp,
-// projected step into z.  res sum-slots: [0] = #bound hits (iword), [1] = dd_p (= g'(z-x)),
-// [2] = dtd ; min-slot [3] = stpmx candidate (the last two only with ndir != nullptr).
-// ndir != nullptr: the Newton direction goes to ndir instead of r and the pass also does the
-// line-search set-up of mainlb :720-722 / lnsrlb :2196-2236: dvec = z - x, tvec = x, r = g.
+// update (cmprlb's r recomputed, :2770-2816, :2824-2827) + the line-search set-up of mainlb
+// :720-722 / lnsrlb :2196-2236 in one pass: zout = projected subspace point from the Cauchy
+// point (evaluated per row from x, g, l, u, iwhere, tsum), dvec = zout - x, tvec = x, r = g.
+// cf/plain = the coefficients the preceding launch_cmprlb_wtv used; wv = K^-1 W'r.
+// res sum-slots: [0] = #bound hits (iword), [1] = dd_p (= g'(z-x)), [2] = dtd ; min-slot [3] =
+// stpmx candidate.
 template <typename T>
-void launch_subsm_update(Queue &q, int64_t n, T *z, T *r, T *xp, const T *l, const T *u,
+void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
-                         WStore<T> w, int head, int col, double theta, const Coef &wv, T *ndir,
-                         T *dvec, T *tvec, int do_stpmx);
+                         WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
+                         const Coef &wv, T *dvec, T *tvec, int do_stpmx);
+// the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
+template <typename T>
+void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const int32_t *iwhere, const T *xx,
+                      const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
+                      int plain, const Coef &wv, T *ndir);
 // backtrack (:2836-2863): res min-slot [0] = alpha; then argmin pass:
 // res min-slot [0] = smallest global index attaining alpha (as double)
 template <typename T>

@@ -186,13 +186,14 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
-        F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart);
+        F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
+        F(d_fix);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
       p = nullptr;
     };
-    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res);
+    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix);
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -258,6 +259,8 @@ class Solver final : public lbfgsb_hip_ctx {
     msg_len = 2 + (size_t)CHUNK_MAX * (2 * m + 4);
     HIPCHK(hipMalloc(&d_msg, msg_len * sizeof(double)));
     HIPCHK(hipHostMalloc(&h_hdr, 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&d_fix, FIX_CAP * sizeof(int64_t)));
+    HIPCHK(hipHostMalloc(&h_fix, FIX_CAP * sizeof(int64_t)));
     CHK(set_ranks(0, 1));
     sy.assign((size_t)m * m, 0.0);
     ss.assign((size_t)m * m, 0.0);
@@ -547,6 +550,52 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
+  // The Cauchy point is kept in functional form (tsum + iwhere, see xcp_row in kernels.hip)
+  // and only written out as a vector where one is needed: subsm skipped, the backtracking
+  // branch of subsm, state export.
+  struct Gcp {
+    double tsum = 0.0, last_t = -1.0;
+    int64_t last_i = -1;
+    bool copy_x = false;  // xcp = x without a cauchy scan behind it (tbrk is stale)
+  } gcp;
+  bool z_valid = false;
+  static constexpr size_t FIX_CAP = 65536;
+  std::vector<int64_t> fixlist;
+  bool fix_overflow = false;
+  int64_t *d_fix = nullptr, *h_fix = nullptr;
+
+  int write_xcp(T *dst, const T *x, const T *l, const T *u, const T *g) {
+    if (gcp.copy_x) {
+      HIPCHK(hipMemcpyAsync(dst, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    } else {
+      lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, dst, gcp.tsum, gcp.last_t,
+                                   gcp.last_i);
+    }
+    return 0;
+  }
+  int ensure_z(const T *x, const T *l, const T *u, const T *g) {
+    if (!z_valid) CHK(write_xcp(z, x, l, u, g));
+    z_valid = true;
+    return 0;
+  }
+  // end of cauchy: make iwhere final (rows fixed by the walk) without writing xcp
+  int close_gcp(double tsum, double last_t, int64_t last_i) {
+    gcp.tsum = tsum, gcp.last_t = last_t, gcp.last_i = last_i, gcp.copy_x = false;
+    z_valid = false;
+    if (fix_overflow) {  // long walk: the cursor-based kernel (it writes z on the way)
+      lbk::launch_cauchy_finish<T>(q, n, row0, (const T *)cx, (const T *)cl, (const T *)cu,
+                                   (const T *)cg, tbrk, iwhere, z, tsum, last_t, last_i);
+      z_valid = true;
+    } else if (!fixlist.empty()) {
+      std::memcpy(h_fix, fixlist.data(), fixlist.size() * sizeof(int64_t));
+      HIPCHK(hipMemcpyAsync(d_fix, h_fix, fixlist.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                            stream));
+      lbk::launch_cauchy_fix(q, d_fix, (int)fixlist.size(), row0, n, iwhere);
+    }
+    return 0;
+  }
+  const void *cx = nullptr, *cl = nullptr, *cu = nullptr, *cg = nullptr;  // this call's operands
+
   // Generalized Cauchy point, reference :1157-1532.  p,c,wbp,v = wa8m slots.
   // results of the n-loop of cauchy when it was fused into the matupd pass
   struct ScanOut {
@@ -558,9 +607,14 @@ class Solver final : public lbfgsb_hip_ctx {
   int cauchy(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
              int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
     double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
+    cx = x, cl = l, cu = u, cg = g;
+    fixlist.clear();
+    fix_overflow = false;
     if (sbgnrm <= 0.0) {  // :1245-1249
       scan.ready = false;
-      HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      gcp = Gcp{};
+      gcp.copy_x = true;
+      z_valid = false;
       return 0;
     }
     const int col2 = 2 * col;
@@ -588,8 +642,7 @@ class Solver final : public lbfgsb_hip_ctx {
     double last_t = -1.0;
     int64_t last_i = -1;
     if (nbreak == 0 && nunb == 0) {  // d = 0: xcp = x (:1343-1347)
-      lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, 0.0, last_t, last_i);
-      return 0;
+      return close_gcp(0.0, last_t, last_i);
     }
     for (int j = 0; j < col2; ++j) c[j] = 0.0;
     double f2 = -theta * f1;  // :1357-1363
@@ -609,6 +662,9 @@ class Solver final : public lbfgsb_hip_ctx {
       const double tstar = 1.0 / theta;
       lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tstar, tstar,
                                    std::numeric_limits<int64_t>::max(), 1);
+      gcp = Gcp{};
+      gcp.tsum = tstar, gcp.last_t = tstar, gcp.last_i = std::numeric_limits<int64_t>::max();
+      z_valid = true;
       CHK(fetch(1, 0, 0));
       const int64_t done = (int64_t)h_res[0];
       // the walk counts a segment per fixed variable except a last one that fixes all n (:1436)
@@ -671,13 +727,15 @@ class Solver final : public lbfgsb_hip_ctx {
         const double zibp = rec[3];
         last_t = tj;
         last_i = rec_gi;
+        if (fixlist.size() < FIX_CAP)
+          fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
+        else
+          fix_overflow = true;
         if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
           dtm = dt;
           if (col > 0)
             for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];
-          lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, 0.0, last_t,
-                                       last_i);
-          return 0;
+          return close_gcp(tsum, last_t, last_i);  // no row is left to move: tsum is moot
         }
         nseg = nseg + 1;
         const double dibp2 = dibp * dibp;
@@ -719,10 +777,9 @@ class Solver final : public lbfgsb_hip_ctx {
                    last_t, (long long)last_i);
     if (dtm <= 0.0) dtm = 0.0;  // :1509
     tsum = tsum + dtm;
-    lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tsum, last_t, last_i);
     if (col > 0 && dtm != 0.0)
       for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
-    return 0;
+    return close_gcp(tsum, last_t, last_i);
   }
 
   // ==================================================================== formk
@@ -840,15 +897,20 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // ========================================================== cmprlb + subsm
   // coefficients of cmprlb: wa(1:2m) = M c (bmv, :1569) -> a1_j, a2_j = theta * (.) (:1576-1577)
+  // (kept in cm_cf / cm_plain: subsm_update_kernel recomputes r from them)
+  lbk::Coef cm_cf;
+  bool cm_plain = false;
   bool cmprlb_coef(int col, double theta, bool cnstnd, lbk::Coef &cf, bool &plain) {
     std::memset(&cf, 0, sizeof cf);
     plain = !cnstnd && col > 0;
-    if (plain) return true;
-    if (lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]) != 0) return false;
-    for (int j = 0; j < col; ++j) {
-      cf.a[j] = wa8m[j];
-      cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
+    if (!plain) {
+      if (lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]) != 0) return false;
+      for (int j = 0; j < col; ++j) {
+        cf.a[j] = wa8m[j];
+        cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
+      }
     }
+    cm_cf = cf, cm_plain = plain;
     return true;
   }
 
@@ -871,8 +933,8 @@ class Solver final : public lbfgsb_hip_ctx {
         info = -8;
         return 0;
       }
-      lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf, plain ? 1 : 0,
-                                newrow ? 1 : 0);
+      lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
+                                plain ? 1 : 0, newrow ? 1 : 0);
       CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
       res = h_res;
     }
@@ -901,10 +963,12 @@ class Solver final : public lbfgsb_hip_ctx {
       cw.a[j] = wv[j];
       cw.a[lbk::MAXM + j] = wv[col + j];
     }
-    // the Newton direction lives in tbrk (free since cauchy_finish); d, t, r get their
-    // line-search values in the same pass (see subsm_update_kernel)
-    lbk::launch_subsm_update<T>(q, n, z, r, xp, l, u, nbd, iwhere, x, g, W(), head, col, theta,
-                                cw, tbrk, d, t, ls_do_stpmx ? 1 : 0);
+    // d, t, r get their line-search values in the same pass (see subsm_update_kernel); xp = xcp
+    // (:2787) is written out only for state export -- and below if the backtracking branch runs
+    if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
+    lbk::launch_subsm_update<T>(q, n, gcp.tsum, z, r, l, u, nbd, iwhere, x, g, W(), head, col, theta,
+                                cm_cf, cm_plain ? 1 : 0, cw, d, t, ls_do_stpmx ? 1 : 0);
+    z_valid = true;
     CHK(fetch(3, 1, 0));
     iword = h_res[0] > 0.0 ? 1 : 0;
     const double dd_p = h_res[1];
@@ -918,6 +982,11 @@ class Solver final : public lbfgsb_hip_ctx {
       std::fprintf(rep.out, " Positive dir derivative in projection \n");
       std::fprintf(rep.out, " Using the backtracking step \n");
     }
+    // xp = xcp and the Newton direction as vectors (the direction goes to tbrk, which the
+    // cursor-based cauchy_finish_kernel has read by then)
+    if (!(flags & LBFGSB_F_MIRROR_INDEX)) CHK(write_xcp(xp, x, l, u, g));
+    lbk::launch_subsm_dir<T>(q, n, xp, iwhere, x, g, W(), head, col, theta, cm_cf, cm_plain ? 1 : 0,
+                             cw, tbrk);
     lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
     CHK(fetch(0, 1, 0));
     const double alpha = std::min(1.0, h_res[0]);
@@ -1100,8 +1169,10 @@ class Solver final : public lbfgsb_hip_ctx {
         iword = -1;
         ls.ready = false;
         ls_do_stpmx = cnstnd && iter != 0;
-        if (!cnstnd && col > 0) {  // :607-611
-          HIPCHK(hipMemcpyAsync(z, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
+          gcp = Gcp{};
+          gcp.copy_x = true;
+          z_valid = false;
           wrk = updatd;
           nseg = 0;
           pre_valid = false;
@@ -1134,7 +1205,7 @@ class Solver final : public lbfgsb_hip_ctx {
             if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
               const bool newrow = updatd && col <= 20;  // updatd implies wrk
               q.res_off = 3;
-              lbk::launch_cmprlb_wtv<T>(q, n, x, g, z, r, iwhere, W(), head, col, theta, cf,
+              lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
                                         plain ? 1 : 0, newrow ? 1 : 0);
               q.res_off = 0;
               npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
@@ -1163,7 +1234,8 @@ class Solver final : public lbfgsb_hip_ctx {
         }
 
         if (nfree_g == 0 || col == 0) {
-          // skip the subspace minimization :648-651
+          // skip the subspace minimization :648-651: the line search starts from z = xcp
+          CHK(ensure_z(x, l, u, g));
         } else {
           cpu1 = now_s();
           const bool incr = wrk && col <= 20;  // incremental WN1, fused into the cmprlb pass
@@ -1446,6 +1518,7 @@ class Solver final : public lbfgsb_hip_ctx {
       ps += n;
     }
     get(wa8m);
+    z_valid = true;  // z as imported
     HIPCHK(hipMemcpyAsync(iwhere, iwa + n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
     // free-set membership as of the last freev: Index(1:nfree)
     std::vector<int8_t> wf((size_t)n, 0);
@@ -1501,7 +1574,7 @@ class Solver final : public lbfgsb_hip_ctx {
     lbk::Coef cf;
     std::memset(&cf, 0, sizeof cf);
     if (which == 0 || which == 2)
-      lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, z, r, iwhere, W(), head, col, 1.0,
+      lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
                                 cf, 0, which == 2 ? 1 : 0);
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
