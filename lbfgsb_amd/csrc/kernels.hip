@@ -1498,10 +1498,10 @@ template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, double tsum, T *__restrict__ zout, T *__restrict__ r,
     const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
-    const int32_t *__restrict__ iwhere, const T *__restrict__ xx, const T *__restrict__ gg,
+    const int32_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
     double theta, Coef cf, int plain, Coef wv, T *__restrict__ dvec, T *__restrict__ tvec,
-    int do_stpmx, double *part) {
+    T *xout, int do_stpmx, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
@@ -1570,6 +1570,9 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     st<W>(dvec + i, dv);
     st<W>(tvec + i, xv);  // t = x (:2235)
     st<W>(r + i, gv);     // r = g (:2236)
+    // first trial point of the line search when its step is known to be 1: x = z (:2265);
+    // xout aliases xx (each row is read above before it is written here)
+    if (xout) st<W>(xout + i, zv);
   });
   block_reduce_store<4>(acc, 3, 1, 0, part, MAX_BLOCKS);
 }
@@ -1577,12 +1580,12 @@ template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
-                         const Coef &wv, T *dvec, T *tvec, int do_stpmx) {
+                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx) {
   const int gr = grid_for(n, VecOf<T>::V);
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                         q.stream, n, tsum, zout, r, l, u, nbd, iwhere, xx, gg, w.ws,
                                         w.wy, w.ld, w.m, head, col, theta, cf, plain, wv, dvec, tvec,
-                                        do_stpmx, q.d_part));
+                                        xout, do_stpmx, q.d_part));
   q.launches++;
   launch_finalize(q, gr, 3, 1, 0);
 }
@@ -1931,6 +1934,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     ldx<W, NT>(d + i, dv);
     ldi<W>(nbd + i, nb);
     ldi<W>(iwhere + i, iw);
+    bool iw_changed = false;
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
@@ -1950,6 +1954,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         if (nb[k] >= 2) tu = uv[k] - xv[k];
         const bool xlower = nb[k] <= 2 && tl <= 0.0;
         const bool xupper = nb[k] >= 2 && tu <= 0.0;
+        const int iw_old = iw[k];
         iw[k] = 0;
         if (xlower) {
           if (neggi <= 0.0) iw[k] = 1;
@@ -1958,6 +1963,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         } else {
           if (fabs(neggi) <= 0.0) iw[k] = -3;
         }
+        iw_changed = iw_changed || iw[k] != iw_old;
       }
       if (iw[k] != 0 && iw[k] != -1) {
         tb[k] = -1.0;
@@ -1994,7 +2000,8 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     }
     st<W>(ws + offn + i, dv);
     st<W>(wy + offn + i, rv);
-    sti<W>(iwhere + i, iw);
+    // iwhere settles after the first iterations: store only from waves that changed a row
+    if (__ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
     st<W>(tbrk + i, tb);
   });
   block_reduce_store<NA>(acc, 4 * MC + 7, 1, 0, part, MAX_BLOCKS);
@@ -2136,7 +2143,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
   template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *,              \
                                        const T *, const int32_t *, const int32_t *, const T *,     \
                                        const T *, WStore<T>, int, int, double, const Coef &, int,  \
-                                       const Coef &, T *, T *, int);                               \
+                                       const Coef &, T *, T *, T *, int);                          \
   template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const int32_t *, const T *,       \
                                     const T *, WStore<T>, int, int, double, const Coef &, int,     \
                                     const Coef &, T *);                                            \

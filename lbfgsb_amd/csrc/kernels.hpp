@@ -171,12 +171,13 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 // point (evaluated per row from x, g, l, u, iwhere, tsum), dvec = zout - x, tvec = x, r = g.
 // cf/plain = the coefficients the preceding launch_cmprlb_wtv used; wv = K^-1 W'r.
 // res sum-slots: [0] = #bound hits (iword), [1] = dd_p (= g'(z-x)), [2] = dtd ; min-slot [3] =
-// stpmx candidate.
+// stpmx candidate.  xout (= the caller's x, or nullptr): also store the first trial point of the
+// line search, x = z, when its step length is known to be 1 (:2265).
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
-                         const Coef &wv, T *dvec, T *tvec, int do_stpmx);
+                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx);
 // the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
 template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const int32_t *iwhere, const T *xx,

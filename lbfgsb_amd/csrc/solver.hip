@@ -967,17 +967,23 @@ class Solver final : public lbfgsb_hip_ctx {
     // (:2787) is written out only for state export -- and below if the backtracking branch runs
     if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, z, r, l, u, nbd, iwhere, x, g, W(), head, col, theta,
-                                cm_cf, cm_plain ? 1 : 0, cw, d, t, ls_do_stpmx ? 1 : 0);
+                                cm_cf, cm_plain ? 1 : 0, cw, d, t, ls_unit_step ? xmut : nullptr,
+                                ls_do_stpmx ? 1 : 0);
     z_valid = true;
     CHK(fetch(3, 1, 0));
     iword = h_res[0] > 0.0 ? 1 : 0;
     const double dd_p = h_res[1];
     ls.ready = true;
+    ls.x_is_z = ls_unit_step;
     ls.gd = dd_p;
     ls.dtd = h_res[2];
     ls.stpmx = h_res[3];
     if (iword == 0 || dd_p <= 0.0) return 0;  // :2820, :2828
     ls.ready = false;  // z changes below: lnsrlb_begin redoes d, t, r
+    if (ls.x_is_z) {   // ... from the iterate itself, which the pass above saved in t
+      HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      ls.x_is_z = false;
+    }
     if (rep.out && !quiet && print_level >= 0) {
       std::fprintf(rep.out, " Positive dir derivative in projection \n");
       std::fprintf(rep.out, " Using the backtracking step \n");
@@ -1003,9 +1009,12 @@ class Solver final : public lbfgsb_hip_ctx {
   // line-search set-up values when they were produced by the subsm pass
   struct LsOut {
     bool ready = false;
+    bool x_is_z = false;  // the pass already stored the first trial point x = z
     double gd = 0, dtd = 0, stpmx = 0;
   } ls;
   bool ls_do_stpmx = false;
+  bool ls_unit_step = false;  // the first trial step of this iteration's line search is 1
+  T *xmut = nullptr;          // the caller's x of this call
   // sums of a cmprlb_wtv pass that was launched together with freev's counts
   double pre_res[6 * lbk::MAXM];
   bool pre_valid = false;
@@ -1168,7 +1177,10 @@ class Solver final : public lbfgsb_hip_ctx {
         if (ipr >= 99) std::fprintf(rep.out, "\n\nITERATION %5d\n", iter + 1);
         iword = -1;
         ls.ready = false;
+        ls.x_is_z = false;
         ls_do_stpmx = cnstnd && iter != 0;
+        ls_unit_step = !(iter == 0 && !boxed);  // lnsrlb :2228-2232
+        xmut = x;
         if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
           gcp = Gcp{};
           gcp.copy_x = true;
@@ -1316,7 +1328,9 @@ class Solver final : public lbfgsb_hip_ctx {
             ifun++;
             nfgv++;
             iback = ifun - 1;
-            lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
+            if (!(ls.x_is_z && ifun == 1 && stp == 1.0))  // else x = z is already in place
+              lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
+            ls.x_is_z = false;
           } else {
             lbh::str60_set(task, "NEW_X");
           }
