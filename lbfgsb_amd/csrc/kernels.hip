@@ -468,6 +468,112 @@ void launch_cauchy_window(Queue &q, int64_t n, int64_t row0, const T *tbrk, doub
   q.launches++;
 }
 
+// Breakpoint time of one row from its own data, exactly as the scans store it in tbrk (incl.
+// the rounding to T): -1 = the row does not move, +inf = it moves without meeting a bound.
+// iw is iwhere AFTER the scan's update (cauchy :1284-1291).
+template <typename T>
+__device__ __forceinline__ double brk_time(double xk, double lk, double uk, int nb, double gk,
+                                           int iw) {
+  if (iw != 0 && iw != -1) return -1.0;
+  const double neggi = -gk;
+  double tb = LB_INF;
+  if (nb <= 2 && nb != 0 && neggi < 0.0) {
+    tb = (xk - lk) / (-neggi);
+  } else if (nb >= 2 && neggi > 0.0) {
+    tb = (uk - xk) / neggi;
+  }
+  return (double)(T)tb;
+}
+
+// The window compaction without a stored tbrk: breakpoint times are recomputed per row
+// (read-only pass over x, l, u, nbd, g, iwhere; the iteration's update pass then writes no
+// n-vector at all, see update_scan_kernel).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
+    int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
+    const T *__restrict__ u, const int32_t *__restrict__ nbd, const T *__restrict__ g,
+    const int32_t *__restrict__ iwhere, double lo_t, int64_t lo_i, double hi_t, uint64_t *keys,
+    uint32_t *idx, uint32_t cap, uint32_t *count) {
+  const int lane = threadIdx.x & 63;
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W], tv[W];
+    int nb[W], iw[W];
+    ldx<W, true>(x + i, xv);
+    ldx<W, true>(l + i, lv);
+    ldx<W, true>(u + i, uv);
+    ldx<W, true>(g + i, gv);
+    ldi<W>(nbd + i, nb);
+    ldi<W>(iwhere + i, iw);
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      tv[k] = brk_time<T>(xv[k], lv[k], uv[k], nb[k], gv[k], iw[k]);
+      const bool pred =
+          tv[k] >= 0.0 && tv[k] <= hi_t && after_cursor(tv[k], row0 + i + k, lo_t, lo_i);
+      bits |= pred ? (1u << k) : 0u;
+    }
+    if (__ballot(bits != 0) == 0ull) return;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const bool pred = (bits >> k) & 1u;
+      const unsigned long long mask = __ballot(pred);
+      if (mask == 0ull) continue;
+      const int leader = __ffsll((long long)mask) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+      base = __shfl(base, leader);
+      if (pred) {
+        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < cap) {
+          keys[pos] = key_of(tv[k]);
+          idx[pos] = (uint32_t)(i + k);
+        }
+      }
+    }
+  });
+}
+template <typename T>
+void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
+                              const int32_t *nbd, const T *g, const int32_t *iwhere, double lo_t,
+                              int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
+                              uint32_t *d_count) {
+  (void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), q.stream);
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(cauchy_window_fly_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, l,
+                     u, nbd, g, iwhere, lo_t, lo_i, hi_t, keys, idx, cap, d_count);
+  q.launches++;
+}
+// tbrk as a vector, for the paths that want one (full sort, cursor-based cauchy_finish)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void tbrk_fill_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, const int32_t *__restrict__ iwhere,
+    T *tbrk) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W], tv[W];
+    int nb[W], iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ldi<W>(nbd + i, nb);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int k = 0; k < W; ++k) tv[k] = brk_time<T>(xv[k], lv[k], uv[k], nb[k], gv[k], iw[k]);
+    st<W>(tbrk + i, tv);
+  });
+}
+template <typename T>
+void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
+                      const T *g, const int32_t *iwhere, T *tbrk) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(tbrk_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
+                     iwhere, tbrk);
+  q.launches++;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void cauchy_allkeys_kernel(int64_t n, int64_t row0,
                                                                const T *__restrict__ tbrk,
@@ -517,9 +623,9 @@ void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
-    const uint32_t *__restrict__ idx, uint32_t cnt, int64_t row0, const T *__restrict__ x,
-    const T *__restrict__ l, const T *__restrict__ u, const T *__restrict__ g,
-    const T *__restrict__ tbrk, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
+    const uint32_t *__restrict__ idx, const uint64_t *__restrict__ keys, uint32_t cnt,
+    int64_t row0, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const T *__restrict__ g, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
     int m, int head, int col, double *rec) {
   const int rl = 2 * col + 4;
   const int64_t total = (int64_t)cnt * rl;
@@ -530,7 +636,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
     const int64_t i = idx[k];
     double v;
     if (f == 0) {
-      v = (double)tbrk[i];
+      v = __longlong_as_double((long long)keys[k]);  // the breakpoint time IS the sort key
     } else if (f == 1) {
       v = (double)(row0 + i);
     } else if (f == 2) {
@@ -552,10 +658,11 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
 // short walk needs; the host orders the few records itself.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
-    const uint32_t *__restrict__ idx, const uint32_t *__restrict__ d_count, uint32_t cap,
-    int64_t row0, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
-    const T *__restrict__ g, const T *__restrict__ tbrk, const T *__restrict__ ws,
-    const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double *msg) {
+    const uint32_t *__restrict__ idx, const uint64_t *__restrict__ keys,
+    const uint32_t *__restrict__ d_count, uint32_t cap, int64_t row0, const T *__restrict__ x,
+    const T *__restrict__ l, const T *__restrict__ u, const T *__restrict__ g,
+    const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
+    double *msg) {
   const uint32_t total_cnt = *d_count;
   const uint32_t cnt = total_cnt < cap ? total_cnt : cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -572,7 +679,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
     const int64_t i = idx[k];
     double v;
     if (f == 0) {
-      v = (double)tbrk[i];
+      v = __longlong_as_double((long long)keys[k]);  // the breakpoint time IS the sort key
     } else if (f == 1) {
       v = (double)(row0 + i);
     } else if (f == 2) {
@@ -589,27 +696,28 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
   }
 }
 template <typename T>
-void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint32_t *d_count, uint32_t cap,
-                              int64_t row0, const T *x, const T *l, const T *u, const T *g,
-                              const T *tbrk, WStore<T> w, int head, int col, double *msg) {
+void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *keys,
+                              const uint32_t *d_count, uint32_t cap, int64_t row0, const T *x,
+                              const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
+                              double *msg) {
   const int64_t total = (int64_t)cap * (2 * col + 4);
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > 64) gr = 64;
-  hipLaunchKernelGGL(cauchy_gather_dyn_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, d_count,
-                     cap, row0, x, l, u, g, tbrk, w.ws, w.wy, w.ld, w.m, head, col, msg);
+  hipLaunchKernelGGL(cauchy_gather_dyn_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys,
+                     d_count, cap, row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, msg);
   q.launches++;
 }
 
 template <typename T>
-void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t row0, const T *x,
-                          const T *l, const T *u, const T *g, const T *tbrk, WStore<T> w, int head,
-                          int col, double *rec) {
+void launch_cauchy_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, uint32_t cnt,
+                          int64_t row0, const T *x, const T *l, const T *u, const T *g, WStore<T> w,
+                          int head, int col, double *rec) {
   if (cnt == 0) return;
   const int64_t total = (int64_t)cnt * (2 * col + 4);
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
-  hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, cnt, row0, x,
-                     l, u, g, tbrk, w.ws, w.wy, w.ld, w.m, head, col, rec);
+  hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, cnt,
+                     row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, rec);
   q.launches++;
 }
 
@@ -1590,6 +1698,34 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
   launch_finalize(q, gr, 3, 1, 0);
 }
 
+// The Cauchy point as a vector, by the same per-row rule the fused passes use (xcp_row).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void xcp_fill_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ l,
+    const T *__restrict__ u, const int32_t *__restrict__ iwhere, double tsum, T *dst) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], lv[W], uv[W], out[W];
+    int iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(g + i, gv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[k] = xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], tsum);
+    st<W>(dst + i, out);
+  });
+}
+template <typename T>
+void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
+                     const int32_t *iwhere, double tsum, T *dst) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(xcp_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, l, u, iwhere,
+                     tsum, dst);
+  q.launches++;
+}
+
 // The Newton direction as a vector (free rows; 0 elsewhere), for the backtracking branch only.
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
@@ -2002,7 +2138,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     st<W>(wy + offn + i, rv);
     // iwhere settles after the first iterations: store only from waves that changed a row
     if (__ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
-    st<W>(tbrk + i, tb);
+    if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
   });
   block_reduce_store<NA>(acc, 4 * MC + 7, 1, 0, part, MAX_BLOCKS);
 }
@@ -2124,12 +2260,21 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                         double, uint64_t *, uint32_t *, uint32_t, uint32_t *);     \
   template void launch_cauchy_allkeys<T>(Queue &, int64_t, int64_t, const T *, double, int64_t,    \
                                          uint64_t *, uint32_t *);                                  \
-  template void launch_cauchy_gather<T>(Queue &, const uint32_t *, uint32_t, int64_t, const T *,  \
-                                        const T *, const T *, const T *, const T *, WStore<T>,    \
-                                        int, int, double *);                                                 \
-  template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint32_t *, uint32_t, \
-                                            int64_t, const T *, const T *, const T *, const T *,   \
-                                            const T *, WStore<T>, int, int, double *);            \
+  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *,       \
+                                            const T *, const int32_t *, const T *,                 \
+                                            const int32_t *, double, int64_t, double, uint64_t *,  \
+                                            uint32_t *, uint32_t, uint32_t *);                     \
+  template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *, const T *,   \
+                                   const int32_t *, double, T *);                                  \
+  template void launch_tbrk_fill<T>(Queue &, int64_t, const T *, const T *, const T *,             \
+                                    const int32_t *, const T *, const int32_t *, T *);             \
+  template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t,     \
+                                        int64_t, const T *, const T *, const T *, const T *,       \
+                                        WStore<T>, int, int, double *);                            \
+  template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint64_t *,           \
+                                            const uint32_t *, uint32_t, int64_t, const T *,        \
+                                            const T *, const T *, const T *, WStore<T>, int, int,  \
+                                            double *);                                             \
   template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
                                         const T *, const T *, const T *, int32_t *, T *, double,   \
                                         double, int64_t, int);                                     \

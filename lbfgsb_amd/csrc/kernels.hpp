@@ -103,15 +103,31 @@ void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_
                         size_t count);
 // records for `cnt` breakpoints listed in idx (local rows): rec[k*(2col+4)+..] =
 // { t, global index, d_i (= -g_i), zibp (= bound - x_i), Wy(i,0..col), Ws(i,0..col) }
+// (t comes from keys[k]: the sort key is the bit pattern of the breakpoint time)
 template <typename T>
-void launch_cauchy_gather(Queue &q, const uint32_t *idx, uint32_t cnt, int64_t row0, const T *x,
-                          const T *l, const T *u, const T *g, const T *tbrk, WStore<T> w, int head,
-                          int col, double *rec);
+void launch_cauchy_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, uint32_t cnt,
+                          int64_t row0, const T *x, const T *l, const T *u, const T *g, WStore<T> w,
+                          int head, int col, double *rec);
 // one-sync fast path: msg = { *d_count, 0, records of the first min(*d_count, cap) candidates }
 template <typename T>
-void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint32_t *d_count, uint32_t cap,
-                              int64_t row0, const T *x, const T *l, const T *u, const T *g,
-                              const T *tbrk, WStore<T> w, int head, int col, double *msg);
+void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *keys,
+                              const uint32_t *d_count, uint32_t cap, int64_t row0, const T *x,
+                              const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
+                              double *msg);
+// the window compaction with the breakpoint times recomputed per row (no stored tbrk)
+template <typename T>
+void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
+                              const int32_t *nbd, const T *g, const int32_t *iwhere, double lo_t,
+                              int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
+                              uint32_t *d_count);
+// the Cauchy point as a vector from (x, g, l, u, iwhere-after-the-walk, tsum)
+template <typename T>
+void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
+                     const int32_t *iwhere, double tsum, T *dst);
+// tbrk as a vector from (x, l, u, nbd, g, iwhere-after-the-scan, BEFORE the walk fixes rows)
+template <typename T>
+void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
+                      const T *g, const int32_t *iwhere, T *tbrk);
 // finish (:1425-1433, :1515): fix every processed breakpoint variable at its bound,
 // move the others by tsum*d.  processed = (t, gidx) <= (last_t, last_i).
 // count != 0: res[0] = number of rows fixed (finalize launched).

@@ -391,7 +391,20 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMemcpyAsync(d_msg, h_hdr, 2 * sizeof(double), hipMemcpyHostToDevice, stream));
     return 0;
   }
+  // breakpoint times as a vector: written by cauchy_scan_kernel; the fused update pass does
+  // not store them (the usual short walk recomputes the few it needs), so the rare consumers
+  // of the vector (full sort, cursor-based cauchy_finish) fill it in first
+  bool tbrk_valid = false;
+  const int32_t *cnbd = nullptr;
+  int ensure_tbrk() {
+    if (!tbrk_valid)
+      lbk::launch_tbrk_fill<T>(q, n, (const T *)cx, (const T *)cl, (const T *)cu, cnbd, (const T *)cg,
+                               iwhere, tbrk);
+    tbrk_valid = true;
+    return 0;
+  }
   int local_count(double lo_t, int64_t lo_i, double hi, uint32_t cap, uint32_t &cnt) {
+    CHK(ensure_tbrk());
     lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], cap, d_count);
     HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -406,10 +419,14 @@ class Solver final : public lbfgsb_hip_ctx {
                    const T *u, const T *g, int head, int col) {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
     const int recl = 2 * col + 4;
-    lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
-                                 d_count);
-    lbk::launch_cauchy_gather_dyn<T>(q, idx[0], d_count, FAST_CAP, row0, x, l, u, g, tbrk, W(), head,
-                                     col, d_msg);
+    if (tbrk_valid)
+      lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
+                                   d_count);
+    else
+      lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, cnbd, g, iwhere, lo_t, lo_i, hi, keys[0],
+                                       idx[0], SEL_CAP, d_count);
+    lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
+                                     head, col, d_msg);
     const size_t fcount = 2 + (size_t)FAST_CAP * recl;
     CHK(exchange(fcount));
     double gsum = 0.0;
@@ -467,7 +484,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // too many candidates in the window: order ALL remaining breakpoints once
       nfullsort++;
       CHK(ensure_sel((size_t)n));
-      CHK(local_count(lo_t, lo_i, std::numeric_limits<double>::max(), 0, cnt));
+      CHK(local_count(lo_t, lo_i, std::numeric_limits<double>::max(), 0, cnt));  // (fills tbrk)
       lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, lo_t, lo_i, keys[0], idx[0]);
       lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1],
                              (size_t)n);
@@ -488,8 +505,8 @@ class Solver final : public lbfgsb_hip_ctx {
     const uint32_t chunk_cap = (uint32_t)((msg_len - 2) / (size_t)recl);
     pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, chunk_cap);
     const uint32_t len = std::min<uint32_t>(chunk, pv.Cl - pv.pl);
-    lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, len, row0, x, l, u, g, tbrk, W(), head,
-                                 col, d_msg + 2);
+    lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
+                                 W(), head, col, d_msg + 2);
     CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
     const size_t count = 2 + (size_t)chunk * recl;
     CHK(exchange(count));
@@ -568,8 +585,7 @@ class Solver final : public lbfgsb_hip_ctx {
     if (gcp.copy_x) {
       HIPCHK(hipMemcpyAsync(dst, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
     } else {
-      lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, dst, gcp.tsum, gcp.last_t,
-                                   gcp.last_i);
+      lbk::launch_xcp_fill<T>(q, n, x, g, l, u, iwhere, gcp.tsum, dst);
     }
     return 0;
   }
@@ -583,6 +599,7 @@ class Solver final : public lbfgsb_hip_ctx {
     gcp.tsum = tsum, gcp.last_t = last_t, gcp.last_i = last_i, gcp.copy_x = false;
     z_valid = false;
     if (fix_overflow) {  // long walk: the cursor-based kernel (it writes z on the way)
+      CHK(ensure_tbrk());
       lbk::launch_cauchy_finish<T>(q, n, row0, (const T *)cx, (const T *)cl, (const T *)cu,
                                    (const T *)cg, tbrk, iwhere, z, tsum, last_t, last_i);
       z_valid = true;
@@ -607,7 +624,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int cauchy(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
              int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
     double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
-    cx = x, cl = l, cu = u, cg = g;
+    cx = x, cl = l, cu = u, cg = g, cnbd = nbd;
     fixlist.clear();
     fix_overflow = false;
     if (sbgnrm <= 0.0) {  // :1245-1249
@@ -621,6 +638,7 @@ class Solver final : public lbfgsb_hip_ctx {
     const int MC = col ? lbk::maxc_for(col) : 0;
     if (!scan.ready) {
       lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
+      tbrk_valid = true;
       CHK(fetch(2 * MC + 4, 1, 0));
       for (int j = 0; j < col; ++j) {
         scan.p[j] = h_res[j];
@@ -993,6 +1011,7 @@ class Solver final : public lbfgsb_hip_ctx {
     if (!(flags & LBFGSB_F_MIRROR_INDEX)) CHK(write_xcp(xp, x, l, u, g));
     lbk::launch_subsm_dir<T>(q, n, xp, iwhere, x, g, W(), head, col, theta, cm_cf, cm_plain ? 1 : 0,
                              cw, tbrk);
+    tbrk_valid = false;
     lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
     CHK(fetch(0, 1, 0));
     const double alpha = std::min(1.0, h_res[0]);
@@ -1435,8 +1454,9 @@ class Solver final : public lbfgsb_hip_ctx {
       double rr;
       if (cnstnd) {
         // the next loop trip starts with cauchy: do its n-loop in the same pass over W
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, W(), head, col,
-                                   itail);
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
+                                   col, itail);
+        tbrk_valid = false;
         CHK(fetch(4 * MCo + 7, 1, 0));
         rr = h_res[2 * MCo];
         const int nold = col - 1;
