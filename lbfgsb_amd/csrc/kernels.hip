@@ -72,6 +72,58 @@ __device__ __forceinline__ int64_t col_off(int j, int col, int head, int m, int6
   return (int64_t)((head - 1 + jj) % m) * ld;
 }
 
+// ---- pending pair ----
+// Between matupd and the subspace pass of the same setulb call the newest pair (logical column
+// col-1) is not in W yet: update_scan_kernel only reduces, so that it stays a read-only pass
+// (a single store stream drops a streaming pass on MI355X from ~6.5 to ~4.8 TB/s,
+// profiles/scripts/write_cost.hip).  Until subsm_update_kernel -- which stores vectors anyway --
+// commits it, the column is defined by the vectors it was formed from, with the rounding of a
+// store to T:   y = T(g - r),   s = T(stp * d)   (mainlb :813-822, matupd :2313-2314).
+template <typename T>
+__device__ __forceinline__ double pend_y(double gk, double rk) {
+  return (double)(T)(gk - rk);
+}
+template <typename T>
+__device__ __forceinline__ double pend_s(double dk, double stp) {
+  return stp != 1.0 ? (double)(T)(stp * dk) : dk;
+}
+// columns j = 0..MC-1 of one row group; the pending column is read from (r, d) instead
+template <typename T, int MC, int W, bool NT>
+__device__ __forceinline__ void load_cols(const T *__restrict__ wy, const T *__restrict__ ws,
+                                          const T *pr, const T *pd, int64_t i, int col, int head,
+                                          int m, int64_t ldw, Pend pe, double (&a)[MC][W],
+                                          double (&b)[MC][W]) {
+  // one base pointer per matrix and a selected element offset (selecting between two base
+  // pointers per column makes the compiler keep a table of addresses in scratch memory);
+  // all buffers are allocations of T, so the distances are whole elements
+  const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
+  const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
+#pragma unroll
+  for (int j = 0; j < MC; ++j) {
+    const int64_t off = col_off(j, col, head, m, ldw);
+    const bool pj = pe.on && j == col - 1;
+    ldx<W, NT>(wy + ((pj ? dy : off) + i), a[j]);
+    ldx<W, NT>(ws + ((pj ? ds : off) + i), b[j]);
+  }
+}
+template <typename T, int MC, int W>
+__device__ __forceinline__ void fix_pending(int col, Pend pe, const double (&gv)[W],
+                                            double (&a)[MC][W], double (&b)[MC][W]) {
+  // branch-free selects: a predicated write a[col-1][k] = ... would turn the register arrays
+  // into dynamically indexed ones (scratch memory)
+#pragma unroll
+  for (int j = 0; j < MC; ++j) {
+    const bool pj = pe.on && j == col - 1;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const double yk = pend_y<T>(gv[k], a[j][k]);
+      const double sk = pend_s<T>(b[j][k], pe.stp);
+      a[j][k] = pj ? yk : a[j][k];
+      b[j][k] = pj ? sk : b[j][k];
+    }
+  }
+}
+
 // =========================== finalize ======================================
 // One workgroup per output slot: fixed-order sum / min / max of the per-block
 // partials.
@@ -626,7 +678,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
     const uint32_t *__restrict__ idx, const uint64_t *__restrict__ keys, uint32_t cnt,
     int64_t row0, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const T *__restrict__ g, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
-    int m, int head, int col, double *rec) {
+    int m, int head, int col, const T *pr, const T *pd, Pend pe, double *rec) {
   const int rl = 2 * col + 4;
   const int64_t total = (int64_t)cnt * rl;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
@@ -645,9 +697,12 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
       const double d = -(double)g[i];
       v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
     } else if (f < 4 + col) {
-      v = (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
+      v = (pe.on && f - 4 == col - 1) ? pend_y<T>((double)g[i], (double)pr[i])
+                                      : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
     } else {
-      v = (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
+      v = (pe.on && f - 4 - col == col - 1)
+              ? pend_s<T>((double)pd[i], pe.stp)
+              : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
     }
     rec[q] = v;
   }
@@ -662,7 +717,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
     const uint32_t *__restrict__ d_count, uint32_t cap, int64_t row0, const T *__restrict__ x,
     const T *__restrict__ l, const T *__restrict__ u, const T *__restrict__ g,
     const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
-    double *msg) {
+    const T *pr, const T *pd, Pend pe, double *msg) {
   const uint32_t total_cnt = *d_count;
   const uint32_t cnt = total_cnt < cap ? total_cnt : cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -688,9 +743,12 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
       const double d = -(double)g[i];
       v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
     } else if (f < 4 + col) {
-      v = (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
+      v = (pe.on && f - 4 == col - 1) ? pend_y<T>((double)g[i], (double)pr[i])
+                                      : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
     } else {
-      v = (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
+      v = (pe.on && f - 4 - col == col - 1)
+              ? pend_s<T>((double)pd[i], pe.stp)
+              : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
     }
     rec[q] = v;
   }
@@ -699,25 +757,25 @@ template <typename T>
 void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *keys,
                               const uint32_t *d_count, uint32_t cap, int64_t row0, const T *x,
                               const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
-                              double *msg) {
+                              const T *pr, const T *pd, Pend pe, double *msg) {
   const int64_t total = (int64_t)cap * (2 * col + 4);
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > 64) gr = 64;
   hipLaunchKernelGGL(cauchy_gather_dyn_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys,
-                     d_count, cap, row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, msg);
+                     d_count, cap, row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, msg);
   q.launches++;
 }
 
 template <typename T>
 void launch_cauchy_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, uint32_t cnt,
                           int64_t row0, const T *x, const T *l, const T *u, const T *g, WStore<T> w,
-                          int head, int col, double *rec) {
+                          int head, int col, const T *pr, const T *pd, Pend pe, double *rec) {
   if (cnt == 0) return;
   const int64_t total = (int64_t)cnt * (2 * col + 4);
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
   hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, cnt,
-                     row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, rec);
+                     row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, rec);
   q.launches++;
 }
 
@@ -1398,7 +1456,8 @@ template <typename T, int MC, bool NEWROW, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
     const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
-    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, double *part) {
+    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
+    const T *pd, Pend pe, double *part) {
   constexpr int NA = NEWROW ? 6 * MC : 2 * MC;
   double acc[NA];
 #pragma unroll
@@ -1415,12 +1474,8 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
 #pragma unroll
       for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
     }
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
-    }
+    load_cols<T, MC, W, NT>(wy, ws, pr, pd, i, col, head, m, ldw, pe, a, b);
+    fix_pending<T, MC, W>(col, pe, gv, a, b);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
@@ -1474,16 +1529,16 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
-                       const Coef &a, int plain, int newrow) {
+                       const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (newrow) {
     DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
-                                          head, col, theta, a, plain, q.d_part));
+                                          head, col, theta, a, plain, pr, pd, pe, q.d_part));
   } else {
     DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
-                                          head, col, theta, a, plain, q.d_part));
+                                          head, col, theta, a, plain, pr, pd, pe, q.d_part));
   }
   q.launches++;
   launch_finalize(q, gr, (newrow ? 6 : 2) * maxc_for(col), 0, 0);
@@ -1604,12 +1659,12 @@ __device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, con
 // res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
-    int64_t n, double tsum, T *__restrict__ zout, T *__restrict__ r,
+    int64_t n, double tsum, T *__restrict__ zout, T *r,
     const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
     const int32_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
-    double theta, Coef cf, int plain, Coef wv, T *__restrict__ dvec, T *__restrict__ tvec,
-    T *xout, int do_stpmx, double *part) {
+    double theta, Coef cf, int plain, Coef wv, T *dvec, T *__restrict__ tvec,
+    T *xout, int do_stpmx, Pend pe, T *cwy, T *cws, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
@@ -1627,11 +1682,24 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
 #pragma unroll
       for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
     }
+    // a pending pair is read from (r, d) -- which this pass overwrites further down -- and
+    // committed to its W slot (cwy, cws) here
+    load_cols<T, MC, W, NT>(wy, ws, r, dvec, i, col, head, m, ldw, pe, a, b);
+    fix_pending<T, MC, W>(col, pe, gv, a, b);
+    if (pe.on) {
+      double yn[W], sn[W];
 #pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
+      for (int k = 0; k < W; ++k) {
+        yn[k] = 0.0, sn[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+          if (j == col - 1) {
+            yn[k] = a[j][k];
+            sn[k] = b[j][k];
+          }
+      }
+      st<W>(cwy + i, yn);
+      st<W>(cws + i, sn);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) zv[k] = xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], tsum);
@@ -1688,14 +1756,47 @@ template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
-                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx) {
+                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe) {
   const int gr = grid_for(n, VecOf<T>::V);
+  const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                         q.stream, n, tsum, zout, r, l, u, nbd, iwhere, xx, gg, w.ws,
                                         w.wy, w.ld, w.m, head, col, theta, cf, plain, wv, dvec, tvec,
-                                        xout, do_stpmx, q.d_part));
+                                        xout, do_stpmx, pe, w.wy + slot, w.ws + slot, q.d_part));
   q.launches++;
   launch_finalize(q, gr, 3, 1, 0);
+}
+
+// Store a pending pair into its W slot without a subspace pass (subsm skipped, from-scratch
+// formk, ...): Wy(:,slot) = T(g - r), Ws(:,slot) = T(stp*d).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pair_commit_kernel(int64_t n, const T *__restrict__ g,
+                                                            const T *__restrict__ r,
+                                                            const T *__restrict__ d, double stp,
+                                                            T *cwy, T *cws) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double gv[W], rv[W], dv[W];
+    ld<W>(g + i, gv);
+    ld<W>(r + i, rv);
+    ld<W>(d + i, dv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rv[k] = pend_y<T>(gv[k], rv[k]);
+      dv[k] = pend_s<T>(dv[k], stp);
+    }
+    st<W>(cwy + i, rv);
+    st<W>(cws + i, dv);
+  });
+}
+template <typename T>
+void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
+                        WStore<T> w, int head, int col) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;
+  hipLaunchKernelGGL(pair_commit_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, g, r, d, pe.stp,
+                     w.wy + slot, w.ws + slot);
+  q.launches++;
 }
 
 // The Cauchy point as a vector, by the same per-row rule the fused passes use (xcp_row).
@@ -2051,7 +2152,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
     const T *__restrict__ d, double stp, int32_t *iwhere, T *tbrk, T *ws, T *wy, int64_t ldw,
-    int m, int head, int nold, int itail, double *part) {
+    int m, int head, int nold, int itail, int store_pair, double *part) {
   constexpr int NA = 4 * MC + 8;
   double acc[NA];
 #pragma unroll
@@ -2134,8 +2235,10 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         acc[3 * MC + 2 + j] += b[j][k] * ng[k];  // p_{col+j}  (:1302)
       }
     }
-    st<W>(ws + offn + i, dv);
-    st<W>(wy + offn + i, rv);
+    if (store_pair) {  // else the pair stays pending (see Pend)
+      st<W>(ws + offn + i, dv);
+      st<W>(wy + offn + i, rv);
+    }
     // iwhere settles after the first iterations: store only from waves that changed a row
     if (__ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
     if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
@@ -2145,12 +2248,12 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
                         const T *g, const T *r, const T *d, double stp, int32_t *iwhere, T *tbrk,
-                        WStore<T> w, int head, int col, int itail) {
+                        WStore<T> w, int head, int col, int itail, int store_pair) {
   const int gr = grid_for(n, VecOf<T>::V);
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,
-                                         w.wy, w.ld, w.m, head, nold, itail, q.d_part));
+                                         w.wy, w.ld, w.m, head, nold, itail, store_pair, q.d_part));
   q.launches++;
   launch_finalize(q, gr, 4 * maxc_for(nold) + 7, 1, 0);
 }
@@ -2270,11 +2373,12 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                     const int32_t *, const T *, const int32_t *, T *);             \
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t,     \
                                         int64_t, const T *, const T *, const T *, const T *,       \
-                                        WStore<T>, int, int, double *);                            \
+                                        WStore<T>, int, int, const T *, const T *, Pend,           \
+                                        double *);                                                 \
   template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint64_t *,           \
                                             const uint32_t *, uint32_t, int64_t, const T *,        \
                                             const T *, const T *, const T *, WStore<T>, int, int,  \
-                                            double *);                                             \
+                                            const T *, const T *, Pend, double *);                 \
   template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
                                         const T *, const T *, const T *, int32_t *, T *, double,   \
                                         double, int64_t, int);                                     \
@@ -2283,12 +2387,14 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                  const int32_t *, WStore<T>, int, int, double, const Coef &, int); \
   template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double,               \
                                      const int32_t *, WStore<T>, int, int, double, const Coef &,  \
-                                     int, int);                                                     \
+                                     int, int, const T *, const T *, Pend);                         \
   template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int);    \
   template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *,              \
                                        const T *, const int32_t *, const int32_t *, const T *,     \
                                        const T *, WStore<T>, int, int, double, const Coef &, int,  \
-                                       const Coef &, T *, T *, T *, int);                          \
+                                       const Coef &, T *, T *, T *, int, Pend);                    \
+  template void launch_pair_commit<T>(Queue &, int64_t, const T *, const T *, const T *, Pend,     \
+                                      WStore<T>, int, int);                                        \
   template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const int32_t *, const T *,       \
                                     const T *, WStore<T>, int, int, double, const Coef &, int,     \
                                     const Coef &, T *);                                            \
@@ -2309,7 +2415,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                        WStore<T>, int, int, int);                                  \
   template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *,           \
                                       const int32_t *, const T *, const T *, const T *, double,    \
-                                      int32_t *, T *, WStore<T>, int, int, int);                   \
+                                      int32_t *, T *, WStore<T>, int, int, int, int);              \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *);                \
   template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *,       \
                                          double, double);                                          \

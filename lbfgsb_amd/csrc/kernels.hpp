@@ -42,6 +42,13 @@ struct Coef {
   double a[2 * MAXM];
 };
 
+// A pair that matupd has accepted but that is not stored in W yet (see "pending pair" in
+// kernels.hip): logical column col-1 is  y = T(g - r), s = T(stp * d)  until it is committed.
+struct Pend {
+  int on;      // 0: every column is in W
+  double stp;  // step length of the accepted trial
+};
+
 int grid_for(int64_t n, int vec);
 // compile-time column capacity the kernels are unrolled to for `col` pairs (5, 10, 20, 32).
 // Reduction slots that depend on col use MC = maxc_for(col) as their stride.
@@ -107,13 +114,13 @@ void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_
 template <typename T>
 void launch_cauchy_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, uint32_t cnt,
                           int64_t row0, const T *x, const T *l, const T *u, const T *g, WStore<T> w,
-                          int head, int col, double *rec);
+                          int head, int col, const T *pr, const T *pd, Pend pe, double *rec);
 // one-sync fast path: msg = { *d_count, 0, records of the first min(*d_count, cap) candidates }
 template <typename T>
 void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *keys,
                               const uint32_t *d_count, uint32_t cap, int64_t row0, const T *x,
                               const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
-                              double *msg);
+                              const T *pr, const T *pd, Pend pe, double *msg);
 // the window compaction with the breakpoint times recomputed per row (no stored tbrk)
 template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
@@ -175,7 +182,7 @@ void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
-                       const Coef &a, int plain, int newrow);
+                       const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe);
 // formk patches (ref :1801-1851): signed Gram over the listed rows (+ entered, - left the free
 // set) for the first upcl logical columns; res layout as launch_formk_gram with col = upcl.
 template <typename T>
@@ -193,7 +200,7 @@ template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
-                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx);
+                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe);
 // the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
 template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const int32_t *iwhere, const T *xx,
@@ -241,7 +248,12 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
-                        int32_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail);
+                        int32_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
+                        int store_pair);
+// Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
+template <typename T>
+void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
+                        WStore<T> w, int head, int col);
 
 // ---- built-in objectives -------------------------------------------------------
 // res sum [0] = f contribution of this rank

@@ -396,6 +396,13 @@ class Solver final : public lbfgsb_hip_ctx {
   // of the vector (full sort, cursor-based cauchy_finish) fill it in first
   bool tbrk_valid = false;
   const int32_t *cnbd = nullptr;
+  // the pair accepted by matupd in this call, not yet stored in W (see lbk::Pend)
+  lbk::Pend pend{0, 1.0};
+  int commit_pending(const T *g, int col, int head) {
+    if (pend.on) lbk::launch_pair_commit<T>(q, n, g, r, d, pend, W(), head, col);
+    pend.on = 0;
+    return 0;
+  }
   int ensure_tbrk() {
     if (!tbrk_valid)
       lbk::launch_tbrk_fill<T>(q, n, (const T *)cx, (const T *)cl, (const T *)cu, cnbd, (const T *)cg,
@@ -426,7 +433,7 @@ class Solver final : public lbfgsb_hip_ctx {
       lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, cnbd, g, iwhere, lo_t, lo_i, hi, keys[0],
                                        idx[0], SEL_CAP, d_count);
     lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
-                                     head, col, d_msg);
+                                     head, col, r, d, pend, d_msg);
     const size_t fcount = 2 + (size_t)FAST_CAP * recl;
     CHK(exchange(fcount));
     double gsum = 0.0;
@@ -506,7 +513,7 @@ class Solver final : public lbfgsb_hip_ctx {
     pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, chunk_cap);
     const uint32_t len = std::min<uint32_t>(chunk, pv.Cl - pv.pl);
     lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
-                                 W(), head, col, d_msg + 2);
+                                 W(), head, col, r, d, pend, d_msg + 2);
     CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
     const size_t count = 2 + (size_t)chunk * recl;
     CHK(exchange(count));
@@ -804,6 +811,7 @@ class Solver final : public lbfgsb_hip_ctx {
   // WN1 from scratch: one masked Gram pass over W (any col; also the fallback when too many
   // variables changed status for the sparse patches)
   int formk_scratch(int col, int head) {
+    CHK(commit_pending((const T *)cg, col, head));
     lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     const int E = 2 * col * col + col;
     CHK(fetch(E, 0, 0));
@@ -952,7 +960,7 @@ class Solver final : public lbfgsb_hip_ctx {
         return 0;
       }
       lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
-                                plain ? 1 : 0, newrow ? 1 : 0);
+                                plain ? 1 : 0, newrow ? 1 : 0, r, d, pend);
       CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
       res = h_res;
     }
@@ -986,7 +994,8 @@ class Solver final : public lbfgsb_hip_ctx {
     if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, z, r, l, u, nbd, iwhere, x, g, W(), head, col, theta,
                                 cm_cf, cm_plain ? 1 : 0, cw, d, t, ls_unit_step ? xmut : nullptr,
-                                ls_do_stpmx ? 1 : 0);
+                                ls_do_stpmx ? 1 : 0, pend);
+    pend.on = 0;  // the pass stored the pair into its W slot
     z_valid = true;
     CHK(fetch(3, 1, 0));
     iword = h_res[0] > 0.0 ? 1 : 0;
@@ -1086,6 +1095,7 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     auto refresh = [&]() {
       info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
+      pend.on = 0;  // the memory is dropped, an uncommitted pair with it
     };
 
     if (lbh::str60_eq(task, "START")) {  // :430-507
@@ -1237,7 +1247,7 @@ class Solver final : public lbfgsb_hip_ctx {
               const bool newrow = updatd && col <= 20;  // updatd implies wrk
               q.res_off = 3;
               lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
-                                        plain ? 1 : 0, newrow ? 1 : 0);
+                                        plain ? 1 : 0, newrow ? 1 : 0, r, d, pend);
               q.res_off = 0;
               npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
             }
@@ -1266,6 +1276,7 @@ class Solver final : public lbfgsb_hip_ctx {
 
         if (nfree_g == 0 || col == 0) {
           // skip the subspace minimization :648-651: the line search starts from z = xcp
+          CHK(commit_pending(g, col, head));
           CHK(ensure_z(x, l, u, g));
         } else {
           cpu1 = now_s();
@@ -1455,8 +1466,9 @@ class Solver final : public lbfgsb_hip_ctx {
       if (cnstnd) {
         // the next loop trip starts with cauchy: do its n-loop in the same pass over W
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
-                                   col, itail);
+                                   col, itail, 0);
         tbrk_valid = false;
+        pend.on = 1, pend.stp = stp;  // committed by the subspace pass of this same call
         CHK(fetch(4 * MCo + 7, 1, 0));
         rr = h_res[2 * MCo];
         const int nold = col - 1;
@@ -1609,7 +1621,7 @@ class Solver final : public lbfgsb_hip_ctx {
     std::memset(&cf, 0, sizeof cf);
     if (which == 0 || which == 2)
       lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
-                                cf, 0, which == 2 ? 1 : 0);
+                                cf, 0, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5});
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     else
