@@ -2146,18 +2146,22 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // the new pair (s, y) is used from registers.  Per element the arithmetic is exactly that
 // of update_pairs_kernel and cauchy_scan_kernel.
 // slots: [0,MC) s'Wy_j | [MC,2MC) Ws_j's | [2MC] y'y | [2MC+1,3MC+1) Wy_j'd | [3MC+1] y'd |
-//        [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | f1, nbreak, nunb, nunbnz | min: bkmin
+//        [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | f1, nbreak, nunb, nunbnz | [4MC+7] g'd (unscaled d)
+//        | [4MC+8] #rows whose iwhere changed | min [4MC+9] bkmin | max [4MC+10] |proj g|
+// The same pass serves as the line search's evaluation at a trial point (g'd, |proj g|): run
+// speculatively there (store_pair = 0; it writes nothing but -- with store_iw -- the few iwhere
+// entries that changed), its sums ARE the matupd + cauchy-scan results if the trial is accepted.
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
     const T *__restrict__ d, double stp, int32_t *iwhere, T *tbrk, T *ws, T *wy, int64_t ldw,
-    int m, int head, int nold, int itail, int store_pair, double *part) {
-  constexpr int NA = 4 * MC + 8;
+    int m, int head, int nold, int itail, int store_pair, int store_iw, double *part) {
+  constexpr int NA = 4 * MC + 11;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
-  acc[4 * MC + 7] = LB_INF;
+  acc[4 * MC + 9] = LB_INF;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -2180,6 +2184,9 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
+      // ---- the line search's own sums at this trial point: g'd (:2244), |proj g| (:781) ----
+      acc[4 * MC + 7] = acc[4 * MC + 7] + gv[k] * dv[k];
+      acc[4 * MC + 10] = fmax(acc[4 * MC + 10], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
       rv[k] = gv[k] - rv[k];                              // y (:813-815)
       acc[2 * MC] = acc[2 * MC] + rv[k] * rv[k];          // rr (:816)
       if (stp != 1.0) dv[k] = stp * dv[k];                // s (:822)
@@ -2201,6 +2208,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
           if (fabs(neggi) <= 0.0) iw[k] = -3;
         }
         iw_changed = iw_changed || iw[k] != iw_old;
+        if (iw[k] != iw_old) acc[4 * MC + 8] += 1.0;
       }
       if (iw[k] != 0 && iw[k] != -1) {
         tb[k] = -1.0;
@@ -2211,11 +2219,11 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         if (nb[k] <= 2 && nb[k] != 0 && neggi < 0.0) {
           tb[k] = tl / (-neggi);
           acc[4 * MC + 4] += 1.0;
-          acc[4 * MC + 7] = fmin(acc[4 * MC + 7], tb[k]);
+          acc[4 * MC + 9] = fmin(acc[4 * MC + 9], tb[k]);
         } else if (nb[k] >= 2 && neggi > 0.0) {
           tb[k] = tu / neggi;
           acc[4 * MC + 4] += 1.0;
-          acc[4 * MC + 7] = fmin(acc[4 * MC + 7], tb[k]);
+          acc[4 * MC + 9] = fmin(acc[4 * MC + 9], tb[k]);
         } else {
           tb[k] = LB_INF;
           acc[4 * MC + 5] += 1.0;
@@ -2240,22 +2248,23 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
       st<W>(wy + offn + i, rv);
     }
     // iwhere settles after the first iterations: store only from waves that changed a row
-    if (__ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
+    if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
     if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
   });
-  block_reduce_store<NA>(acc, 4 * MC + 7, 1, 0, part, MAX_BLOCKS);
+  block_reduce_store<NA>(acc, 4 * MC + 9, 1, 1, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
                         const T *g, const T *r, const T *d, double stp, int32_t *iwhere, T *tbrk,
-                        WStore<T> w, int head, int col, int itail, int store_pair) {
+                        WStore<T> w, int head, int col, int itail, int store_pair, int store_iw) {
   const int gr = grid_for(n, VecOf<T>::V);
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,
-                                         w.wy, w.ld, w.m, head, nold, itail, store_pair, q.d_part));
+                                         w.wy, w.ld, w.m, head, nold, itail, store_pair, store_iw,
+                                         q.d_part));
   q.launches++;
-  launch_finalize(q, gr, 4 * maxc_for(nold) + 7, 1, 0);
+  launch_finalize(q, gr, 4 * maxc_for(nold) + 9, 1, 1);
 }
 
 // =========================== built-in objectives =============================
@@ -2415,7 +2424,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                        WStore<T>, int, int, int);                                  \
   template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *,           \
                                       const int32_t *, const T *, const T *, const T *, double,    \
-                                      int32_t *, T *, WStore<T>, int, int, int, int);              \
+                                      int32_t *, T *, WStore<T>, int, int, int, int, int);         \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *);                \
   template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *,       \
                                          double, double);                                          \

@@ -244,12 +244,13 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 
 // the two above fused (one pass over the old columns); slots, MC = maxc_for(col-1):
 // [0,MC) s'Wy_j | [MC,2MC) Ws_j's | [2MC] y'y | [2MC+1,3MC+1) Wy_j'd | [3MC+1] y'd |
-// [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | [4MC+3] f1, nbreak, nunb, nunbnz | min [4MC+7] bkmin
+// [3MC+2,4MC+2) Ws_j'd | [4MC+2] s'd | [4MC+3] f1, nbreak, nunb, nunbnz | [4MC+7] g'd |
+// [4MC+8] #iwhere changes | min [4MC+9] bkmin | max [4MC+10] |proj g|
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
                         int32_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
-                        int store_pair);
+                        int store_pair, int store_iw);
 // Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
 template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,

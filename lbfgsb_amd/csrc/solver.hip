@@ -398,6 +398,15 @@ class Solver final : public lbfgsb_hip_ctx {
   const int32_t *cnbd = nullptr;
   // the pair accepted by matupd in this call, not yet stored in W (see lbk::Pend)
   lbk::Pend pend{0, 1.0};
+  // sums of an update_scan pass that ran as the evaluation of an accepted trial point (kept
+  // from the FG_LNSRCH entry that returned NEW_X to the NEW_X entry that performs the update)
+  struct Spec {
+    bool valid = false;
+    const void *x = nullptr, *g = nullptr;
+    double stp = 0.0;
+    int head = 0, col = 0, itail = 0;
+    double res[lbk::RES_MAX];
+  } spec;
   int commit_pending(const T *g, int col, int head) {
     if (pend.on) lbk::launch_pair_commit<T>(q, n, g, r, d, pend, W(), head, col);
     pend.on = 0;
@@ -1099,6 +1108,7 @@ class Solver final : public lbfgsb_hip_ctx {
     };
 
     if (lbh::str60_eq(task, "START")) {  // :430-507
+      spec.valid = false, pend.on = 0, scan.ready = false;
       epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
                               : std::numeric_limits<double>::epsilon();
       time1 = now_s();
@@ -1165,11 +1175,35 @@ class Solver final : public lbfgsb_hip_ctx {
     double spec_sbgnrm = 0.0;
     if (lbh::str60_pre(task, "FG_LN")) {
       compute_pg = false, prelims = false;
-      // g.d for the line search and, speculatively, |proj g| for the NEW_X return
-      lbk::launch_lnsrlb_eval<T>(q, n, x, l, u, nbd, g, d);
-      CHK(fetch(1, 0, 1));
-      gd = h_res[0];
-      spec_sbgnrm = h_res[1];
+      spec.valid = false;
+      // First trial of a line search on a bounded problem: it is accepted far more often than
+      // not, so evaluate it with the pass that matupd + the next cauchy scan would run anyway
+      // (read-only with the pair pending); g'd and |proj g| are two of its sums.  Contexts
+      // that mirror the reference's arrays keep iwhere untouched until the update is real.
+      if (cnstnd && ifun == 1 && !(flags & LBFGSB_F_MIRROR_INDEX)) {
+        int c2, h2, it2;  // matupd's pointer update (:2303-2309), as if this trial is accepted
+        if (iupdat + 1 <= m) {
+          c2 = iupdat + 1, h2 = head, it2 = (head + iupdat - 1) % m + 1;
+        } else {
+          c2 = col, it2 = itail % m + 1, h2 = head % m + 1;
+        }
+        const int MCo = lbk::maxc_for(c2 - 1);
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
+                                   it2, 0, 1);
+        CHK(fetch(4 * MCo + 9, 1, 1));
+        gd = h_res[4 * MCo + 7];
+        spec_sbgnrm = h_res[4 * MCo + 10];
+        std::memcpy(spec.res, h_res, sizeof(double) * (4 * MCo + 11));
+        spec.valid = true;  // dropped below unless dcsrch accepts this point
+        spec.x = x, spec.g = g, spec.stp = stp, spec.head = h2, spec.col = c2, spec.itail = it2;
+        tbrk_valid = false;
+      } else {
+        // g.d for the line search and, speculatively, |proj g| for the NEW_X return
+        lbk::launch_lnsrlb_eval<T>(q, n, x, l, u, nbd, g, d);
+        CHK(fetch(1, 0, 1));
+        gd = h_res[0];
+        spec_sbgnrm = h_res[1];
+      }
     } else if (lbh::str60_pre(task, "NEW_X")) {
       compute_pg = false, prelims = false, linesearch = false;
     } else if (!lbh::str60_pre(task, "FG_ST")) {
@@ -1361,9 +1395,12 @@ class Solver final : public lbfgsb_hip_ctx {
             if (!(ls.x_is_z && ifun == 1 && stp == 1.0))  // else x = z is already in place
               lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
             ls.x_is_z = false;
+            spec.valid = false;  // the trial point was not accepted
           } else {
             lbh::str60_set(task, "NEW_X");
           }
+        } else {
+          spec.valid = false;
         }
 
         if (info != 0 || iback >= 20) {  // :734-769
@@ -1444,6 +1481,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (dr <= epsmch * ddum) {
         nskip++;
         updatd = false;
+        spec.valid = false;
         if (ipr >= 1)
           std::fprintf(rep.out, "  ys=%s  -gs=%s BFGS update SKIPPED\n", lbr::fE(dr, 10, 3).c_str(),
                        lbr::fE(ddum, 10, 3).c_str());
@@ -1464,12 +1502,20 @@ class Solver final : public lbfgsb_hip_ctx {
       const int MCo = lbk::maxc_for(col - 1);
       double rr;
       if (cnstnd) {
-        // the next loop trip starts with cauchy: do its n-loop in the same pass over W
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
-                                   col, itail, 0);
+        // the next loop trip starts with cauchy: do its n-loop in the same pass over W --
+        // unless that pass already ran as the evaluation of the accepted trial point
+        const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
+                           spec.head == head && spec.col == col && spec.itail == itail;
+        if (reuse) {
+          std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11));
+        } else {
+          lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
+                                     col, itail, 0, 1);
+          CHK(fetch(4 * MCo + 9, 1, 1));
+        }
+        spec.valid = false;
         tbrk_valid = false;
         pend.on = 1, pend.stp = stp;  // committed by the subspace pass of this same call
-        CHK(fetch(4 * MCo + 7, 1, 0));
         rr = h_res[2 * MCo];
         const int nold = col - 1;
         for (int j = 0; j < nold; ++j) {
@@ -1480,7 +1526,7 @@ class Solver final : public lbfgsb_hip_ctx {
         scan.p[2 * col - 1] = h_res[4 * MCo + 2];
         scan.f1 = h_res[4 * MCo + 3], scan.nbreak = h_res[4 * MCo + 4];
         scan.nunb = h_res[4 * MCo + 5], scan.nunbnz = h_res[4 * MCo + 6];
-        scan.bkmin = h_res[4 * MCo + 7];
+        scan.bkmin = h_res[4 * MCo + 9];
         scan.ready = true;
       } else {
         lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
@@ -1565,6 +1611,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     get(wa8m);
     z_valid = true;  // z as imported
+    spec.valid = false, pend.on = 0, tbrk_valid = false, scan.ready = false;
     HIPCHK(hipMemcpyAsync(iwhere, iwa + n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
     // free-set membership as of the last freev: Index(1:nfree)
     std::vector<int8_t> wf((size_t)n, 0);
