@@ -204,6 +204,28 @@ def main():
                 "frac": ach_fused / HBM_PEAK_GBS, "traffic": traffic_of("cmprlb_wtv_traffic.json", n_loc),
                 "algorithmic_bytes_per_launch": alg_fused, "avg_launch_ms": ms_fused,
                 "rows_per_launch": n_loc, "col": col}
+    # the other two passes over W of an iteration, for the whole picture: the update/scan pass
+    # (read-only: W old columns + x, l, u, g, r, d + nbd, iwhere) and the subspace pass (the one
+    # pass that stores vectors: z, d, t, r, the trial x and the new W column pair)
+    others = []
+    try:
+        ms_us = sol.kernel_time(4, x, g, col, head, a.roofline_reps)
+        by_us = ((2 * (col - 1) + 6) * rbytes + 8) * n_loc
+        others.append({"kernel": "update_scan_kernel<%s, %d, %s> (as trial-point evaluation)"
+                       % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
+                       "achieved": by_us / (ms_us * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": by_us / (ms_us * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_us,
+                       "algorithmic_bytes_per_launch": by_us, "stores": "none"})
+        ms_su = sol.kernel_time(3, x, g, col, head, a.roofline_reps)
+        by_su = ((2 * col + 4 + 6) * rbytes + 8) * n_loc
+        others.append({"kernel": "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
+                       % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
+                       "achieved": by_su / (ms_su * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": by_su / (ms_su * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_su,
+                       "algorithmic_bytes_per_launch": by_su,
+                       "stores": "z, d, t, r + Ws/Wy column (6 of %d streams)" % (2 * col + 10)})
+    except Exception as e:
+        others.append({"error": repr(e)})
     ms_kernel = sol.wtv_time(g, col, head, a.roofline_reps)
     alg_bytes = (2 * col + 1) * n_loc * rbytes
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
@@ -243,6 +265,7 @@ def main():
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
         "roofline": roofline,
         "roofline_wtv": roofline_wtv,
+        "roofline_other_w_passes": others,
     }
     sol.close()
     # the opt-in closed-form GCP (LBFGSB_F_PARALLEL_GCP): only the first iteration differs

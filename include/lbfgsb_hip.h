@@ -189,8 +189,12 @@ int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, i
  * cmprlb_wtv_kernel (r of cmprlb + W'r of subsm, src/lbfgsb.f90:1565-1583 + :2742-2754),
  * which = 2 the same with formk's new row/column sums riding along (:1756-1793; the variant
  * the iteration runs after a BFGS update), which = 1 the from-scratch formk Gram kernel
- * (:1756-1851).  Uses the context's current W, z, iwhere;
- * x, g are device pointers; r is overwritten. */
+ * (:1756-1851), which = 3 subsm_update_kernel (Newton direction + projected step + line-search
+ * set-up, :2770-2827, with a pending pair committed to W), which = 4 update_scan_kernel run as
+ * the evaluation of a trial point (matupd's and the next cauchy scan's sums, :2335-2336 +
+ * :1270-1330; reduces only).  Uses the context's current W and iwhere and, for 3 and 4, the
+ * l, u, nbd of the last setulb call; x, g are device pointers; z, r, d, t and the newest
+ * column of W are overwritten by which = 3. */
 int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const void *g, int col,
                            int head, int reps, double *h_ms_per_launch);
 int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx);

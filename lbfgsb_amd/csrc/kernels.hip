@@ -71,6 +71,17 @@ __device__ __forceinline__ int64_t col_off(int j, int col, int head, int m, int6
   const int jj = j < col ? j : 0;
   return (int64_t)((head - 1 + jj) % m) * ld;
 }
+// one column's rows for this lane, or zeros for the unroll slots beyond the stored pairs
+// (the kernels are unrolled to MC = 5/10/20/32 columns; col need not fill that)
+template <typename T, int W, bool NT>
+__device__ __forceinline__ void ld_col(bool active, const T *p, double (&o)[W]) {
+  if (active) {
+    ldx<W, NT>(p, o);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) o[k] = 0.0;
+  }
+}
 
 // ---- pending pair ----
 // Between matupd and the subspace pass of the same setulb call the newest pair (logical column
@@ -102,8 +113,8 @@ __device__ __forceinline__ void load_cols(const T *__restrict__ wy, const T *__r
   for (int j = 0; j < MC; ++j) {
     const int64_t off = col_off(j, col, head, m, ldw);
     const bool pj = pe.on && j == col - 1;
-    ldx<W, NT>(wy + ((pj ? dy : off) + i), a[j]);
-    ldx<W, NT>(ws + ((pj ? ds : off) + i), b[j]);
+    ld_col<T, W, NT>(j < col, wy + ((pj ? dy : off) + i), a[j]);
+    ld_col<T, W, NT>(j < col, ws + ((pj ? ds : off) + i), b[j]);
   }
 }
 template <typename T, int MC, int W>
@@ -308,8 +319,8 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
+      ld_col<T, W, NT>(j < col, wy + off, a[j]);
+      ld_col<T, W, NT>(j < col, ws + off, b[j]);
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
@@ -363,8 +374,8 @@ __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
 #pragma unroll
       for (int j = 0; j < MC; ++j) {
         const int64_t off = col_off(j, col, head, m, ldw) + i;
-        ldx<W, NT>(wy + off, a[j]);
-        ldx<W, NT>(ws + off, b[j]);
+        ld_col<T, W, NT>(j < col, wy + off, a[j]);
+        ld_col<T, W, NT>(j < col, ws + off, b[j]);
       }
     }
 #pragma unroll
@@ -1395,8 +1406,8 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_kernel(
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
+      ld_col<T, W, NT>(j < col, wy + off, a[j]);
+      ld_col<T, W, NT>(j < col, ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -1851,8 +1862,8 @@ __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
+      ld_col<T, W, NT>(j < col, wy + off, a[j]);
+      ld_col<T, W, NT>(j < col, ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -2104,8 +2115,8 @@ __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
     for (int j = 0; j < MC; ++j) {
       // nold may be 0: then logical column 0 is the NEW column; read d's own slot instead
       const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
+      ld_col<T, W, NT>(j < nold, wy + off, a[j]);
+      ld_col<T, W, NT>(j < nold, ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -2179,8 +2190,8 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
-      ldx<W, NT>(wy + off, a[j]);
-      ldx<W, NT>(ws + off, b[j]);
+      ld_col<T, W, NT>(j < nold, wy + off, a[j]);
+      ld_col<T, W, NT>(j < nold, ws + off, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {

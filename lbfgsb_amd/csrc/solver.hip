@@ -1671,7 +1671,17 @@ class Solver final : public lbfgsb_hip_ctx {
                                 cf, 0, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5});
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
-    else
+    else if (which == 3 || which == 4) {
+      if (!cl || !cu || !cnbd) return fail(LBFGSB_E_STATE, "kernel_time: run an iteration first");
+      const T *l = (const T *)cl, *u = (const T *)cu;
+      if (which == 3)  // with a pending pair: the variant every iteration after an update runs
+        lbk::launch_subsm_update<T>(q, n, 0.5, z, r, l, u, cnbd, iwhere, (const T *)x, (const T *)g,
+                                    W(), head, col, 1.0, cf, 0, cf, d, t, (T *)nullptr, 1,
+                                    lbk::Pend{1, 0.5});
+      else             // as the evaluation of a trial point: reduces only
+        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, d, 0.5, iwhere,
+                                   (T *)nullptr, W(), head, col, (head + col - 2) % m + 1, 0, 0);
+    } else
       return fail(LBFGSB_E_ARG, "unknown kernel");
     return 0;
   }
