@@ -71,15 +71,23 @@ __device__ __forceinline__ int64_t col_off(int j, int col, int head, int m, int6
   const int jj = j < col ? j : 0;
   return (int64_t)((head - 1 + jj) % m) * ld;
 }
-// one column's rows for this lane, or zeros for the unroll slots beyond the stored pairs
-// (the kernels are unrolled to MC = 5/10/20/32 columns; col need not fill that)
+// Unroll slots beyond the stored pairs (the kernels are unrolled to MC = 5/10/20/32 columns;
+// e.g. the update pass at col - 1 = 9 old columns runs the MC = 10 code).  col_off sends such a
+// slot to column 0 again, and with nontemporal loads that second request goes to HBM like the
+// first (PMC: +1.3 GB per launch at n = 1e8).  The fp64 kernels therefore skip the load; the
+// fp32 kernels, which already live at the register limit, lose 2x to the guarded form and keep
+// the duplicate load.
 template <typename T, int W, bool NT>
-__device__ __forceinline__ void ld_col(bool active, const T *p, double (&o)[W]) {
-  if (active) {
-    ldx<W, NT>(p, o);
-  } else {
+__device__ __forceinline__ void ld_col(bool live, const T *p, double (&o)[W]) {
+  if constexpr (sizeof(T) == 8) {
+    if (live) {
+      ldx<W, NT>(p, o);
+    } else {
 #pragma unroll
-    for (int k = 0; k < W; ++k) o[k] = 0.0;
+      for (int k = 0; k < W; ++k) o[k] = 0.0;
+    }
+  } else {
+    ldx<W, NT>(p, o);
   }
 }
 
