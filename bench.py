@@ -208,6 +208,15 @@ def main():
     # (read-only: W old columns + x, l, u, g, r, d + nbd, iwhere) and the subspace pass (the one
     # pass that stores vectors: z, d, t, r, the trial x and the new W column pair)
     others = []
+
+    def pass_traffic(key, rows):
+        tf = os.path.join(ROOT, "profiles", "w_pass_traffic.json")
+        if os.path.exists(tf) and not a.real32 and col == 10:
+            try:
+                return json.load(open(tf))[key]["hbm_bytes_per_row"] * rows
+            except Exception:
+                return None
+        return None
     try:
         ms_us = sol.kernel_time(4, x, g, col, head, a.roofline_reps)
         by_us = ((2 * (col - 1) + 6) * rbytes + 8) * n_loc
@@ -215,7 +224,8 @@ def main():
                        % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
                        "achieved": by_us / (ms_us * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": by_us / (ms_us * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_us,
-                       "algorithmic_bytes_per_launch": by_us, "stores": "none"})
+                       "algorithmic_bytes_per_launch": by_us, "stores": "none",
+                       "traffic": pass_traffic("update_scan", n_loc)})
         ms_su = sol.kernel_time(3, x, g, col, head, a.roofline_reps)
         by_su = ((2 * col + 4 + 6) * rbytes + 8) * n_loc
         others.append({"kernel": "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
@@ -223,7 +233,8 @@ def main():
                        "achieved": by_su / (ms_su * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": by_su / (ms_su * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_su,
                        "algorithmic_bytes_per_launch": by_su,
-                       "stores": "z, d, t, r + Ws/Wy column (6 of %d streams)" % (2 * col + 10)})
+                       "stores": "z, d, t, r + Ws/Wy column (6 of %d streams)" % (2 * col + 10),
+                       "traffic": pass_traffic("subsm_update", n_loc)})
     except Exception as e:
         others.append({"error": repr(e)})
     ms_kernel = sol.wtv_time(g, col, head, a.roofline_reps)
