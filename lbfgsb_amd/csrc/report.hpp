@@ -52,6 +52,31 @@ struct Report {
   FILE *out = stdout;
   FILE *itf = nullptr;
 
+  // n-vector dumps of iprint >= 100 (:2404-2408, :2449-2452, :2511-2514):
+  // '(/,a4,1p,6(1x,d11.4),/,(4x,1p,6(1x,d11.4)))'
+  void vec_a4(const char *label, const double *v, long long n) {
+    std::fprintf(out, "\n%4s", label);
+    for (long long i = 0; i < n; ++i) {
+      if (i > 0 && i % 6 == 0) std::fprintf(out, "\n    ");
+      std::fprintf(out, " %s", fD(v[i], 11, 4).c_str());
+    }
+    std::fprintf(out, "\n");
+  }
+  // '(A,/,(4x,1p,6(1x,d11.4)))' (:1345, :1527)
+  void vec_rows(const char *label, const double *v, long long n) {
+    std::fprintf(out, "%s", label);
+    for (long long i = 0; i < n; ++i) {
+      if (i % 6 == 0) std::fprintf(out, "\n    ");
+      std::fprintf(out, " %s", fD(v[i], 11, 4).c_str());
+    }
+    std::fprintf(out, "\n");
+  }
+  // cauchy's per-segment report (:1408-1412, :1502-1508)
+  void piece(int nseg, double f1, double f2) {
+    std::fprintf(out, "Piece    %3d --f1, f2 at start point  %s %s\n", nseg, fD(f1, 11, 4).c_str(),
+                 fD(f2, 11, 4).c_str());
+  }
+
   // prn1lb :2363-2412
   void prn1lb(long long n, int m, int iprint, double epsmch) {
     if (iprint < 0) return;
@@ -146,7 +171,7 @@ struct Report {
   void prn3lb(long long n, double f, const char *task60, int iprint, int info, int iter, int nfgv,
               int nintol, int nskip, int nact, double sbgnrm, double time, int nseg,
               const char *word, int iback, double stp, double xstep, long long k, double cachyt,
-              double sbtime, double lnscht) {
+              double sbtime, double lnscht, const double *xfinal = nullptr) {
     const bool err = std::strncmp(task60, "ERROR", 5) == 0;
     if (!err && iprint >= 0) {
       std::fprintf(out,
@@ -162,6 +187,7 @@ struct Report {
       std::fprintf(out, "\n   N    Tit     Tnf  Tnint  Skip  Nact     Projg        F\n");
       std::fprintf(out, "%5lld %6d %6d %6d  %4d %5d  %s  %s\n", n, iter, nfgv, nintol, nskip, nact,
                    fD(sbgnrm, 10, 3).c_str(), fD(f, 10, 3).c_str());
+      if (iprint >= 100 && xfinal) vec_a4("X =", xfinal, n);  // :2511-2514
       if (iprint >= 1) std::fprintf(out, "  F =%s\n", flist(f).c_str());
     }
     if (iprint >= 0) {

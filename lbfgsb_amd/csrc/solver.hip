@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -629,6 +630,19 @@ class Solver final : public lbfgsb_hip_ctx {
   }
   const void *cx = nullptr, *cl = nullptr, *cu = nullptr, *cg = nullptr;  // this call's operands
 
+  // an n-vector on the host, for the iprint >= 100 dumps (debugging sizes, this rank's rows)
+  std::vector<double> host_vec(const T *dptr) {
+    std::vector<T> tmp((size_t)n);
+    (void)hipMemcpyAsync(tmp.data(), dptr, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    return std::vector<double>(tmp.begin(), tmp.end());
+  }
+  void dump_cauchy_x(const T *x, const T *l, const T *u, const T *g) {  // :1345, :1527
+    (void)write_xcp(xp, x, l, u, g);
+    const std::vector<double> v = host_vec(xp);
+    rep.vec_rows("Cauchy X =  ", v.data(), n);
+  }
+
   // Generalized Cauchy point, reference :1157-1532.  p,c,wbp,v = wa8m slots.
   // results of the n-loop of cauchy when it was fused into the matupd pass
   struct ScanOut {
@@ -643,6 +657,7 @@ class Solver final : public lbfgsb_hip_ctx {
     cx = x, cl = l, cu = u, cg = g, cnbd = nbd;
     fixlist.clear();
     fix_overflow = false;
+    const int ipr = quiet ? -1 : print_level;
     if (sbgnrm <= 0.0) {  // :1245-1249
       scan.ready = false;
       gcp = Gcp{};
@@ -652,6 +667,13 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     const int col2 = 2 * col;
     const int MC = col ? lbk::maxc_for(col) : 0;
+    if (ipr >= 99) std::fprintf(rep.out, "\n---------------- CAUCHY entered-------------------\n");
+    auto leave = [&](double tsum_, double lt, int64_t li) -> int {  // update() :1519-1530
+      CHK(close_gcp(tsum_, lt, li));
+      if (ipr > 100) dump_cauchy_x(x, l, u, g);
+      if (ipr >= 99) std::fprintf(rep.out, "\n---------------- exit CAUCHY----------------------\n\n");
+      return 0;
+    };
     if (!scan.ready) {
       lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
       tbrk_valid = true;
@@ -676,7 +698,9 @@ class Solver final : public lbfgsb_hip_ctx {
     double last_t = -1.0;
     int64_t last_i = -1;
     if (nbreak == 0 && nunb == 0) {  // d = 0: xcp = x (:1343-1347)
-      return close_gcp(0.0, last_t, last_i);
+      CHK(close_gcp(0.0, last_t, last_i));
+      if (ipr > 100) dump_cauchy_x(x, l, u, g);
+      return 0;
     }
     for (int j = 0; j < col2; ++j) c[j] = 0.0;
     double f2 = -theta * f1;  // :1357-1363
@@ -689,6 +713,7 @@ class Solver final : public lbfgsb_hip_ctx {
     double dtm = -f1 / f2;
     double tsum = 0.0;
     nseg = 1;
+    if (ipr >= 99) std::fprintf(rep.out, " There are %11lld   breakpoints \n", (long long)nbreak);  // :1367
 
     if (col == 0 && nbreak != 0 && (flags & LBFGSB_F_PARALLEL_GCP) && dtm >= bkmin) {
       // B = theta*I: phi'(t) = -(1 - theta t) * (remaining d'd), so the walk stops at t = 1/theta
@@ -704,6 +729,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // the walk counts a segment per fixed variable except a last one that fixes all n (:1436)
       const int64_t ns = 1 + done - ((done == nbreak && nbreak == nglob) ? 1 : 0);
       nseg = (int)std::min<int64_t>(ns, std::numeric_limits<int>::max());
+      if (ipr >= 99) std::fprintf(rep.out, "\n---------------- exit CAUCHY----------------------\n\n");
       return 0;
     }
 
@@ -715,11 +741,14 @@ class Solver final : public lbfgsb_hip_ctx {
       const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
       for (;;) {
         const double tj0 = tj;
-        if (iter == 1) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
+        if (iter == 1 && ipr < 100) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
           if (dtm < bkmin - tj0) break;
         }
         // ---- next breakpoint after (last_t, last_i), if it can matter: t <= tj0 + dtm ----
-        const double hi_need = (tj0 + dtm) * INFL;
+        // (iprint >= 100 reports the distance to the next breakpoint of every segment, :1408-1412:
+        //  then the next one is always fetched)
+        const double hi_need =
+            ipr >= 100 ? std::numeric_limits<double>::infinity() : (tj0 + dtm) * INFL;
         const double *rec = nullptr;
         int64_t rec_gi = -1;
         for (;;) {
@@ -749,6 +778,12 @@ class Solver final : public lbfgsb_hip_ctx {
         if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
         tj = rec[0];
         const double dt = tj - tj0;
+        if (dt != 0.0 && ipr >= 100) {  // :1408-1412
+          std::fprintf(rep.out, "\n");
+          rep.piece(nseg, f1, f2);
+          std::fprintf(rep.out, "Distance to the next break point =  %s\n", lbr::fD(dt, 11, 4).c_str());
+          std::fprintf(rep.out, "Distance to the stationary point =  %s\n", lbr::fD(dtm, 11, 4).c_str());
+        }
         if (dtm < dt) break;  // :1416
 
         // fix this variable (:1421-1434)
@@ -765,11 +800,13 @@ class Solver final : public lbfgsb_hip_ctx {
           fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
         else
           fix_overflow = true;
+        if (ipr >= 100)  // :1435
+          std::fprintf(rep.out, " Variable  %11lld   is fixed.\n", (long long)rec_gi + 1);
         if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
           dtm = dt;
           if (col > 0)
             for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];
-          return close_gcp(tsum, last_t, last_i);  // no row is left to move: tsum is moot
+          return leave(tsum, last_t, last_i);  // no row is left to move: tsum is moot
         }
         nseg = nseg + 1;
         const double dibp2 = dibp * dibp;
@@ -809,11 +846,16 @@ class Solver final : public lbfgsb_hip_ctx {
     if (std::getenv("LBFGSB_DEBUG"))
       std::fprintf(stderr, "[cauchy] nseg=%d tsum=%g dtm=%g last=(%.17g,%lld)\n", nseg, tsum, dtm,
                    last_t, (long long)last_i);
+    if (ipr >= 99) {  // :1502-1508
+      std::fprintf(rep.out, "\n GCP found in this segment\n");
+      rep.piece(nseg, f1, f2);
+      std::fprintf(rep.out, "Distance to the stationary point =  %s\n", lbr::fD(dtm, 11, 4).c_str());
+    }
     if (dtm <= 0.0) dtm = 0.0;  // :1509
     tsum = tsum + dtm;
     if (col > 0 && dtm != 0.0)
       for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
-    return close_gcp(tsum, last_t, last_i);
+    return leave(tsum, last_t, last_i);
   }
 
   // ==================================================================== formk
@@ -959,6 +1001,7 @@ class Solver final : public lbfgsb_hip_ctx {
     const int MC = lbk::maxc_for(col);
     const bool newrow = do_formk && updatd;
     const double *res = pre;
+    const int ipr = quiet ? -1 : print_level;
     if (!pre) {
       lbk::Coef cf;
       bool plain;
@@ -985,6 +1028,7 @@ class Solver final : public lbfgsb_hip_ctx {
       formk_factor(col, theta, info);
       if (info != 0) return 0;
     }
+    if (ipr >= 99) std::fprintf(rep.out, "\n----------------SUBSM entered-----------------\n\n");  // :2738
     lbh::Mat WN{wn.data(), 2 * m};
     const int col2 = 2 * col;
     info = lbh::dtrsl(WN, col2, wv, 11);
@@ -1014,7 +1058,10 @@ class Solver final : public lbfgsb_hip_ctx {
     ls.gd = dd_p;
     ls.dtd = h_res[2];
     ls.stpmx = h_res[3];
-    if (iword == 0 || dd_p <= 0.0) return 0;  // :2820, :2828
+    if (iword == 0 || dd_p <= 0.0) {  // :2820, :2828
+      if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");  // :2883
+      return 0;
+    }
     ls.ready = false;  // z changes below: lnsrlb_begin redoes d, t, r
     if (ls.x_is_z) {   // ... from the iterate itself, which the pass above saved in t
       HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
@@ -1040,6 +1087,7 @@ class Solver final : public lbfgsb_hip_ctx {
       ibd = (int64_t)h_res[0];
     }
     lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, tbrk, l, u, iwhere, alpha, ibd);
+    if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");
     return 0;
   }
 
@@ -1096,10 +1144,13 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     auto finish = [&]() {  // :892-902
       const double time = now_s() - time1;
-      if (!quiet)
+      if (!quiet) {
+        std::vector<double> xf;
+        if (ipr >= 100 && !lbh::str60_pre(task, "ERROR")) xf = host_vec(x);
         rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip,
                    (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm, time, nseg, word,
-                   iback, stp, xstep, err_k, cachyt, sbtime, lnscht);
+                   iback, stp, xstep, err_k, cachyt, sbtime, lnscht, xf.empty() ? nullptr : xf.data());
+      }
       save_locals();
     };
     auto refresh = [&]() {
@@ -1147,6 +1198,11 @@ class Solver final : public lbfgsb_hip_ctx {
         return 0;
       }
       if (!quiet) rep.prn1lb(nglob, m, ipr, epsmch);
+      if (ipr > 100) {  // :2404-2408
+        rep.vec_a4("L =", host_vec(l).data(), n);
+        rep.vec_a4("X0 =", host_vec(x).data(), n);
+        rep.vec_a4("U =", host_vec(u).data(), n);
+      }
       lbk::launch_active<T>(q, n, x, l, u, nbd, iwhere, wasfree);  // :965-1040
       CHK(fetch(4, 0, 0));
       prjctd = h_res[0] > 0.0;
@@ -1303,6 +1359,33 @@ class Solver final : public lbfgsb_hip_ctx {
             ileave_g = nglob + 1;
           }
           wrk = (ileave_g < nglob + 1) || (nenter_g > 0) || updatd;
+          if (ipr >= 99) {  // :2023-2057
+            if (iter > 0 && cnstnd) {
+              if (ipr >= 100 && chg_local > 0 && chg_local <= CHG_CAP) {
+                // this rank's rows that changed status: leaving rows in ascending order (the scan
+                // of Index(1:nfree)), entering rows in descending order (the active part of Index
+                // is filled from the back)
+                std::vector<uint32_t> ch(chg_local);
+                (void)hipMemcpyAsync(ch.data(), d_chg, chg_local * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, stream);
+                (void)hipStreamSynchronize(stream);
+                std::vector<int64_t> lv, en;
+                for (uint32_t e : ch) ((e & 0x80000000u) ? lv : en).push_back((int64_t)(e & 0x7fffffffu));
+                std::sort(lv.begin(), lv.end());
+                std::sort(en.begin(), en.end(), std::greater<int64_t>());
+                for (int64_t k : lv)
+                  std::fprintf(rep.out, " Variable %11lld  leaves the set of free variables\n",
+                               (long long)(row0 + k + 1));
+                for (int64_t k : en)
+                  std::fprintf(rep.out, " Variable %11lld  enters the set of free variables\n",
+                               (long long)(row0 + k + 1));
+              }
+              std::fprintf(rep.out, " %11lld  variables leave; %11lld  variables enter\n",
+                           (long long)(nglob + 1 - ileave_g), (long long)nenter_g);
+            }
+            std::fprintf(rep.out, " %11lld  variables are free at GCP %11d\n", (long long)nfree_g,
+                         iter + 1);
+          }
           if (index)
             lbk::launch_freev_lists(q, n, iwhere, prevfree, (iter > 0 && cnstnd) ? 1 : 0, index,
                                     indx2, scan_tmp);
@@ -1450,6 +1533,10 @@ class Solver final : public lbfgsb_hip_ctx {
           if (!quiet)
             rep.prn2lb(ipr, iter, nfgv, (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm,
                        nseg, word, iback, stp, xstep, *f);
+          if (ipr > 100) {  // :2449-2452
+            rep.vec_a4("X =", host_vec(x).data(), n);
+            rep.vec_a4("G =", host_vec(g).data(), n);
+          }
           save_locals();
           return 0;
         }

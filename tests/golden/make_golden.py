@@ -49,6 +49,21 @@ def driver2_stop(s):
     return None
 
 
+def transcripts():
+    """The reference's debugging output (iprint = 99, 100, 101) on two small problems, captured
+    from its stdout: expected text for the product's report layer (src/lbfgsb.f90 iprint >= 99)."""
+    import subprocess
+    worker = os.path.join(ROOT, "tests", "_iprint_worker.py")
+    for problem, n, m, ipr, iters in (("rosen", 7, 5, 101, 6), ("quadmix", 12, 4, 100, 6),
+                                      ("quadmix", 12, 4, 99, 6)):
+        out = subprocess.run([sys.executable, worker, "ref", problem, str(n), str(m), str(ipr),
+                              str(iters)], capture_output=True, text=True, check=True).stdout
+        path = os.path.join(OUT, "ref_outputs", "iprint%d_%s_n%d_m%d.txt" % (ipr, problem, n, m))
+        with open(path, "w") as fh:
+            fh.write(out)
+        print("wrote", path, len(out.splitlines()), "lines")
+
+
 def record(kind, name, p, full_calls, on_new_x=None, max_calls=10**9, lite_xg=None):
     eng = po.Engine(kind)
     traj = dict(task=[], f=[], x=[], g=[], isave=[], dsave=[], lsave=[])
@@ -114,4 +129,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["transcripts"]:
+        transcripts()
+    else:
+        main()
+        transcripts()
