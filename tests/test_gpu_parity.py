@@ -580,3 +580,44 @@ def test_parallel_gcp_opt_in(env, kind):
         assert a[:2] == b[:2], (a, b)
         assert abs(a[2] - b[2]) <= 2 and abs(a[3] - b[3]) <= 2, (a, b)
         assert a[4] == pytest.approx(b[4], rel=1e-9)
+
+
+@pytest.mark.parametrize("n,m,mixed,min_agree", [(1000, 10, False, 72), (4096, 10, True, 80),
+                                                 (100003, 5, False, 60)])
+def test_device_path_to_convergence_against_oracle(env, n, m, mixed, min_agree):
+    """The production path (device pointers, speculative update pass, pending pair, functional
+    Cauchy point, on-device objective) run to CONVERGENCE with factr = pgtol = 0: the integer
+    columns (iteration, nfg, nseg, nfree) equal the oracle's for at least `min_agree` iterations
+    (all 72 of the n = 1000 fixture; beyond that the stop test acts on rounding noise), f agrees
+    to 1e-11 throughout, same final message."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    p = po.problem_quadratic(n, m, mixed_nbd=mixed)
+    rows_o = []
+    so = po.run(po.Engine("oracle"), p,
+                snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                     int(s.isave[37]), float(s.f[0])))
+                if s.task_s.startswith("NEW_X") else None)
+    sol = la.DeviceSolver(n, m)
+    x = torch.from_numpy(p.x0.copy()).cuda()
+    g = torch.zeros_like(x)
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+    rows_g = []
+    for _ in range(100000):
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(0, x, g)
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
+                           int(sol.isave[37]), float(sol.f[0])))
+        else:
+            break
+    sol.close()
+    assert t == so.task_s and t.startswith("CONVERGENCE")
+    k = 0
+    while k < min(len(rows_o), len(rows_g)) and rows_o[k][:4] == rows_g[k][:4]:
+        k += 1
+    assert k >= min_agree, (k, rows_o[k - 1:k + 1], rows_g[k - 1:k + 1])
+    for a, b in zip(rows_g, rows_o):
+        assert a[4] == pytest.approx(b[4], rel=1e-11)
+    assert float(sol.f[0]) == pytest.approx(float(so.f[0]), rel=1e-11)
