@@ -152,6 +152,16 @@ template <typename T, int MC>
 struct RowsPer {
   static constexpr int V = MC >= 20 ? VecOf<T>::V / 2 : VecOf<T>::V;
 };
+// the same for kernels that also carry NACC fp64 accumulators per lane: rows per lane are halved
+// while operands (2*MC*V values) + accumulators would not fit the 256 VGPRs (fp32: 4 rows of 20
+// operands + 60 sums spill to AGPRs and run one wave per SIMD; 2 rows fit)
+template <typename T, int MC, int NACC>
+struct RowsPerAcc {
+  static constexpr int V0 = RowsPer<T, MC>::V;
+  // (never below 8 bytes per lane: 4-byte loads cost more than the spills they avoid)
+  static constexpr int V =
+      (V0 > 1 && (V0 / 2) * (int)sizeof(T) >= 8 && 2 * (2 * MC * V0 + NACC) > 240) ? V0 / 2 : V0;
+};
 
 // Grid-stride over rows in groups of V (16 B per lane per array by default), scalar tail.
 // f(i, WTag<W>) handles rows i .. i+W-1.

@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
-  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPerAcc<T, MC, NA>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], rv[W], a[MC][W], b[MC][W];
     int iw[W];
@@ -2182,7 +2182,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   acc[4 * MC + 9] = LB_INF;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
-  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
+  for_rows<T, RowsPerAcc<T, MC, NA>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
