@@ -615,6 +615,56 @@ void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, con
                      u, nbd, g, iwhere, lo_t, lo_i, hi_t, keys, idx, cap, d_count);
   q.launches++;
 }
+// iwhere update of cauchy's n-loop alone (:1284-1291), for contexts whose speculative update pass
+// must leave iwhere untouched until the trial point is accepted (state mirrored at every return)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void iwhere_update_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, int32_t *iwhere) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W];
+    int nb[W], iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ldi<W>(nbd + i, nb);
+    ldi<W>(iwhere + i, iw);
+    bool changed = false;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (iw[k] != 3 && iw[k] != -1) {
+        const double neggi = -gv[k];
+        double tl = 0.0, tu = 0.0;
+        if (nb[k] <= 2) tl = xv[k] - lv[k];
+        if (nb[k] >= 2) tu = uv[k] - xv[k];
+        const bool xlower = nb[k] <= 2 && tl <= 0.0;
+        const bool xupper = nb[k] >= 2 && tu <= 0.0;
+        const int old = iw[k];
+        iw[k] = 0;
+        if (xlower) {
+          if (neggi <= 0.0) iw[k] = 1;
+        } else if (xupper) {
+          if (neggi >= 0.0) iw[k] = 2;
+        } else {
+          if (fabs(neggi) <= 0.0) iw[k] = -3;
+        }
+        changed = changed || iw[k] != old;
+      }
+    }
+    if (__ballot(changed) != 0ull) sti<W>(iwhere + i, iw);
+  });
+}
+template <typename T>
+void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                          const int32_t *nbd, const T *g, int32_t *iwhere) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(iwhere_update_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
+                     iwhere);
+  q.launches++;
+}
+
 // tbrk as a vector, for the paths that want one (full sort, cursor-based cauchy_finish)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void tbrk_fill_kernel(
@@ -2397,6 +2447,8 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                             uint32_t *, uint32_t, uint32_t *);                     \
   template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *, const T *,   \
                                    const int32_t *, double, T *);                                  \
+  template void launch_iwhere_update<T>(Queue &, int64_t, const T *, const T *, const T *,         \
+                                        const int32_t *, const T *, int32_t *);                    \
   template void launch_tbrk_fill<T>(Queue &, int64_t, const T *, const T *, const T *,             \
                                     const int32_t *, const T *, const int32_t *, T *);             \
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t,     \

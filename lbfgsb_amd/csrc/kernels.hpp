@@ -127,6 +127,10 @@ void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, con
                               const int32_t *nbd, const T *g, const int32_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
                               uint32_t *d_count);
+// cauchy's iwhere update (:1284-1291) alone
+template <typename T>
+void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                          const int32_t *nbd, const T *g, int32_t *iwhere);
 // the Cauchy point as a vector from (x, g, l, u, iwhere-after-the-walk, tsum)
 template <typename T>
 void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,

@@ -1235,8 +1235,10 @@ class Solver final : public lbfgsb_hip_ctx {
       // First trial of a line search on a bounded problem: it is accepted far more often than
       // not, so evaluate it with the pass that matupd + the next cauchy scan would run anyway
       // (read-only with the pair pending); g'd and |proj g| are two of its sums.  Contexts
-      // that mirror the reference's arrays keep iwhere untouched until the update is real.
-      if (cnstnd && ifun == 1 && !(flags & LBFGSB_F_MIRROR_INDEX)) {
+      // that mirror the reference's arrays at every return keep iwhere untouched until the
+      // update is real (iwhere_update_kernel at the NEW_X entry).
+      if (cnstnd && ifun == 1) {
+        const int store_iw = (flags & LBFGSB_F_MIRROR_INDEX) ? 0 : 1;
         int c2, h2, it2;  // matupd's pointer update (:2303-2309), as if this trial is accepted
         if (iupdat + 1 <= m) {
           c2 = iupdat + 1, h2 = head, it2 = (head + iupdat - 1) % m + 1;
@@ -1245,7 +1247,7 @@ class Solver final : public lbfgsb_hip_ctx {
         }
         const int MCo = lbk::maxc_for(c2 - 1);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
-                                   it2, 0, 1);
+                                   it2, 0, store_iw);
         CHK(fetch(4 * MCo + 9, 1, 1));
         gd = h_res[4 * MCo + 7];
         spec_sbgnrm = h_res[4 * MCo + 10];
@@ -1595,6 +1597,8 @@ class Solver final : public lbfgsb_hip_ctx {
                            spec.head == head && spec.col == col && spec.itail == itail;
         if (reuse) {
           std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11));
+          if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
+            lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
         } else {
           lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
                                      col, itail, 0, 1);
