@@ -1441,55 +1441,6 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
   finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
 }
 
-// =========================== cmprlb (:1548-1586) =============================
-template <typename T, int MC, bool NT>
-__global__ __launch_bounds__(BLOCK) void cmprlb_kernel(
-    int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ z, T *r,
-    const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
-    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain) {
-  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
-    constexpr int W = decltype(wt)::value;
-    double xv[W], gv[W], zv[W], rv[W], a[MC][W], b[MC][W];
-    int iw[W];
-    ldx<W, NT>(g + i, gv);
-    if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
-#pragma unroll
-      for (int k = 0; k < W; ++k) rv[k] = -gv[k];
-      st<W>(r + i, rv);
-      return;
-    }
-    ldx<W, NT>(x + i, xv);
-    ldx<W, NT>(z + i, zv);
-    ldi<W>(iwhere + i, iw);
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld_col<T, W, NT>(j < col, wy + off, a[j]);
-      ld_col<T, W, NT>(j < col, ws + off, b[j]);
-    }
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      double rr = -theta * (zv[k] - xv[k]) - gv[k];
-#pragma unroll
-      for (int j = 0; j < MC; ++j) {
-        if (j < col) rr = rr + a[j][k] * cf.a[j] + b[j][k] * cf.a[MAXM + j];
-      }
-      rv[k] = iw[k] <= 0 ? rr : 0.0;
-    }
-    st<W>(r + i, rv);
-  });
-}
-template <typename T>
-void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
-                   const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
-                   const Coef &a, int plain) {
-  const int gr = grid_for(n, VecOf<T>::V);
-  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0, q.stream,
-                                        n, x, g, z, r, iwhere, w.ws, w.wy, w.ld, w.m, head, col,
-                                        theta, a, plain));
-  q.launches++;
-}
-
 // The generalized Cauchy point is not stored as a vector on the main path: after the walk,
 // xcp(k) is a function of row k's own x, g, bounds and iwhere (cauchy :1341, :1425-1433, :1515):
 //   iwhere in {0,-1} (the row moves with d = -g and was not fixed):  x + tsum*d
@@ -1511,9 +1462,11 @@ __device__ __forceinline__ double xcp_row(double xk, double gk, int iw, double l
   return xcp_free<T>(xk, gk, iw, tsum);
 }
 
+// =========================== cmprlb (:1548-1586) =============================
 // cmprlb fused with the first matvec of subsm (:2742-2754): r_k depends only on row k, so
-// W'r is accumulated in the same pass that computes and stores r (one pass over W instead
-// of two).  Per element the arithmetic is exactly cmprlb_kernel's.
+// W'r is accumulated in the same pass that computes r (one pass over W instead of two).  Per
+// element the arithmetic is the reference's: r = -theta (z - x) - g, then + Wy(k,j) a1_j +
+// Ws(k,j) a2_j for j = 1..col in that order (:1565-1583).
 // NEWROW: the same pass also yields the new row/column of formk's WN1 (:1756-1793) for the
 // pair just stored (logical column col-1): with y = Wy_new, s = Ws_new,
 //   t1_j = sum_free y Wy_j, t2_j = sum_act s Ws_j, t3_j = sum_act s Wy_j, t4_j = sum_free Ws_j y.
@@ -2637,8 +2590,6 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                         const T *, const T *, const T *, int32_t *, T *, double,   \
                                         double, int64_t, int);                                     \
   template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const int32_t *);      \
-  template void launch_cmprlb<T>(Queue &, int64_t, const T *, const T *, const T *, T *,           \
-                                 const int32_t *, WStore<T>, int, int, double, const Coef &, int); \
   template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double,               \
                                      const int32_t *, WStore<T>, int, int, double, const Coef &,  \
                                      int, int, const T *, const T *, Pend);                         \

@@ -171,12 +171,6 @@ template <typename T>
 void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
                        const int32_t *iwhere);
 
-// ---- cmprlb (ref :1548-1586): r (full length, 0 on non-free rows) ------------
-template <typename T>
-void launch_cmprlb(Queue &q, int64_t n, const T *x, const T *g, const T *z, T *r,
-                   const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
-                   const Coef &a, int plain);
-
 // cmprlb + the first matvec of subsm (W'r, :2742-2754) in one pass over W.
 // res sum-slots (MC = maxc_for(col)): [0..col) Wy'r, [MC..MC+col) Ws'r; with newrow also the
 // new row/column of formk's WN1 for the pair in logical column col-1 (ref :1756-1793):

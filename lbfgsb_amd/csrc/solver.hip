@@ -6,15 +6,18 @@
 // launch from kernels.hip; every 2m x 2m operation is host code from
 // host_dense.hpp.  One host thread per context, one HIP stream per context.
 //
-// Phase -> kernels -> one host sync each:
-//   projgr                      : projgr_kernel
-//   cauchy  (:1157-1532)        : cauchy_scan -> [window/sort/gather]* -> cauchy_finish
-//   freev   (:1980-2059)        : freev_count (+ freev_lists when mirroring Index)
-//   formk   (:1681-1908)        : formk_gram, then assemble + 2 Cholesky on host
-//   cmprlb  (:1548-1586)        : host bmv, cmprlb_kernel
-//   subsm   (:2676-2885)        : wtv_kernel, host 2 dtrsl, subsm_update (+ backtrack)
-//   lnsrlb  (:2174-2275)        : lnsrlb_begin | lnsrlb_eval, host dcsrch, lnsrlb_step
-//   matupd  (:2291-2346)        : update_pairs, host formt
+// One steady-state iteration on a bounded problem (kernels.hip has the why):
+//   FG_LNSRCH entry : update_scan as the evaluation of the first trial point  [read-only, 1 sync]
+//                     (g'd and |proj g| for dcsrch; if accepted also matupd's and the next
+//                      cauchy scan's sums) -- later trials: lnsrlb_eval
+//   NEW_X entry     : host matupd/formt from those sums (the new pair stays pending)
+//     cauchy        : host walk; window/gather only when it passes the first breakpoint
+//     freev+cmprlb  : freev_count + cmprlb_wtv (r, W'r, formk's new row)          [read-only, 1 sync]
+//     formk         : patches for rows that changed status (sparse), host assembly + 2 Cholesky
+//     subsm+lnsrlb  : subsm_update: Newton step, projection, line-search set-up, first trial x,
+//                     commits the pending pair                                    [stores, 1 sync]
+// Other paths (col = 0, restarts, unconstrained, fallbacks): projgr, cauchy_scan, cauchy_finish,
+// formk_gram, update_pairs, lnsrlb_begin/step, pair_commit, xcp_fill, subsm_dir/backtrack.
 //
 // There is no CPU fallback anywhere in this file.
 #include <dlfcn.h>
