@@ -1,0 +1,89 @@
+"""Randomised differential test: random box-constrained problems (random n, m, bound types incl.
+fixed and unbounded variables, separable + coupled + non-convex objectives, random factr/pgtol)
+solved call by call through the reference-shaped host entry and by the oracle.  Every setulb
+return must match (task, iteration, nfg, nseg, nfree; f to 1e-8) -- except that a run may part
+ways late (second half), where with factr = 0 the stop test acts on rounding noise, provided
+the final f agrees to 1e-7.  Exercises the production iteration (speculative update pass, pending
+pair, functional Cauchy point, skipped updates, restarts) on shapes no hand-written case covers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make(po, seed, nmax, mlo, mhi):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, nmax))
+    m = int(rng.integers(mlo, mhi))
+    a = 1.0 + 99.0 * rng.random(n)
+    c = rng.normal(0, 2, n)
+    mu = float(rng.choice([0.0, 0.5, 5.0]))
+    kind = int(rng.integers(0, 3))
+
+    def fg(x, g):
+        d = x - c
+        f = 0.5 * np.sum(a * d * d)
+        g[:] = a * d
+        if n > 1 and mu > 0:
+            e = x[:-1] - x[1:]
+            f += 0.5 * mu * np.sum(e * e)
+            g[:-1] += mu * e
+            g[1:] -= mu * e
+        if kind == 2:       # non-convex term: provokes several line-search trials
+            f += np.sum(np.cos(3 * x))
+            g[:] -= 3 * np.sin(3 * x)
+        return float(f)
+    l = rng.normal(-1, 1, n)
+    u = l + np.abs(rng.normal(1.5, 1, n))
+    fixed = rng.random(n) < 0.03
+    u[fixed] = l[fixed]
+    nbd = rng.integers(0, 4, n).astype(np.int32)
+    if rng.random() < 0.15:
+        nbd[:] = 0
+    if rng.random() < 0.15:
+        nbd[:] = 2
+    x0 = rng.normal(0, 3, n)
+    factr = 0.0 if rng.random() < 0.5 else 1e7
+    pgtol = 0.0 if rng.random() < 0.5 else 1e-5
+    return po.Problem("fuzz%d" % seed, n, m, x0, l, u, nbd, factr, pgtol, fg, np.float64)
+
+
+@pytest.mark.parametrize("first,count,nmax,mlo,mhi", [(0, 120, 400, 1, 13), (5000, 40, 3000, 11, 33)])
+def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi):
+    po = oracle_built
+    import lbfgsb_amd as la
+
+    def row(s):
+        return (s.task_s[:12], int(s.isave[29]), int(s.isave[33]), int(s.isave[32]), int(s.isave[37]),
+                float(s.f[0]))
+    late = 0
+    for seed in range(first, first + count):
+        p = make(po, seed, nmax, mlo, mhi)
+        ro = []
+        so = po.run(po.Engine("oracle"), p, max_iter=80, snapshot=lambda k, s: ro.append(row(s)))
+        s = po.State.fresh(p)
+        nbd = p.nbd.astype(np.int32)
+        rg = []
+        for _ in range(100000):
+            la.setulb(p.n, p.m, s.x, p.l, p.u, nbd, s.f, s.g, p.factr, p.pgtol, s.wa, s.iwa, s.task,
+                      -1, s.csave, s.lsave, s.isave, s.dsave)
+            rg.append(row(s))
+            t = s.task_s
+            if t.startswith("FG"):
+                s.f[0] = p.fg(s.x, s.g)
+            elif t.startswith("NEW_X"):
+                if s.isave[29] >= 80:
+                    break
+            else:
+                break
+        k = 0
+        while (k < min(len(ro), len(rg)) and ro[k][:5] == rg[k][:5]
+               and abs(ro[k][5] - rg[k][5]) <= 1e-8 * max(1.0, abs(ro[k][5]))):
+            k += 1
+        if k == len(ro) == len(rg):
+            continue
+        late += 1
+        fo, fgp = float(so.f[0]), float(s.f[0])
+        assert k >= 0.4 * len(ro) and abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), \
+            (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
+    assert late <= 0.2 * count      # the vast majority match through the last call
