@@ -158,10 +158,12 @@ def main():
     barrier()
     ts0 = t_setulb
     st0 = sol.stats()
+    sol.pass_clock(1)            # hipEvents around every launch of the three W passes
     t0 = time.perf_counter()
     advance(a.steps)
     barrier()
     dt = time.perf_counter() - t0
+    clocks = sol.pass_clock(0)   # {pass: (ms_total, launches)} over the timed region
     dt_setulb = t_setulb - ts0
     if world > 1:
         tt = torch.tensor([dt, dt_setulb], dtype=torch.float64, device=dev)
@@ -196,14 +198,24 @@ def main():
                 return None
         return None
 
-    ms_fused = sol.kernel_time(2, x, g, col, head, a.roofline_reps)  # the variant the iteration runs
+    def in_run(name):
+        ms, cnt = clocks[name]
+        return (ms / cnt, cnt) if cnt else (None, 0)
+
+    # average launch duration over the timed region (in-run hipEvents); the same kernel launched
+    # back to back after the run is kept beside it as a cross-check
+    ms_iso = sol.kernel_time(2, x, g, col, head, a.roofline_reps)  # the variant the iteration runs
+    ms_fused, n_fused = in_run("cmprlb_wtv")
+    if ms_fused is None:
+        ms_fused = ms_iso
     alg_fused = ((2 * col + 2) * rbytes + 4) * n_loc
     ach_fused = alg_fused / (ms_fused * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s, %d, true, %s>" % ("float" if a.real32 else "double", mc, nts),
                 "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_fused / HBM_PEAK_GBS, "traffic": traffic_of("cmprlb_wtv_traffic.json", n_loc),
                 "algorithmic_bytes_per_launch": alg_fused, "avg_launch_ms": ms_fused,
-                "rows_per_launch": n_loc, "col": col}
+                "launches_timed": n_fused, "timing": "hipEvents around each launch inside the timed region",
+                "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col}
     # the other two passes over W of an iteration, for the whole picture: the update/scan pass
     # (read-only: W old columns + x, l, u, g, r, d + nbd, iwhere) and the subspace pass (the one
     # pass that stores vectors: z, d, t, r, the trial x and the new W column pair)
@@ -218,23 +230,30 @@ def main():
                 return None
         return None
     try:
-        ms_us = sol.kernel_time(4, x, g, col, head, a.roofline_reps)
+        ms_us_iso = sol.kernel_time(4, x, g, col, head, a.roofline_reps)
+        ms_us = in_run("update_scan")[0] or ms_us_iso
         by_us = ((2 * (col - 1) + 6) * rbytes + 8) * n_loc
         others.append({"kernel": "update_scan_kernel<%s, %d, %s> (as trial-point evaluation)"
                        % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
                        "achieved": by_us / (ms_us * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": by_us / (ms_us * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_us,
+                       "avg_launch_ms_back_to_back": ms_us_iso,
                        "algorithmic_bytes_per_launch": by_us, "stores": "none",
                        "traffic": pass_traffic("update_scan", n_loc)})
-        ms_su = sol.kernel_time(3, x, g, col, head, a.roofline_reps)
-        by_su = ((2 * col + 4 + 6) * rbytes + 8) * n_loc
+        ms_su_iso = sol.kernel_time(3, x, g, col, head, a.roofline_reps)
+        ms_su = in_run("subsm_update")[0] or ms_su_iso
+        # in the run the pass also stores the first trial point x (one more vector)
+        by_su = ((2 * col + 4 + 6 + (1 if in_run("subsm_update")[0] else 0)) * rbytes + 8) * n_loc
         others.append({"kernel": "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
                        % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
                        "achieved": by_su / (ms_su * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": by_su / (ms_su * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_su,
+                       "avg_launch_ms_back_to_back": ms_su_iso,
                        "algorithmic_bytes_per_launch": by_su,
-                       "stores": "z, d, t, r + Ws/Wy column (6 of %d streams)" % (2 * col + 10),
-                       "traffic": pass_traffic("subsm_update", n_loc)})
+                       "stores": "z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11),
+                       "traffic": pass_traffic("subsm_update", n_loc),
+                       "traffic_note": "PMC pass of the back-to-back variant, which does not store the "
+                                       "trial x (one vector less than in the run)"})
     except Exception as e:
         others.append({"error": repr(e)})
     ms_kernel = sol.wtv_time(g, col, head, a.roofline_reps)

@@ -210,6 +210,13 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
                      int64_t *cauchy_fullsorts, double *wait_seconds);
 
+/* In-run clocks of the three passes over W of an iteration (hipEvents on the context's stream
+ * around every launch, read back at the next host sync): [0] cmprlb_wtv_kernel, [1]
+ * update_scan_kernel, [2] subsm_update_kernel -- each reading covers the kernel and the few-us
+ * finalize_kernel launched with it.  enable = 1: reset and start; 0: stop; -1: just read.
+ * ms_total[3] / count[3] receive the accumulated milliseconds and the number of launches. */
+int lbfgsb_hip_pass_clock(lbfgsb_hip_ctx *ctx, int enable, double *ms_total, int64_t *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "lbfgsb_hip_setulb_host": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
                                          C.c_double, C.c_double, _vp, _vp, _vp, C.c_int32, _vp,
                                          _vp, _vp, _vp, _cp, C.c_int32, C.c_int32]),
+    "lbfgsb_hip_pass_clock": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "lbfgsb_hip_minimize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_export_state": (C.c_int, [_vp, _vp, _vp]),

@@ -132,6 +132,40 @@ struct lbfgsb_hip_ctx {
   int rank = 0, nranks = 1;
   int64_t nsync = 0, nfullsort = 0;
   double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
+  // in-run clocks of the three passes over W (hipEvents on the solver's stream around each
+  // launch, read at the next host sync): 0 cmprlb_wtv, 1 update_scan, 2 subsm_update
+  bool clock_on = false;
+  hipEvent_t clk_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool clk_pending[3] = {false, false, false};
+  double clk_ms[3] = {0.0, 0.0, 0.0};
+  int64_t clk_n[3] = {0, 0, 0};
+  hipStream_t clk_stream = nullptr;
+  void clk_begin(int k) {
+    if (!clock_on) return;
+    if (!clk_ev[k][0]) {
+      (void)hipEventCreate(&clk_ev[k][0]);
+      (void)hipEventCreate(&clk_ev[k][1]);
+    }
+    clk_collect();  // (a pass launched twice between two syncs: keep the first reading)
+    (void)hipEventRecord(clk_ev[k][0], clk_stream);
+  }
+  void clk_end(int k) {
+    if (!clock_on) return;
+    (void)hipEventRecord(clk_ev[k][1], clk_stream);
+    clk_pending[k] = true;
+  }
+  void clk_collect() {  // call after a stream sync (or when the events are known complete)
+    for (int k = 0; k < 3; ++k) {
+      if (!clk_pending[k]) continue;
+      if (hipEventQuery(clk_ev[k][1]) != hipSuccess) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, clk_ev[k][0], clk_ev[k][1]) == hipSuccess) {
+        clk_ms[k] += ms;
+        clk_n[k]++;
+      }
+      clk_pending[k] = false;
+    }
+  }
   lbk::Queue q{};
 };
 
@@ -198,6 +232,11 @@ class Solver final : public lbfgsb_hip_ctx {
       p = nullptr;
     };
     H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix);
+    for (auto &pair : clk_ev)
+      for (auto &e : pair) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -331,6 +370,7 @@ class Solver final : public lbfgsb_hip_ctx {
       t_wait += now_s() - t0;
     }
     nsync++;
+    if (clock_on) clk_collect();
     if (nranks > 1 && !comm) {
       if (!cb_ar) return fail(LBFGSB_E_COMM, "multi-rank context without a reducer");
       if (cb_ar(cb_user, h_res, nsum, nmin, nmax) != 0)
@@ -1014,8 +1054,10 @@ class Solver final : public lbfgsb_hip_ctx {
         info = -8;
         return 0;
       }
+      clk_begin(0);
       lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
                                 plain ? 1 : 0, newrow ? 1 : 0, r, d, pend);
+      clk_end(0);
       CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
       res = h_res;
     }
@@ -1048,9 +1090,11 @@ class Solver final : public lbfgsb_hip_ctx {
     // d, t, r get their line-search values in the same pass (see subsm_update_kernel); xp = xcp
     // (:2787) is written out only for state export -- and below if the backtracking branch runs
     if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
+    clk_begin(2);
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, z, r, l, u, nbd, iwhere, x, g, W(), head, col, theta,
                                 cm_cf, cm_plain ? 1 : 0, cw, d, t, ls_unit_step ? xmut : nullptr,
                                 ls_do_stpmx ? 1 : 0, pend);
+    clk_end(2);
     pend.on = 0;  // the pass stored the pair into its W slot
     z_valid = true;
     CHK(fetch(3, 1, 0));
@@ -1249,8 +1293,10 @@ class Solver final : public lbfgsb_hip_ctx {
           c2 = col, it2 = itail % m + 1, h2 = head % m + 1;
         }
         const int MCo = lbk::maxc_for(c2 - 1);
+        clk_begin(1);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
                                    it2, 0, store_iw);
+        clk_end(1);
         CHK(fetch(4 * MCo + 9, 1, 1));
         gd = h_res[4 * MCo + 7];
         spec_sbgnrm = h_res[4 * MCo + 10];
@@ -1341,8 +1387,10 @@ class Solver final : public lbfgsb_hip_ctx {
             if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
               const bool newrow = updatd && col <= 20;  // updatd implies wrk
               q.res_off = 3;
+              clk_begin(0);
               lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
                                         plain ? 1 : 0, newrow ? 1 : 0, r, d, pend);
+              clk_end(0);
               q.res_off = 0;
               npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
             }
@@ -1603,8 +1651,10 @@ class Solver final : public lbfgsb_hip_ctx {
           if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
             lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
         } else {
+          clk_begin(1);
           lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
                                      col, itail, 0, 1);
+          clk_end(1);
           CHK(fetch(4 * MCo + 9, 1, 1));
         }
         spec.valid = false;
@@ -2024,6 +2074,25 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
   if (syncs) *syncs = ctx->nsync;
   if (cauchy_fullsorts) *cauchy_fullsorts = ctx->nfullsort;
   if (wait_seconds) *wait_seconds = ctx->t_wait;
+  return 0;
+}
+
+int lbfgsb_hip_pass_clock(lbfgsb_hip_ctx *ctx, int enable, double *ms_total, int64_t *count) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->clk_stream = ctx->q.stream;
+  if (enable == 1) {
+    for (int k = 0; k < 3; ++k) ctx->clk_ms[k] = 0.0, ctx->clk_n[k] = 0, ctx->clk_pending[k] = false;
+    ctx->clock_on = true;
+  } else {
+    HIPCHK(hipStreamSynchronize(ctx->q.stream));
+    ctx->clk_collect();
+    if (enable == 0) ctx->clock_on = false;
+  }
+  for (int k = 0; k < 3; ++k) {
+    if (ms_total) ms_total[k] = ctx->clk_ms[k];
+    if (count) count[k] = ctx->clk_n[k];
+  }
   return 0;
 }
 

@@ -227,6 +227,15 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_objective(self.h, kind, _p(x), _p(g), _p(out)))
         return float(out[0])
 
+    def pass_clock(self, enable: int):
+        """In-run hipEvent clocks of the three passes over W (see lbfgsb_hip_pass_clock):
+        enable 1 = reset and start, 0 = stop, -1 = read.  -> {name: (ms_total, launches)}"""
+        ms = (C.c_double * 3)()
+        cnt = (C.c_int64 * 3)()
+        check(self.lib.lbfgsb_hip_pass_clock(self.h, int(enable), ms, cnt))
+        names = ("cmprlb_wtv", "update_scan", "subsm_update")
+        return {nm: (ms[k], cnt[k]) for k, nm in enumerate(names)}
+
     def stats(self):
         a, b, c, w = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
         check(self.lib.lbfgsb_hip_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(w)))
