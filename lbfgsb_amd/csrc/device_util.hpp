@@ -117,6 +117,33 @@ __device__ __forceinline__ void st(float *p, const double (&o)[W]) {
     for (int k = 0; k < W; ++k) p[k] = (float)o[k];
   }
 }
+// nontemporal stores (streamed out, not re-read by this kernel)
+template <int W>
+__device__ __forceinline__ void stnt(double *p, const double (&o)[W]) {
+  if constexpr (W == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 v = {o[0], o[1]};
+    __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p));
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) __builtin_nontemporal_store(o[k], p + k);
+  }
+}
+template <int W>
+__device__ __forceinline__ void stnt(float *p, const double (&o)[W]) {
+  if constexpr (W == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  } else if constexpr (W == 2) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {(float)o[0], (float)o[1]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f2 *>(p));
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) __builtin_nontemporal_store((float)o[k], p + k);
+  }
+}
 template <int W>
 __device__ __forceinline__ void ldi(const int32_t *p, int (&o)[W]) {
   if constexpr (W == 2) {

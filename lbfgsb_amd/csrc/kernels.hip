@@ -1894,8 +1894,13 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
             sn[k] = b[j][k];
           }
       }
-      st<W>(cwy + i, yn);
-      st<W>(cws + i, sn);
+      if (NT) {
+        stnt<W>(cwy + i, yn);
+        stnt<W>(cws + i, sn);
+      } else {
+        st<W>(cwy + i, yn);
+        st<W>(cws + i, sn);
+      }
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) zv[k] = xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], tsum);
@@ -1938,13 +1943,23 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
         }
       }
     }
-    st<W>(zout + i, zv);
-    st<W>(dvec + i, dv);
-    st<W>(tvec + i, xv);  // t = x (:2235)
-    st<W>(r + i, gv);     // r = g (:2236)
-    // first trial point of the line search when its step is known to be 1: x = z (:2265);
-    // xout aliases xx (each row is read above before it is written here)
-    if (xout) st<W>(xout + i, zv);
+    // (nontemporal stores with the nontemporal loads: large problems, nothing here is re-read
+    //  by this pass; the next readers stream it from HBM anyway)
+    if (NT) {
+      stnt<W>(zout + i, zv);
+      stnt<W>(dvec + i, dv);
+      stnt<W>(tvec + i, xv);
+      stnt<W>(r + i, gv);
+      if (xout) stnt<W>(xout + i, zv);
+    } else {
+      st<W>(zout + i, zv);
+      st<W>(dvec + i, dv);
+      st<W>(tvec + i, xv);  // t = x (:2235)
+      st<W>(r + i, gv);     // r = g (:2236)
+      // first trial point of the line search when its step is known to be 1: x = z (:2265);
+      // xout aliases xx (each row is read above before it is written here)
+      if (xout) st<W>(xout + i, zv);
+    }
   });
   block_reduce_store<4>(acc, 3, 1, 0, part, MAX_BLOCKS);
 }
