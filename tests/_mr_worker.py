@@ -68,6 +68,87 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     dist.destroy_process_group()
 
 
+def fuzz_problem(po, seed):
+    """Random separable box-constrained problem (all bound types, fixed and unbounded variables,
+    optional non-convex term), shared by the sharded fuzz run and its single-rank oracle."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 2000))
+    m = int(rng.integers(1, 13))
+    a = 1.0 + 99.0 * rng.random(n)
+    c = rng.normal(0, 2, n)
+    wavy = bool(rng.random() < 0.4)
+
+    def fg(x, g, lo=0, hi=None):
+        hi = n if hi is None else hi
+        d = x - c[lo:hi]
+        f = 0.5 * np.sum(a[lo:hi] * d * d)
+        g[:] = a[lo:hi] * d
+        if wavy:
+            f += np.sum(np.cos(3 * x))
+            g[:] -= 3 * np.sin(3 * x)
+        return float(f)
+    l = rng.normal(-1, 1, n)
+    u = l + np.abs(rng.normal(1.5, 1, n))
+    fixed = rng.random(n) < 0.03
+    u[fixed] = l[fixed]
+    nbd = rng.integers(0, 4, n).astype(np.int32)
+    x0 = rng.normal(0, 3, n)
+    return po.Problem("mrfuzz%d" % seed, n, m, x0, l, u, nbd, 0.0, 0.0, fg, np.float64)
+
+
+def run_fuzz(rank, world, port, first, count, iters, out_path):
+    """`count` random problems, rows cut over `world` ranks sharing cuda:0 (gloo host reducers);
+    the objective is evaluated per shard on the host and summed over the ranks."""
+    import torch
+    import torch.distributed as dist
+    import lbfgsb_amd
+    from oracle import pyoracle as po
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    results = {}
+    for seed in range(first, first + count):
+        p = fuzz_problem(po, seed)
+        row0, n_loc = lbfgsb_amd.block_partition(p.n, world, rank)
+        sol = lbfgsb_amd.DeviceSolver(n_loc, p.m, n_global=p.n, row0=row0, device=0)
+        lbfgsb_amd.attach_host_group(sol, rank, world)
+        sl = slice(row0, row0 + n_loc)
+        x = torch.from_numpy(p.x0[sl].copy()).to(dev)
+        g = torch.zeros_like(x)
+        l = torch.from_numpy(p.l[sl].copy()).to(dev)
+        u = torch.from_numpy(p.u[sl].copy()).to(dev)
+        nbd = torch.from_numpy(p.nbd[sl].astype(np.int32)).to(dev)
+        rows = []
+        for _ in range(100000):
+            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                ft = torch.tensor([p.fg(xh, gh, row0, row0 + n_loc)], dtype=torch.float64)
+                dist.all_reduce(ft)
+                g.copy_(torch.from_numpy(gh))
+                sol.f[0] = float(ft[0])
+            elif t.startswith("NEW_X"):
+                rows.append([int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
+                             int(sol.isave[37]), float(sol.f[0])])
+                if sol.isave[29] >= iters:
+                    break
+            else:
+                break
+        results[str(seed)] = {"rows": rows, "task": sol.task_s}
+        sol.close()
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump(results, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     a = sys.argv
-    run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]), int(a[7]), a[8], a[9])
+    if a[4] == "fuzz":   # rank world port "fuzz" first count iters - out
+        run_fuzz(int(a[1]), int(a[2]), int(a[3]), int(a[5]), int(a[6]), int(a[7]), a[9])
+    else:
+        run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]), int(a[7]), a[8], a[9])
