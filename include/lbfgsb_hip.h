@@ -202,7 +202,10 @@ int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx);
 /* built-in device objectives: evaluate f, g on the
  * context's stream.  kind 0 = separable bounded quadratic,
  * kind 1 = extended Rosenbrock (test/driver1.f90:274-289; sharded: the 1-element halo x(row0-1), x(row0+n) is all-gathered through the communicator).
- * *h_f receives the GLOBAL value (reduced over ranks). */
+ * *h_f receives the GLOBAL value (reduced over ranks).  h_f == NULL defers it: the value stays
+ * on the device and the NEXT lbfgsb_hip_setulb_dev call on this context -- which must be the
+ * 'FG...' re-entry for this evaluation -- brings it over with the sums of its own first pass
+ * (one host sync and one all-reduce less per evaluation) and stores it through its f argument. */
 int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f);
 
 /* counters for bench/profiling: kernel launches, host syncs, full breakpoint sorts so far,

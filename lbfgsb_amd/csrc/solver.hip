@@ -132,6 +132,10 @@ struct lbfgsb_hip_ctx {
   int rank = 0, nranks = 1;
   int64_t nsync = 0, nfullsort = 0;
   double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
+  // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
+  // the next setulb_dev call fetches it together with the sums of its own first pass
+  bool f_pending = false;
+  double f_scale = 1.0;
   // in-run clocks of the three passes over W (hipEvents on the solver's stream around each
   // launch, read at the next host sync): 0 cmprlb_wtv, 1 update_scan, 2 subsm_update
   bool clock_on = false;
@@ -1276,6 +1280,17 @@ class Solver final : public lbfgsb_hip_ctx {
 
     bool compute_pg = true, prelims = true, linesearch = true;
     double spec_sbgnrm = 0.0;
+    // value of a deferred built-in objective: one more sum in front of this call's first fetch
+    int fo = 0;
+    if (f_pending) {
+      f_pending = false;
+      if (lbh::str60_pre(task, "FG")) {
+        fo = 1;
+      } else {  // (not an f,g return after all: just bring the value over)
+        CHK(fetch(1, 0, 0));
+        *f = f_scale * h_res[0];
+      }
+    }
     if (lbh::str60_pre(task, "FG_LN")) {
       compute_pg = false, prelims = false;
       spec.valid = false;
@@ -1294,22 +1309,29 @@ class Solver final : public lbfgsb_hip_ctx {
         }
         const int MCo = lbk::maxc_for(c2 - 1);
         clk_begin(1);
+        q.res_off = fo;
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
                                    it2, 0, store_iw);
+        q.res_off = 0;
         clk_end(1);
-        CHK(fetch(4 * MCo + 9, 1, 1));
-        gd = h_res[4 * MCo + 7];
-        spec_sbgnrm = h_res[4 * MCo + 10];
-        std::memcpy(spec.res, h_res, sizeof(double) * (4 * MCo + 11));
+        CHK(fetch(fo + 4 * MCo + 9, 1, 1));
+        if (fo) *f = f_scale * h_res[0];
+        const double *R = h_res + fo;
+        gd = R[4 * MCo + 7];
+        spec_sbgnrm = R[4 * MCo + 10];
+        std::memcpy(spec.res, R, sizeof(double) * (4 * MCo + 11));
         spec.valid = true;  // dropped below unless dcsrch accepts this point
         spec.x = x, spec.g = g, spec.stp = stp, spec.head = h2, spec.col = c2, spec.itail = it2;
         tbrk_valid = false;
       } else {
         // g.d for the line search and, speculatively, |proj g| for the NEW_X return
+        q.res_off = fo;
         lbk::launch_lnsrlb_eval<T>(q, n, x, l, u, nbd, g, d);
-        CHK(fetch(1, 0, 1));
-        gd = h_res[0];
-        spec_sbgnrm = h_res[1];
+        q.res_off = 0;
+        CHK(fetch(fo + 1, 0, 1));
+        if (fo) *f = f_scale * h_res[0];
+        gd = h_res[fo];
+        spec_sbgnrm = h_res[fo + 1];
       }
     } else if (lbh::str60_pre(task, "NEW_X")) {
       compute_pg = false, prelims = false, linesearch = false;
@@ -1331,9 +1353,12 @@ class Solver final : public lbfgsb_hip_ctx {
 
     if (compute_pg) {  // :579-596
       nfgv = 1;
+      q.res_off = fo;
       lbk::launch_projgr<T>(q, n, x, l, u, nbd, g);
-      CHK(fetch(0, 0, 1));
-      sbgnrm = h_res[0];
+      q.res_off = 0;
+      CHK(fetch(fo, 0, 1));
+      if (fo) *f = f_scale * h_res[0];
+      sbgnrm = h_res[fo];
       if (!quiet) rep.iterate0(ipr, iter, nfgv, *f, sbgnrm);
       if (sbgnrm <= pgtol) {
         lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
@@ -1855,8 +1880,13 @@ class Solver final : public lbfgsb_hip_ctx {
     } else {
       return fail(LBFGSB_E_ARG, "unknown objective kind");
     }
+    f_scale = kind == 0 ? 0.5 : 4.0;
+    if (!f) {  // deferred: no host sync here
+      f_pending = true;
+      return 0;
+    }
     CHK(fetch(1, 0, 0));
-    *f = kind == 0 ? 0.5 * h_res[0] : 4.0 * h_res[0];
+    *f = f_scale * h_res[0];
     return 0;
   }
   int sync() override {
@@ -1978,7 +2008,7 @@ int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void 
         if (rc) return rc;
         *f = fg(user, x, g);
       } else {
-        rc = ctx->k_objective(builtin_kind, x, g, f);
+        rc = ctx->k_objective(builtin_kind, x, g, nullptr);  // f comes back with the next call
         if (rc) return rc;
       }
     } else if (lbh::str60_pre(task, "NEW_X")) {

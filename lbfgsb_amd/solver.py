@@ -222,7 +222,13 @@ class DeviceSolver:
     def sync(self):
         check(self.lib.lbfgsb_hip_sync(self.h))
 
-    def objective(self, kind: int, x, g) -> float:
+    def objective(self, kind: int, x, g, deferred: bool = False):
+        """Built-in objective on the solver's stream.  deferred=True leaves f on the device: the
+        next setulb() call (the FG re-entry) fetches it with its own sums and stores it in
+        self.f -- one host sync less per evaluation; returns None then."""
+        if deferred:
+            check(self.lib.lbfgsb_hip_objective(self.h, kind, _p(x), _p(g), None))
+            return None
         out = np.zeros(1)
         check(self.lib.lbfgsb_hip_objective(self.h, kind, _p(x), _p(g), _p(out)))
         return float(out[0])

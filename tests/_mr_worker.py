@@ -48,7 +48,7 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     for _ in range(100000):
         t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
         if t.startswith("FG"):
-            sol.f[0] = sol.objective(kind, x, g)   # global f (reduced over ranks)
+            sol.objective(kind, x, g, deferred=True)   # global f: fetched by the next setulb call
         elif t.startswith("NEW_X"):
             rows.append([int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
                          int(sol.isave[37]), float(sol.f[0]), float(sol.dsave[12])])
