@@ -788,14 +788,15 @@ class Solver final : public lbfgsb_hip_ctx {
       const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
       for (;;) {
         const double tj0 = tj;
-        if (iter == 1 && ipr < 100) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
+        // (control flow follows print_level, which every rank shares -- ipr is -1 on the quiet ranks)
+        if (iter == 1 && print_level < 100) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
           if (dtm < bkmin - tj0) break;
         }
         // ---- next breakpoint after (last_t, last_i), if it can matter: t <= tj0 + dtm ----
         // (iprint >= 100 reports the distance to the next breakpoint of every segment, :1408-1412:
         //  then the next one is always fetched)
         const double hi_need =
-            ipr >= 100 ? std::numeric_limits<double>::infinity() : (tj0 + dtm) * INFL;
+            print_level >= 100 ? std::numeric_limits<double>::infinity() : (tj0 + dtm) * INFL;
         const double *rec = nullptr;
         int64_t rec_gi = -1;
         for (;;) {
