@@ -114,8 +114,26 @@ def main():
                                   same_stream_objective=True, real32=a.real32)
     rdt = torch.float32 if a.real32 else torch.float64
     rbytes = 4 if a.real32 else 8
+    collective = "none"
     if world > 1:
-        lbfgsb_amd.attach_rccl(sol, rank, world, dev)
+        # RCCL on the solver's stream; if the communicator cannot be created on some rank, every
+        # rank falls back to completing the (tiny) reductions through a gloo host group
+        ok = 1
+        try:
+            lbfgsb_amd.attach_rccl(sol, rank, world, dev)
+        except Exception as e:   # noqa: BLE001
+            ok = 0
+            sys.stderr.write("rank %d: RCCL communicator failed (%r)\n" % (rank, e))
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            collective = "RCCL all-reduce of <=4m+11 fp64 partials per phase"
+        else:
+            sol.close()
+            sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,
+                                          same_stream_objective=True, real32=a.real32)
+            lbfgsb_amd.attach_host_group(sol, rank, world, group=dist.new_group(backend="gloo"))
+            collective = "gloo host all-reduce (RCCL communicator unavailable)"
 
     x = torch.zeros(n_loc, dtype=rdt, device=dev)
     g = torch.zeros_like(x)
@@ -282,7 +300,7 @@ def main():
                                "l=-1,u=1,x0=0, on-device objective"
                                % (n, m, "fp32 storage/fp64 accumulate" if a.real32 else "fp64"),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "parallelism": "rows/%d" % world,
-                   "collective": "RCCL all-reduce of <=4m+5 fp64 partials per phase" if world > 1 else "none"},
+                   "collective": collective},
         "iters_per_sec_setulb_only": a.steps / dt_setulb,
         "first_iteration_s": first_iter_s,
         "first_iteration_nseg": nseg_first,
