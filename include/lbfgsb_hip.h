@@ -60,7 +60,11 @@ enum {
                                 rounding noise, so tsum (and nseg by a few units) may differ.  Also
                                 ignores the clamp f2 >= epsmch*f2_org (:1483), which only acts once
                                 the remaining gradient mass is below epsmch of the total.
-                                Calls with col > 0 always replay the walk exactly. */
+                                With pairs stored (col > 0) the flag replaces LONG walks (more than
+                                32768 breakpoints within reach; single rank) by a full sort + prefix
+                                scans of the walk's state on the device -- again the reference's
+                                result in exact arithmetic, without the clamp.  Short walks and
+                                multi-rank contexts always replay the walk exactly. */
 };
 
 /* -------------------------------------------------------------------------

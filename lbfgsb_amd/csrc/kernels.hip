@@ -665,6 +665,207 @@ void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *
   q.launches++;
 }
 
+// =========================== parallel GCP search, col > 0 (opt-in) ============
+// SURVEY.md 8f-2.  With the breakpoints sorted, the walk's state at breakpoint k is a prefix
+// sum: p_k = p_0 - sum_{j<k} d_j wbp_j, c_k = t_k p_0 - sum_{j<=k} dt_j P_j, and the f1/f2
+// recurrences (:1452-1481, without the f2 >= epsmch*f2_org clamp) become two more scans once
+// the quadratic forms with M are known per breakpoint.  Equal to the reference in exact
+// arithmetic, not operation for operation: LBFGSB_F_PARALLEL_GCP only, single rank.
+// Arrays are component-major: a[c * nbp + k], k = sorted position of the breakpoint.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pgcp_gather_kernel(
+    const uint32_t *__restrict__ idx, const uint64_t *__restrict__ keys, int64_t nb, int64_t nbp,
+    const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
+    const T *__restrict__ g, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
+    int m, int head, int col, double theta, const T *pr, const T *pd, Pend pe, double *tt,
+    double *dd, double *a0, double *wb, double *uu) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += stride) {
+    const int64_t i = idx[k];
+    const double d = -(double)g[i];
+    const double z = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
+    tt[k] = __longlong_as_double((long long)keys[k]);
+    dd[k] = d;
+    a0[k] = d * d - theta * d * z;
+    for (int j = 0; j < col; ++j) {
+      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
+      const bool pj = pe.on && j == col - 1;
+      const double yv = pj ? pend_y<T>((double)g[i], (double)pr[i]) : (double)wy[off];
+      const double sv = theta * (pj ? pend_s<T>((double)pd[i], pe.stp) : (double)ws[off]);
+      wb[(int64_t)j * nbp + k] = yv;
+      wb[(int64_t)(col + j) * nbp + k] = sv;
+      uu[(int64_t)j * nbp + k] = d * yv;
+      uu[(int64_t)(col + j) * nbp + k] = d * sv;
+    }
+  }
+}
+// q[c][k] = dt_k * P[c][k]  (P = exclusive scan of uu)
+__global__ __launch_bounds__(BLOCK) void pgcp_dtp_kernel(int64_t nb, int64_t nbp, int col2,
+                                                         const double *__restrict__ tt,
+                                                         const double *__restrict__ pp, double *qq) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += stride) {
+    const double dt = tt[k] - (k > 0 ? tt[k - 1] : 0.0);
+    for (int c = 0; c < col2; ++c) qq[(int64_t)c * nbp + k] = dt * pp[(int64_t)c * nbp + k];
+  }
+}
+// per breakpoint: y = M wbp, wmc = c.y, wmp = p.y, wmw = wbp.y with p = p0 - P_k (before this
+// breakpoint), c = t_k p0 - SQ_k (after c += dt p);  df2 and the f2-free part of df1
+__global__ __launch_bounds__(BLOCK) void pgcp_terms_kernel(
+    int64_t nb, int64_t nbp, int col2, double theta, const double *__restrict__ mm /* col2 x col2 */,
+    const double *__restrict__ p0, const double *__restrict__ tt, const double *__restrict__ dd,
+    const double *__restrict__ a0, const double *__restrict__ wb, const double *__restrict__ pp,
+    const double *__restrict__ sq, double *df2, double *a1) {
+  __shared__ double sm[4 * MAXM * MAXM];
+  __shared__ double sp0[2 * MAXM];
+  for (int e = threadIdx.x; e < col2 * col2; e += blockDim.x) sm[e] = mm[e];
+  for (int e = threadIdx.x; e < col2; e += blockDim.x) sp0[e] = p0[e];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += stride) {
+    double w[2 * MAXM];
+    for (int c = 0; c < col2; ++c) w[c] = wb[(int64_t)c * nbp + k];
+    const double tk = tt[k];
+    double wmc = 0.0, wmp = 0.0, wmw = 0.0;
+    for (int a = 0; a < col2; ++a) {
+      double y = 0.0;
+      for (int b = 0; b < col2; ++b) y += sm[a + b * col2] * w[b];
+      const double pa = sp0[a] - pp[(int64_t)a * nbp + k];
+      const double ca = tk * sp0[a] - sq[(int64_t)a * nbp + k];
+      wmc += ca * y;
+      wmp += pa * y;
+      wmw += w[a] * y;
+    }
+    const double d = dd[k];
+    df2[k] = -theta * d * d + 2.0 * d * wmp - d * d * wmw;
+    a1[k] = a0[k] + d * wmc;
+  }
+}
+// df1_k = dt_k * f2_{k-1} + a1_k with f2_{k-1} = f2_0 + SF2[k-1]
+__global__ __launch_bounds__(BLOCK) void pgcp_f1_kernel(int64_t nb, double f2_0,
+                                                        const double *__restrict__ tt,
+                                                        const double *__restrict__ sf2,
+                                                        const double *__restrict__ a1, double *df1) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += stride) {
+    const double dt = tt[k] - (k > 0 ? tt[k - 1] : 0.0);
+    const double f2p = f2_0 + (k > 0 ? sf2[k - 1] : 0.0);
+    df1[k] = dt * f2p + a1[k];
+  }
+}
+// first breakpoint k whose segment contains the minimiser: dtm_{k-1} < dt_k  (:1416)
+__global__ __launch_bounds__(BLOCK) void pgcp_find_kernel(int64_t nb, double f1_0, double f2_0,
+                                                          const double *__restrict__ tt,
+                                                          const double *__restrict__ sf1,
+                                                          const double *__restrict__ sf2,
+                                                          double *part) {
+  double acc[1] = {LB_INF};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += stride) {
+    const double dt = tt[k] - (k > 0 ? tt[k - 1] : 0.0);
+    const double f1p = f1_0 + (k > 0 ? sf1[k - 1] : 0.0);
+    const double f2p = f2_0 + (k > 0 ? sf2[k - 1] : 0.0);
+    const double dtm = -f1p / f2p;
+    if (dtm < dt) acc[0] = fmin(acc[0], (double)k);
+  }
+  block_reduce_store<1>(acc, 0, 1, 0, part, MAX_BLOCKS);
+}
+// the state the host needs at k* (number of breakpoints crossed): out = { t_{k*-1}, f1, f2 before
+// breakpoint k*, idx of breakpoint k*-1, then P[c][k*] (c < col2), then SQ[c][k*-1] }
+__global__ void pgcp_pick_kernel(int64_t ks, int64_t nb, int64_t nbp, int col2, double f1_0,
+                                 double f2_0, const double *__restrict__ tt,
+                                 const double *__restrict__ sf1, const double *__restrict__ sf2,
+                                 const double *__restrict__ pp, const double *__restrict__ uu_last,
+                                 const double *__restrict__ sq, const uint32_t *__restrict__ idx,
+                                 double *out) {
+  const int c = threadIdx.x;
+  if (c == 0) {
+    out[0] = ks > 0 ? tt[ks - 1] : 0.0;
+    out[1] = f1_0 + (ks > 0 ? sf1[ks - 1] : 0.0);
+    out[2] = f2_0 + (ks > 0 ? sf2[ks - 1] : 0.0);
+    out[3] = ks > 0 ? (double)idx[ks - 1] : -1.0;
+  }
+  if (c < col2) {
+    // exclusive prefix at ks; for ks == nb it is the last exclusive prefix plus the last term,
+    // which the caller kept in uu_last (the scan ran in place)
+    out[4 + c] = ks < nb ? pp[(int64_t)c * nbp + ks] : pp[(int64_t)c * nbp + nb - 1] + uu_last[c];
+    out[4 + col2 + c] = ks > 0 ? sq[(int64_t)c * nbp + ks - 1] : 0.0;
+  }
+}
+// uu_last[c] = uu[c][nb-1] before the in-place exclusive scan
+__global__ void pgcp_last_kernel(int64_t nb, int64_t nbp, int col2, const double *__restrict__ uu,
+                                 double *uu_last) {
+  const int c = threadIdx.x;
+  if (c < col2) uu_last[c] = uu[(int64_t)c * nbp + nb - 1];
+}
+
+size_t scan_temp_bytes(size_t count) {
+  size_t b1 = 0, b2 = 0;
+  (void)rocprim::inclusive_scan(nullptr, b1, (const double *)nullptr, (double *)nullptr, count,
+                                rocprim::plus<double>(), (hipStream_t)0);
+  (void)rocprim::exclusive_scan(nullptr, b2, (const double *)nullptr, (double *)nullptr, 0.0, count,
+                                rocprim::plus<double>(), (hipStream_t)0);
+  return b1 > b2 ? b1 : b2;
+}
+void launch_scan(Queue &q, void *d_temp, size_t temp_bytes, const double *in, double *out,
+                 size_t count, int exclusive) {
+  if (exclusive)
+    (void)rocprim::exclusive_scan(d_temp, temp_bytes, in, out, 0.0, count, rocprim::plus<double>(),
+                                  q.stream);
+  else
+    (void)rocprim::inclusive_scan(d_temp, temp_bytes, in, out, count, rocprim::plus<double>(),
+                                  q.stream);
+  q.launches++;
+}
+template <typename T>
+void launch_pgcp_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, int64_t nb, int64_t nbp,
+                        const T *x, const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
+                        double theta, const T *pr, const T *pd, Pend pe, double *tt, double *dd,
+                        double *a0, double *wb, double *uu) {
+  const int gr = grid_for(nb, 1);
+  hipLaunchKernelGGL(pgcp_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, nb, nbp, x,
+                     l, u, g, w.ws, w.wy, w.ld, w.m, head, col, theta, pr, pd, pe, tt, dd, a0, wb, uu);
+  q.launches++;
+}
+void launch_pgcp_last(Queue &q, int64_t nb, int64_t nbp, int col2, const double *uu, double *uu_last) {
+  hipLaunchKernelGGL(pgcp_last_kernel, dim3(1), dim3(64), 0, q.stream, nb, nbp, col2, uu, uu_last);
+  q.launches++;
+}
+void launch_pgcp_dtp(Queue &q, int64_t nb, int64_t nbp, int col2, const double *tt, const double *pp,
+                     double *qq) {
+  hipLaunchKernelGGL(pgcp_dtp_kernel, dim3(grid_for(nb, 1)), dim3(BLOCK), 0, q.stream, nb, nbp, col2,
+                     tt, pp, qq);
+  q.launches++;
+}
+void launch_pgcp_terms(Queue &q, int64_t nb, int64_t nbp, int col2, double theta, const double *mm,
+                       const double *p0, const double *tt, const double *dd, const double *a0,
+                       const double *wb, const double *pp, const double *sq, double *df2, double *a1) {
+  hipLaunchKernelGGL(pgcp_terms_kernel, dim3(grid_for(nb, 1)), dim3(BLOCK), 0, q.stream, nb, nbp, col2,
+                     theta, mm, p0, tt, dd, a0, wb, pp, sq, df2, a1);
+  q.launches++;
+}
+void launch_pgcp_f1(Queue &q, int64_t nb, double f2_0, const double *tt, const double *sf2,
+                    const double *a1, double *df1) {
+  hipLaunchKernelGGL(pgcp_f1_kernel, dim3(grid_for(nb, 1)), dim3(BLOCK), 0, q.stream, nb, f2_0, tt, sf2,
+                     a1, df1);
+  q.launches++;
+}
+void launch_pgcp_find(Queue &q, int64_t nb, double f1_0, double f2_0, const double *tt,
+                      const double *sf1, const double *sf2) {
+  const int gr = grid_for(nb, 1);
+  hipLaunchKernelGGL(pgcp_find_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, nb, f1_0, f2_0, tt, sf1, sf2,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 1, 0);
+}
+void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, double f1_0, double f2_0,
+                      const double *tt, const double *sf1, const double *sf2, const double *pp,
+                      const double *uu_last, const double *sq, const uint32_t *idx, double *out) {
+  hipLaunchKernelGGL(pgcp_pick_kernel, dim3(1), dim3(64), 0, q.stream, ks, nb, nbp, col2, f1_0, f2_0, tt,
+                     sf1, sf2, pp, uu_last, sq, idx, out);
+  q.launches++;
+}
+
 // tbrk as a vector, for the paths that want one (full sort, cursor-based cauchy_finish)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void tbrk_fill_kernel(
@@ -2591,6 +2792,10 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
                                    const int32_t *, double, T *);                                  \
   template void launch_iwhere_update<T>(Queue &, int64_t, const T *, const T *, const T *,         \
                                         const int32_t *, const T *, int32_t *);                    \
+  template void launch_pgcp_gather<T>(Queue &, const uint32_t *, const uint64_t *, int64_t,        \
+                                      int64_t, const T *, const T *, const T *, const T *,         \
+                                      WStore<T>, int, int, double, const T *, const T *, Pend,     \
+                                      double *, double *, double *, double *, double *);           \
   template void launch_tbrk_fill<T>(Queue &, int64_t, const T *, const T *, const T *,             \
                                     const int32_t *, const T *, const int32_t *, T *);             \
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t,     \

@@ -135,6 +135,28 @@ void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *
 template <typename T>
 void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
                      const int32_t *iwhere, double tsum, T *dst);
+// ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; see kernels.hip) ----
+size_t scan_temp_bytes(size_t count);
+void launch_scan(Queue &q, void *d_temp, size_t temp_bytes, const double *in, double *out,
+                 size_t count, int exclusive);
+template <typename T>
+void launch_pgcp_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, int64_t nb, int64_t nbp,
+                        const T *x, const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
+                        double theta, const T *pr, const T *pd, Pend pe, double *tt, double *dd,
+                        double *a0, double *wb, double *uu);
+void launch_pgcp_last(Queue &q, int64_t nb, int64_t nbp, int col2, const double *uu, double *uu_last);
+void launch_pgcp_dtp(Queue &q, int64_t nb, int64_t nbp, int col2, const double *tt, const double *pp,
+                     double *qq);
+void launch_pgcp_terms(Queue &q, int64_t nb, int64_t nbp, int col2, double theta, const double *mm,
+                       const double *p0, const double *tt, const double *dd, const double *a0,
+                       const double *wb, const double *pp, const double *sq, double *df2, double *a1);
+void launch_pgcp_f1(Queue &q, int64_t nb, double f2_0, const double *tt, const double *sf2,
+                    const double *a1, double *df1);
+void launch_pgcp_find(Queue &q, int64_t nb, double f1_0, double f2_0, const double *tt,
+                      const double *sf1, const double *sf2);  // res min-slot [0] = k* (or +inf)
+void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, double f1_0, double f2_0,
+                      const double *tt, const double *sf1, const double *sf2, const double *pp,
+                      const double *uu_last, const double *sq, const uint32_t *idx, double *out);
 // tbrk as a vector from (x, l, u, nbd, g, iwhere-after-the-scan, BEFORE the walk fixes rows)
 template <typename T>
 void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,

@@ -229,7 +229,7 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(d_fix);
+        F(d_fix), F(pg_buf), F(pg_tmp);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
@@ -479,8 +479,11 @@ class Solver final : public lbfgsb_hip_ctx {
 
   static constexpr uint32_t FAST_CAP = 256;  // candidates delivered by the one-sync fast path
 
+  // *big != nullptr: if more than PG_MIN candidates lie in the window, only report their number
+  // (the caller switches to the parallel search) instead of ordering them
+  static constexpr double PG_MIN = 32768.0;
   int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, const T *x, const T *l,
-                   const T *u, const T *g, int head, int col) {
+                   const T *u, const T *g, int head, int col, double *big = nullptr) {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
     const int recl = 2 * col + 4;
     if (tbrk_valid)
@@ -501,6 +504,10 @@ class Solver final : public lbfgsb_hip_ctx {
       if (c > (double)FAST_CAP) all_small = false;
     }
     uint32_t cnt = (uint32_t)h_msg_all[(size_t)rank * fcount];
+    if (big) {
+      *big = gsum;
+      if (gsum > PG_MIN) return 0;
+    }
     if (all_small) {
       pv.have = true;
       pv.full = false;
@@ -677,6 +684,110 @@ class Solver final : public lbfgsb_hip_ctx {
   }
   const void *cx = nullptr, *cl = nullptr, *cu = nullptr, *cg = nullptr;  // this call's operands
 
+  // ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; kernels.hip "parallel GCP") ----
+  double *pg_buf = nullptr;
+  size_t pg_bytes = 0;
+  void *pg_tmp = nullptr;
+  size_t pg_tmp_bytes = 0;
+  int parallel_gcp(const T *x, const T *l, const T *u, const T *g, double theta, int col, int head,
+                   const double *p0, double *c, double f1_0, double f2_0, bool bnded, int64_t nbreak,
+                   int &nseg, int &info, bool &done) {
+    done = false;
+    const int col2 = 2 * col;
+    // all breakpoints in (t, index) order
+    CHK(ensure_sel((size_t)n));
+    uint32_t cnt = 0;
+    CHK(local_count(-1.0, -1, std::numeric_limits<double>::max(), 0, cnt));  // (fills tbrk)
+    const int64_t nb = cnt, nbp = (nb + 31) / 32 * 32;
+    if (nb != nbreak || nb == 0) return 0;
+    const size_t narr = 6 + 3 * (size_t)col2;
+    const size_t small = (size_t)col2 * col2 + 4 * (size_t)col2 + 16;
+    const size_t bytes = (narr * (size_t)nbp + small) * sizeof(double);
+    if (bytes > ((size_t)48 << 30)) return 0;
+    if (bytes > pg_bytes) {
+      if (pg_buf) (void)hipFree(pg_buf);
+      pg_buf = nullptr, pg_bytes = 0;
+      if (hipMalloc(&pg_buf, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+      }
+      pg_bytes = bytes;
+    }
+    const size_t tb = lbk::scan_temp_bytes((size_t)nb) + 256;
+    if (tb > pg_tmp_bytes) {
+      if (pg_tmp) (void)hipFree(pg_tmp);
+      pg_tmp = nullptr, pg_tmp_bytes = 0;
+      HIPCHK(hipMalloc(&pg_tmp, tb));
+      pg_tmp_bytes = tb;
+    }
+    nfullsort++;
+    lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, -1.0, -1, keys[0], idx[0]);
+    lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1], (size_t)n);
+    double *tt = pg_buf, *dd = tt + nbp, *a0 = dd + nbp, *df2 = a0 + nbp, *a1 = df2 + nbp,
+           *df1 = a1 + nbp, *wb = df1 + nbp, *pp = wb + (size_t)col2 * nbp,
+           *sq = pp + (size_t)col2 * nbp, *dM = sq + (size_t)col2 * nbp, *dp0 = dM + (size_t)col2 * col2,
+           *ulast = dp0 + col2, *pick = ulast + col2;
+    // M as a dense matrix: column a = bmv(e_a)   (host, O(col^3))
+    std::vector<double> M((size_t)col2 * col2), e(col2), out(col2);
+    for (int a = 0; a < col2; ++a) {
+      std::fill(e.begin(), e.end(), 0.0);
+      e[a] = 1.0;
+      info = lbh::bmv(m, sy.data(), wt.data(), col, e.data(), out.data());
+      if (info != 0) return 0;
+      for (int b = 0; b < col2; ++b) M[(size_t)b + (size_t)a * col2] = out[b];
+    }
+    HIPCHK(hipMemcpyAsync(dM, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dp0, p0, col2 * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));  // (M, p0 are host temporaries)
+    lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], nb, nbp, x, l, u, g, W(), head, col, theta, r, d,
+                               pend, tt, dd, a0, wb, pp);
+    lbk::launch_pgcp_last(q, nb, nbp, col2, pp, ulast);
+    for (int cc = 0; cc < col2; ++cc)
+      lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, pp + (size_t)cc * nbp, pp + (size_t)cc * nbp, (size_t)nb, 1);
+    lbk::launch_pgcp_dtp(q, nb, nbp, col2, tt, pp, sq);
+    for (int cc = 0; cc < col2; ++cc)
+      lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, sq + (size_t)cc * nbp, sq + (size_t)cc * nbp, (size_t)nb, 0);
+    lbk::launch_pgcp_terms(q, nb, nbp, col2, theta, dM, dp0, tt, dd, a0, wb, pp, sq, df2, a1);
+    lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, df2, df2, (size_t)nb, 0);
+    lbk::launch_pgcp_f1(q, nb, f2_0, tt, df2, a1, df1);
+    lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, df1, df1, (size_t)nb, 0);
+    lbk::launch_pgcp_find(q, nb, f1_0, f2_0, tt, df1, df2);
+    CHK(fetch(0, 1, 0));
+    const int64_t ks = h_res[0] < (double)nb ? (int64_t)h_res[0] : nb;  // breakpoints crossed
+    lbk::launch_pgcp_pick(q, ks, nb, nbp, col2, f1_0, f2_0, tt, df1, df2, pp, ulast, sq, idx[1], pick);
+    std::vector<double> pk(4 + 2 * (size_t)col2);
+    HIPCHK(hipMemcpyAsync(pk.data(), pick, pk.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    nsync++;
+    const double t_last = pk[0], f1p = pk[1], f2p = pk[2];
+    const int64_t i_last = ks > 0 ? row0 + (int64_t)pk[3] : -1;
+    double dtm;
+    bool all_fixed = false;
+    if (ks < nb) {
+      dtm = -f1p / f2p;
+    } else if (nb == nglob) {  // every variable fixed (:1436-1442)
+      dtm = 0.0;
+      all_fixed = true;
+    } else if (bnded) {
+      dtm = 0.0;
+    } else {
+      dtm = -f1p / f2p;
+    }
+    if (dtm <= 0.0) dtm = 0.0;
+    const double tsum = t_last + dtm;
+    for (int a = 0; a < col2; ++a)
+      c[a] = (t_last * p0[a] - pk[4 + col2 + a]) + dtm * (p0[a] - pk[4 + a]);
+    const int64_t ns = 1 + ks - (all_fixed ? 1 : 0);
+    nseg = (int)std::min<int64_t>(ns, std::numeric_limits<int>::max());
+    // iwhere and z by the cursor: everything up to the last crossed breakpoint is fixed
+    gcp = Gcp{};
+    gcp.tsum = tsum, gcp.last_t = ks > 0 ? t_last : -1.0, gcp.last_i = i_last;
+    lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tsum, gcp.last_t, gcp.last_i);
+    z_valid = true;
+    done = true;
+    return 0;
+  }
+
   // an n-vector on the host, for the iprint >= 100 dumps (debugging sizes, this rank's rows)
   std::vector<double> host_vec(const T *dptr) {
     std::vector<T> tmp((size_t)n);
@@ -821,7 +932,20 @@ class Solver final : public lbfgsb_hip_ctx {
             hi = base + (hi_need - base) * std::ldexp(1.0, std::min(pv.grow, 40));
           }
           pv.grow++;
-          CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col));
+          double in_window = 0.0;
+          const bool may_pg = col > 0 && (flags & LBFGSB_F_PARALLEL_GCP) && nranks == 1 && !comm &&
+                              iter == 1 && !pv.have && print_level < 99;
+          CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col, may_pg ? &in_window : nullptr));
+          if (may_pg && in_window > PG_MIN) {
+            // many breakpoints within reach and pairs stored: sort + scans on the device (opt-in)
+            bool done = false;
+            CHK(parallel_gcp(x, l, u, g, theta, col, head, p, c, f1, f2, bnded, nbreak, nseg, info, done));
+            if (info != 0) return 0;
+            if (done) return 0;
+            pv.grow = 0;  // (did not fit in memory: replay the walk as usual)
+            pv.have = false;
+            CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col));
+          }
         }
         if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
         tj = rec[0];

@@ -621,3 +621,60 @@ def test_device_path_to_convergence_against_oracle(env, n, m, mixed, min_agree):
     for a, b in zip(rows_g, rows_o):
         assert a[4] == pytest.approx(b[4], rel=1e-11)
     assert float(sol.f[0]) == pytest.approx(float(so.f[0]), rel=1e-11)
+
+
+def test_parallel_gcp_with_pairs_stored(env):
+    """LBFGSB_F_PARALLEL_GCP when pairs are stored (col > 0): a two-scale
+    separable quadratic whose 2nd and 6th iterations each cross ~91 000 breakpoints with col = 1
+    and col = m = 5.  The walk is replaced by a full sort + prefix scans on the device
+    (parallel_gcp in solver.hip); nseg / nfree must agree with the oracle's sequential walk to
+    within 2, f to 1e-9, and the path must really have been taken (two full sorts; the exact
+    replay needs none on this problem)."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 200_000, 5, 8
+    rng = np.random.default_rng(7)
+    a = 1.0 + 99.0 * rng.random(n)
+    a[n // 2:] *= 1e-4
+    c = rng.choice([-1.0, 1.0], n) * 5.0 * (1.0 + rng.random(n))
+    eps = 1e-3
+
+    def fg(x, g):
+        d = x - c
+        g[:] = eps * a * d
+        return float(0.5 * eps * np.sum(a * d * d))
+    p = po.Problem("two_scale", n, m, np.zeros(n), -np.ones(n), np.ones(n), np.full(n, 2, np.int32),
+                   0.0, 0.0, fg, np.float64)
+    rows_o = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                int(s.isave[37]), int(s.isave[27]), float(s.f[0])))
+           if s.task_s.startswith("NEW_X") else None)
+    assert sum(1 for r in rows_o if r[2] > 50_000 and r[4] > 0) >= 2      # long walks with col > 0
+    sol = la.DeviceSolver(n, m, parallel_gcp=True)
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    g = torch.zeros_like(x)
+    l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+    nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    rows_g = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            xh = x.cpu().numpy()
+            gh = np.empty_like(xh)
+            sol.f[0] = fg(xh, gh)
+            g.copy_(torch.from_numpy(gh))
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
+                           int(sol.isave[37]), int(sol.isave[27]), float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    st = sol.stats()
+    sol.close()
+    assert len(rows_g) == len(rows_o)
+    for a_, b_ in zip(rows_g, rows_o):
+        assert a_[:2] == b_[:2] and a_[4] == b_[4], (a_, b_)
+        assert abs(a_[2] - b_[2]) <= 2 and abs(a_[3] - b_[3]) <= 2, (a_, b_)
+        assert a_[5] == pytest.approx(b_[5], rel=1e-9)
+    assert st["cauchy_fullsorts"] >= 2
