@@ -416,18 +416,30 @@ class Solver final : public lbfgsb_hip_ctx {
     if (nranks == 1 && !comm) {
       HIPCHK(hipMemcpyAsync(h_msg_all, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
                             stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      {
+        const double t0 = now_s();
+        HIPCHK(hipStreamSynchronize(stream));
+        t_wait += now_s() - t0;
+      }
     } else if (comm) {
       if (g_rccl.AllGather(d_msg, d_msg_all, count, ncclDouble, comm, stream) != ncclSuccess)
         return fail(LBFGSB_E_COMM, "ncclAllGather failed");
       HIPCHK(hipMemcpyAsync(h_msg_all, d_msg_all, (size_t)nranks * count * sizeof(double),
                             hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      {
+        const double t0 = now_s();
+        HIPCHK(hipStreamSynchronize(stream));
+        t_wait += now_s() - t0;
+      }
     } else {
       if (!cb_ag) return fail(LBFGSB_E_COMM, "multi-rank context without an all-gather");
       HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
                             stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      {
+        const double t0 = now_s();
+        HIPCHK(hipStreamSynchronize(stream));
+        t_wait += now_s() - t0;
+      }
       if (cb_ag(cb_user, h_msg_loc, h_msg_all, (int64_t)(count * sizeof(double))) != 0)
         return fail(LBFGSB_E_COMM, "host all-gather callback failed");
     }
@@ -588,9 +600,12 @@ class Solver final : public lbfgsb_hip_ctx {
     for (int rk = 0; rk < nranks; ++rk) {
       const double *base = h_msg_all + (size_t)rk * count;
       const uint32_t lr = (uint32_t)base[0];
+      const size_t at = pv.M.size();
+      pv.M.resize(at + lr);
+      MRec *out = pv.M.data() + at;
       for (uint32_t k = 0; k < lr; ++k) {
         const double *rec = base + 2 + (size_t)k * recl;
-        pv.M.push_back(MRec{rec[0], (int64_t)rec[1], rk, rec});
+        out[k] = MRec{rec[0], (int64_t)rec[1], rk, rec};
       }
       if (base[1] > 0.0) {  // this rank holds later records: nothing beyond its last one is safe
         pv.more_anywhere = true;
@@ -621,7 +636,7 @@ class Solver final : public lbfgsb_hip_ctx {
       }
     }
     pv.safe_end = pv.M.size();
-    if (pv.more_anywhere) {
+    if (pv.more_anywhere && nranks > 1) {  // (a single rank's own run is safe to its end)
       size_t k = 0;
       while (k < pv.M.size() && (pv.M[k].t < bt || (pv.M[k].t == bt && pv.M[k].gidx <= bi))) ++k;
       pv.safe_end = k;
@@ -902,6 +917,70 @@ class Solver final : public lbfgsb_hip_ctx {
         // (control flow follows print_level, which every rank shares -- ipr is -1 on the quiet ranks)
         if (iter == 1 && print_level < 100) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
           if (dtm < bkmin - tj0) break;
+        }
+        // ---- no pair stored and records on the host: the same steps as below in a tight loop
+        //      (the first iteration walks ~n of them; per record only :1416-1434, :1452-1453,
+        //       :1483-1497 remain, in the reference's operation order) ----
+        if (col == 0 && print_level < 100 && pv.have && pv.mpos < pv.safe_end) {
+          const MRec *M = pv.M.data();
+          size_t pos = pv.mpos;
+          const size_t end = pv.safe_end;
+          const double inf = std::numeric_limits<double>::infinity();
+          bool stop = false;
+          while (pos < end) {
+            const MRec &mr = M[pos];
+            if (!(mr.t <= (tj + dtm) * INFL && mr.t < inf)) {  // beyond reach: dtm < dt
+              stop = true;
+              break;
+            }
+            const double dt = mr.t - tj;
+            if (dtm < dt) {  // :1416
+              stop = true;
+              break;
+            }
+            pv.taken[mr.rank]++;
+            ++pos;
+            tsum = tsum + dt;
+            nleft = nleft - 1;
+            iter = iter + 1;
+            const double dibp = mr.rec[2];
+            const double zibp = mr.rec[3];
+            tj = mr.t;
+            last_t = mr.t;
+            last_i = mr.gidx;
+            if (!fix_overflow) {
+              if (fixlist.size() < FIX_CAP)
+                fixlist.push_back(mr.gidx * 2 + (dibp > 0.0 ? 1 : 0));
+              else
+                fix_overflow = true;
+            }
+            if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
+              dtm = dt;
+              pv.mpos = pos;
+              return leave(tsum, last_t, last_i);
+            }
+            nseg = nseg + 1;
+            const double dibp2 = dibp * dibp;
+            f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;  // :1452-1453
+            f2 = f2 - theta * dibp2;
+            f2 = std::max(epsmch * f2_org, f2);  // :1483
+            if (nleft > 0) {
+              dtm = -f1 / f2;
+            } else if (bnded) {
+              f1 = 0.0;
+              f2 = 0.0;
+              dtm = 0.0;
+              stop = true;
+              break;
+            } else {
+              dtm = -f1 / f2;
+              stop = true;
+              break;
+            }
+          }
+          pv.mpos = pos;
+          if (stop) break;
+          continue;  // records used up: refill below on the next trip
         }
         // ---- next breakpoint after (last_t, last_i), if it can matter: t <= tj0 + dtm ----
         // (iprint >= 100 reports the distance to the next breakpoint of every segment, :1408-1412:
