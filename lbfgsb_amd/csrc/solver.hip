@@ -198,6 +198,13 @@ class Solver final : public lbfgsb_hip_ctx {
   uint32_t *d_chg = nullptr;
   uint32_t chg_local = 0;
   double *d_msg = nullptr, *d_msg_all = nullptr, *h_msg_all = nullptr, *h_msg_loc = nullptr;
+  // single rank: the next chunk of walk records is gathered and copied while the host walks the
+  // current one (second pair of message buffers; h_msg_loc doubles as the landing buffer)
+  double *d_msg2 = nullptr;
+  hipEvent_t pf_ev = nullptr;
+  bool pf_valid = false;
+  uint32_t pf_pl = 0, pf_len = 0, pf_rem = 0;
+  int pf_cur = 0;
   double *h_hdr = nullptr;
   size_t msg_len = 0;  // doubles per rank message
   // reductions
@@ -228,7 +235,7 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
-        F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
+        F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
         F(d_fix), F(pg_buf), F(pg_tmp);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
@@ -236,6 +243,8 @@ class Solver final : public lbfgsb_hip_ctx {
       p = nullptr;
     };
     H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix);
+    if (pf_ev) (void)hipEventDestroy(pf_ev);
+    pf_ev = nullptr;
     for (auto &pair : clk_ev)
       for (auto &e : pair) {
         if (e) (void)hipEventDestroy(e);
@@ -305,6 +314,8 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipHostMalloc(&h_count, sizeof(uint32_t)));
     msg_len = 2 + (size_t)CHUNK_MAX * (2 * m + 4);
     HIPCHK(hipMalloc(&d_msg, msg_len * sizeof(double)));
+    HIPCHK(hipMalloc(&d_msg2, msg_len * sizeof(double)));
+    HIPCHK(hipEventCreateWithFlags(&pf_ev, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(&h_hdr, 2 * sizeof(double)));
     HIPCHK(hipMalloc(&d_fix, FIX_CAP * sizeof(int64_t)));
     HIPCHK(hipHostMalloc(&h_fix, FIX_CAP * sizeof(int64_t)));
@@ -404,6 +415,8 @@ class Solver final : public lbfgsb_hip_ctx {
     uint32_t pl = 0;     // local list position of the first record not yet consumed
     int cur = 0;         // which keys/idx buffer holds the sorted local list
     std::vector<MRec> M; // merged chunk, all ranks
+    const double *raw = nullptr;  // single rank, col = 0: the chunk itself is in order (records of
+                                  // 4 doubles); M is then only sized, not filled
     size_t mpos = 0, safe_end = 0;
     bool more_anywhere = false;
     std::vector<uint32_t> taken;
@@ -498,6 +511,7 @@ class Solver final : public lbfgsb_hip_ctx {
                    const T *u, const T *g, int head, int col, double *big = nullptr) {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
     const int recl = 2 * col + 4;
+    pf_valid = false;  // (new candidate lists: a prefetched chunk of the old ones is void)
     if (tbrk_valid)
       lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
                                    d_count);
@@ -528,6 +542,7 @@ class Solver final : public lbfgsb_hip_ctx {
       pv.pl = cnt;  // everything is already on the host
       pv.cur = 0;
       pv.M.clear();
+      pv.raw = nullptr;
       for (int rk = 0; rk < nranks; ++rk) {
         const double *base = h_msg_all + (size_t)rk * fcount;
         const uint32_t lr = (uint32_t)base[0];
@@ -588,11 +603,36 @@ class Solver final : public lbfgsb_hip_ctx {
     const uint32_t chunk_cap = (uint32_t)((msg_len - 2) / (size_t)recl);
     pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, chunk_cap);
     const uint32_t len = std::min<uint32_t>(chunk, pv.Cl - pv.pl);
-    lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
-                                 W(), head, col, r, d, pend, d_msg + 2);
-    CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
     const size_t count = 2 + (size_t)chunk * recl;
-    CHK(exchange(count));
+    const bool single = nranks == 1 && !comm;
+    if (single && pf_valid && pf_pl == pv.pl && pf_len == len && pf_cur == pv.cur) {
+      // this chunk was gathered and copied while the host walked the previous one
+      const double t0 = now_s();
+      HIPCHK(hipEventSynchronize(pf_ev));
+      t_wait += now_s() - t0;
+      nsync++;
+      std::swap(h_msg_all, h_msg_loc);
+      std::swap(d_msg, d_msg2);
+      h_msg_all[0] = (double)pf_len, h_msg_all[1] = (double)pf_rem;
+    } else {
+      lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
+                                   W(), head, col, r, d, pend, d_msg + 2);
+      CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
+      CHK(exchange(count));
+    }
+    pf_valid = false;
+    const bool rawmode = single && col == 0 && print_level < 100 && !std::getenv("LBFGSB_DEBUG");
+    pv.raw = nullptr;
+    if (single && pv.Cl - pv.pl > len) {  // prefetch the chunk after this one
+      const uint32_t npl = pv.pl + len;
+      const uint32_t nlen = std::min<uint32_t>(pv.next_chunk, pv.Cl - npl);
+      lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + npl, keys[pv.cur] + npl, nlen, row0, x, l, u, g, W(),
+                                   head, col, r, d, pend, d_msg2 + 2);
+      HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg2, (2 + (size_t)nlen * recl) * sizeof(double),
+                            hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipEventRecord(pf_ev, stream));
+      pf_valid = true, pf_pl = npl, pf_len = nlen, pf_rem = pv.Cl - npl - nlen, pf_cur = pv.cur;
+    }
     pv.M.clear();
     pv.more_anywhere = false;
     double bt = std::numeric_limits<double>::infinity();
@@ -602,10 +642,14 @@ class Solver final : public lbfgsb_hip_ctx {
       const uint32_t lr = (uint32_t)base[0];
       const size_t at = pv.M.size();
       pv.M.resize(at + lr);
-      MRec *out = pv.M.data() + at;
-      for (uint32_t k = 0; k < lr; ++k) {
-        const double *rec = base + 2 + (size_t)k * recl;
-        out[k] = MRec{rec[0], (int64_t)rec[1], rk, rec};
+      if (rawmode) {
+        pv.raw = base + 2;
+      } else {
+        MRec *out = pv.M.data() + at;
+        for (uint32_t k = 0; k < lr; ++k) {
+          const double *rec = base + 2 + (size_t)k * recl;
+          out[k] = MRec{rec[0], (int64_t)rec[1], rk, rec};
+        }
       }
       if (base[1] > 0.0) {  // this rank holds later records: nothing beyond its last one is safe
         pv.more_anywhere = true;
@@ -828,6 +872,7 @@ class Solver final : public lbfgsb_hip_ctx {
              int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
     double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
     cx = x, cl = l, cu = u, cg = g, cnbd = nbd;
+    pf_valid = false;
     fixlist.clear();
     fix_overflow = false;
     const int ipr = quiet ? -1 : print_level;
@@ -928,29 +973,31 @@ class Solver final : public lbfgsb_hip_ctx {
           const double inf = std::numeric_limits<double>::infinity();
           bool stop = false;
           while (pos < end) {
-            const MRec &mr = M[pos];
-            if (!(mr.t <= (tj + dtm) * INFL && mr.t < inf)) {  // beyond reach: dtm < dt
+            // (single rank: the records themselves, 4 doubles each, in order; else the merged list)
+            const double *rec = pv.raw ? pv.raw + pos * 4 : M[pos].rec;
+            const double mt = rec[0];
+            if (!(mt <= (tj + dtm) * INFL && mt < inf)) {  // beyond reach: dtm < dt
               stop = true;
               break;
             }
-            const double dt = mr.t - tj;
+            const double dt = mt - tj;
             if (dtm < dt) {  // :1416
               stop = true;
               break;
             }
-            pv.taken[mr.rank]++;
+            pv.taken[pv.raw ? 0 : M[pos].rank]++;
             ++pos;
             tsum = tsum + dt;
             nleft = nleft - 1;
             iter = iter + 1;
-            const double dibp = mr.rec[2];
-            const double zibp = mr.rec[3];
-            tj = mr.t;
-            last_t = mr.t;
-            last_i = mr.gidx;
+            const double dibp = rec[2];
+            const double zibp = rec[3];
+            tj = mt;
+            last_t = mt;
+            last_i = (int64_t)rec[1];
             if (!fix_overflow) {
               if (fixlist.size() < FIX_CAP)
-                fixlist.push_back(mr.gidx * 2 + (dibp > 0.0 ? 1 : 0));
+                fixlist.push_back(last_i * 2 + (dibp > 0.0 ? 1 : 0));
               else
                 fix_overflow = true;
             }
@@ -989,7 +1036,12 @@ class Solver final : public lbfgsb_hip_ctx {
             print_level >= 100 ? std::numeric_limits<double>::infinity() : (tj0 + dtm) * INFL;
         const double *rec = nullptr;
         int64_t rec_gi = -1;
+        bool to_tight_loop = false;
         for (;;) {
+          if (pv.raw && pv.have && pv.mpos < pv.safe_end) {  // (M is not filled in this mode)
+            to_tight_loop = true;
+            break;
+          }
           if (pv.have && pv.mpos < pv.safe_end) {
             const MRec &mr = pv.M[pv.mpos];
             if (mr.t <= hi_need && mr.t < std::numeric_limits<double>::infinity()) {
@@ -1026,6 +1078,7 @@ class Solver final : public lbfgsb_hip_ctx {
             CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col));
           }
         }
+        if (to_tight_loop) continue;
         if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
         tj = rec[0];
         const double dt = tj - tj0;
