@@ -225,6 +225,7 @@ class Solver final : public lbfgsb_hip_ctx {
   char word[4] = {'-', '-', '-', 0};
   int64_t err_k = 0;
   bool quiet = false;  // ranks > 0 never print
+  const bool debug_walk = std::getenv("LBFGSB_DEBUG") != nullptr;  // trace of the breakpoint walk
 
   ~Solver() override { release(); }
 
@@ -621,7 +622,7 @@ class Solver final : public lbfgsb_hip_ctx {
       CHK(exchange(count));
     }
     pf_valid = false;
-    const bool rawmode = single && col == 0 && print_level < 100 && !std::getenv("LBFGSB_DEBUG");
+    const bool rawmode = single && col == 0 && print_level < 100 && !debug_walk;
     pv.raw = nullptr;
     if (single && pv.Cl - pv.pl > len) {  // prefetch the chunk after this one
       const uint32_t npl = pv.pl + len;
@@ -687,7 +688,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     pv.mpos = 0;
     pv.taken.assign(nranks, 0);
-    if (std::getenv("LBFGSB_DEBUG")) {
+    if (debug_walk) {
       std::fprintf(stderr, "[refill] chunk=%u len=%u Cl=%u pl=%u cur=%d M=%zu safe=%zu more=%d\n", chunk,
                    len, pv.Cl, pv.pl, pv.cur, pv.M.size(), pv.safe_end, (int)pv.more_anywhere);
       for (size_t k = 0; k < pv.M.size() && k < 30; ++k)
@@ -1147,7 +1148,7 @@ class Solver final : public lbfgsb_hip_ctx {
         }
       }
     }
-    if (std::getenv("LBFGSB_DEBUG"))
+    if (debug_walk)
       std::fprintf(stderr, "[cauchy] nseg=%d tsum=%g dtm=%g last=(%.17g,%lld)\n", nseg, tsum, dtm,
                    last_t, (long long)last_i);
     if (ipr >= 99) {  // :1502-1508
