@@ -80,8 +80,12 @@ struct Rccl {
   ncclResult_t (*GroupEnd)() = nullptr;
   bool load() {
     if (h) return true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // LBFGSB_RCCL_LIBRARY: a specific build of the library (tests point it at a small
+    // shared-memory stand-in so that the communicator code path runs with several ranks on one GPU)
+    const char *names[] = {std::getenv("LBFGSB_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
+                           "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
+      if (!nm || !*nm) continue;
       h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
       if (h) break;
     }

@@ -1,7 +1,9 @@
 """Worker for the multi-rank tests: `world` processes, one shard of the rows each.
 mode 'gloo': ranks share cuda:0, reductions through a gloo host group (host callbacks).
 mode 'rccl1': world must be 1; an RCCL communicator of one rank is attached so that the
-ncclAllReduce / ncclAllGather code path runs on a single GPU."""
+ncclAllReduce / ncclAllGather code path runs on a single GPU.
+mode 'fakerccl': several ranks on cuda:0 through the library's communicator code path, with a
+shared-memory stand-in for librccl (tests/fake_rccl.cpp, LBFGSB_RCCL_LIBRARY)."""
 import json
 import os
 import sys
@@ -33,6 +35,13 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     elif mode == "rccl1":
         assert world == 1
         lbfgsb_amd.attach_rccl(sol, 0, 1, dev)
+    elif mode == "fakerccl":
+        # the library's communicator code path (ncclAllReduce / ncclAllGather on the solver's
+        # stream) with several ranks on ONE GPU: LBFGSB_RCCL_LIBRARY points at tests/fake_rccl.cpp
+        ids = [lbfgsb_amd.DeviceSolver.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, 0)
+        sol.init_rccl(ids[0], rank, world)
+        assert "libfake_rccl" in open("/proc/self/maps").read()   # (not the real library)
     if variant == "rosen":
         p = po.problem_rosenbrock(n, m, factr=0.0, pgtol=0.0)
     else:

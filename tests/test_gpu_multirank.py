@@ -131,3 +131,38 @@ def test_sharded_random_problems_match_oracle(oracle_built, tmp_path, world, fir
         late += 1
         assert k >= 0.5 * len(rows), (seed, p.n, p.m, k, len(rows), len(got), rows[k - 1:k + 1], got[k - 1:k + 1])
     assert late <= 0.2 * count
+
+
+def _fake_rccl():
+    """Build tests/fake_rccl.cpp (shared-memory stand-in for the RCCL entry points) on demand."""
+    so = os.path.join(HERE, "_build", "libfake_rccl.so")
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so,
+                               "-lrt"])
+    return so
+
+
+@pytest.mark.parametrize("world,n,m,iters,mixed", [
+    (2, 20011, 7, 8, True),
+    (3, 300000, 10, 3, False),     # long first walk: all-gathered record chunks, merged on every rank
+    (4, 10007, 5, 6, "rosen"),     # halo exchange of the sharded objective through ncclAllGather
+])
+def test_communicator_code_path_with_several_ranks(oracle_built, tmp_path, monkeypatch, world, n, m,
+                                                   iters, mixed):
+    """The solver's RCCL code path (lbfgsb_hip_comm_init_rccl; grouped sum/min/max ncclAllReduce of
+    the partials, ncclAllGather of breakpoint records and halos, all on the solver's stream) with
+    2-4 ranks.  Real RCCL refuses ranks that share a GPU, so LBFGSB_RCCL_LIBRARY points the
+    library at a shared-memory stand-in for those seven entry points; everything above them is
+    the production code.  Same trajectory as the single-rank oracle."""
+    po = oracle_built
+    monkeypatch.setenv("LBFGSB_RCCL_LIBRARY", _fake_rccl())
+    res = launch(world, "fakerccl", n, m, iters, mixed, str(tmp_path / "out.json"))
+    rows, x = oracle_rows(po, n, m, iters, mixed)
+    assert len(res["rows"]) == len(rows) == iters
+    for a, b in zip(res["rows"], rows):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
+    xa = np.array(res["x"])
+    assert np.max(np.abs(xa - x)) <= 1e-8 * max(1.0, np.max(np.abs(x)))
