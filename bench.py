@@ -24,6 +24,9 @@ import time
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: RCCL needs this for multi-process runs
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
