@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=100_000_000,
+                    help="global number of variables (--rows: spelling that torch.distributed.run's "
+                         "own parser does not mistake for one of its options)")
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--real32", action="store_true", help="REAL32 context (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,10 +105,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    # LBFGSB_BENCH_SHARE_GPU=1 (tests): every rank on cuda:0 with a gloo group, so that this
+    # file's multi-rank flow can be rehearsed on a one-GPU box (with LBFGSB_RCCL_LIBRARY pointing
+    # the library at the shared-memory stand-in of tests/fake_rccl.cpp)
+    share_gpu = os.environ.get("LBFGSB_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n, m = a.n, a.m
     # contiguous block sharding of the rows

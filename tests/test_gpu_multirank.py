@@ -166,3 +166,26 @@ def test_communicator_code_path_with_several_ranks(oracle_built, tmp_path, monke
         assert a[4] == pytest.approx(b[4], rel=1e-9)
     xa = np.array(res["x"])
     assert np.max(np.abs(xa - x)) <= 1e-8 * max(1.0, np.max(np.abs(x)))
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's multi-rank flow (row partition, communicator set-up with the id broadcast,
+    barriers, MAX over ranks of the timings, rank-0 JSON line) launched exactly as the driver
+    launches it -- torch.distributed.run, 2 ranks -- on ONE GPU: LBFGSB_BENCH_SHARE_GPU puts both
+    ranks on cuda:0 with a gloo group, LBFGSB_RCCL_LIBRARY swaps librccl for the stand-in."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, LBFGSB_BENCH_SHARE_GPU="1", LBFGSB_RCCL_LIBRARY=_fake_rccl(),
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "2000000", "--steps", "5", "--warmup", "12",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert out["config"]["rows_per_gpu"] == 1000000 and out["config"]["collective"].startswith("RCCL")
+    assert out["first_iteration_nseg"] > 1900000     # ~0.977 n segments, walked across both ranks
+    assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
