@@ -2683,7 +2683,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void obj_quadratic_kernel(int64_t n, int64_t row0,
                                                               const T *__restrict__ x, T *g,
-                                                              double *part) {
+                                                              int nt, double *part) {
   double acc[1] = {0.0};
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -2698,14 +2698,19 @@ __global__ __launch_bounds__(BLOCK) void obj_quadratic_kernel(int64_t n, int64_t
       gv[k] = a * dx;
       acc[0] = acc[0] + a * dx * dx;
     }
-    st<W>(g + i, gv);
+    // large problems: stream g out, so that no dirty lines linger in the cache hierarchy and
+    // drain into the read-only pass that follows
+    if (nt)
+      stnt<W>(g + i, gv);
+    else
+      st<W>(g + i, gv);
   });
   block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
   const int gr = grid_for(n, VecOf<T>::V);
-  hipLaunchKernelGGL(obj_quadratic_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, g,
+  hipLaunchKernelGGL(obj_quadratic_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, g, q.nt ? 1 : 0,
                      q.d_part);
   q.launches++;
   launch_finalize(q, gr, 1, 0, 0);
@@ -2716,7 +2721,8 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, int64_t row0,
                                                                int64_t nglob,
                                                                const T *__restrict__ x, T *g,
-                                                               double xl, double xr, double *part) {
+                                                               double xl, double xr, int nt,
+                                                               double *part) {
   double acc[1] = {0.0};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -2740,7 +2746,10 @@ __global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, int64_
         gi = 8.0 * t2 - 16.0 * xi * t1;
       }
     }
-    g[i] = (T)gi;
+    if (nt)
+      __builtin_nontemporal_store((T)gi, g + i);  // (see obj_quadratic_kernel)
+    else
+      g[i] = (T)gi;
   }
   block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
 }
@@ -2749,7 +2758,7 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, con
                            double xl, double xr) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, nglob,
-                     x, g, xl, xr, q.d_part);
+                     x, g, xl, xr, q.nt ? 1 : 0, q.d_part);
   q.launches++;
   launch_finalize(q, gr, 1, 0, 0);
 }
