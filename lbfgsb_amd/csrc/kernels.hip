@@ -1165,7 +1165,8 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
         const uint32_t pos = atomicAdd(&lcount, 1u);  // LDS atomic; pos < LCAP by the flush rule
         lbuf[pos] = (uint32_t)i | (fr ? 0u : 0x80000000u);
       }
-      wasfree[i] = fr ? 1 : 0;
+      if (fr != was) wasfree[i] = fr ? 1 : 0;  // (few rows: keeps the pass that follows free of
+                                               //  drained store traffic)
     }
     if (chg) {
       __syncthreads();
