@@ -209,7 +209,7 @@ def main():
     # ---- roofline, live, hipEvents on the solver's stream ----
     # (1) the kernel that carries the WS/WY matvec INSIDE the iteration: cmprlb_wtv_kernel
     #     (r of cmprlb + W'r of subsm + formk's new row sums in one pass); algorithmic bytes per
-    #     row = 2col reads of W + x, g reads (fp64) + iwhere (int32); xcp and r stay in registers
+    #     row = 2col reads of W + x, g reads (fp64) + iwhere (1 byte); xcp and r stay in registers
     #     (subsm_update_kernel recomputes it), so the pass writes nothing but its partials
     # (2) the bare W'v kernel (wtv_kernel), (2col+1) n s bytes -- BASELINE.md's definition
     head = int(sol.isave[26])
@@ -240,7 +240,7 @@ def main():
     ms_fused, n_fused = in_run("cmprlb_wtv")
     if ms_fused is None:
         ms_fused = ms_iso
-    alg_fused = ((2 * col + 2) * rbytes + 4) * n_loc
+    alg_fused = ((2 * col + 2) * rbytes + 1) * n_loc
     ach_fused = alg_fused / (ms_fused * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s, %d, true, %s>" % ("float" if a.real32 else "double", mc, nts),
                 "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -264,7 +264,7 @@ def main():
     try:
         ms_us_iso = sol.kernel_time(4, x, g, col, head, a.roofline_reps)
         ms_us = in_run("update_scan")[0] or ms_us_iso
-        by_us = ((2 * (col - 1) + 6) * rbytes + 8) * n_loc
+        by_us = ((2 * (col - 1) + 6) * rbytes + 5) * n_loc   # + nbd (int32) + iwhere (int8)
         others.append({"kernel": "update_scan_kernel<%s, %d, %s> (as trial-point evaluation)"
                        % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
                        "achieved": by_us / (ms_us * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -275,7 +275,7 @@ def main():
         ms_su_iso = sol.kernel_time(3, x, g, col, head, a.roofline_reps)
         ms_su = in_run("subsm_update")[0] or ms_su_iso
         # in the run the pass also stores the first trial point x (one more vector)
-        by_su = ((2 * col + 4 + 6 + (1 if in_run("subsm_update")[0] else 0)) * rbytes + 8) * n_loc
+        by_su = ((2 * col + 4 + 6 + (1 if in_run("subsm_update")[0] else 0)) * rbytes + 5) * n_loc
         others.append({"kernel": "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
                        % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
                        "achieved": by_su / (ms_su * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

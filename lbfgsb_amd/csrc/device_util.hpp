@@ -161,6 +161,32 @@ __device__ __forceinline__ void ldi(const int32_t *p, int (&o)[W]) {
     for (int k = 0; k < W; ++k) o[k] = p[k];
   }
 }
+// iwhere (values -3..3) and the solver's copy of nbd (0..3) are kept as one byte per row
+template <int W>
+__device__ __forceinline__ void ldi(const int8_t *p, int (&o)[W]) {
+  if constexpr (W == 2) {
+    const char2 v = *reinterpret_cast<const char2 *>(p);
+    o[0] = v.x, o[1] = v.y;
+  } else if constexpr (W == 4) {
+    const char4 v = *reinterpret_cast<const char4 *>(p);
+    o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) o[k] = p[k];
+  }
+}
+template <int W>
+__device__ __forceinline__ void sti(int8_t *p, const int (&o)[W]) {
+  if constexpr (W == 2) {
+    *reinterpret_cast<char2 *>(p) = make_char2((signed char)o[0], (signed char)o[1]);
+  } else if constexpr (W == 4) {
+    *reinterpret_cast<char4 *>(p) =
+        make_char4((signed char)o[0], (signed char)o[1], (signed char)o[2], (signed char)o[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) p[k] = (int8_t)o[k];
+  }
+}
 template <int W>
 __device__ __forceinline__ void sti(int32_t *p, const int (&o)[W]) {
   if constexpr (W == 2) {

@@ -185,7 +185,7 @@ void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax) {
 // =========================== active / errclb ================================
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void active_kernel(int64_t n, T *x, const T *l, const T *u,
-                                                       const int32_t *nbd, int32_t *iwhere,
+                                                       const int32_t *nbd, iw_t *iwhere,
                                                        int8_t *wasfree, double *part) {
   double acc[4] = {0, 0, 0, 0};
   for_rows<T>(n, [&](int64_t i, auto wt) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void active_kernel(int64_t n, T *x, const T 
 }
 template <typename T>
 void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd,
-                   int32_t *iwhere, int8_t *wasfree) {
+                   iw_t *iwhere, int8_t *wasfree) {
   const int g = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(active_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd,
                      iwhere, wasfree, q.d_part);
@@ -359,7 +359,7 @@ void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v)
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
-    const int32_t *__restrict__ nbd, const T *__restrict__ g, int32_t *iwhere, T *tbrk,
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, iw_t *iwhere, T *tbrk,
     const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
     double *part) {
   constexpr int NA = 2 * MC + 5;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
 }
 template <typename T>
 void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
-                        const int32_t *nbd, const T *g, int32_t *iwhere, T *tbrk, WStore<T> w,
+                        const int32_t *nbd, const T *g, iw_t *iwhere, T *tbrk, WStore<T> w,
                         int head, int col) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (col == 0) {
@@ -563,7 +563,7 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
     int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
     const T *__restrict__ u, const int32_t *__restrict__ nbd, const T *__restrict__ g,
-    const int32_t *__restrict__ iwhere, double lo_t, int64_t lo_i, double hi_t, uint64_t *keys,
+    const iw_t *__restrict__ iwhere, double lo_t, int64_t lo_i, double hi_t, uint64_t *keys,
     uint32_t *idx, uint32_t cap, uint32_t *count) {
   const int lane = threadIdx.x & 63;
   for_rows<T>(n, [&](int64_t i, auto wt) {
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
 }
 template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
-                              const int32_t *nbd, const T *g, const int32_t *iwhere, double lo_t,
+                              const int32_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
                               uint32_t *d_count) {
   (void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), q.stream);
@@ -620,7 +620,7 @@ void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, con
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void iwhere_update_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
-    const int32_t *__restrict__ nbd, const T *__restrict__ g, int32_t *iwhere) {
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, iw_t *iwhere) {
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W];
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(BLOCK) void iwhere_update_kernel(
 }
 template <typename T>
 void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *u,
-                          const int32_t *nbd, const T *g, int32_t *iwhere) {
+                          const int32_t *nbd, const T *g, iw_t *iwhere) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(iwhere_update_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
                      iwhere);
@@ -870,7 +870,7 @@ void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, d
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void tbrk_fill_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
-    const int32_t *__restrict__ nbd, const T *__restrict__ g, const int32_t *__restrict__ iwhere,
+    const int32_t *__restrict__ nbd, const T *__restrict__ g, const iw_t *__restrict__ iwhere,
     T *tbrk) {
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(BLOCK) void tbrk_fill_kernel(
 }
 template <typename T>
 void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
-                      const T *g, const int32_t *iwhere, T *tbrk) {
+                      const T *g, const iw_t *iwhere, T *tbrk) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(tbrk_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
                      iwhere, tbrk);
@@ -1054,7 +1054,7 @@ template <typename T, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
     int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
     const T *__restrict__ u, const T *__restrict__ g, const T *__restrict__ tbrk,
-    int32_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i, double *part) {
+    iw_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i, double *part) {
   double acc[1] = {0.0};
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
 }
 template <typename T>
 void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
-                          const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
+                          const T *g, const T *tbrk, iw_t *iwhere, T *xcp, double tsum,
                           double last_t, int64_t last_i, int count) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (count) {
@@ -1123,14 +1123,14 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
 
 // rows fixed by a short walk, as a list: entry = global row * 2 + (1 if fixed at the upper bound)
 __global__ void cauchy_fix_kernel(const int64_t *__restrict__ list, int count, int64_t row0,
-                                  int64_t n, int32_t *iwhere) {
+                                  int64_t n, iw_t *iwhere) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= count) return;
   const int64_t gi = list[k] >> 1;
   if (gi >= row0 && gi < row0 + n) iwhere[gi - row0] = (list[k] & 1) ? 2 : 1;
 }
 void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, int64_t n,
-                       int32_t *iwhere) {
+                       iw_t *iwhere) {
   hipLaunchKernelGGL(cauchy_fix_kernel, dim3((count + 255) / 256), dim3(256), 0, q.stream, list, count,
                      row0, n, iwhere);
   q.launches++;
@@ -1138,7 +1138,7 @@ void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, i
 
 // =========================== freev (:1980-2059) ==============================
 __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
-                                                            const int32_t *__restrict__ iwhere,
+                                                            const iw_t *__restrict__ iwhere,
                                                             int8_t *wasfree, double *part,
                                                             uint32_t *chg, uint32_t chg_cap,
                                                             uint32_t *chg_count) {
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
   }
   block_reduce_store<3>(acc, 3, 0, 0, part, MAX_BLOCKS);
 }
-void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree, uint32_t *chg,
+void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree, uint32_t *chg,
                         uint32_t chg_cap, uint32_t *chg_count) {
   const int gr = grid_for(n, 1);
   if (chg) (void)hipMemsetAsync(chg_count, 0, sizeof(uint32_t), q.stream);
@@ -1201,7 +1201,7 @@ void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasf
 constexpr int LIST_ITEMS = 4;
 constexpr int LIST_CHUNK = BLOCK * LIST_ITEMS;
 
-__device__ __forceinline__ void list_flags(int64_t i, int64_t n, const int32_t *iwhere,
+__device__ __forceinline__ void list_flags(int64_t i, int64_t n, const iw_t *iwhere,
                                            const int8_t *prev, int do_el, int &fr, int &en,
                                            int &lv) {
   fr = en = lv = 0;
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void list_flags(int64_t i, int64_t n, const int32_t *
     }
   }
 }
-__global__ __launch_bounds__(BLOCK) void list_count_kernel(int64_t n, const int32_t *iwhere,
+__global__ __launch_bounds__(BLOCK) void list_count_kernel(int64_t n, const iw_t *iwhere,
                                                            const int8_t *prev, int do_el,
                                                            int32_t *tmp) {
   __shared__ int s[3];
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(BLOCK) void list_scan_kernel(int nch, int32_t *tmp)
       run[k] += v;
     }
 }
-__global__ __launch_bounds__(BLOCK) void list_write_kernel(int64_t n, const int32_t *iwhere,
+__global__ __launch_bounds__(BLOCK) void list_write_kernel(int64_t n, const iw_t *iwhere,
                                                            const int8_t *prev, int do_el,
                                                            const int32_t *tmp, int nch,
                                                            int32_t *index, int32_t *indx2) {
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(BLOCK) void list_write_kernel(int64_t n, const int3
     }
   }
 }
-void launch_freev_lists(Queue &q, int64_t n, const int32_t *iwhere, const int8_t *prevfree,
+void launch_freev_lists(Queue &q, int64_t n, const iw_t *iwhere, const int8_t *prevfree,
                         int do_enterleave, int32_t *index, int32_t *indx2, int32_t *scan_tmp) {
   const int nch = (int)((n + LIST_CHUNK - 1) / LIST_CHUNK);
   hipLaunchKernelGGL(list_count_kernel, dim3(nch), dim3(BLOCK), 0, q.stream, n, iwhere, prevfree,
@@ -1343,7 +1343,7 @@ template <typename T, int MC>
 __global__ __launch_bounds__(BLOCK) void formk_gram_kernel(int64_t n, const T *__restrict__ ws,
                                                            const T *__restrict__ wy, int64_t ldw,
                                                            int m, int head, int col,
-                                                           const int32_t *__restrict__ iwhere,
+                                                           const iw_t *__restrict__ iwhere,
                                                            double *gpart) {
   using C = GramCfg<MC>;
   __shared__ double tile[C::R * C::RS];
@@ -1524,7 +1524,7 @@ __device__ __forceinline__ void gram_store(const double (&acc)[GramRows<MC>::NAC
 template <typename T, int MC>
 __global__ __launch_bounds__(512) void formk_gram_rows_kernel(
     int64_t n, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head,
-    int col, const int32_t *__restrict__ iwhere, double *gpart) {
+    int col, const iw_t *__restrict__ iwhere, double *gpart) {
   using G = GramRows<MC>;
   constexpr int NC = 2 * MC;                      // columns: [0,MC) = Wy, [MC,2MC) = Ws
   constexpr int PER = (NC + G::NW - 1) / G::NW;   // columns loaded per wave
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(512) void formk_gram_rows_kernel(
 
 template <typename T>
 void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
-                       const int32_t *iwhere) {
+                       const iw_t *iwhere) {
   int gr = 0;
   if (col <= 10) {
     const int64_t nslab = (n + 127) / 128;
@@ -1679,7 +1679,7 @@ __device__ __forceinline__ double xcp_row(double xk, double gk, int iw, double l
 template <typename T, int MC, bool NEWROW, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
-    const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
+    const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
     int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
     const T *pd, Pend pe, double *part) {
   constexpr int NA = NEWROW ? 6 * MC : 2 * MC;
@@ -1778,7 +1778,7 @@ __device__ __forceinline__ double widen_late(double v) { return v; }
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
-    const int32_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
+    const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
     int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
     const T *pd, Pend pe, double *part) {
   constexpr int H = MC / 2, NA = 6 * H;
@@ -1906,7 +1906,7 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
 
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
-                       const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
+                       const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
                        const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe) {
   const int gr = grid_for(n, VecOf<T>::V);
   if (newrow && maxc_for(col) >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
@@ -2059,7 +2059,7 @@ template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, double tsum, T *__restrict__ zout, T *r,
     const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
-    const int32_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
+    const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
     double theta, Coef cf, int plain, Coef wv, T *dvec, T *__restrict__ tvec,
     T *xout, int do_stpmx, Pend pe, T *cwy, T *cws, double *part) {
@@ -2167,7 +2167,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
 }
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
-                         const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
+                         const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe) {
   const int gr = grid_for(n, VecOf<T>::V);
@@ -2216,7 +2216,7 @@ void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d,
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void xcp_fill_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ l,
-    const T *__restrict__ u, const int32_t *__restrict__ iwhere, double tsum, T *dst) {
+    const T *__restrict__ u, const iw_t *__restrict__ iwhere, double tsum, T *dst) {
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], lv[W], uv[W], out[W];
@@ -2233,7 +2233,7 @@ __global__ __launch_bounds__(BLOCK) void xcp_fill_kernel(
 }
 template <typename T>
 void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
-                     const int32_t *iwhere, double tsum, T *dst) {
+                     const iw_t *iwhere, double tsum, T *dst) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(xcp_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, l, u, iwhere,
                      tsum, dst);
@@ -2243,7 +2243,7 @@ void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, co
 // The Newton direction as a vector (free rows; 0 elsewhere), for the backtracking branch only.
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
-    int64_t n, const T *__restrict__ xcp, const int32_t *__restrict__ iwhere,
+    int64_t n, const T *__restrict__ xcp, const iw_t *__restrict__ iwhere,
     const T *__restrict__ xx, const T *__restrict__ gg, const T *__restrict__ ws,
     const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double theta, Coef cf,
     int plain, Coef wv, T *__restrict__ ndir) {
@@ -2281,7 +2281,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
   });
 }
 template <typename T>
-void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const int32_t *iwhere, const T *xx,
+void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
                       const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
                       int plain, const Coef &wv, T *ndir) {
   const int gr = grid_for(n, VecOf<T>::V);
@@ -2312,7 +2312,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_alpha_kernel(int64_t n, int64_t r
                                                             const T *__restrict__ l,
                                                             const T *__restrict__ u,
                                                             const int32_t *__restrict__ nbd,
-                                                            const int32_t *__restrict__ iwhere,
+                                                            const iw_t *__restrict__ iwhere,
                                                             int pass, double alpha, double *part) {
   double acc[1] = {pass == 0 ? 1.0 : LB_INF};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2328,7 +2328,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_alpha_kernel(int64_t n, int64_t r
 }
 template <typename T>
 void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l, const T *u,
-                        const int32_t *nbd, const int32_t *iwhere) {
+                        const int32_t *nbd, const iw_t *iwhere) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, (int64_t)0, xp,
                      r, l, u, nbd, iwhere, 0, 0.0, q.d_part);
@@ -2337,7 +2337,7 @@ void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l
 }
 template <typename T>
 void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const T *r, const T *l,
-                           const T *u, const int32_t *nbd, const int32_t *iwhere, double alpha) {
+                           const T *u, const int32_t *nbd, const iw_t *iwhere, double alpha) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, xp, r, l,
                      u, nbd, iwhere, 1, alpha, q.d_part);
@@ -2349,7 +2349,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_backtrack_kernel(int64_t n, int64
                                                                 const T *__restrict__ xp, T *r,
                                                                 const T *__restrict__ l,
                                                                 const T *__restrict__ u,
-                                                                const int32_t *__restrict__ iwhere,
+                                                                const iw_t *__restrict__ iwhere,
                                                                 double alpha, int64_t ibd) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -2373,7 +2373,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_backtrack_kernel(int64_t n, int64
 }
 template <typename T>
 void launch_subsm_backtrack(Queue &q, int64_t n, int64_t row0, T *z, const T *xp, T *r, const T *l,
-                            const T *u, const int32_t *iwhere, double alpha, int64_t ibd) {
+                            const T *u, const iw_t *iwhere, double alpha, int64_t ibd) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_backtrack_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, z, xp,
                      r, l, u, iwhere, alpha, ibd);
@@ -2568,7 +2568,7 @@ template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
-    const T *__restrict__ d, double stp, int32_t *iwhere, T *tbrk, T *ws, T *wy, int64_t ldw,
+    const T *__restrict__ d, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy, int64_t ldw,
     int m, int head, int nold, int itail, int store_pair, int store_iw, double *part) {
   constexpr int NA = 4 * MC + 11;
   double acc[NA];
@@ -2668,7 +2668,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
 }
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
-                        const T *g, const T *r, const T *d, double stp, int32_t *iwhere, T *tbrk,
+                        const T *g, const T *r, const T *d, double stp, iw_t *iwhere, T *tbrk,
                         WStore<T> w, int head, int col, int itail, int store_pair, int store_iw) {
   const int gr = grid_for(n, VecOf<T>::V);
   const int nold = col - 1;
@@ -2780,82 +2780,73 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T)                                                                             \
   template void launch_active<T>(Queue &, int64_t, T *, const T *, const T *, const int32_t *,     \
-                                 int32_t *, int8_t *);                                             \
+      iw_t *, int8_t *);                                                                           \
   template void launch_errclb<T>(Queue &, int64_t, int64_t, const T *, const T *,                  \
-                                 const int32_t *);                                                 \
+      const int32_t *);                                                                            \
   template void launch_projgr<T>(Queue &, int64_t, const T *, const T *, const T *,                \
-                                 const int32_t *, const T *);                                      \
+      const int32_t *, const T *);                                                                 \
   template void launch_wtv<T>(Queue &, int64_t, WStore<T>, int, int, const T *);                   \
   template void launch_wtv_nofinalize<T>(Queue &, int64_t, WStore<T>, int, int, const T *);        \
   template void launch_cauchy_scan<T>(Queue &, int64_t, const T *, const T *, const T *,           \
-                                      const int32_t *, const T *, int32_t *, T *, WStore<T>, int,  \
-                                      int);                                                        \
+      const int32_t *, const T *, iw_t *, T *, WStore<T>, int, int);                               \
   template void launch_cauchy_window<T>(Queue &, int64_t, int64_t, const T *, double, int64_t,     \
-                                        double, uint64_t *, uint32_t *, uint32_t, uint32_t *);     \
+      double, uint64_t *, uint32_t *, uint32_t, uint32_t *);                                       \
   template void launch_cauchy_allkeys<T>(Queue &, int64_t, int64_t, const T *, double, int64_t,    \
-                                         uint64_t *, uint32_t *);                                  \
-  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *,       \
-                                            const T *, const int32_t *, const T *,                 \
-                                            const int32_t *, double, int64_t, double, uint64_t *,  \
-                                            uint32_t *, uint32_t, uint32_t *);                     \
-  template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *, const T *,   \
-                                   const int32_t *, double, T *);                                  \
-  template void launch_iwhere_update<T>(Queue &, int64_t, const T *, const T *, const T *,         \
-                                        const int32_t *, const T *, int32_t *);                    \
-  template void launch_pgcp_gather<T>(Queue &, const uint32_t *, const uint64_t *, int64_t,        \
-                                      int64_t, const T *, const T *, const T *, const T *,         \
-                                      WStore<T>, int, int, double, const T *, const T *, Pend,     \
-                                      double *, double *, double *, double *, double *);           \
-  template void launch_tbrk_fill<T>(Queue &, int64_t, const T *, const T *, const T *,             \
-                                    const int32_t *, const T *, const int32_t *, T *);             \
+      uint64_t *, uint32_t *);                                                                     \
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t,     \
-                                        int64_t, const T *, const T *, const T *, const T *,       \
-                                        WStore<T>, int, int, const T *, const T *, Pend,           \
-                                        double *);                                                 \
+      int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, const T *,         \
+      const T *, Pend, double *);                                                                  \
   template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint64_t *,           \
-                                            const uint32_t *, uint32_t, int64_t, const T *,        \
-                                            const T *, const T *, const T *, WStore<T>, int, int,  \
-                                            const T *, const T *, Pend, double *);                 \
+      const uint32_t *, uint32_t, int64_t, const T *, const T *, const T *, const T *,             \
+      WStore<T>, int, int, const T *, const T *, Pend, double *);                                  \
+  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *,       \
+      const T *, const int32_t *, const T *, const iw_t *, double, int64_t, double, uint64_t *,    \
+      uint32_t *, uint32_t, uint32_t *);                                                           \
+  template void launch_iwhere_update<T>(Queue &, int64_t, const T *, const T *, const T *,         \
+      const int32_t *, const T *, iw_t *);                                                         \
+  template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *,              \
+      const T *, const iw_t *, double, T *);                                                       \
+  template void launch_pgcp_gather<T>(Queue &, const uint32_t *, const uint64_t *, int64_t,        \
+      int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, double,            \
+      const T *, const T *, Pend, double *, double *, double *, double *, double *);               \
+  template void launch_tbrk_fill<T>(Queue &, int64_t, const T *, const T *, const T *,             \
+      const int32_t *, const T *, const iw_t *, T *);                                              \
   template void launch_cauchy_finish<T>(Queue &, int64_t, int64_t, const T *, const T *,           \
-                                        const T *, const T *, const T *, int32_t *, T *, double,   \
-                                        double, int64_t, int);                                     \
-  template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const int32_t *);      \
+      const T *, const T *, const T *, iw_t *, T *, double, double, int64_t, int);                 \
+  template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const iw_t *);         \
   template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double,               \
-                                     const int32_t *, WStore<T>, int, int, double, const Coef &,  \
-                                     int, int, const T *, const T *, Pend);                         \
-  template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int);    \
+      const iw_t *, WStore<T>, int, int, double, const Coef &, int, int, const T *, const T *,     \
+      Pend);                                                                                       \
+  template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int,         \
+      int);                                                                                        \
   template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *,              \
-                                       const T *, const int32_t *, const int32_t *, const T *,     \
-                                       const T *, WStore<T>, int, int, double, const Coef &, int,  \
-                                       const Coef &, T *, T *, T *, int, Pend);                    \
-  template void launch_pair_commit<T>(Queue &, int64_t, const T *, const T *, const T *, Pend,     \
-                                      WStore<T>, int, int);                                        \
-  template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const int32_t *, const T *,       \
-                                    const T *, WStore<T>, int, int, double, const Coef &, int,     \
-                                    const Coef &, T *);                                            \
+      const T *, const int32_t *, const iw_t *, const T *, const T *, WStore<T>, int, int,         \
+      double, const Coef &, int, const Coef &, T *, T *, T *, int, Pend);                          \
+  template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *,          \
+      const T *, WStore<T>, int, int, double, const Coef &, int, const Coef &, T *);               \
   template void launch_subsm_alpha<T>(Queue &, int64_t, const T *, const T *, const T *,           \
-                                      const T *, const int32_t *, const int32_t *);                \
+      const T *, const int32_t *, const iw_t *);                                                   \
   template void launch_subsm_argalpha<T>(Queue &, int64_t, int64_t, const T *, const T *,          \
-                                         const T *, const T *, const int32_t *, const int32_t *,   \
-                                         double);                                                  \
+      const T *, const T *, const int32_t *, const iw_t *, double);                                \
   template void launch_subsm_backtrack<T>(Queue &, int64_t, int64_t, T *, const T *, T *,          \
-                                          const T *, const T *, const int32_t *, double, int64_t); \
+      const T *, const T *, const iw_t *, double, int64_t);                                        \
   template void launch_lnsrlb_begin<T>(Queue &, int64_t, const T *, const T *, const T *,          \
-                                       const T *, const T *, const int32_t *, T *, T *, T *, int); \
+      const T *, const T *, const int32_t *, T *, T *, T *, int);                                  \
   template void launch_lnsrlb_step<T>(Queue &, int64_t, T *, const T *, const T *, const T *,      \
-                                      double);                                                     \
+      double);                                                                                     \
   template void launch_lnsrlb_eval<T>(Queue &, int64_t, const T *, const T *, const T *,           \
-                                      const int32_t *, const T *, const T *);                      \
-  template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double,  \
-                                       WStore<T>, int, int, int);                                  \
+      const int32_t *, const T *, const T *);                                                      \
+  template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *,          \
+      double, WStore<T>, int, int, int);                                                           \
   template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *,           \
-                                      const int32_t *, const T *, const T *, const T *, double,    \
-                                      int32_t *, T *, WStore<T>, int, int, int, int, int);         \
+      const int32_t *, const T *, const T *, const T *, double, iw_t *, T *, WStore<T>, int,       \
+      int, int, int, int);                                                                         \
+  template void launch_pair_commit<T>(Queue &, int64_t, const T *, const T *, const T *, Pend,     \
+      WStore<T>, int, int);                                                                        \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *);                \
   template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *,       \
-                                         double, double);                                          \
+      double, double);                                                                             \
   template void launch_halo_pack<T>(Queue &, int64_t, const T *, double *);
-
 INSTANTIATE(double)
 INSTANTIATE(float)
 

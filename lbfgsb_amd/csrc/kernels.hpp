@@ -37,6 +37,10 @@ struct WStore {
   int m;
 };
 
+// iwhere (cauchy's per-variable status, -3..3) is kept as one byte per row on the device; the
+// reference's int32 layout exists only in export_state / import_state
+using iw_t = int8_t;
+
 // small coefficient vectors travel as kernel arguments (scalar loads)
 struct Coef {
   double a[2 * MAXM];
@@ -59,7 +63,7 @@ int maxc_for(int col);
 // [1]=#(nbd!=0) (sum), [2]=#(nbd!=2) (sum), [3]=nbdd (sum)
 template <typename T>
 void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd,
-                   int32_t *iwhere, int8_t *wasfree);
+                   iw_t *iwhere, int8_t *wasfree);
 // errclb (ref :1601-1643): res max-slots: [0]=largest 1-based global index with invalid nbd
 // (0 if none), [1]=largest index with l>u and nbd==2.
 template <typename T>
@@ -85,7 +89,7 @@ void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, 
 // breakpoint, [2MC+3] #of those with g!=0; min-slot [2MC+4] = bkmin (+inf if none)
 template <typename T>
 void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
-                        const int32_t *nbd, const T *g, int32_t *iwhere, T *tbrk,
+                        const int32_t *nbd, const T *g, iw_t *iwhere, T *tbrk,
                         WStore<T> w, int head, int col);
 // candidates with (lo_t, lo_i) < (t, gidx) and t <= hi_t, appended (unordered)
 // to keys/idx (capacity cap); *d_count receives the total number found.
@@ -124,17 +128,17 @@ void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *key
 // the window compaction with the breakpoint times recomputed per row (no stored tbrk)
 template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
-                              const int32_t *nbd, const T *g, const int32_t *iwhere, double lo_t,
+                              const int32_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
                               uint32_t *d_count);
 // cauchy's iwhere update (:1284-1291) alone
 template <typename T>
 void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *u,
-                          const int32_t *nbd, const T *g, int32_t *iwhere);
+                          const int32_t *nbd, const T *g, iw_t *iwhere);
 // the Cauchy point as a vector from (x, g, l, u, iwhere-after-the-walk, tsum)
 template <typename T>
 void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
-                     const int32_t *iwhere, double tsum, T *dst);
+                     const iw_t *iwhere, double tsum, T *dst);
 // ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; see kernels.hip) ----
 size_t scan_temp_bytes(size_t count);
 void launch_scan(Queue &q, void *d_temp, size_t temp_bytes, const double *in, double *out,
@@ -160,28 +164,28 @@ void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, d
 // tbrk as a vector from (x, l, u, nbd, g, iwhere-after-the-scan, BEFORE the walk fixes rows)
 template <typename T>
 void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
-                      const T *g, const int32_t *iwhere, T *tbrk);
+                      const T *g, const iw_t *iwhere, T *tbrk);
 // finish (:1425-1433, :1515): fix every processed breakpoint variable at its bound,
 // move the others by tsum*d.  processed = (t, gidx) <= (last_t, last_i).
 // count != 0: res[0] = number of rows fixed (finalize launched).
 template <typename T>
 void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
-                          const T *g, const T *tbrk, int32_t *iwhere, T *xcp, double tsum,
+                          const T *g, const T *tbrk, iw_t *iwhere, T *xcp, double tsum,
                           double last_t, int64_t last_i, int count = 0);
 
 // rows fixed by a short walk (list entry = global row * 2 + upper?): iwhere = 1 / 2
 void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, int64_t n,
-                       int32_t *iwhere);
+                       iw_t *iwhere);
 
 // ---- freev (ref :1980-2059) -------------------------------------------------
 // res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave; updates wasfree.
 // chg (optional): rows whose free/active status changed are appended (unordered) as
 // row | 0x80000000 if it LEFT the free set; *chg_count = number found (may exceed chg_cap).
-void launch_freev_count(Queue &q, int64_t n, const int32_t *iwhere, int8_t *wasfree,
+void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree,
                         uint32_t *chg, uint32_t chg_cap, uint32_t *chg_count);
 // mirror of Index / Indx2 (1-based global numbers, reference ordering).  prev = wasfree
 // BEFORE launch_freev_count of this iteration (copy kept by the solver).
-void launch_freev_lists(Queue &q, int64_t n, const int32_t *iwhere, const int8_t *prevfree,
+void launch_freev_lists(Queue &q, int64_t n, const iw_t *iwhere, const int8_t *prevfree,
                         int do_enterleave, int32_t *index, int32_t *indx2, int32_t *scan_tmp);
 
 // ---- formk inner products (ref :1756-1851, from scratch) --------------------
@@ -191,7 +195,7 @@ void launch_freev_lists(Queue &q, int64_t n, const int32_t *iwhere, const int8_t
 //   [ 2T + i*col + j ]              all  : sum_{i>j ? act : free} Ws_i Wy_j
 template <typename T>
 void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
-                       const int32_t *iwhere);
+                       const iw_t *iwhere);
 
 // cmprlb + the first matvec of subsm (W'r, :2742-2754) in one pass over W.
 // res sum-slots (MC = maxc_for(col)): [0..col) Wy'r, [MC..MC+col) Ws'r; with newrow also the
@@ -201,7 +205,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
 // The Cauchy point is evaluated per row from (x, g, iwhere, tsum), see xcp_free in kernels.hip.
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
-                       const int32_t *iwhere, WStore<T> w, int head, int col, double theta,
+                       const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
                        const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe);
 // formk patches (ref :1801-1851): signed Gram over the listed rows (+ entered, - left the free
 // set) for the first upcl logical columns; res layout as launch_formk_gram with col = upcl.
@@ -218,26 +222,26 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 // line search, x = z, when its step length is known to be 1 (:2265).
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
-                         const int32_t *nbd, const int32_t *iwhere, const T *xx, const T *gg,
+                         const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe);
 // the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
 template <typename T>
-void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const int32_t *iwhere, const T *xx,
+void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
                       const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
                       int plain, const Coef &wv, T *ndir);
 // backtrack (:2836-2863): res min-slot [0] = alpha; then argmin pass:
 // res min-slot [0] = smallest global index attaining alpha (as double)
 template <typename T>
 void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l, const T *u,
-                        const int32_t *nbd, const int32_t *iwhere);
+                        const int32_t *nbd, const iw_t *iwhere);
 template <typename T>
 void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const T *r,
-                           const T *l, const T *u, const int32_t *nbd, const int32_t *iwhere,
+                           const T *l, const T *u, const int32_t *nbd, const iw_t *iwhere,
                            double alpha);
 template <typename T>
 void launch_subsm_backtrack(Queue &q, int64_t n, int64_t row0, T *z, const T *xp, T *r,
-                            const T *l, const T *u, const int32_t *iwhere, double alpha,
+                            const T *l, const T *u, const iw_t *iwhere, double alpha,
                             int64_t ibd);
 
 // ---- lnsrlb (ref :2174-2275) + mainlb d=z-x (:720-722) ------------------------
@@ -269,7 +273,7 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
-                        int32_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
+                        iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
                         int store_pair, int store_iw);
 // Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
 template <typename T>

@@ -186,7 +186,8 @@ class Solver final : public lbfgsb_hip_ctx {
   T *ws = nullptr, *wy = nullptr;
   int64_t ld = 0;
   T *z = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *xp = nullptr, *tbrk = nullptr;
-  int32_t *iwhere = nullptr, *index = nullptr, *indx2 = nullptr, *scan_tmp = nullptr;
+  lbk::iw_t *iwhere = nullptr;  // one byte per row (the reference's int32 only in export/import)
+  int32_t *index = nullptr, *indx2 = nullptr, *scan_tmp = nullptr;
   int8_t *wasfree = nullptr, *prevfree = nullptr;
   // cauchy selection
   static constexpr uint32_t SEL_CAP = 1u << 18;
@@ -291,8 +292,8 @@ class Solver final : public lbfgsb_hip_ctx {
       HIPCHK(hipMalloc(p, vb));
       HIPCHK(hipMemsetAsync(*p, 0, vb, stream));
     }
-    HIPCHK(hipMalloc(&iwhere, (size_t)(n + 32) * sizeof(int32_t)));
-    HIPCHK(hipMemsetAsync(iwhere, 0, (size_t)(n + 32) * sizeof(int32_t), stream));
+    HIPCHK(hipMalloc(&iwhere, (size_t)(n + 32) * sizeof(lbk::iw_t)));
+    HIPCHK(hipMemsetAsync(iwhere, 0, (size_t)(n + 32) * sizeof(lbk::iw_t), stream));
     HIPCHK(hipMalloc(&wasfree, (size_t)n + 32));
     HIPCHK(hipMemsetAsync(wasfree, 1, (size_t)n + 32, stream));
     if (flags & LBFGSB_F_MIRROR_INDEX) {
@@ -2017,9 +2018,13 @@ class Solver final : public lbfgsb_hip_ctx {
         HIPCHK(hipMemcpyAsync(iwa, index, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(iwa + 2 * n, indx2, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
       }
-      HIPCHK(hipMemcpyAsync(iwa + n, iwhere, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     }
     HIPCHK(hipStreamSynchronize(stream));
+    if (iwa) {  // iwhere: one byte per row on the device, int32 in the reference's layout
+      std::vector<lbk::iw_t> h((size_t)n);
+      HIPCHK(hipMemcpy(h.data(), iwhere, (size_t)n * sizeof(lbk::iw_t), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < n; ++i) iwa[n + i] = h[(size_t)i];
+    }
     return 0;
   }
 
@@ -2043,7 +2048,11 @@ class Solver final : public lbfgsb_hip_ctx {
     get(wa8m);
     z_valid = true;  // z as imported
     spec.valid = false, pend.on = 0, tbrk_valid = false, scan.ready = false;
-    HIPCHK(hipMemcpyAsync(iwhere, iwa + n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    {
+      std::vector<lbk::iw_t> h((size_t)n);
+      for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)iwa[n + i];
+      HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
+    }
     // free-set membership as of the last freev: Index(1:nfree)
     std::vector<int8_t> wf((size_t)n, 0);
     const int iter = isave_user[29];
