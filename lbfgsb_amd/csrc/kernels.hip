@@ -45,12 +45,14 @@ int grid_for(int64_t n, int vec) {
 // The passes over W keep 2-3 workgroups resident per CU (132-250 VGPRs): a grid of about that
 // many workgroups, each striding over more rows, reads 3-6 % faster than 2048 of them (sweep at
 // n = 1e8: 512 and 768 workgroups are equal, 1024+ slower).  LBFGSB_WGRID overrides.
-int grid_for_w(int64_t n, int vec) {
-  static const int cap = [] {
+// (fp32, m = 10 measured the other way round -- 2048: 150 it/s, 768: 144 -- and keeps 2048.)
+int grid_for_w(int64_t n, int vec, int elem_bytes) {
+  static const int env_cap = [] {
     const char *e = std::getenv("LBFGSB_WGRID");
     const int v = e ? std::atoi(e) : 0;
-    return v >= 1 && v <= MAX_BLOCKS ? v : 768;
+    return v >= 1 && v <= MAX_BLOCKS ? v : 0;
   }();
+  const int cap = env_cap ? env_cap : (elem_bytes == 8 ? 768 : MAX_BLOCKS);
   const int g = grid_for(n, vec);
   return g > cap ? cap : g;
 }
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
 }
 template <typename T>
 void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
-  const int g = grid_for_w(n, VecOf<T>::V);
+  const int g = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((wtv_kernel<T, MC, NTV>), dim3(g), dim3(BLOCK), 0, q.stream, n,
                                         w.ws, w.wy, w.ld, w.m, head, col, v, q.d_part));
   q.launches++;
@@ -372,7 +374,7 @@ void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, 
 template <typename T>
 void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
   launch_wtv_nofinalize(q, n, w, head, col, v);
-  launch_finalize(q, grid_for_w(n, VecOf<T>::V), 2 * maxc_for(col), 0, 0);
+  launch_finalize(q, grid_for_w(n, VecOf<T>::V, (int)sizeof(T)), 2 * maxc_for(col), 0, 0);
 }
 
 // =========================== cauchy scan (:1270-1330) ========================
@@ -465,7 +467,7 @@ template <typename T>
 void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, iw_t *iwhere, T *tbrk, WStore<T> w,
                         int head, int col) {
-  const int gr = grid_for_w(n, VecOf<T>::V);
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   if (col == 0) {
     hipLaunchKernelGGL((cauchy_scan_kernel<T, 0, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
                        nbd, g, iwhere, tbrk, w.ws, w.wy, w.ld, w.m, head, col, q.d_part);
@@ -1928,7 +1930,7 @@ template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
                        const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe) {
-  const int gr = grid_for_w(n, VecOf<T>::V);
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   if (newrow && maxc_for(col) >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
     if (maxc_for(col) == 20) {
       if (q.nt)
@@ -2190,7 +2192,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
                          const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe) {
-  const int gr = grid_for_w(n, VecOf<T>::V);
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                         q.stream, n, tsum, zout, r, l, u, nbd, iwhere, xx, gg, w.ws,
@@ -2304,7 +2306,7 @@ template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
                       const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
                       int plain, const Coef &wv, T *ndir) {
-  const int gr = grid_for_w(n, VecOf<T>::V);
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_dir_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                         q.stream, n, xcp, iwhere, xx, gg, w.ws, w.wy, w.ld, w.m, head,
                                         col, theta, cf, plain, wv, ndir));
@@ -2563,7 +2565,7 @@ __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
 template <typename T>
 void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d, double stp,
                          WStore<T> w, int head, int col, int itail) {
-  const int gr = grid_for_w(n, VecOf<T>::V);
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_pairs_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, g, r, d, stp, w.ws, w.wy, w.ld, w.m, head,
@@ -2690,7 +2692,7 @@ template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
                         const T *g, const T *r, const T *d, double stp, iw_t *iwhere, T *tbrk,
                         WStore<T> w, int head, int col, int itail, int store_pair, int store_iw) {
-  const int gr = grid_for_w(n, VecOf<T>::V);
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,

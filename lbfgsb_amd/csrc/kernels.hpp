@@ -54,7 +54,7 @@ struct Pend {
 };
 
 int grid_for(int64_t n, int vec);
-int grid_for_w(int64_t n, int vec);  // the same for the passes over W (fewer, resident workgroups)
+int grid_for_w(int64_t n, int vec, int elem_bytes);  // the same for the passes over W (fewer, resident workgroups)
 // compile-time column capacity the kernels are unrolled to for `col` pairs (5, 10, 20, 32).
 // Reduction slots that depend on col use MC = maxc_for(col) as their stride.
 int maxc_for(int col);
