@@ -34,20 +34,20 @@ __global__ __launch_bounds__(256) void k(int64_t n, const double *__restrict__ i
 }
 
 template <int NR, int NW, bool NTS>
-void run(int64_t n, const double *in, double *out, double *sink) {
+void run(int64_t n, const double *in, double *out, double *sink, int grid = 2048) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<NR, NW, NTS>), dim3(2048), dim3(256), 0, 0, n, in, out, n, sink);
+  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<NR, NW, NTS>), dim3(grid), dim3(256), 0, 0, n, in, out, n, sink);
   CK(hipEventRecord(e0, 0));
   const int reps = 10;
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k<NR, NW, NTS>), dim3(2048), dim3(256), 0, 0, n, in, out, n, sink);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k<NR, NW, NTS>), dim3(grid), dim3(256), 0, 0, n, in, out, n, sink);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
-  printf("reads %2d writes %d %s  %7.3f ms  %7.1f GB/s\n", NR, NW, NTS ? "nt-store" : "plain   ", ms,
+  printf("reads %2d writes %d %s grid %4d  %7.3f ms  %7.1f GB/s\n", NR, NW, NTS ? "nt-store" : "plain   ", grid, ms,
          (NR + NW) * 8.0 * n / ms / 1e6);
   fflush(stdout);
 }
@@ -56,10 +56,10 @@ int main() {
   const int64_t n = 100000000;
   double *in, *out, *sink;
   CK(hipMalloc(&in, (size_t)n * 24 * 8));
-  CK(hipMalloc(&out, (size_t)n * 6 * 8));
+  CK(hipMalloc(&out, (size_t)n * 8 * 8));
   CK(hipMalloc(&sink, 64));
   CK(hipMemset(in, 0, (size_t)n * 24 * 8));
-  CK(hipMemset(out, 0, (size_t)n * 6 * 8));
+  CK(hipMemset(out, 0, (size_t)n * 8 * 8));
   for (int pass = 0; pass < 2; ++pass) {
     run<24, 0, false>(n, in, out, sink);
     run<24, 1, false>(n, in, out, sink);
@@ -78,6 +78,13 @@ int main() {
     run<0, 1, false>(n, in, out, sink);
     run<0, 4, false>(n, in, out, sink);
     run<0, 4, true>(n, in, out, sink);
+    // fewer, resident workgroups (what the library uses for its fp64 passes over W)
+    run<24, 0, false>(n, in, out, sink, 768);
+    run<24, 1, true>(n, in, out, sink, 768);
+    run<24, 4, true>(n, in, out, sink, 768);
+    run<24, 7, true>(n, in, out, sink, 768);
+    run<24, 7, true>(n, in, out, sink, 2048);
+    run<12, 0, false>(n, in, out, sink, 768);
     printf("\n");
   }
   return 0;
