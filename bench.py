@@ -44,26 +44,75 @@ def parse():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--real32", action="store_true", help="REAL32 context (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=4_000_000)
+    ap.add_argument("--cpu-n", type=int, default=20_000_000,
+                    help="rows of the CPU reference sample (same problem, same m)")
+    ap.add_argument("--rccl-self", action="store_true",
+                    help="single GPU: attach a 1-rank RCCL communicator, so that every reduction pays a "
+                         "real ncclAllReduce + D2H + sync (latency floor of the sharded path; use with "
+                         "--rows 12500000 = the per-rank shape of n=1e8 over 8 GPUs)")
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="multi-GPU: if the RCCL communicator cannot be created, complete the reductions "
+                         "through a gloo host group instead of exiting non-zero")
     ap.add_argument("--roofline-reps", type=int, default=20)
     return ap.parse_args()
 
 
-def cpu_baseline(m, n_full, n_sample):
-    """The untouched reference (oracle/_ref, amdflang -O2) on one host core -- it is single
-    threaded by construction -- on the same problem at n_sample rows; steady-state (col = m)
-    iterations timed inside setulb only; value scaled linearly to n_full rows."""
-    from oracle import pyoracle as po
-    kind = "reference"
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; this file must print
+    exactly one JSON line there.  Inside the block file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def host_cpu():
+    """model name / core counts of the host this process runs on"""
+    model = "unknown"
     try:
-        eng = po.Engine("ref")
-    except (FileNotFoundError, OSError):
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"model": model, "cores_total": os.cpu_count(), "cores_usable": usable}
+
+
+def cpu_baseline(m, n_full, n_sample):
+    """The untouched reference (oracle/_ref, amdflang -O2; the -fdefault-integer-8 build, which is
+    the one that can run n = 1e8 at all) on ONE host core -- it is single
+    threaded by construction -- on the same problem at n_sample rows.  Iterations with col = m
+    are timed inside setulb only (the objective is excluded); the value is scaled linearly in n
+    to n_full rows (every loop of the reference is O(n) at fixed m; SURVEY.md section 6 measured
+    0.19 / 1.95 / 21.8 s per iteration at n = 1e6 / 1e7 / 1e8)."""
+    from oracle import pyoracle as po
+    kind, eng = "reference", None
+    for name in ("ref_i8", "ref"):
+        try:
+            eng = po.Engine(name)
+            break
+        except (FileNotFoundError, OSError):
+            continue
+    if eng is None:
         eng = po.Engine("oracle")
         kind = "port"
     p = po.problem_quadratic(n_sample, m)
     s = po.State.fresh(p, eng.int)
-    t_in, marks = 0.0, []
-    total_iters = m + 5
+    t_in, marks, cols = 0.0, [], []
+    timed = 3                        # iterations timed at col = m
     t_start = time.time()
     while True:
         t0 = time.perf_counter()
@@ -74,22 +123,39 @@ def cpu_baseline(m, n_full, n_sample):
             s.f[0] = p.fg(s.x, s.g)
         elif t.startswith("NEW_X"):
             marks.append(t_in)
-            if s.isave[29] >= total_iters or time.time() - t_start > 60:
+            cols.append(int(s.isave[27]))
+            # col at NEW_X k is the col of iteration k's own work; iteration k+1 runs matupd first
+            full = [k for k, c in enumerate(cols) if c == m]
+            if len(full) >= timed + 1 or time.time() - t_start > 240:
                 break
         else:
             break
-    k = min(4, len(marks) - 1)
-    per_iter = (marks[-1] - marks[-1 - k]) / k
-    ips_sample = 1.0 / per_iter
+    full = [k for k, c in enumerate(cols) if c == m]
+    if len(full) >= 2:
+        k0, k1 = full[0], full[-1]       # iterations k0+1 .. k1 ran entirely with col = m
+    else:
+        k0, k1 = max(0, len(marks) - 3), len(marks) - 1
+    k = max(1, k1 - k0)
+    per_iter = (marks[k1] - marks[k0]) / k
+    cpu = host_cpu()
     return {
-        "value": ips_sample * n_sample / n_full,
+        "value": 1.0 / per_iter * n_sample / n_full,
         "unit": "iters/sec",
         "cores": 1,
         "kind": kind,
-        "sample": "n=%d rows (1/%g of the workload), m=%d, last %d of %d iterations (col=m), "
-                  "time inside setulb only: %.4f s/iter at the sample size; value scaled "
-                  "linearly in n to n=%d; first iteration (nseg~0.977n) took %.2f s"
-                  % (n_sample, n_full / n_sample, m, k, len(marks), per_iter, n_full, marks[0]),
+        "engine": eng.kind,
+        "n_sample": n_sample,
+        "s_per_iter_at_sample": per_iter,
+        "iters_timed": k,
+        "host_cpu_model": cpu["model"],
+        "host_cores_total": cpu["cores_total"],
+        "host_cores_usable": cpu["cores_usable"],
+        "sample": "n=%d rows (1/%g of the workload), m=%d, %d iterations with col=m (of %d run), "
+                  "time inside setulb only: %.4f s/iter at the sample size; value scaled linearly "
+                  "in n to n=%d; first iteration (nseg~0.977n) took %.2f s; %s on 1 of %d cores "
+                  "(the reference is single-threaded)"
+                  % (n_sample, n_full / n_sample, m, k, len(marks), per_iter, n_full, marks[0],
+                     cpu["model"], cpu["cores_total"]),
     }
 
 
@@ -114,10 +180,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        with stdout_to_stderr():
+            if share_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
 
     n, m = a.n, a.m
     # contiguous block sharding of the rows
@@ -130,24 +197,35 @@ def main():
     rbytes = 4 if a.real32 else 8
     collective = "none"
     if world > 1:
-        # RCCL on the solver's stream; if the communicator cannot be created on some rank, every
-        # rank falls back to completing the (tiny) reductions through a gloo host group
+        # RCCL on the solver's stream.  A scaling curve must never silently be a gloo curve: if
+        # the communicator cannot be created on some rank the run exits non-zero, unless
+        # --allow-gloo-fallback asks for the (tiny) reductions to go through a gloo host group.
         ok = 1
-        try:
-            lbfgsb_amd.attach_rccl(sol, rank, world, dev)
-        except Exception as e:   # noqa: BLE001
-            ok = 0
-            sys.stderr.write("rank %d: RCCL communicator failed (%r)\n" % (rank, e))
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        with stdout_to_stderr():
+            try:
+                lbfgsb_amd.attach_rccl(sol, rank, world, dev)
+            except Exception as e:   # noqa: BLE001
+                ok = 0
+                sys.stderr.write("rank %d: RCCL communicator failed (%r)\n" % (rank, e))
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             collective = "RCCL all-reduce of <=4m+11 fp64 partials per phase"
+        elif not a.allow_gloo_fallback:
+            sol.close()
+            dist.destroy_process_group()
+            raise SystemExit("RCCL communicator unavailable on some rank (pass --allow-gloo-fallback "
+                             "to measure with a gloo host group instead)")
         else:
             sol.close()
             sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,
                                           same_stream_objective=True, real32=a.real32)
             lbfgsb_amd.attach_host_group(sol, rank, world, group=dist.new_group(backend="gloo"))
-            collective = "gloo host all-reduce (RCCL communicator unavailable)"
+            collective = "gloo host all-reduce (RCCL communicator unavailable; --allow-gloo-fallback)"
+    elif a.rccl_self:
+        with stdout_to_stderr():
+            lbfgsb_amd.attach_rccl(sol, 0, 1, dev)
+        collective = "RCCL all-reduce on a 1-rank communicator (--rccl-self: latency floor)"
 
     x = torch.zeros(n_loc, dtype=rdt, device=dev)
     g = torch.zeros_like(x)
@@ -185,17 +263,29 @@ def main():
     barrier()
     first_iter_s = time.perf_counter() - tw0
     nseg_first = int(sol.isave[32])
-    if a.warmup > 1:
-        advance(a.warmup - 1)
+    # Untimed until the memory is full (col == m): whatever --warmup says, at least m + 1
+    # iterations run first, so that every timed launch streams all 2m columns of W and the
+    # roofline bytes below (computed for col = m) are the bytes each timed launch really moved.
+    warm_done = 1
+    warm_min = max(a.warmup, m + 1)
+    while warm_done < warm_min or int(sol.isave[27]) < m:
+        advance(1)
+        warm_done += 1
+        if warm_done > warm_min + 4 * m + 20:
+            raise SystemExit("col never reached m = %d (skipped updates?)" % m)
     barrier()
     ts0 = t_setulb
     st0 = sol.stats()
     sol.pass_clock(1)            # hipEvents around every launch of the three W passes
+    cols_timed = []
     t0 = time.perf_counter()
-    advance(a.steps)
+    for _ in range(a.steps):
+        advance(1)
+        cols_timed.append(int(sol.isave[27]))
     barrier()
     dt = time.perf_counter() - t0
     clocks = sol.pass_clock(0)   # {pass: (ms_total, launches)} over the timed region
+    assert min(cols_timed) == max(cols_timed) == m, cols_timed
     dt_setulb = t_setulb - ts0
     if world > 1:
         tt = torch.tensor([dt, dt_setulb], dtype=torch.float64, device=dev)
@@ -245,6 +335,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s, %d, true, %s>" % ("float" if a.real32 else "double", mc, nts),
                 "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_fused / HBM_PEAK_GBS, "traffic": traffic_of("cmprlb_wtv_traffic.json", n_loc),
+                "traffic_source": "profiles/cmprlb_wtv_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes of the same kernel at n=1e8, bytes per row x rows; "
+                                  "not re-measured in this run)",
                 "algorithmic_bytes_per_launch": alg_fused, "avg_launch_ms": ms_fused,
                 "launches_timed": n_fused, "timing": "hipEvents around each launch inside the timed region",
                 "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col}
@@ -294,6 +387,7 @@ def main():
     roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s, %d, %s>" % ("float" if a.real32 else "double", mc, nts),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of("wtv_traffic.json", n_loc),
+                    "traffic_source": "profiles/wtv_traffic.json (static PMC measurement, see roofline)",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_kernel,
                     "rows_per_launch": n_loc, "col": col}
 
@@ -304,6 +398,9 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
+        "warmup_run": warm_done,
+        "col_min_timed": min(cols_timed),
+        "col_max_timed": max(cols_timed),
         "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",

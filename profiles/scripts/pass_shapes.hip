@@ -1,0 +1,204 @@
+// Micro-benchmark for the shape of the library's passes over W (n = 1e8 rows, fp64):
+//   NR read streams + NW write streams, 16 B per lane, as in write_cost.hip, in these forms:
+//   base      grid-stride loop, loads -> compute -> stores per trip (what round 1 shipped)
+//   pipe      software-pipelined: the NEXT trip's loads are issued BEFORE this trip's stores, so
+//             the wait for those loads is a counted vmcnt(NW) and never waits for a store
+//             (CDNA4's vmcnt counts stores too: a loop that stores stalls on its own stores)
+//   flat      one trip per workgroup (grid = n / 512), no loop at all
+//   tiled     the 20 "W columns" live in ONE array tiled [row block of 512][column][512 rows], so
+//             a workgroup trip reads one contiguous 80 KB region instead of 20 separate streams
+//             (4 n-vectors stay separate streams, like x, g, l, u)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 pass_shapes.hip -o pass_shapes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ d2 ldnt(const double *p) { return __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p)); }
+__device__ __forceinline__ void stnt(double *p, d2 v) { __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p)); }
+
+// address of "column" j for row pair iv (rows 2iv, 2iv+1)
+template <bool TILED, int NCOL>
+__device__ __forceinline__ const double *caddr(const double *w, const double *vec, int64_t ld, int j, int64_t iv) {
+  if constexpr (TILED) {
+    if (j < NCOL) return w + (iv >> 8) * (int64_t)(NCOL * 512) + j * 512 + ((iv & 255) << 1);
+    return vec + (int64_t)(j - NCOL) * ld + iv * 2;
+  } else {
+    return w + (int64_t)j * ld + iv * 2;
+  }
+}
+
+template <int NR, int NW, bool TILED>
+__global__ __launch_bounds__(256) void k_base(int64_t n, const double *__restrict__ w, const double *__restrict__ vec,
+                                              double *out, int64_t ld, double *sink) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  d2 acc = {0.0, 0.0};
+  for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += stride) {
+    d2 v[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) v[j] = ldnt(caddr<TILED, 20>(w, vec, ld, j, iv));
+    d2 s = {1.0, 2.0};
+#pragma unroll
+    for (int j = 0; j < NR; ++j) s += v[j];
+    acc += s;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) stnt(out + (int64_t)j * ld + iv * 2, s + (double)j);
+  }
+  if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
+}
+
+template <int NR, int NW, bool TILED>
+__global__ __launch_bounds__(256) void k_pipe(int64_t n, const double *__restrict__ w, const double *__restrict__ vec,
+                                              double *out, int64_t ld, double *sink) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  d2 acc = {0.0, 0.0};
+  int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  d2 v[NR];
+  if (iv < nv) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) v[j] = ldnt(caddr<TILED, 20>(w, vec, ld, j, iv));
+  }
+  while (iv < nv) {
+    d2 s = {1.0, 2.0};
+#pragma unroll
+    for (int j = 0; j < NR; ++j) s += v[j];
+    acc += s;
+    const int64_t nx = iv + stride;
+    const int64_t nxc = nx < nv ? nx : iv;   // past the end: re-read this trip's rows (no branch)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) v[j] = ldnt(caddr<TILED, 20>(w, vec, ld, j, nxc));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) stnt(out + (int64_t)j * ld + iv * 2, s + (double)j);
+    __builtin_amdgcn_sched_barrier(0);
+    iv = nx;
+  }
+  if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
+}
+
+
+// pipe with hand-placed waits: loads are inline asm (the compiler does not track them), the wait
+// for them is a counted s_waitcnt vmcnt(NW) AFTER this trip's stores were issued, so the stores
+// of a trip are never waited for inside the loop (the compiler's own wait placement merges the
+// loop-entry state with the back-edge state and ends in vmcnt(0) at the loop header)
+__device__ __forceinline__ d2 ldnt_asm(const double *p) {
+  d2 v;
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin(d2 &v) { asm volatile("" : "+v"(v)); }
+
+template <int NR, int NW, bool TILED>
+__global__ __launch_bounds__(256) void k_pipe_asm(int64_t n, const double *__restrict__ w, const double *__restrict__ vec,
+                                                  double *out, int64_t ld, double *sink) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  d2 acc = {0.0, 0.0};
+  int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (iv >= nv) return;
+  d2 v[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) v[j] = ldnt_asm(caddr<TILED, 20>(w, vec, ld, j, iv));
+  wait_vm<0>();
+#pragma unroll
+  for (int j = 0; j < NR; ++j) pin(v[j]);
+  while (iv < nv) {
+    d2 s = {1.0, 2.0};
+#pragma unroll
+    for (int j = 0; j < NR; ++j) s += v[j];
+    acc += s;
+    const int64_t nx = iv + stride;
+    const int64_t nxc = nx < nv ? nx : iv;
+    pin(s);   // the sums are complete before the operand registers are overwritten
+#pragma unroll
+    for (int j = 0; j < NR; ++j) v[j] = ldnt_asm(caddr<TILED, 20>(w, vec, ld, j, nxc));
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      d2 o = s + (double)j;
+      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(out + (int64_t)j * ld + iv * 2), "v"(o) : "memory");
+    }
+    wait_vm<NW>();   // every load has landed; the NW stores may still be in flight
+#pragma unroll
+    for (int j = 0; j < NR; ++j) pin(v[j]);
+    iv = nx;
+  }
+  if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
+}
+
+template <int NR, int NW, bool TILED>
+__global__ __launch_bounds__(256) void k_flat(int64_t n, const double *__restrict__ w, const double *__restrict__ vec,
+                                              double *out, int64_t ld, double *sink) {
+  const int64_t nv = n / 2;
+  const int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (iv >= nv) return;
+  d2 v[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) v[j] = ldnt(caddr<TILED, 20>(w, vec, ld, j, iv));
+  d2 s = {1.0, 2.0};
+#pragma unroll
+  for (int j = 0; j < NR; ++j) s += v[j];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) stnt(out + (int64_t)j * ld + iv * 2, s + (double)j);
+  if (s.x + s.y == 12345.678) sink[0] = s.x;
+}
+
+static hipEvent_t e0, e1;
+template <typename F>
+float timeit(F &&launch, int reps = 8) {
+  for (int r = 0; r < 2; ++r) launch();
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) launch();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+template <int NR, int NW, bool TILED>
+void suite(int64_t n, const double *w, const double *vec, double *out, double *sink) {
+  const double gb = (NR + NW) * 8.0 * n / 1e9;
+  const char *lay = TILED ? "tiled " : "column";
+  for (int grid : {512, 768, 1024, 2048}) {
+    float ms = timeit([&] { hipLaunchKernelGGL((k_base<NR, NW, TILED>), dim3(grid), dim3(256), 0, 0, n, w, vec, out, n, sink); });
+    printf("reads %2d writes %d %s base grid %6d  %7.3f ms %7.1f GB/s\n", NR, NW, lay, grid, ms, gb / ms * 1e3);
+    if (NW > 0) {
+      ms = timeit([&] { hipLaunchKernelGGL((k_pipe<NR, NW, TILED>), dim3(grid), dim3(256), 0, 0, n, w, vec, out, n, sink); });
+      printf("reads %2d writes %d %s pipe grid %6d  %7.3f ms %7.1f GB/s\n", NR, NW, lay, grid, ms, gb / ms * 1e3);
+      ms = timeit([&] { hipLaunchKernelGGL((k_pipe_asm<NR, NW, TILED>), dim3(grid), dim3(256), 0, 0, n, w, vec, out, n, sink); });
+      printf("reads %2d writes %d %s pasm grid %6d  %7.3f ms %7.1f GB/s\n", NR, NW, lay, grid, ms, gb / ms * 1e3);
+    }
+  }
+  const int gflat = (int)((n / 2 + 255) / 256);
+  const float ms = timeit([&] { hipLaunchKernelGGL((k_flat<NR, NW, TILED>), dim3(gflat), dim3(256), 0, 0, n, w, vec, out, n, sink); });
+  printf("reads %2d writes %d %s flat grid %6d  %7.3f ms %7.1f GB/s\n", NR, NW, lay, gflat, ms, gb / ms * 1e3);
+  fflush(stdout);
+}
+
+int main() {
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int64_t n = 100000000;   // multiple of 512
+  double *w, *out, *sink;
+  CK(hipMalloc(&w, (size_t)n * 24 * 8));
+  CK(hipMalloc(&out, (size_t)n * 8 * 8));
+  CK(hipMalloc(&sink, 64));
+  CK(hipMemset(w, 0, (size_t)n * 24 * 8));
+  CK(hipMemset(out, 0, (size_t)n * 8 * 8));
+  const double *vec = w + (size_t)n * 20;   // the 4 separate n-vectors of the tiled form
+  for (int pass = 0; pass < 2; ++pass) {
+    suite<24, 0, false>(n, w, vec, out, sink);
+    suite<24, 0, true>(n, w, vec, out, sink);
+    suite<24, 7, false>(n, w, vec, out, sink);
+    suite<24, 7, true>(n, w, vec, out, sink);
+    suite<22, 0, false>(n, w, vec, out, sink);
+    suite<22, 0, true>(n, w, vec, out, sink);
+    printf("\n");
+  }
+  return 0;
+}

@@ -74,3 +74,172 @@ def test_real32_trajectory_tolerance_sweep(env):
     # first iterations are identical decisions: tight agreement there
     for it in (1, 2, 3):
         assert got[it] == pytest.approx(f64[it], rel=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] (m = 20, REAL32): one-step parity of the fp32 MC = 20 / 32 kernels.
+# Every setulb return of the REAL32 oracle's trajectory is the INPUT state of one GPU call
+# (REAL32 context: fp32 storage, fp64 partial sums and host algebra).  The output is compared
+# with two CPU results computed from that same state:
+#   * the REAL64 oracle fed the state widened to fp64 ("what exact arithmetic on these fp32
+#     inputs gives"): the GPU must agree to fp32 STORAGE rounding -- a tolerance sweep records
+#     the tightest power of ten that holds per array, and asserts the bar below;
+#   * the REAL32 oracle (= the reference's -DREAL32 build, everything in fp32,
+#     src/lbfgsb_kinds_module.F90:29-37): agreement to fp32 ARITHMETIC noise.
+# Decisions (task, counters, iwhere) must equal at least one of the two -- near convergence the
+# all-fp32 line search and the fp64 one can legitimately part ways.
+# ---------------------------------------------------------------------------------------------
+def _widen(po, s):
+    f64 = np.float64
+    return po.State(s.n, s.m, s.x.astype(f64), s.g.astype(f64), s.f.astype(f64), s.wa.astype(f64),
+                    s.iwa.copy(), s.task.copy(), s.csave.copy(), s.lsave.copy(), s.isave.copy(),
+                    s.dsave.astype(f64))
+
+
+def _gpu_one_call_r32(env, p32, s):
+    po, torch, la = env["po"], env["torch"], env["la"]
+    sol = la.DeviceSolver(p32.n, p32.m, real32=True, mirror_index=True)
+    try:
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+        x, g = dev(s.x), dev(s.g)
+        l, u, nbd = dev(p32.l), dev(p32.u), dev(p32.nbd.astype(np.int32))
+        if not s.task_s.startswith("START"):
+            sol.import_state(s.wa, s.iwa, s.isave)
+        sol.task[:] = s.task
+        sol.csave[:] = s.csave
+        sol.lsave[:] = s.lsave
+        sol.isave[:] = s.isave
+        sol.dsave[:] = s.dsave.astype(np.float64)
+        sol.f[0] = float(s.f[0])
+        sol.setulb(x, l, u, nbd, g, p32.factr, p32.pgtol)
+        torch.cuda.synchronize()
+        wa, iwa = sol.export_state()
+        assert wa.dtype == np.float32
+        return po.State(p32.n, p32.m, x.cpu().numpy(), g.cpu().numpy(), sol.f.copy(), wa, iwa,
+                        sol.task.copy(), sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(),
+                        sol.dsave.copy())
+    finally:
+        sol.close()
+
+
+def _relerr(a, b, floor=0.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(float(np.max(np.abs(b))) if b.size else 0.0, floor, 1e-300)
+    return float(np.max(np.abs(a - b))) / scale if b.size else 0.0
+
+
+SWEEP = [10.0 ** -k for k in range(8, 1, -1)]       # 1e-8 ... 1e-2
+
+
+def _tightest(err):
+    for tol in SWEEP:
+        if err <= tol:
+            return tol
+    return float("inf")
+
+
+R32_CASES = [
+    ("quadmix20000_m20", dict(n=20000, m=20, mixed=True), 64),     # MC = 20: configs[4]'s kernels
+    ("quad6007_m17", dict(n=6007, m=17, mixed=False), 52),         # MC = 20, col < MC slots unused
+    ("quadmix3001_m25", dict(n=3001, m=25, mixed=True), 70),       # MC = 32, from-scratch formk
+]
+
+
+@pytest.mark.parametrize("name,spec,ncalls", R32_CASES, ids=[c[0] for c in R32_CASES])
+def test_real32_one_step_parity_m20(env, name, spec, ncalls):
+    po = env["po"]
+    n, m = spec["n"], spec["m"]
+    p32 = po.problem_quadratic(n, m, mixed_nbd=spec["mixed"], real=np.float32)
+    p64 = po.problem_quadratic(n, m, mixed_nbd=spec["mixed"])
+    e32, e64 = po.Engine("oracle_r32"), po.Engine("oracle")
+    snaps = []
+    po.run(e32, p32, max_calls=ncalls, snapshot=lambda k, s: snaps.append(s.copy()))
+    off = po.wa_offsets(n, m)
+    worst64, worst32 = {}, {}
+    tested = decided_by_r32_only = 0
+    for k in range(len(snaps) - 1):
+        s = snaps[k].copy()
+        t = s.task_s
+        if not (t.startswith("FG") or t.startswith("NEW_X")):
+            continue
+        if t.startswith("FG"):
+            s.f[0] = p32.fg(s.x, s.g)
+        got = _gpu_one_call_r32(env, p32, s)
+        exp32 = snaps[k + 1]
+        exp64 = _widen(po, s)
+        po.call(e64, p64, exp64)
+
+        def same_decisions(exp):
+            gi, ei = got.isave[21:44].copy(), exp.isave[21:44].copy()
+            gi[2] = ei[2] = 0
+            return (got.task_s == exp.task_s and np.array_equal(gi, ei)
+                    and np.array_equal(got.iwa[n:2 * n], exp.iwa[n:2 * n])
+                    and np.array_equal(got.iwa[:n], exp.iwa[:n]))
+        ok64, ok32 = same_decisions(exp64), same_decisions(exp32)
+        assert ok64 or ok32, "call %d (%s): decisions match neither oracle" % (k, t)
+        if not ok64:
+            decided_by_r32_only += 1
+            continue                       # compared the floats against a different branch otherwise
+        tested += 1
+        xs = float(np.max(np.abs(exp64.x)))
+
+        def errs(exp, into):
+            rows = {"x": _relerr(got.x, exp.x), "g": _relerr(got.g, exp.g), "f": _relerr(got.f, exp.f)}
+            for nm in ("z", "r", "d", "t", "xp", "ws", "wy"):
+                o, ln = off[nm]
+                rows[nm] = _relerr(got.wa[o:o + ln], exp.wa[o:o + ln], floor=xs * 1e-3)
+            for kk in (0, 3, 10, 11, 12, 13, 14, 15):          # theta dnorm gd stpmx sbgnrm stp gdold dtd
+                rows["dsave%d" % (kk + 1)] = _relerr([got.dsave[kk]], [exp.dsave[kk]], floor=1e-30)
+            for kk, v in rows.items():
+                into[kk] = max(into.get(kk, 0.0), v)
+        errs(exp64, worst64)
+        errs(exp32, worst32)
+    assert tested >= 20 and decided_by_r32_only <= 2, (tested, decided_by_r32_only)
+    table = {kk: (_tightest(worst64[kk]), _tightest(worst32[kk])) for kk in worst64}
+    print("\n%s: tightest tolerance that holds (vs REAL64-from-same-state, vs REAL32 oracle)" % name)
+    for kk, (a64, a32) in table.items():
+        print("   %-8s %8.0e %8.0e   (max err %.2e / %.2e)" % (kk, a64, a32, worst64[kk], worst32[kk]))
+    # the bars: storage rounding (2^-24 = 6e-8 per stored element) against exact arithmetic on the
+    # same fp32 inputs; differences of nearly equal vectors (d = z - x) carry that absolute error
+    # on a much smaller norm
+    for kk in ("x", "g", "z", "t", "r", "xp", "ws", "wy"):
+        assert worst64[kk] <= 1e-6, (kk, worst64[kk])
+    assert worst64["f"] <= 1e-6 and worst64["d"] <= 1e-3
+    for kk in ("dsave1", "dsave4", "dsave11", "dsave13", "dsave15", "dsave16"):
+        assert worst64[kk] <= 1e-3, (kk, worst64[kk])
+    # and fp32-arithmetic noise against the all-fp32 reference build
+    for kk in ("x", "z", "t", "r"):
+        assert worst32[kk] <= 1e-4, (kk, worst32[kk])
+
+
+def test_real32_config5_full_shape_anchors(env):
+    """BASELINE.json configs[4] at its stated size: n = 1e8, m = 20, REAL32, on-device objective.
+    Size-independent anchors measured on the reference: the first iteration walks
+    nseg = 97,671,921 Cauchy segments, iteration 2 has nfree = 49,999,496.  W = 16 GB of fp32."""
+    torch, la = env["torch"], env["la"]
+    n, m = 100_000_000, 20
+    free_b, _tot = torch.cuda.mem_get_info()
+    if free_b < 40 * (1 << 30):
+        pytest.skip("needs ~30 GB of HBM")
+    sol = la.DeviceSolver(n, m, real32=True)
+    x = torch.zeros(n, dtype=torch.float32, device="cuda")
+    g = torch.zeros_like(x)
+    l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+    nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    rows = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(0, x, g)
+        elif t.startswith("NEW_X"):
+            rows.append((int(sol.isave[29]), int(sol.isave[32]), int(sol.isave[37]), float(sol.f[0])))
+            if sol.isave[29] >= 3:
+                break
+        else:
+            break
+    sol.close()
+    del x, g, l, u, nbd
+    torch.cuda.empty_cache()
+    assert rows[0][1] == 97_671_921, rows
+    assert rows[1][2] == 49_999_496, rows
+    assert rows[2][3] < rows[1][3] < rows[0][3]
