@@ -1,0 +1,292 @@
+// k_cmprlb.hip -- cmprlb fused with W'r of subsm and formk's new row
+// (part of the gfx950 kernel set; kernels_common.hpp has the overview)
+#include "kernels_common.hpp"
+
+namespace lbk {
+
+// =========================== cmprlb (:1548-1586) =============================
+// cmprlb fused with the first matvec of subsm (:2742-2754): r_k depends only on row k, so
+// W'r is accumulated in the same pass that computes r (one pass over W instead of two).  Per
+// element the arithmetic is the reference's: r = -theta (z - x) - g, then + Wy(k,j) a1_j +
+// Ws(k,j) a2_j for j = 1..col in that order (:1565-1583).
+// NEWROW: the same pass also yields the new row/column of formk's WN1 (:1756-1793) for the
+// pair just stored (logical column col-1): with y = Wy_new, s = Ws_new,
+//   t1_j = sum_free y Wy_j, t2_j = sum_act s Ws_j, t3_j = sum_act s Wy_j, t4_j = sum_free Ws_j y.
+// slots: [0,MC) Wy'r | [MC,2MC) Ws'r | NEWROW: [2MC,3MC) t1 | [3MC,4MC) t2 | [4MC,5MC) t3 | [5MC,6MC) t4
+// r itself is NOT stored: its only consumer, subsm_update_kernel, streams the same operands
+// anyway and recomputes it bit for bit (a store stream costs this HBM-bound pass more than it
+// moves: +0.8 GB written = +0.45 ms at n = 1e8, profiles/scripts/cmprlb_wtv_variants.hip).
+template <typename T, int MC, bool NEWROW, bool NT>
+__global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
+    const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
+    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
+    const T *pd, Pend pe, double *part) {
+  constexpr int NA = NEWROW ? 6 * MC : 2 * MC;
+  double acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  for_rows<T, RowsPerAcc<T, MC, NA>::V>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], rv[W], a[MC][W], b[MC][W];
+    int iw[W];
+    ldx<W, NT>(g + i, gv);
+    if (!plain) {
+      ldx<W, NT>(x + i, xv);
+      ldi<W>(iwhere + i, iw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
+    }
+    load_cols<T, MC, W, NT>(wy, ws, pr, pd, i, col, head, m, ldw, pe, a, b);
+    fix_pending<T, MC, W>(col, pe, gv, a, b);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
+        rv[k] = -gv[k];
+      } else {
+        const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);  // only free rows are used
+        double rr = -theta * (zk - xv[k]) - gv[k];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+          if (j < col) rr = rr + a[j][k] * cf.a[j] + b[j][k] * cf.a[MAXM + j];
+        }
+        rv[k] = iw[k] <= 0 ? rr : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += a[j][k] * rv[k];
+        acc[MC + j] += b[j][k] * rv[k];
+      }
+    }
+    if constexpr (NEWROW) {
+      double yf[W], sa[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        double yn = 0.0, sn = 0.0;
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+          if (j == col - 1) {
+            yn = a[j][k];
+            sn = b[j][k];
+          }
+        yf[k] = iw[k] <= 0 ? yn : 0.0;  // free rows
+        sa[k] = iw[k] <= 0 ? 0.0 : sn;  // active rows
+      }
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          acc[2 * MC + j] += yf[k] * a[j][k];  // temp1 (:1764)
+          acc[3 * MC + j] += sa[k] * b[j][k];  // temp2 (:1769)
+          acc[4 * MC + j] += sa[k] * a[j][k];  // temp3 (:1770)
+          acc[5 * MC + j] += b[j][k] * yf[k];  // temp3 of the new column (:1789)
+        }
+      }
+    }
+  });
+  block_reduce_store<NA>(acc, NA, 0, 0, part, MAX_BLOCKS);
+}
+// The same pass for MC >= 20 with the new-row sums: 6*MC accumulators per lane do not fit the
+// register file (they spill to AGPRs and the pass runs one wave per SIMD at ~4 TB/s).  Here two
+// neighbouring lanes share the work on their two row groups: every lane still loads all columns
+// of its own rows (r needs them), but accumulates only ONE HALF of the columns -- for its own
+// rows and, through lane shuffles, for its neighbour's -- so 6*MC/2 accumulators suffice, and the
+// operands stay in storage precision until they are used.  Per-element arithmetic is unchanged;
+// the sums are merely grouped differently.  Rows without a neighbour (odd group count, scalar
+// tail) are loaded by both lanes 0 and 1 of the first workgroup, each taking its half.
+// fp64, m = 20, n = 1e8: 7.5 -> 5.4 ms (4.5 -> 6.3 TB/s).  Used for fp64 only: the fp32 build of
+// it is slower than the plain kernel (operand widening + ds_bpermute shuffles).
+template <typename T, int W, bool NT>
+__device__ __forceinline__ void ldraw(const T *p, T (&o)[W]) {
+  double t[W];
+  ldx<W, NT>(p, t);
+#pragma unroll
+  for (int k = 0; k < W; ++k) o[k] = (T)t[k];  // exact: t came from a T
+}
+// fp32 operand -> fp64 at the point of use.  Opaque to the optimiser on purpose: a plain cast
+// would be hoisted and shared with the earlier use, keeping all operands live as doubles.
+__device__ __forceinline__ double widen_late(float v) {
+  double d;
+  asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(v));
+  return d;
+}
+__device__ __forceinline__ double widen_late(double v) { return v; }
+template <typename T, int MC, bool NT>
+__global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
+    const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
+    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
+    const T *pd, Pend pe, double *part) {
+  constexpr int H = MC / 2, NA = 6 * H;
+  constexpr int V = RowsPer<T, MC>::V;
+  double acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane & 1;  // this lane sums columns [H, MC), its neighbour [0, H)
+  const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
+  const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
+  auto process = [&](int64_t i, auto wt, bool paired) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], rv[W], yf[W], sa[W];
+    T a[MC][W], b[MC][W];
+    int iw[W];
+    ldx<W, NT>(g + i, gv);
+    if (!plain) {
+      ldx<W, NT>(x + i, xv);
+      ldi<W>(iwhere + i, iw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) iw[k] = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw);
+      const bool pj = pe.on && j == col - 1;
+      ldraw<T, W, NT>(wy + ((pj ? dy : off) + i), a[j]);
+      ldraw<T, W, NT>(ws + ((pj ? ds : off) + i), b[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {  // the pending column, with the rounding of a store
+      const bool pj = pe.on && j == col - 1;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const T yk = (T)pend_y<T>(gv[k], (double)a[j][k]);
+        const T sk = (T)pend_s<T>((double)b[j][k], pe.stp);
+        a[j][k] = pj ? yk : a[j][k];
+        b[j][k] = pj ? sk : b[j][k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      double yn = 0.0, sn = 0.0;
+      if (plain) {
+        rv[k] = -gv[k];
+      } else {
+        const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);
+        double rr = -theta * (zk - xv[k]) - gv[k];
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+          if (j < col) rr = rr + (double)a[j][k] * cf.a[j] + (double)b[j][k] * cf.a[MAXM + j];
+        rv[k] = iw[k] <= 0 ? rr : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < MC; ++j)
+        if (j == col - 1) {
+          yn = (double)a[j][k];
+          sn = (double)b[j][k];
+        }
+      yf[k] = iw[k] <= 0 ? yn : 0.0;
+      sa[k] = iw[k] <= 0 ? 0.0 : sn;
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      double prv = 0.0, pyf = 0.0, psa = 0.0;
+      if (paired) {
+        prv = __shfl_xor(rv[k], 1);
+        pyf = __shfl_xor(yf[k], 1);
+        psa = __shfl_xor(sa[k], 1);
+      }
+#pragma unroll
+      for (int jj = 0; jj < H; ++jj) {
+        // own rows, own half of the columns
+        const double aj = widen_late(hi ? a[H + jj][k] : a[jj][k]);
+        const double bj = widen_late(hi ? b[H + jj][k] : b[jj][k]);
+        acc[jj] += aj * rv[k];
+        acc[H + jj] += bj * rv[k];
+        acc[2 * H + jj] += yf[k] * aj;
+        acc[3 * H + jj] += sa[k] * bj;
+        acc[4 * H + jj] += sa[k] * aj;
+        acc[5 * H + jj] += bj * yf[k];
+        if (paired) {  // the neighbour's rows: it sends the half it does not sum itself
+          const T sa_ = hi ? a[jj][k] : a[H + jj][k];
+          const T sb_ = hi ? b[jj][k] : b[H + jj][k];
+          const double paj = widen_late(__shfl_xor(sa_, 1));
+          const double pbj = widen_late(__shfl_xor(sb_, 1));
+          acc[jj] += paj * prv;
+          acc[H + jj] += pbj * prv;
+          acc[2 * H + jj] += pyf * paj;
+          acc[3 * H + jj] += psa * pbj;
+          acc[4 * H + jj] += psa * paj;
+          acc[5 * H + jj] += pbj * pyf;
+        }
+      }
+    }
+  };
+  const int64_t nv = n / V, nve = nv & ~(int64_t)1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nve; iv += stride)
+    process(iv * V, WTag<V>{}, true);
+  if (blockIdx.x == 0 && threadIdx.x < 2) {  // rows without a neighbour: both lanes, one half each
+    if (nv > nve) process(nve * V, WTag<V>{}, false);
+    for (int64_t rrow = nv * V; rrow < n; ++rrow) process(rrow, WTag<1>{}, false);
+  }
+  // lanes of equal parity hold the same slots: reduce over them, then across the 4 waves
+  __shared__ double sm[4][2][NA];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane < 2) sm[w][lane][k] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * NA; e += blockDim.x) {
+    const int par = e / NA, k = e % NA;
+    const double sum = ((sm[0][par][k] + sm[1][par][k]) + sm[2][par][k]) + sm[3][par][k];
+    const int grp = k / H, jj = k % H;
+    part[(size_t)(grp * MC + par * H + jj) * MAX_BLOCKS + blockIdx.x] = sum;
+  }
+}
+
+template <typename T>
+void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
+                       const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
+                       const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe) {
+  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  if (newrow && maxc_for(col) >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
+    if (maxc_for(col) == 20) {
+      if (q.nt)
+        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 20, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x,
+                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr, pd,
+                           pe, q.d_part);
+      else
+        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 20, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
+                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr,
+                           pd, pe, q.d_part);
+    } else {
+      if (q.nt)
+        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 32, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x,
+                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr, pd,
+                           pe, q.d_part);
+      else
+        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 32, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
+                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr,
+                           pd, pe, q.d_part);
+    }
+  } else if (newrow) {
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK), 0,
+                                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
+                                          head, col, theta, a, plain, pr, pd, pe, q.d_part));
+  } else {
+    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK), 0,
+                                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
+                                          head, col, theta, a, plain, pr, pd, pe, q.d_part));
+  }
+  q.launches++;
+  launch_finalize(q, gr, (newrow ? 6 : 2) * maxc_for(col), 0, 0);
+}
+
+// =========================== explicit instantiations =========================
+#define INSTANTIATE(T) \
+  template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double, const iw_t *, WStore<T>, int, int, double, const Coef &, int, int, const T *, const T *, Pend);
+INSTANTIATE(double)
+INSTANTIATE(float)
+#undef INSTANTIATE
+
+}  // namespace lbk

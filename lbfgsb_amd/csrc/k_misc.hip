@@ -1,0 +1,623 @@
+// k_misc.hip -- launch sizing, finalize, active/errclb, projgr, W'v, line-search vectors, objectives
+// (part of the gfx950 kernel set; kernels_common.hpp has the overview)
+#include "kernels_common.hpp"
+
+namespace lbk {
+
+int grid_for(int64_t n, int vec) {
+  // LBFGSB_GRID: cap on the number of workgroups (<= MAX_BLOCKS), for tuning experiments
+  static const int cap = [] {
+    const char *e = std::getenv("LBFGSB_GRID");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= MAX_BLOCKS ? v : MAX_BLOCKS;
+  }();
+  int64_t g = (n / vec + BLOCK - 1) / BLOCK;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// The passes over W keep 2-3 workgroups resident per CU (132-250 VGPRs): a grid of about that
+// many workgroups, each striding over more rows, reads 3-6 % faster than 2048 of them (sweep at
+// n = 1e8: 512 and 768 workgroups are equal, 1024+ slower).  LBFGSB_WGRID overrides.
+// (fp32, m = 10 measured the other way round -- 2048: 150 it/s, 768: 144 -- and keeps 2048.)
+int grid_for_w(int64_t n, int vec, int elem_bytes) {
+  static const int env_cap = [] {
+    const char *e = std::getenv("LBFGSB_WGRID");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= MAX_BLOCKS ? v : 0;
+  }();
+  const int cap = env_cap ? env_cap : (elem_bytes == 8 ? 768 : MAX_BLOCKS);
+  const int g = grid_for(n, vec);
+  return g > cap ? cap : g;
+}
+
+int maxc_for(int col) { return col <= 5 ? 5 : (col <= 10 ? 10 : (col <= 20 ? 20 : 32)); }
+
+// =========================== finalize ======================================
+// One workgroup per output slot: fixed-order sum / min / max of the per-block
+// partials.
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double *__restrict__ part,
+                                                         int pstride, int nblocks,
+                                                         double *__restrict__ res, int nsum,
+                                                         int nmin, int nmax) {
+  __shared__ double sm[BLOCK];
+  const int k = blockIdx.x;
+  const int op = k < nsum ? 0 : (k < nsum + nmin ? 1 : 2);
+  double v = op == 0 ? 0.0 : (op == 1 ? LB_INF : -LB_INF);
+  for (int b = threadIdx.x; b < nblocks; b += BLOCK) {
+    const double p = part[(size_t)k * pstride + b];
+    v = op == 0 ? v + p : (op == 1 ? fmin(v, p) : fmax(v, p));
+  }
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double a = sm[threadIdx.x], b = sm[threadIdx.x + s];
+      sm[threadIdx.x] = op == 0 ? a + b : (op == 1 ? fmin(a, b) : fmax(a, b));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) res[k] = sm[0];
+}
+
+void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int nsum,
+                          int nmin, int nmax) {
+  const int k = nsum + nmin + nmax;
+  if (k <= 0) return;
+  hipLaunchKernelGGL(finalize_kernel, dim3(k), dim3(BLOCK), 0, q.stream, part, pstride, nblocks,
+                     q.d_res + q.res_off, nsum, nmin, nmax);
+  q.launches++;
+}
+void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax) {
+  finalize_from(q, q.d_part, MAX_BLOCKS, nblocks, nsum, nmin, nmax);
+}
+
+// =========================== active / errclb ================================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void active_kernel(int64_t n, T *x, const T *l, const T *u,
+                                                       const int32_t *nbd, iw_t *iwhere,
+                                                       int8_t *wasfree, double *part) {
+  double acc[4] = {0, 0, 0, 0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W];
+    int nb[W], iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (nb[k] > 0) {
+        if (nb[k] <= 2 && xv[k] <= lv[k]) {
+          if (xv[k] < lv[k]) {
+            acc[0] += 1.0;
+            xv[k] = lv[k];
+          }
+          acc[3] += 1.0;
+        } else if (nb[k] >= 2 && xv[k] >= uv[k]) {
+          if (xv[k] > uv[k]) {
+            acc[0] += 1.0;
+            xv[k] = uv[k];
+          }
+          acc[3] += 1.0;
+        }
+      }
+      if (nb[k] != 2) acc[2] += 1.0;
+      if (nb[k] == 0) {
+        iw[k] = -1;
+      } else {
+        acc[1] += 1.0;
+        iw[k] = (nb[k] == 2 && uv[k] - lv[k] <= 0.0) ? 3 : 0;
+      }
+      wasfree[i + k] = 1;
+    }
+    st<W>(x + i, xv);
+    sti<W>(iwhere + i, iw);
+  });
+  block_reduce_store<4>(acc, 4, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd,
+                   iw_t *iwhere, int8_t *wasfree) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(active_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd,
+                     iwhere, wasfree, q.d_part);
+  q.launches++;
+  launch_finalize(q, g, 4, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void errclb_kernel(int64_t n, int64_t row0, const T *l,
+                                                       const T *u, const int32_t *nbd,
+                                                       double *part) {
+  double acc[2] = {0, 0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double lv[W], uv[W];
+    int nb[W];
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const double gi = (double)(row0 + i + k + 1);
+      if (nb[k] < 0 || nb[k] > 3) acc[0] = fmax(acc[0], gi);
+      if (nb[k] == 2 && lv[k] > uv[k]) acc[1] = fmax(acc[1], gi);
+    }
+  });
+  block_reduce_store<2>(acc, 0, 0, 2, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
+                   const int32_t *nbd) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(errclb_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, row0, l, u, nbd,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, g, 0, 0, 2);
+}
+
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void projgr_kernel(int64_t n, const T *x, const T *l,
+                                                       const T *u, const int32_t *nbd,
+                                                       const T *g, double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W];
+    int nb[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[0] = fmax(acc[0], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
+  });
+  block_reduce_store<1>(acc, 0, 0, 1, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
+                   const T *g) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(projgr_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 0, 1);
+}
+
+// =========================== W'v ============================================
+// The WS/WY correction-pair matvec: out[j] = sum_i Wy(i,j) v_i,
+// out[col+j] = sum_i Ws(i,j) v_i.  Algorithmic bytes (2 col + 1) n s.
+// Per lane and trip: 2*MC + 1 independent 16-byte loads in flight.
+template <typename T, int MC, bool NT>
+__global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restrict__ ws,
+                                                    const T *__restrict__ wy, int64_t ldw, int m,
+                                                    int head, int col, const T *__restrict__ v,
+                                                    double *part) {
+  double acc[2 * MC];
+#pragma unroll
+  for (int k = 0; k < 2 * MC; ++k) acc[k] = 0.0;
+  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double vv[W], a[MC][W], b[MC][W];
+    ldx<W, NT>(v + i, vv);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i;
+      ld_col<T, W, NT>(j < col, wy + off, a[j]);
+      ld_col<T, W, NT>(j < col, ws + off, b[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += a[j][k] * vv[k];
+        acc[MC + j] += b[j][k] * vv[k];
+      }
+    }
+  });
+  // slots [0..MC) = Wy' v, [MC..2MC) = Ws' v; entries >= col are discarded by the host
+  block_reduce_store<2 * MC>(acc, 2 * MC, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
+  const int g = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((wtv_kernel<T, MC, NTV>), dim3(g), dim3(BLOCK), 0, q.stream, n,
+                                        w.ws, w.wy, w.ld, w.m, head, col, v, q.d_part));
+  q.launches++;
+}
+template <typename T>
+void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
+  launch_wtv_nofinalize(q, n, w, head, col, v);
+  launch_finalize(q, grid_for_w(n, VecOf<T>::V, (int)sizeof(T)), 2 * maxc_for(col), 0, 0);
+}
+
+
+// Store a pending pair into its W slot without a subspace pass (subsm skipped, from-scratch
+// formk, ...): Wy(:,slot) = T(g - r), Ws(:,slot) = T(stp*d).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pair_commit_kernel(int64_t n, const T *__restrict__ g,
+                                                            const T *__restrict__ r,
+                                                            const T *__restrict__ d, double stp,
+                                                            T *cwy, T *cws) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double gv[W], rv[W], dv[W];
+    ld<W>(g + i, gv);
+    ld<W>(r + i, rv);
+    ld<W>(d + i, dv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rv[k] = pend_y<T>(gv[k], rv[k]);
+      dv[k] = pend_s<T>(dv[k], stp);
+    }
+    st<W>(cwy + i, rv);
+    st<W>(cws + i, dv);
+  });
+}
+template <typename T>
+void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
+                        WStore<T> w, int head, int col) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;
+  hipLaunchKernelGGL(pair_commit_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, g, r, d, pe.stp,
+                     w.wy + slot, w.ws + slot);
+  q.launches++;
+}
+
+// The Cauchy point as a vector, by the same per-row rule the fused passes use (xcp_row).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void xcp_fill_kernel(
+    int64_t n, const T *__restrict__ x, const T *__restrict__ g, const T *__restrict__ l,
+    const T *__restrict__ u, const iw_t *__restrict__ iwhere, double tsum, T *dst) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W], lv[W], uv[W], out[W];
+    int iw[W];
+    ld<W>(x + i, xv);
+    ld<W>(g + i, gv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(iwhere + i, iw);
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[k] = xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], tsum);
+    st<W>(dst + i, out);
+  });
+}
+template <typename T>
+void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
+                     const iw_t *iwhere, double tsum, T *dst) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(xcp_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, l, u, iwhere,
+                     tsum, dst);
+  q.launches++;
+}
+
+// backtracking ratio of one free variable (:2842-2857); 2.0 = no restriction
+__device__ __forceinline__ double bt_ratio(double dk, double x, double l, double u, int nb) {
+  double c = 2.0;
+  if (nb != 0) {
+    if (dk < 0.0 && nb <= 2) {
+      const double t2 = l - x;
+      c = t2 >= 0.0 ? 0.0 : t2 / dk;
+    } else if (dk > 0.0 && nb >= 2) {
+      const double t2 = u - x;
+      c = t2 <= 0.0 ? 0.0 : t2 / dk;
+    }
+  }
+  return c;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void subsm_alpha_kernel(int64_t n, int64_t row0,
+                                                            const T *__restrict__ xp,
+                                                            const T *__restrict__ r,
+                                                            const T *__restrict__ l,
+                                                            const T *__restrict__ u,
+                                                            const int32_t *__restrict__ nbd,
+                                                            const iw_t *__restrict__ iwhere,
+                                                            int pass, double alpha, double *part) {
+  double acc[1] = {pass == 0 ? 1.0 : LB_INF};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (iwhere[i] > 0) continue;
+    const double c = bt_ratio((double)r[i], (double)xp[i], (double)l[i], (double)u[i], nbd[i]);
+    if (pass == 0)
+      acc[0] = fmin(acc[0], c);
+    else if (c == alpha)
+      acc[0] = fmin(acc[0], (double)(row0 + i));
+  }
+  block_reduce_store<1>(acc, 0, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l, const T *u,
+                        const int32_t *nbd, const iw_t *iwhere) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, (int64_t)0, xp,
+                     r, l, u, nbd, iwhere, 0, 0.0, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 1, 0);
+}
+template <typename T>
+void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const T *r, const T *l,
+                           const T *u, const int32_t *nbd, const iw_t *iwhere, double alpha) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, xp, r, l,
+                     u, nbd, iwhere, 1, alpha, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 0, 1, 0);
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void subsm_backtrack_kernel(int64_t n, int64_t row0, T *z,
+                                                                const T *__restrict__ xp, T *r,
+                                                                const T *__restrict__ l,
+                                                                const T *__restrict__ u,
+                                                                const iw_t *__restrict__ iwhere,
+                                                                double alpha, int64_t ibd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double xk = (double)xp[i];
+    if (iwhere[i] <= 0) {
+      double dk = (double)r[i];
+      if (alpha < 1.0 && row0 + i == ibd) {  // :2865-2875
+        if (dk > 0.0) {
+          xk = (double)u[i];
+          dk = 0.0;
+        } else if (dk < 0.0) {
+          xk = (double)l[i];
+          dk = 0.0;
+        }
+        r[i] = (T)dk;
+      }
+      xk = xk + alpha * dk;
+    }
+    z[i] = (T)xk;
+  }
+}
+template <typename T>
+void launch_subsm_backtrack(Queue &q, int64_t n, int64_t row0, T *z, const T *xp, T *r, const T *l,
+                            const T *u, const iw_t *iwhere, double alpha, int64_t ibd) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_backtrack_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, z, xp,
+                     r, l, u, iwhere, alpha, ibd);
+  q.launches++;
+}
+
+// =========================== lnsrlb (:2174-2275) =============================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void lnsrlb_begin_kernel(
+    int64_t n, const T *__restrict__ z, const T *__restrict__ x, const T *__restrict__ g,
+    const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd, T *d, T *t,
+    T *r, int do_stpmx, double *part) {
+  double acc[3] = {0.0, 0.0, 1.0e10};  // dtd, gd, stpmx (big, :2189)
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double zv[W], xv[W], gv[W], dv[W], lv[W], uv[W];
+    int nb[W];
+    ld<W>(z + i, zv);
+    ld<W>(x + i, xv);
+    ld<W>(g + i, gv);
+    if (do_stpmx) {
+      ld<W>(l + i, lv);
+      ld<W>(u + i, uv);
+      ldi<W>(nbd + i, nb);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      dv[k] = zv[k] - xv[k];  // mainlb :720-722
+      acc[0] = acc[0] + dv[k] * dv[k];
+      acc[1] = acc[1] + gv[k] * dv[k];
+      if (do_stpmx && nb[k] != 0) {  // :2206-2225
+        const double a1 = dv[k];
+        if (a1 < 0.0 && nb[k] <= 2) {
+          const double a2 = lv[k] - xv[k];
+          acc[2] = fmin(acc[2], a2 >= 0.0 ? 0.0 : a2 / a1);
+        } else if (a1 > 0.0 && nb[k] >= 2) {
+          const double a2 = uv[k] - xv[k];
+          acc[2] = fmin(acc[2], a2 <= 0.0 ? 0.0 : a2 / a1);
+        }
+      }
+    }
+    st<W>(d + i, dv);
+    st<W>(t + i, xv);
+    st<W>(r + i, gv);
+  });
+  block_reduce_store<3>(acc, 2, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_lnsrlb_begin(Queue &q, int64_t n, const T *z, const T *x, const T *g, const T *l,
+                         const T *u, const int32_t *nbd, T *d, T *t, T *r, int do_stpmx) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(lnsrlb_begin_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, z, x, g, l, u,
+                     nbd, d, t, r, do_stpmx, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 2, 1, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void lnsrlb_step_kernel(int64_t n, T *x,
+                                                            const T *__restrict__ z,
+                                                            const T *__restrict__ d,
+                                                            const T *__restrict__ t, double stp) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double o[W];
+    if (stp == 1.0) {
+      ld<W>(z + i, o);  // bit copy of z keeps exact bound values (:2264-2265)
+    } else {
+      double dv[W], tv[W];
+      ld<W>(d + i, dv);
+      ld<W>(t + i, tv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) o[k] = stp * dv[k] + tv[k];
+    }
+    st<W>(x + i, o);
+  });
+}
+template <typename T>
+void launch_lnsrlb_step(Queue &q, int64_t n, T *x, const T *z, const T *d, const T *t,
+                        double stp) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(lnsrlb_step_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, z, d, t, stp);
+  q.launches++;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void lnsrlb_eval_kernel(int64_t n, const T *__restrict__ x,
+                                                            const T *__restrict__ l,
+                                                            const T *__restrict__ u,
+                                                            const int32_t *__restrict__ nbd,
+                                                            const T *__restrict__ g,
+                                                            const T *__restrict__ d, double *part) {
+  double acc[2] = {0.0, 0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], lv[W], uv[W], gv[W], dv[W];
+    int nb[W];
+    ld<W>(x + i, xv);
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ld<W>(g + i, gv);
+    ld<W>(d + i, dv);
+    ldi<W>(nbd + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      acc[0] = acc[0] + gv[k] * dv[k];
+      acc[1] = fmax(acc[1], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
+    }
+  });
+  block_reduce_store<2>(acc, 1, 0, 1, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
+                        const int32_t *nbd, const T *g, const T *d) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(lnsrlb_eval_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
+                     d, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 1, 0, 1);
+}
+
+// =========================== built-in objectives =============================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void obj_quadratic_kernel(int64_t n, int64_t row0,
+                                                              const T *__restrict__ x, T *g,
+                                                              int nt, double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], gv[W];
+    ld<W>(x + i, xv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const int64_t gi = row0 + i + k + 1;
+      const double a = 1.0 + 99.0 * (double)((7919 * gi) % 10007) / 10006.0;
+      const double c = -2.0 + 4.0 * (double)((104729 * gi) % 100003) / 100002.0;
+      const double dx = xv[k] - c;
+      gv[k] = a * dx;
+      acc[0] = acc[0] + a * dx * dx;
+    }
+    // large problems: stream g out, so that no dirty lines linger in the cache hierarchy and
+    // drain into the read-only pass that follows
+    if (nt)
+      stnt<W>(g + i, gv);
+    else
+      st<W>(g + i, gv);
+  });
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(obj_quadratic_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, g, q.nt ? 1 : 0,
+                     q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 1, 0, 0);
+}
+// rows [row0, row0+n) of the chain; xl / xr = the neighbours' boundary elements x(row0-1),
+// x(row0+n) (1-element halo, exchanged by the caller; unused at the global ends)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void obj_rosenbrock_kernel(int64_t n, int64_t row0,
+                                                               int64_t nglob,
+                                                               const T *__restrict__ x, T *g,
+                                                               double xl, double xr, int nt,
+                                                               double *part) {
+  double acc[1] = {0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double xi = (double)x[i];
+    const int64_t gi_ = row0 + i;
+    double gi;
+    if (gi_ == 0) {
+      const double xp1 = i + 1 < n ? (double)x[i + 1] : xr;
+      const double t1 = xp1 - xi * xi;
+      gi = 2.0 * (xi - 1.0) - 16.0 * xi * t1;
+      acc[0] = acc[0] + 0.25 * ((xi - 1.0) * (xi - 1.0));
+    } else {
+      const double xm = i > 0 ? (double)x[i - 1] : xl;
+      const double t2 = xi - xm * xm;
+      acc[0] = acc[0] + t2 * t2;
+      if (gi_ == nglob - 1) {
+        gi = 8.0 * t2;
+      } else {
+        const double xp1 = i + 1 < n ? (double)x[i + 1] : xr;
+        const double t1 = xp1 - xi * xi;
+        gi = 8.0 * t2 - 16.0 * xi * t1;
+      }
+    }
+    if (nt)
+      __builtin_nontemporal_store((T)gi, g + i);  // (see obj_quadratic_kernel)
+    else
+      g[i] = (T)gi;
+  }
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, const T *x, T *g,
+                           double xl, double xr) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, nglob,
+                     x, g, xl, xr, q.nt ? 1 : 0, q.d_part);
+  q.launches++;
+  launch_finalize(q, gr, 1, 0, 0);
+}
+// first and last local element, as doubles, into out[0..1] (halo message)
+template <typename T>
+__global__ void halo_pack_kernel(int64_t n, const T *__restrict__ x, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = (double)x[0];
+    out[1] = (double)x[n - 1];
+  }
+}
+template <typename T>
+void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
+  hipLaunchKernelGGL(halo_pack_kernel<T>, dim3(1), dim3(64), 0, q.stream, n, x, out);
+  q.launches++;
+}
+
+// =========================== explicit instantiations =========================
+#define INSTANTIATE(T) \
+  template void launch_active<T>(Queue &, int64_t, T *, const T *, const T *, const int32_t *, iw_t *, int8_t *); \
+  template void launch_errclb<T>(Queue &, int64_t, int64_t, const T *, const T *, const int32_t *); \
+  template void launch_projgr<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *); \
+  template void launch_wtv<T>(Queue &, int64_t, WStore<T>, int, int, const T *); \
+  template void launch_wtv_nofinalize<T>(Queue &, int64_t, WStore<T>, int, int, const T *); \
+  template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *, const T *, const iw_t *, double, T *); \
+  template void launch_subsm_alpha<T>(Queue &, int64_t, const T *, const T *, const T *, const T *, const int32_t *, const iw_t *); \
+  template void launch_subsm_argalpha<T>(Queue &, int64_t, int64_t, const T *, const T *, const T *, const T *, const int32_t *, const iw_t *, double); \
+  template void launch_subsm_backtrack<T>(Queue &, int64_t, int64_t, T *, const T *, T *, const T *, const T *, const iw_t *, double, int64_t); \
+  template void launch_lnsrlb_begin<T>(Queue &, int64_t, const T *, const T *, const T *, const T *, const T *, const int32_t *, T *, T *, T *, int); \
+  template void launch_lnsrlb_step<T>(Queue &, int64_t, T *, const T *, const T *, const T *, double); \
+  template void launch_lnsrlb_eval<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *); \
+  template void launch_pair_commit<T>(Queue &, int64_t, const T *, const T *, const T *, Pend, WStore<T>, int, int); \
+  template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *); \
+  template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *, double, double); \
+  template void launch_halo_pack<T>(Queue &, int64_t, const T *, double *);
+INSTANTIATE(double)
+INSTANTIATE(float)
+#undef INSTANTIATE
+
+}  // namespace lbk

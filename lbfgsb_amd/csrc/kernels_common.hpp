@@ -1,0 +1,203 @@
+// kernels_common.hpp / k_*.hip -- hand-written gfx950 (CDNA4) kernels for the n-dimensional work
+// of the L-BFGS-B iteration (reference src/lbfgsb.f90, routines cited per kernel).
+//
+// Shape of every kernel: tall-skinny, HBM-bound, no reuse.  One lane owns V
+// consecutive rows (16 B per array per load, dwordx4), grid-stride over rows,
+// <= 2048 workgroups of 4 wave64.  The correction-pair matrices Ws, Wy are
+// column-major with a 256-byte aligned leading dimension, so lane i of a wave
+// reads 16 B at column_base + 16*i: every wave-instruction is one fully
+// coalesced 1 KiB request per column.  Reductions: per-lane fp64 accumulators
+// -> wave shuffle -> LDS across the 4 waves -> one partial per workgroup ->
+// fixed-order finalize kernel (deterministic; no float atomics).  2m <= 64
+// columns is far too thin for MFMA: the flop/byte ratio is <= 2 (fp64), the
+// machine balance ~10, so the roofline is HBM bandwidth.
+//
+// Column loops are unrolled to a compile-time MAXC; logical columns >= col are
+// redirected to logical column 0 (an L1/L2 hit, no HBM traffic) and their
+// results discarded, which keeps every load unconditional and in flight
+// together.
+//
+// kernels_common.hpp -- pieces shared by the kernel translation units (k_*.hip): launch-size
+// helpers, the column-count dispatch macros, the circular column addressing of W, the pending
+// pair, and small per-row formulas that several kernels must evaluate identically.
+#pragma once
+#include "kernels.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "device_util.hpp"
+
+namespace lbk {
+
+#define LB_INF (__builtin_huge_val())
+
+// the same, also selecting the load policy at run time (q.nt)
+#define DISPATCH_MAXC_NT(col, ntflag, ...)   \
+  do {                                        \
+    if (ntflag) {                             \
+      constexpr bool NTV = true;              \
+      DISPATCH_MAXC(col, __VA_ARGS__);        \
+    } else {                                  \
+      constexpr bool NTV = false;             \
+      DISPATCH_MAXC(col, __VA_ARGS__);        \
+    }                                         \
+  } while (0)
+
+#define DISPATCH_MAXC(col, ...)       \
+  do {                                \
+    if ((col) <= 5) {                 \
+      constexpr int MC = 5;           \
+      __VA_ARGS__;                    \
+    } else if ((col) <= 10) {         \
+      constexpr int MC = 10;          \
+      __VA_ARGS__;                    \
+    } else if ((col) <= 20) {         \
+      constexpr int MC = 20;          \
+      __VA_ARGS__;                    \
+    } else {                          \
+      constexpr int MC = 32;          \
+      __VA_ARGS__;                    \
+    }                                 \
+  } while (0)
+
+// physical column offset (elements) of logical column j; j >= col -> logical 0
+__device__ __forceinline__ int64_t col_off(int j, int col, int head, int m, int64_t ld) {
+  const int jj = j < col ? j : 0;
+  return (int64_t)((head - 1 + jj) % m) * ld;
+}
+// Unroll slots beyond the stored pairs (the kernels are unrolled to MC = 5/10/20/32 columns;
+// e.g. the update pass at col - 1 = 9 old columns runs the MC = 10 code).  col_off sends such a
+// slot to column 0 again, and with nontemporal loads that second request goes to HBM like the
+// first (PMC: +1.3 GB per launch at n = 1e8).  The fp64 kernels therefore skip the load; the
+// fp32 kernels, which already live at the register limit, lose 2x to the guarded form and keep
+// the duplicate load.
+template <typename T, int W, bool NT>
+__device__ __forceinline__ void ld_col(bool live, const T *p, double (&o)[W]) {
+  if constexpr (sizeof(T) == 8) {
+    if (live) {
+      ldx<W, NT>(p, o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) o[k] = 0.0;
+    }
+  } else {
+    ldx<W, NT>(p, o);
+  }
+}
+
+// ---- pending pair ----
+// Between matupd and the subspace pass of the same setulb call the newest pair (logical column
+// col-1) is not in W yet: update_scan_kernel only reduces, so that it stays a read-only pass
+// (a single store stream drops a streaming pass on MI355X from ~6.5 to ~4.8 TB/s,
+// profiles/scripts/write_cost.hip).  Until subsm_update_kernel -- which stores vectors anyway --
+// commits it, the column is defined by the vectors it was formed from, with the rounding of a
+// store to T:   y = T(g - r),   s = T(stp * d)   (mainlb :813-822, matupd :2313-2314).
+template <typename T>
+__device__ __forceinline__ double pend_y(double gk, double rk) {
+  return (double)(T)(gk - rk);
+}
+template <typename T>
+__device__ __forceinline__ double pend_s(double dk, double stp) {
+  return stp != 1.0 ? (double)(T)(stp * dk) : dk;
+}
+// columns j = 0..MC-1 of one row group; the pending column is read from (r, d) instead
+template <typename T, int MC, int W, bool NT>
+__device__ __forceinline__ void load_cols(const T *__restrict__ wy, const T *__restrict__ ws,
+                                          const T *pr, const T *pd, int64_t i, int col, int head,
+                                          int m, int64_t ldw, Pend pe, double (&a)[MC][W],
+                                          double (&b)[MC][W]) {
+  // one base pointer per matrix and a selected element offset (selecting between two base
+  // pointers per column makes the compiler keep a table of addresses in scratch memory);
+  // all buffers are allocations of T, so the distances are whole elements
+  const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
+  const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
+#pragma unroll
+  for (int j = 0; j < MC; ++j) {
+    const int64_t off = col_off(j, col, head, m, ldw);
+    const bool pj = pe.on && j == col - 1;
+    ld_col<T, W, NT>(j < col, wy + ((pj ? dy : off) + i), a[j]);
+    ld_col<T, W, NT>(j < col, ws + ((pj ? ds : off) + i), b[j]);
+  }
+}
+template <typename T, int MC, int W>
+__device__ __forceinline__ void fix_pending(int col, Pend pe, const double (&gv)[W],
+                                            double (&a)[MC][W], double (&b)[MC][W]) {
+  // branch-free selects: a predicated write a[col-1][k] = ... would turn the register arrays
+  // into dynamically indexed ones (scratch memory)
+#pragma unroll
+  for (int j = 0; j < MC; ++j) {
+    const bool pj = pe.on && j == col - 1;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const double yk = pend_y<T>(gv[k], a[j][k]);
+      const double sk = pend_s<T>(b[j][k], pe.stp);
+      a[j][k] = pj ? yk : a[j][k];
+      b[j][k] = pj ? sk : b[j][k];
+    }
+  }
+}
+
+// fixed-order reduction of per-block partials (k_misc.hip)
+void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int nsum, int nmin,
+                   int nmax);
+
+// ---- projgr (:2594-2622) of one row ----
+__device__ __forceinline__ double proj_g(double x, double l, double u, int nb, double gi) {
+  if (nb != 0) {
+    if (gi < 0.0) {
+      if (nb >= 2) gi = fmax(x - u, gi);
+    } else {
+      if (nb <= 2) gi = fmin(x - l, gi);
+    }
+  }
+  return fabs(gi);
+}
+
+// ---- ordering of breakpoints ----
+__device__ __forceinline__ bool after_cursor(double t, int64_t gi, double lo_t, int64_t lo_i) {
+  return t > lo_t || (t == lo_t && gi > lo_i);
+}
+__device__ __forceinline__ uint64_t key_of(double t) {  // t >= 0: bit pattern is monotone
+  return (uint64_t)__double_as_longlong(t);
+}
+
+// Breakpoint time of one row from its own data, exactly as the scans store it in tbrk (incl.
+// the rounding to T): -1 = the row does not move, +inf = it moves without meeting a bound.
+// iw is iwhere AFTER the scan's update (cauchy :1284-1291).
+template <typename T>
+__device__ __forceinline__ double brk_time(double xk, double lk, double uk, int nb, double gk,
+                                           int iw) {
+  if (iw != 0 && iw != -1) return -1.0;
+  const double neggi = -gk;
+  double tb = LB_INF;
+  if (nb <= 2 && nb != 0 && neggi < 0.0) {
+    tb = (xk - lk) / (-neggi);
+  } else if (nb >= 2 && neggi > 0.0) {
+    tb = (uk - xk) / neggi;
+  }
+  return (double)(T)tb;
+}
+
+// The generalized Cauchy point is not stored as a vector on the main path: after the walk,
+// xcp(k) is a function of row k's own x, g, bounds and iwhere (cauchy :1341, :1425-1433, :1515):
+//   iwhere in {0,-1} (the row moves with d = -g and was not fixed):  x + tsum*d
+//   iwhere == 1 / 2 (at its lower/upper bound, before or by this walk): that bound
+//   otherwise (always fixed, or free with zero gradient): x
+// Every consumer evaluates exactly the expression cauchy_finish_kernel stores (incl. the
+// rounding to T), so results do not depend on whether z was materialised.
+template <typename T>
+__device__ __forceinline__ double xcp_free(double xk, double gk, int iw, double tsum) {
+  if ((iw == 0 || iw == -1) && tsum != 0.0) return (double)(T)(xk + tsum * (-gk));
+  return xk;
+}
+template <typename T>
+__device__ __forceinline__ double xcp_row(double xk, double gk, int iw, double lk, double uk,
+                                          double tsum) {
+  if (tsum == 0.0) return xk;  // a walk that fixed a row has tsum >= its breakpoint > 0
+  if (iw == 1) return xk == lk ? xk : lk;
+  if (iw == 2) return xk == uk ? xk : uk;
+  return xcp_free<T>(xk, gk, iw, tsum);
+}
+
+}  // namespace lbk
