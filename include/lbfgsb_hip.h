@@ -49,7 +49,7 @@ enum {
                                 that lbfgsb_hip_export_state reproduces `iwa` */
   LBFGSB_F_NO_RETURN_SYNC = 4, /* the caller evaluates f,g on the SAME stream: do not block the
                                 host when returning task='FG_LNSRCH' (x is ordered by the stream) */
-  LBFGSB_F_PARALLEL_GCP = 8  /* OPT-IN deviation from the reference's arithmetic: when no pair is
+  LBFGSB_F_PARALLEL_GCP = 8, /* OPT-IN deviation from the reference's arithmetic: when no pair is
                                 stored (col = 0: first iteration, after every memory refresh -- the
                                 calls where nseg ~ n) the model Hessian is theta*I, the derivative
                                 along the projected path is -(1 - theta t) * sum_{t_j >= t} d_j^2,
@@ -65,6 +65,17 @@ enum {
                                 scans of the walk's state on the device -- again the reference's
                                 result in exact arithmetic, without the clamp.  Short walks and
                                 multi-rank contexts always replay the walk exactly. */
+  LBFGSB_F_EXACT_TIES = 16   /* Breakpoints with EQUAL t are handed to the walk in variable order; the
+                                reference pops them in the order of hpsolb's heap (src/lbfgsb.f90:2079,
+                                used at :1384-1403).  Sums over a whole group of equal breakpoints
+                                are merely reassociated; the two orders differ in effect only when
+                                the walk ends INSIDE such a group -- then the order decides which of
+                                its variables are fixed at their bounds.  Such calls are detected
+                                and counted (lbfgsb_hip_tie_splits).  With this flag they are
+                                replayed from the start of the walk in the reference's own order:
+                                all breakpoint times travel to the host (O(n) bytes + an O(n) heap
+                                build), so the active set equals the reference's bit for bit.
+                                Single-rank contexts. */
 };
 
 /* -------------------------------------------------------------------------
@@ -118,12 +129,25 @@ int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const voi
                           char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave,
                           double *dsave);
 
+/* Stream ordering.  Every kernel of a context runs on ITS stream (the one given to
+ * lbfgsb_hip_create, or a private non-blocking stream).  On an 'FG...' re-entry the library
+ * reads g (and x, if the caller touched it) on that stream: whatever produced them must be
+ * complete, or ordered before the context's stream.  Either evaluate f,g on the context's
+ * stream (lbfgsb_hip_get_stream), or call lbfgsb_hip_wait_stream(ctx, producer_stream) before
+ * the re-entry -- it records an event on producer_stream and makes the context's stream wait
+ * for it, without blocking the host -- or synchronise the producer.  Unless
+ * LBFGSB_F_NO_RETURN_SYNC is set, an 'FG...' RETURN has already synchronised the context's
+ * stream, so x may be read from any stream. */
+void *lbfgsb_hip_get_stream(lbfgsb_hip_ctx *ctx);
+int lbfgsb_hip_wait_stream(lbfgsb_hip_ctx *ctx, void *producer_stream);
+
 /* -------------------------------------------------------------------------
  * setulb, host-pointer form: the exact reference signature (what the Fortran
  * shim binds).  x,l,u,g are host arrays of the real kind, nbd/iwa/isave
  * default integers (int32), lsave int32.  The context handle is kept in
  * isave(17:18) (never touched by the reference, src/lbfgsb.f90:250-284),
- * created on task='START' and released when a terminal task is returned.
+ * created on task='START' and released when a terminal task is returned (or by
+ * lbfgsb_hip_release_host).
  * x and g travel over PCIe on every FG return; `wa`'s t-slot
  * (wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175) and, when
  * iprint >= 0, nothing else of wa/iwa is written unless mirror != 0, in which
@@ -135,6 +159,14 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
                            void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
                            int32_t *lsave, int32_t *isave, void *dsave,
                            const char *iteration_file, int32_t real_bytes, int32_t mirror);
+/* A caller that leaves its loop without a terminal task FROM the library -- the reference's own
+ * driver2/driver3 set task = 'STOP...' and exit (test/driver2.f90:174-195) -- releases the
+ * context of the host-pointer form with this call (the Fortran module exports it as
+ * lbfgsb_release).  isave(17:18) hold a registry id + tag, never a raw pointer: a stale or
+ * garbage isave is refused (LBFGSB_E_STATE), a 'START' over a live id frees the old context
+ * first, and whatever is still registered is freed when the process exits.  isave(1:16)
+ * receive the reference's wa offsets (:250-265), saturated at INT32_MAX instead of wrapped. */
+int lbfgsb_hip_release_host(int32_t *isave);
 
 /* -------------------------------------------------------------------------
  * Convenience driver around lbfgsb_hip_setulb_dev -- the "high-level wrapper so the user
@@ -216,6 +248,10 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  * and the seconds the host spent blocked waiting for the stream */
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
                      int64_t *cauchy_fullsorts, double *wait_seconds);
+
+/* number of setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints
+ * (see LBFGSB_F_EXACT_TIES) */
+int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count);
 
 /* In-run clocks of the three passes over W of an iteration (hipEvents on the context's stream
  * around every launch, read back at the next host sync): [0] cmprlb_wtv_kernel, [1]

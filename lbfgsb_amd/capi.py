@@ -27,6 +27,10 @@ PROTOTYPES = {
                                          C.c_double, C.c_double, _vp, _vp, _vp, C.c_int32, _vp,
                                          _vp, _vp, _vp, _cp, C.c_int32, C.c_int32]),
     "lbfgsb_hip_pass_clock": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "lbfgsb_hip_get_stream": (C.c_void_p, [_vp]),
+    "lbfgsb_hip_wait_stream": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_release_host": (C.c_int, [_vp]),
+    "lbfgsb_hip_tie_splits": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_minimize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_export_state": (C.c_int, [_vp, _vp, _vp]),
@@ -46,6 +50,7 @@ F_REAL32 = 1
 F_MIRROR_INDEX = 2
 F_NO_RETURN_SYNC = 4
 F_PARALLEL_GCP = 8
+F_EXACT_TIES = 16
 
 
 class LbfgsbError(RuntimeError):

@@ -199,6 +199,122 @@ __device__ __forceinline__ void sti(int32_t *p, const int (&o)[W]) {
   }
 }
 
+// ---- loads the kernel schedules itself ("raw" loads) -------------------------------------
+// The passes over W want ALL loads of a trip (2*MC columns + the n-vectors) in flight before the
+// first use.  hipcc does not do that by itself when the loop body is cut into basic blocks
+// (guards around single loads) or when every loaded fp32 value is widened at once (fp32, m = 20:
+// load, s_waitcnt vmcnt(0), convert, next load -- a wave that runs alone on its SIMD then pays
+// one memory latency per COLUMN; round 1's 3.7 TB/s).  So the kernels (a) load into register
+// images of the STORAGE type (RawReg: nothing to convert, nothing to wait for), all of them in
+// one straight-line run, (b) put a scheduling barrier behind the run (raw_wait: no instruction
+// crosses it), and (c) convert where the value is used (raw_get).  These are ordinary loads: the
+// compiler tracks them and inserts every s_waitcnt itself (counted waits across the pipelined
+// trips of for_rows_raw included) -- an inline-asm load would be faster to pin down but is
+// unsafe here: with more than 256 live registers the register allocator moves an asm load's
+// destination to the accumulator file BEFORE the data has landed.
+// Protocol, per trip:  raw_issue(...) x k;  raw_wait<N>();  raw_land(...) x k;  raw_get(...).
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <int BYTES>
+struct RawReg;
+template <>
+struct RawReg<16> {
+  i32x4_t v;
+};
+template <>
+struct RawReg<8> {
+  i32x2_t v;
+};
+template <>
+struct RawReg<4> {
+  int v;
+};
+template <>
+struct RawReg<2> {
+  int v;  // two bytes, zero-extended
+};
+template <>
+struct RawReg<1> {
+  int v;  // one byte, sign-extended
+};
+template <int BYTES, bool NT>
+__device__ __forceinline__ void raw_issue(RawReg<BYTES> &r, const void *p) {
+  if constexpr (BYTES == 16) {
+    if constexpr (NT)
+      r.v = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t *>(p));
+    else
+      r.v = *reinterpret_cast<const i32x4_t *>(p);
+  } else if constexpr (BYTES == 8) {
+    if constexpr (NT)
+      r.v = __builtin_nontemporal_load(reinterpret_cast<const i32x2_t *>(p));
+    else
+      r.v = *reinterpret_cast<const i32x2_t *>(p);
+  } else if constexpr (BYTES == 4) {
+    if constexpr (NT)
+      r.v = __builtin_nontemporal_load(reinterpret_cast<const int *>(p));
+    else
+      r.v = *reinterpret_cast<const int *>(p);
+  } else if constexpr (BYTES == 2) {
+    r.v = (int)*reinterpret_cast<const unsigned short *>(p);
+  } else {
+    r.v = (int)*reinterpret_cast<const signed char *>(p);
+  }
+}
+// end of a run of raw_issue calls: nothing is scheduled across this point, so the whole run is
+// issued before the first use of any of it (N documents how many LATER loads/stores may still be
+// in flight when this trip is consumed; the compiler derives the s_waitcnt itself)
+template <int N>
+__device__ __forceinline__ void raw_wait() {
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int BYTES>
+__device__ __forceinline__ void raw_land(RawReg<BYTES> &) {}
+// W consecutive reals / int32 / int8 of a landed register image, as doubles / ints
+template <int W>
+__device__ __forceinline__ void raw_get(const RawReg<8 * W> &r, const double *, double (&o)[W]) {
+  if constexpr (W == 2) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 v = __builtin_bit_cast(d2, r.v);
+    o[0] = v.x, o[1] = v.y;
+  } else {
+    static_assert(W == 1, "fp64: 1 or 2 rows per lane");
+    o[0] = __builtin_bit_cast(double, r.v);
+  }
+}
+template <int W>
+__device__ __forceinline__ void raw_get(const RawReg<4 * W> &r, const float *, double (&o)[W]) {
+  if constexpr (W == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_bit_cast(f4, r.v);
+    o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+  } else if constexpr (W == 2) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = __builtin_bit_cast(f2, r.v);
+    o[0] = v.x, o[1] = v.y;
+  } else {
+    static_assert(W == 1, "fp32: 1, 2 or 4 rows per lane");
+    o[0] = __builtin_bit_cast(float, r.v);
+  }
+}
+template <int W>
+__device__ __forceinline__ void raw_geti(const RawReg<4 * W> &r, const int32_t *, int (&o)[W]) {
+  if constexpr (W == 4) {
+    o[0] = r.v.x, o[1] = r.v.y, o[2] = r.v.z, o[3] = r.v.w;
+  } else if constexpr (W == 2) {
+    o[0] = r.v.x, o[1] = r.v.y;
+  } else {
+    o[0] = r.v;
+  }
+}
+template <int W>
+__device__ __forceinline__ void raw_geti(const RawReg<W> &r, const int8_t *, int (&o)[W]) {
+#pragma unroll
+  for (int k = 0; k < W; ++k) o[k] = (int)(signed char)((unsigned)r.v >> (8 * k));
+}
+// register image of W elements of type E
+template <typename E, int W>
+using RawOf = RawReg<(int)sizeof(E) * W>;
+
 // rows per lane for kernels unrolled to MC column pairs: 16 B per lane per array, halved
 // for MC >= 20 so that the 2*MC operand values of a row group still fit the register file
 template <typename T, int MC>
@@ -226,6 +342,71 @@ __device__ __forceinline__ void for_rows(int64_t n, F &&f) {
   for (int64_t iv = t0; iv < nv; iv += stride) f(iv * V, WTag<V>{});
   const int64_t it = nv * V + t0;
   if (it < n) f(it, WTag<1>{});
+}
+
+// Grid-stride over row groups for the kernels that schedule their own loads.  TripV / Trip1 hold
+// the register images of one trip (V rows per lane / the scalar tail) and provide
+//   static constexpr int NL        loads issued per trip
+//   void issue(const Ctx &, int64_t i)   start every load of rows i .. i+W-1
+//   void land()                          after the wait: hand the registers to the compiler
+// f(trip, i, WTag<W>) consumes a landed trip; NS = the number of store instructions EVERY call of
+// f issues (a lower bound is safe: the counted wait then merely waits for a few stores too).
+// PIPE = false: issue, wait for everything, compute -- waves that share a SIMD overlap each other.
+// PIPE = true : two trips in flight per wave -- the next trip's loads are issued BEFORE this
+//   trip is computed, and the wait is a counted vmcnt that leaves them (and this trip's stores)
+//   in flight.  For kernels that hold > 256 registers and therefore run ONE wave per SIMD, where
+//   nothing else would cover the load latency (fp32 / fp64 at m = 20).  A trip past the end
+//   re-reads the lane's last valid rows (no branch around the loads).
+template <typename TripV, typename Trip1, int V, bool PIPE, int NS, typename Ctx, typename F>
+__device__ __forceinline__ void for_rows_raw(int64_t n, const Ctx &c, F &&f) {
+  const int64_t nv = n / V;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (PIPE) {
+    static_assert(TripV::NL + NS <= 63, "vmcnt counts to 63");
+    if (t0 < nv) {
+      TripV A, B;
+      A.issue(c, t0 * V);
+      int64_t n1 = t0 + stride;
+      B.issue(c, (n1 < nv ? n1 : t0) * V);
+      raw_wait<TripV::NL>();  // A has landed; B's loads stay in flight (no stores issued yet)
+      A.land();
+      f(A, t0 * V, WTag<V>{});
+      while (n1 < nv) {  // B holds trip n1
+        const int64_t n2 = n1 + stride;
+        A.issue(c, (n2 < nv ? n2 : n1) * V);
+        raw_wait<TripV::NL + NS>();  // older than A's loads: B's loads (now done), <= NS stores
+        B.land();
+        f(B, n1 * V, WTag<V>{});
+        if (n2 >= nv) break;
+        const int64_t n3 = n2 + stride;
+        B.issue(c, (n3 < nv ? n3 : n2) * V);
+        raw_wait<TripV::NL + NS>();
+        A.land();
+        f(A, n2 * V, WTag<V>{});
+        n1 = n3;
+      }
+      raw_wait<0>();  // the last prefetch is unused: land it before its registers are reused
+      A.land();
+      B.land();
+    }
+  } else {
+    for (int64_t iv = t0; iv < nv; iv += stride) {
+      TripV A;
+      A.issue(c, iv * V);
+      raw_wait<0>();
+      A.land();
+      f(A, iv * V, WTag<V>{});
+    }
+  }
+  const int64_t it = nv * V + t0;
+  if (it < n) {
+    Trip1 C;
+    C.issue(c, it);
+    raw_wait<0>();
+    C.land();
+    f(C, it, WTag<1>{});
+  }
 }
 
 // ---- reductions: wave shuffle, then LDS across the 4 waves ----

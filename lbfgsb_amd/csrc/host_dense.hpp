@@ -365,4 +365,48 @@ inline void dcsrch(double f, double g, double &stp, double ftol, double gtol, do
   save();
 }
 
+// hpsolb (src/lbfgsb.f90:2079-2157): t(1:n) / iorder(1:n) hold the breakpoints not yet used.
+// iheap == 0: first rearrange them into a min-heap by sifting t(2), t(3), ... up; then move the
+// least element to t(n) and restore the heap on t(1:n-1).  Used only by the opt-in exact replay of
+// the reference's pop order among EQUAL breakpoints (LBFGSB_F_EXACT_TIES); arrays are 0-based
+// here, i and j keep the reference's 1-based meaning.
+inline void hpsolb(int64_t n, double *t, uint32_t *iorder, int iheap) {
+  if (iheap == 0) {
+    for (int64_t k = 2; k <= n; ++k) {
+      const double ddum = t[k - 1];
+      const uint32_t indxin = iorder[k - 1];
+      int64_t i = k;
+      while (i > 1) {
+        const int64_t j = i / 2;
+        if (!(ddum < t[j - 1])) break;
+        t[i - 1] = t[j - 1];
+        iorder[i - 1] = iorder[j - 1];
+        i = j;
+      }
+      t[i - 1] = ddum;
+      iorder[i - 1] = indxin;
+    }
+  }
+  if (n > 1) {
+    int64_t i = 1;
+    const double out = t[0];
+    const uint32_t indxou = iorder[0];
+    const double ddum = t[n - 1];
+    const uint32_t indxin = iorder[n - 1];
+    for (;;) {
+      int64_t j = i + i;
+      if (j > n - 1) break;
+      if (t[j] < t[j - 1]) j = j + 1;  // t(j+1) < t(j)
+      if (!(t[j - 1] < ddum)) break;
+      t[i - 1] = t[j - 1];
+      iorder[i - 1] = iorder[j - 1];
+      i = j;
+    }
+    t[i - 1] = ddum;
+    iorder[i - 1] = indxin;
+    t[n - 1] = out;
+    iorder[n - 1] = indxou;
+  }
+}
+
 }  // namespace lbh

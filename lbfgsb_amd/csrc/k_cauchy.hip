@@ -11,8 +11,8 @@ template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, iw_t *iwhere, T *tbrk,
-    const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
-    double *part) {
+    const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
+    int m, int head, int col, double *part) {
   constexpr int NA = 2 * MC + 5;
   double acc[NA];
 #pragma unroll
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(BLOCK) void cauchy_scan_kernel(
 #pragma unroll
       for (int j = 0; j < MC; ++j) {
         const int64_t off = col_off(j, col, head, m, ldw) + i;
-        ld_col<T, W, NT>(j < col, wy + off, a[j]);
-        ld_col<T, W, NT>(j < col, ws + off, b[j]);
+        ld_col<T, W, NT>(j < col, wy + off, zero, a[j]);
+        ld_col<T, W, NT>(j < col, ws + off, zero, b[j]);
       }
     }
 #pragma unroll
@@ -99,11 +99,11 @@ void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   if (col == 0) {
     hipLaunchKernelGGL((cauchy_scan_kernel<T, 0, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
-                       nbd, g, iwhere, tbrk, w.ws, w.wy, w.ld, w.m, head, col, q.d_part);
+                       nbd, g, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, col, q.d_part);
   } else {
     DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cauchy_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, l, u, nbd, g, iwhere, tbrk, w.ws, w.wy,
-                                          w.ld, w.m, head, col, q.d_part));
+                                          w.zero, w.ld, w.m, head, col, q.d_part));
   }
   q.launches++;
   launch_finalize(q, gr, 2 * (col == 0 ? 0 : maxc_for(col)) + 4, 1, 0);

@@ -16,74 +16,112 @@ namespace lbk {
 // r itself is NOT stored: its only consumer, subsm_update_kernel, streams the same operands
 // anyway and recomputes it bit for bit (a store stream costs this HBM-bound pass more than it
 // moves: +0.8 GB written = +0.45 ms at n = 1e8, profiles/scripts/cmprlb_wtv_variants.hip).
-template <typename T, int MC, bool NEWROW, bool NT>
+// PSPEC: pe.on && col == MC (steady state once the memory is full): no per-column selects.
+// PIPE: two trips in flight per wave (device_util.hpp, for_rows_raw) -- for the instantiations
+// that hold more than 256 registers and run one wave per SIMD.
+template <typename T>
+struct CmprlbCtx {
+  const T *x, *g, *ws, *wy, *zero, *pr, *pd;
+  const iw_t *iwhere;
+  int64_t ldw;
+  int m, head, col;
+  Pend pe;
+};
+template <typename T, int MC, int W, bool NT, bool PSPEC>
+struct CmprlbTrip {
+  static constexpr int NL = 3 + 2 * MC;
+  RawOf<T, W> rg, rx, ra[MC], rb[MC];
+  RawOf<iw_t, W> riw;
+  __device__ __forceinline__ void issue(const CmprlbCtx<T> &c, int64_t i) {
+    constexpr int B = (int)sizeof(T) * W;
+    raw_issue<B, NT>(rg, c.g + i);
+    raw_issue<B, NT>(rx, c.x + i);
+    raw_issue<W, false>(riw, c.iwhere + i);
+    issue_cols<T, MC, W, NT, PSPEC>(c.wy, c.ws, c.pr, c.pd, c.zero, i, c.col, c.head, c.m, c.ldw, c.pe, ra,
+                                    rb);
+  }
+  __device__ __forceinline__ void land() {
+    raw_land(rg);
+    raw_land(rx);
+    raw_land(riw);
+    land_cols<T, MC, W>(ra, rb);
+  }
+};
+template <typename T, int MC, bool NEWROW, bool NT, bool PSPEC, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
     const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
-    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
-    const T *pd, Pend pe, double *part) {
+    const T *__restrict__ zero, int64_t ldw, int m, int head, int col, double theta, Coef cf,
+    const T *pr, const T *pd, Pend pe, double *part) {
   constexpr int NA = NEWROW ? 6 * MC : 2 * MC;
+  constexpr int V = RowsPerAcc<T, MC, NA>::V;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
-  for_rows<T, RowsPerAcc<T, MC, NA>::V>(n, [&](int64_t i, auto wt) {
+  const CmprlbCtx<T> ctx{x, g, ws, wy, zero, pr, pd, iwhere, ldw, m, head, col, pe};
+  for_rows_raw<CmprlbTrip<T, MC, V, NT, PSPEC>, CmprlbTrip<T, MC, 1, NT, PSPEC>, V, PIPE, 0>(
+      n, ctx, [&](auto &tr, int64_t, auto wt) {
     constexpr int W = decltype(wt)::value;
-    double xv[W], gv[W], rv[W], a[MC][W], b[MC][W];
+    // columns are read from the landed registers where they are used (col_pair): keeping all
+    // 2*MC operands widened next to 6*MC fp64 sums does not fit the register file for fp32
+    double xv[W], gv[W], rv[W];
     int iw[W];
-    ldx<W, NT>(g + i, gv);
-    if (!plain) {
-      ldx<W, NT>(x + i, xv);
-      ldi<W>(iwhere + i, iw);
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
-    }
-    load_cols<T, MC, W, NT>(wy, ws, pr, pd, i, col, head, m, ldw, pe, a, b);
-    fix_pending<T, MC, W>(col, pe, gv, a, b);
+    raw_get<W>(tr.rg, (const T *)nullptr, gv);
+    raw_get<W>(tr.rx, (const T *)nullptr, xv);
+    raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      if (plain) {  // unconstrained and col > 0: r = -g (:1560-1563)
-        rv[k] = -gv[k];
+      const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);  // only free rows are used
+      rv[k] = -theta * (zk - xv[k]) - gv[k];
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      double aj[W], bj[W];
+      col_pair<T, MC, W, PSPEC, false>(tr.ra, tr.rb, j, col, pe, gv, aj, bj);
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+        if (PSPEC || j < col) rv[k] = rv[k] + aj[k] * cf.a[j] + bj[k] * cf.a[MAXM + j];
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) rv[k] = iw[k] <= 0 ? rv[k] : 0.0;
+    double yf[W], sa[W];
+    if constexpr (NEWROW) {
+      double yn[W], sn[W];
+      if constexpr (PSPEC) {
+        col_pair<T, MC, W, PSPEC, false>(tr.ra, tr.rb, MC - 1, col, pe, gv, yn, sn);
       } else {
-        const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);  // only free rows are used
-        double rr = -theta * (zk - xv[k]) - gv[k];
+#pragma unroll
+        for (int k = 0; k < W; ++k) yn[k] = 0.0, sn[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < MC; ++j) {
-          if (j < col) rr = rr + a[j][k] * cf.a[j] + b[j][k] * cf.a[MAXM + j];
+          double aj[W], bj[W];
+          col_pair<T, MC, W, PSPEC, false>(tr.ra, tr.rb, j, col, pe, gv, aj, bj);
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            yn[k] = j == col - 1 ? aj[k] : yn[k];
+            sn[k] = j == col - 1 ? bj[k] : sn[k];
+          }
         }
-        rv[k] = iw[k] <= 0 ? rr : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        yf[k] = iw[k] <= 0 ? yn[k] : 0.0;  // free rows
+        sa[k] = iw[k] <= 0 ? 0.0 : sn[k];  // active rows
       }
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
+      double aj[W], bj[W];
+      col_pair<T, MC, W, PSPEC, true>(tr.ra, tr.rb, j, col, pe, gv, aj, bj);
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        acc[j] += a[j][k] * rv[k];
-        acc[MC + j] += b[j][k] * rv[k];
-      }
-    }
-    if constexpr (NEWROW) {
-      double yf[W], sa[W];
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        double yn = 0.0, sn = 0.0;
-#pragma unroll
-        for (int j = 0; j < MC; ++j)
-          if (j == col - 1) {
-            yn = a[j][k];
-            sn = b[j][k];
-          }
-        yf[k] = iw[k] <= 0 ? yn : 0.0;  // free rows
-        sa[k] = iw[k] <= 0 ? 0.0 : sn;  // active rows
-      }
-#pragma unroll
-      for (int j = 0; j < MC; ++j) {
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-          acc[2 * MC + j] += yf[k] * a[j][k];  // temp1 (:1764)
-          acc[3 * MC + j] += sa[k] * b[j][k];  // temp2 (:1769)
-          acc[4 * MC + j] += sa[k] * a[j][k];  // temp3 (:1770)
-          acc[5 * MC + j] += b[j][k] * yf[k];  // temp3 of the new column (:1789)
+        acc[j] += aj[k] * rv[k];
+        acc[MC + j] += bj[k] * rv[k];
+        if constexpr (NEWROW) {
+          acc[2 * MC + j] += yf[k] * aj[k];  // temp1 (:1764)
+          acc[3 * MC + j] += sa[k] * bj[k];  // temp2 (:1769)
+          acc[4 * MC + j] += sa[k] * aj[k];  // temp3 (:1770)
+          acc[5 * MC + j] += bj[k] * yf[k];  // temp3 of the new column (:1789)
         }
       }
     }
@@ -119,7 +157,7 @@ template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
     const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
-    int64_t ldw, int m, int head, int col, double theta, Coef cf, int plain, const T *pr,
+    int64_t ldw, int m, int head, int col, double theta, Coef cf, const T *pr,
     const T *pd, Pend pe, double *part) {
   constexpr int H = MC / 2, NA = 6 * H;
   constexpr int V = RowsPer<T, MC>::V;
@@ -136,13 +174,8 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
     T a[MC][W], b[MC][W];
     int iw[W];
     ldx<W, NT>(g + i, gv);
-    if (!plain) {
-      ldx<W, NT>(x + i, xv);
-      ldi<W>(iwhere + i, iw);
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; ++k) iw[k] = -1;
-    }
+    ldx<W, NT>(x + i, xv);
+    ldi<W>(iwhere + i, iw);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw);
@@ -164,9 +197,7 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       double yn = 0.0, sn = 0.0;
-      if (plain) {
-        rv[k] = -gv[k];
-      } else {
+      {
         const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);
         double rr = -theta * (zk - xv[k]) - gv[k];
 #pragma unroll
@@ -247,44 +278,58 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
-                       const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe) {
+                       const Coef &a, int newrow, const T *pr, const T *pd, Pend pe) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
-  if (newrow && maxc_for(col) >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
-    if (maxc_for(col) == 20) {
+  const int mc = maxc_for(col);
+  if (newrow && mc >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
+    if (mc == 20) {
       if (q.nt)
         hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 20, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x,
-                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr, pd,
-                           pe, q.d_part);
+                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
+                           q.d_part);
       else
         hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 20, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
-                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr,
-                           pd, pe, q.d_part);
+                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
+                           q.d_part);
     } else {
       if (q.nt)
         hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 32, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x,
-                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr, pd,
-                           pe, q.d_part);
+                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
+                           q.d_part);
       else
         hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 32, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
-                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, plain, pr,
-                           pd, pe, q.d_part);
+                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
+                           q.d_part);
     }
-  } else if (newrow) {
-    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, true, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
-                                          head, col, theta, a, plain, pr, pd, pe, q.d_part));
   } else {
-    DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, false, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m,
-                                          head, col, theta, a, plain, pr, pd, pe, q.d_part));
+    // the steady-state shape (pair pending, memory full) has its own instantiation
+    const bool spec = pe.on && col == mc;
+#define LB_CMPRLB(NEWROWV, PSPECV)                                                                  \
+  DISPATCH_MAXC_NT(col, q.nt,                                                                       \
+                   hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, pipe_for(MC)>),\
+                                      dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum, iwhere,    \
+                                      w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta, a, pr, pd,   \
+                                      pe, q.d_part))
+    if (newrow) {
+      if (spec)
+        LB_CMPRLB(true, true);
+      else
+        LB_CMPRLB(true, false);
+    } else {
+      if (spec)
+        LB_CMPRLB(false, true);
+      else
+        LB_CMPRLB(false, false);
+    }
+#undef LB_CMPRLB
   }
   q.launches++;
-  launch_finalize(q, gr, (newrow ? 6 : 2) * maxc_for(col), 0, 0);
+  launch_finalize(q, gr, (newrow ? 6 : 2) * mc, 0, 0);
 }
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
-  template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double, const iw_t *, WStore<T>, int, int, double, const Coef &, int, int, const T *, const T *, Pend);
+  template void launch_cmprlb_wtv<T>(Queue &, int64_t, const T *, const T *, double, const iw_t *, WStore<T>, int, int, double, const Coef &, int, const T *, const T *, Pend);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

@@ -195,7 +195,8 @@ void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, cons
 // Per lane and trip: 2*MC + 1 independent 16-byte loads in flight.
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restrict__ ws,
-                                                    const T *__restrict__ wy, int64_t ldw, int m,
+                                                    const T *__restrict__ wy,
+                                                    const T *__restrict__ zero, int64_t ldw, int m,
                                                     int head, int col, const T *__restrict__ v,
                                                     double *part) {
   double acc[2 * MC];
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld_col<T, W, NT>(j < col, wy + off, a[j]);
-      ld_col<T, W, NT>(j < col, ws + off, b[j]);
+      ld_col<T, W, NT>(j < col, wy + off, zero, a[j]);
+      ld_col<T, W, NT>(j < col, ws + off, zero, b[j]);
     }
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
@@ -227,7 +228,7 @@ template <typename T>
 void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
   const int g = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((wtv_kernel<T, MC, NTV>), dim3(g), dim3(BLOCK), 0, q.stream, n,
-                                        w.ws, w.wy, w.ld, w.m, head, col, v, q.d_part));
+                                        w.ws, w.wy, w.zero, w.ld, w.m, head, col, v, q.d_part));
   q.launches++;
 }
 template <typename T>

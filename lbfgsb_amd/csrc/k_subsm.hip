@@ -7,23 +7,18 @@ namespace lbk {
 // =========================== subsm (:2676-2885) ==============================
 // Newton direction of one free row (cmprlb :1560-1583 then subsm :2770-2780): the reduced
 // gradient r is recomputed here exactly as cmprlb_wtv_kernel computed it for W'r.
-template <int MC>
+template <int MC, bool FULL = false>
 __device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, const double (&a)[MC],
                                             const double (&b)[MC], int col, double theta,
-                                            double rtheta, const Coef &cf, int plain,
-                                            const Coef &wv) {
-  double dk;
-  if (plain) {
-    dk = -gk;
-  } else {
-    dk = -theta * (zk - xk) - gk;
-#pragma unroll
-    for (int j = 0; j < MC; ++j)
-      if (j < col) dk = dk + a[j] * cf.a[j] + b[j] * cf.a[MAXM + j];
-  }
+                                            double rtheta, const Coef &cf, const Coef &wv) {
+  // (unconstrained shortcut of cmprlb, r = -g :1560-1563: zk == xk and cf == 0 give exactly that)
+  double dk = -theta * (zk - xk) - gk;
 #pragma unroll
   for (int j = 0; j < MC; ++j)
-    if (j < col) dk = dk + a[j] * wv.a[j] / theta + b[j] * wv.a[MAXM + j];
+    if (FULL || j < col) dk = dk + a[j] * cf.a[j] + b[j] * cf.a[MAXM + j];
+#pragma unroll
+  for (int j = 0; j < MC; ++j)
+    if (FULL || j < col) dk = dk + a[j] * wv.a[j] / theta + b[j] * wv.a[MAXM + j];
   return rtheta * dk;  // dscal (:2780)
 }
 
@@ -34,47 +29,73 @@ __device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, con
 // (xcp_row), the subspace minimiser written to `zout`; neither xp (:2787) nor the direction is
 // stored (the backtracking branch regenerates both: cauchy_finish_kernel, subsm_dir_kernel).
 // res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
-template <typename T, int MC, bool NT>
+template <typename T>
+struct SubsmCtx {
+  const T *l, *u, *xx, *gg, *ws, *wy, *zero, *r, *dvec;
+  const int32_t *nbd;
+  const iw_t *iwhere;
+  int64_t ldw;
+  int m, head, col;
+  Pend pe;
+};
+template <typename T, int MC, int W, bool NT, bool PSPEC>
+struct SubsmTrip {
+  static constexpr int NL = 6 + 2 * MC;
+  RawOf<T, W> rl, ru, rx, rg, ra[MC], rb[MC];
+  RawOf<int32_t, W> rnb;
+  RawOf<iw_t, W> riw;
+  __device__ __forceinline__ void issue(const SubsmCtx<T> &c, int64_t i) {
+    constexpr int B = (int)sizeof(T) * W;
+    raw_issue<B, NT>(rl, c.l + i);
+    raw_issue<B, NT>(ru, c.u + i);
+    raw_issue<B, NT>(rx, c.xx + i);
+    raw_issue<B, NT>(rg, c.gg + i);
+    raw_issue<4 * W, false>(rnb, c.nbd + i);
+    raw_issue<W, false>(riw, c.iwhere + i);
+    // a pending pair is read from (r, d) -- which this pass overwrites further down
+    issue_cols<T, MC, W, NT, PSPEC>(c.wy, c.ws, c.r, c.dvec, c.zero, i, c.col, c.head, c.m, c.ldw, c.pe,
+                                    ra, rb);
+  }
+  __device__ __forceinline__ void land() {
+    raw_land(rl);
+    raw_land(ru);
+    raw_land(rx);
+    raw_land(rg);
+    raw_land(rnb);
+    raw_land(riw);
+    land_cols<T, MC, W>(ra, rb);
+  }
+};
+template <typename T, int MC, bool NT, bool PSPEC, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, double tsum, T *__restrict__ zout, T *r,
     const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
-    const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
-    double theta, Coef cf, int plain, Coef wv, T *dvec, T *__restrict__ tvec,
+    const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
+    int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *__restrict__ tvec,
     T *xout, int do_stpmx, Pend pe, T *cwy, T *cws, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
-  for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
+  constexpr int V = RowsPer<T, MC>::V;
+  // stores every trip issues: z, d, t, r (+ the committed pair in the steady-state shape)
+  constexpr int NS = PSPEC ? 6 : 4;
+  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, r, dvec, nbd, iwhere, ldw, m, head, col, pe};
+  for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(
+      n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double zv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
-    ldx<W, NT>(l + i, lv);
-    ldx<W, NT>(u + i, uv);
-    ldx<W, NT>(xx + i, xv);
-    ldx<W, NT>(gg + i, gv);
-    ldi<W>(nbd + i, nb);
-    if (!plain) {
-      ldi<W>(iwhere + i, iw);
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; ++k) iw[k] = -1;  // unconstrained: every row is free
-    }
-    // a pending pair is read from (r, d) -- which this pass overwrites further down -- and
-    // committed to its W slot (cwy, cws) here
-    load_cols<T, MC, W, NT>(wy, ws, r, dvec, i, col, head, m, ldw, pe, a, b);
-    fix_pending<T, MC, W>(col, pe, gv, a, b);
-    if (pe.on) {
+    raw_get<W>(tr.rl, (const T *)nullptr, lv);
+    raw_get<W>(tr.ru, (const T *)nullptr, uv);
+    raw_get<W>(tr.rx, (const T *)nullptr, xv);
+    raw_get<W>(tr.rg, (const T *)nullptr, gv);
+    raw_geti<W>(tr.rnb, (const int32_t *)nullptr, nb);
+    raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
+    get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
+    fix_pending<T, MC, W, PSPEC>(col, pe, gv, a, b);
+    if (PSPEC || pe.on) {
       double yn[W], sn[W];
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        yn[k] = 0.0, sn[k] = 0.0;
-#pragma unroll
-        for (int j = 0; j < MC; ++j)
-          if (j == col - 1) {
-            yn[k] = a[j][k];
-            sn[k] = b[j][k];
-          }
-      }
+      newest_cols<MC, W, PSPEC>(col, a, b, yn, sn);
       if (NT) {
         stnt<W>(cwy + i, yn);
         stnt<W>(cws + i, sn);
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
         double ak[MC], bk[MC];
 #pragma unroll
         for (int j = 0; j < MC; ++j) ak[j] = a[j][k], bk[j] = b[j][k];
-        const double dk = subsm_dir<MC>(xv[k], zv[k], gv[k], ak, bk, col, theta, rtheta, cf, plain, wv);
+        const double dk = subsm_dir<MC, PSPEC>(xv[k], zv[k], gv[k], ak, bk, col, theta, rtheta, cf, wv);
         const double xk = zv[k];
         if (nb[k] != 0) {
           if (nb[k] == 1) {
@@ -147,14 +168,23 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
-                         WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
+                         WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
-  DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                        q.stream, n, tsum, zout, r, l, u, nbd, iwhere, xx, gg, w.ws,
-                                        w.wy, w.ld, w.m, head, col, theta, cf, plain, wv, dvec, tvec,
-                                        xout, do_stpmx, pe, w.wy + slot, w.ws + slot, q.d_part));
+  const bool spec = pe.on && col == maxc_for(col);
+#define LB_SUBSM(PSPECV)                                                                            \
+  DISPATCH_MAXC_NT(col, q.nt,                                                                       \
+                   hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV, PSPECV, pipe_for(MC)>),      \
+                                      dim3(gr), dim3(BLOCK), 0, q.stream, n, tsum, zout, r, l, u, nbd, \
+                                      iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head, col,     \
+                                      theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, w.wy + slot,   \
+                                      w.ws + slot, q.d_part))
+  if (spec)
+    LB_SUBSM(true);
+  else
+    LB_SUBSM(false);
+#undef LB_SUBSM
   q.launches++;
   launch_finalize(q, gr, 3, 1, 0);
 }
@@ -164,8 +194,8 @@ template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
     int64_t n, const T *__restrict__ xcp, const iw_t *__restrict__ iwhere,
     const T *__restrict__ xx, const T *__restrict__ gg, const T *__restrict__ ws,
-    const T *__restrict__ wy, int64_t ldw, int m, int head, int col, double theta, Coef cf,
-    int plain, Coef wv, T *__restrict__ ndir) {
+    const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw, int m, int head, int col,
+    double theta, Coef cf, Coef wv, T *__restrict__ ndir) {
   const double rtheta = 1.0 / theta;
   for_rows<T, RowsPer<T, MC>::V>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -174,17 +204,12 @@ __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
     ldx<W, NT>(xcp + i, zv);
     ldx<W, NT>(xx + i, xv);
     ldx<W, NT>(gg + i, gv);
-    if (!plain) {
-      ldi<W>(iwhere + i, iw);
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; ++k) iw[k] = -1;
-    }
+    ldi<W>(iwhere + i, iw);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       const int64_t off = col_off(j, col, head, m, ldw) + i;
-      ld_col<T, W, NT>(j < col, wy + off, a[j]);
-      ld_col<T, W, NT>(j < col, ws + off, b[j]);
+      ld_col<T, W, NT>(j < col, wy + off, zero, a[j]);
+      ld_col<T, W, NT>(j < col, ws + off, zero, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -193,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
         double ak[MC], bk[MC];
 #pragma unroll
         for (int j = 0; j < MC; ++j) ak[j] = a[j][k], bk[j] = b[j][k];
-        out[k] = subsm_dir<MC>(xv[k], zv[k], gv[k], ak, bk, col, theta, rtheta, cf, plain, wv);
+        out[k] = subsm_dir<MC>(xv[k], zv[k], gv[k], ak, bk, col, theta, rtheta, cf, wv);
       }
     }
     st<W>(ndir + i, out);
@@ -202,18 +227,18 @@ __global__ __launch_bounds__(BLOCK) void subsm_dir_kernel(
 template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
                       const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
-                      int plain, const Coef &wv, T *ndir) {
+                      const Coef &wv, T *ndir) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_dir_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                        q.stream, n, xcp, iwhere, xx, gg, w.ws, w.wy, w.ld, w.m, head,
-                                        col, theta, cf, plain, wv, ndir));
+                                        q.stream, n, xcp, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m,
+                                        head, col, theta, cf, wv, ndir));
   q.launches++;
 }
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
-  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const int32_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, int, const Coef &, T *, T *, T *, int, Pend); \
-  template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, int, const Coef &, T *);
+  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const int32_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend); \
+  template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

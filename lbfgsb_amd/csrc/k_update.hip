@@ -10,7 +10,8 @@ namespace lbk {
 template <typename T, int MC, bool NT>
 __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
     int64_t n, const T *__restrict__ g, const T *__restrict__ r, const T *__restrict__ d,
-    double stp, T *ws, T *wy, int64_t ldw, int m, int head, int nold, int itail, double *part) {
+    double stp, T *ws, T *wy, const T *__restrict__ zero, int64_t ldw, int m, int head, int nold,
+    int itail, double *part) {
   constexpr int NA = 2 * MC + 1;
   double acc[NA];
 #pragma unroll
@@ -24,10 +25,9 @@ __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
     ldx<W, NT>(d + i, dv);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
-      // nold may be 0: then logical column 0 is the NEW column; read d's own slot instead
-      const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
-      ld_col<T, W, NT>(j < nold, wy + off, a[j]);
-      ld_col<T, W, NT>(j < nold, ws + off, b[j]);
+      const int64_t off = col_off(j, nold, head, m, ldw) + i;
+      ld_col<T, W, NT>(j < nold, wy + off, zero, a[j]);
+      ld_col<T, W, NT>(j < nold, ws + off, zero, b[j]);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -55,8 +55,8 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_pairs_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
-                                         q.stream, n, g, r, d, stp, w.ws, w.wy, w.ld, w.m, head,
-                                         nold, itail, q.d_part));
+                                         q.stream, n, g, r, d, stp, w.ws, w.wy, w.zero, w.ld, w.m,
+                                         head, nold, itail, q.d_part));
   q.launches++;
   launch_finalize(q, gr, 2 * maxc_for(nold) + 1, 0, 0);
 }
@@ -73,37 +73,75 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // The same pass serves as the line search's evaluation at a trial point (g'd, |proj g|): run
 // speculatively there (store_pair = 0; it writes nothing but -- with store_iw -- the few iwhere
 // entries that changed), its sums ARE the matupd + cauchy-scan results if the trial is accepted.
-template <typename T, int MC, bool NT>
+template <typename T>
+struct UpdScanCtx {
+  const T *x, *l, *u, *g, *r, *d, *ws, *wy, *zero;
+  const int32_t *nbd;
+  const iw_t *iwhere;
+  int64_t ldw;
+  int m, head, nold;
+};
+template <typename T, int MC, int W, bool NT>
+struct UpdScanTrip {
+  static constexpr int NL = 8 + 2 * MC;
+  RawOf<T, W> rx, rl, ru, rg, rr, rd, ra[MC], rb[MC];
+  RawOf<int32_t, W> rnb;
+  RawOf<iw_t, W> riw;
+  __device__ __forceinline__ void issue(const UpdScanCtx<T> &c, int64_t i) {
+    constexpr int B = (int)sizeof(T) * W;
+    raw_issue<B, NT>(rx, c.x + i);
+    raw_issue<B, NT>(rl, c.l + i);
+    raw_issue<B, NT>(ru, c.u + i);
+    raw_issue<B, NT>(rg, c.g + i);
+    raw_issue<B, NT>(rr, c.r + i);
+    raw_issue<B, NT>(rd, c.d + i);
+    raw_issue<4 * W, false>(rnb, c.nbd + i);
+    raw_issue<W, false>(riw, c.iwhere + i);
+    issue_cols<T, MC, W, NT>(c.wy, c.ws, (const T *)nullptr, (const T *)nullptr, c.zero, i, c.nold, c.head,
+                             c.m, c.ldw, Pend{0, 1.0}, ra, rb);
+  }
+  __device__ __forceinline__ void land() {
+    raw_land(rx);
+    raw_land(rl);
+    raw_land(ru);
+    raw_land(rg);
+    raw_land(rr);
+    raw_land(rd);
+    raw_land(rnb);
+    raw_land(riw);
+    land_cols<T, MC, W>(ra, rb);
+  }
+};
+template <typename T, int MC, bool NT, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
-    const T *__restrict__ d, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy, int64_t ldw,
-    int m, int head, int nold, int itail, int store_pair, int store_iw, double *part) {
+    const T *__restrict__ d, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
+    const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
+    int store_iw, double *part) {
   constexpr int NA = 4 * MC + 11;
+  constexpr int V = RowsPerAcc<T, MC, NA>::V;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   acc[4 * MC + 9] = LB_INF;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
-  for_rows<T, RowsPerAcc<T, MC, NA>::V>(n, [&](int64_t i, auto wt) {
+  const UpdScanCtx<T> ctx{x, l, u, g, r, d, ws, wy, zero, nbd, iwhere, ldw, m, head, nold};
+  for_rows_raw<UpdScanTrip<T, MC, V, NT>, UpdScanTrip<T, MC, 1, NT>, V, PIPE, 0>(
+      n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
-    ldx<W, NT>(x + i, xv);
-    ldx<W, NT>(l + i, lv);
-    ldx<W, NT>(u + i, uv);
-    ldx<W, NT>(g + i, gv);
-    ldx<W, NT>(r + i, rv);
-    ldx<W, NT>(d + i, dv);
-    ldi<W>(nbd + i, nb);
-    ldi<W>(iwhere + i, iw);
+    raw_get<W>(tr.rx, (const T *)nullptr, xv);
+    raw_get<W>(tr.rl, (const T *)nullptr, lv);
+    raw_get<W>(tr.ru, (const T *)nullptr, uv);
+    raw_get<W>(tr.rg, (const T *)nullptr, gv);
+    raw_get<W>(tr.rr, (const T *)nullptr, rv);
+    raw_get<W>(tr.rd, (const T *)nullptr, dv);
+    raw_geti<W>(tr.rnb, (const int32_t *)nullptr, nb);
+    raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
+    get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     bool iw_changed = false;
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      const int64_t off = (nold > 0 ? col_off(j, nold, head, m, ldw) : offn) + i;
-      ld_col<T, W, NT>(j < nold, wy + off, a[j]);
-      ld_col<T, W, NT>(j < nold, ws + off, b[j]);
-    }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       // ---- the line search's own sums at this trial point: g'd (:2244), |proj g| (:781) ----
@@ -181,10 +219,10 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         WStore<T> w, int head, int col, int itail, int store_pair, int store_iw) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
-  DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
+  DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, pipe_for(MC)>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,
-                                         w.wy, w.ld, w.m, head, nold, itail, store_pair, store_iw,
-                                         q.d_part));
+                                         w.wy, w.zero, w.ld, w.m, head, nold, itail, store_pair,
+                                         store_iw, q.d_part));
   q.launches++;
   launch_finalize(q, gr, 4 * maxc_for(nold) + 9, 1, 1);
 }

@@ -35,6 +35,7 @@ struct WStore {
   T *wy;
   int64_t ld;
   int m;
+  const T *zero;  // >= 64 bytes of zeros: what the unroll slots beyond the stored pairs read
 };
 
 // iwhere (cauchy's per-variable status, -3..3) is kept as one byte per row on the device; the
@@ -207,7 +208,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
-                       const Coef &a, int plain, int newrow, const T *pr, const T *pd, Pend pe);
+                       const Coef &a, int newrow, const T *pr, const T *pd, Pend pe);
 // formk patches (ref :1801-1851): signed Gram over the listed rows (+ entered, - left the free
 // set) for the first upcl logical columns; res layout as launch_formk_gram with col = upcl.
 template <typename T>
@@ -217,20 +218,22 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 // update (cmprlb's r recomputed, :2770-2816, :2824-2827) + the line-search set-up of mainlb
 // :720-722 / lnsrlb :2196-2236 in one pass: zout = projected subspace point from the Cauchy
 // point (evaluated per row from x, g, l, u, iwhere, tsum), dvec = zout - x, tvec = x, r = g.
-// cf/plain = the coefficients the preceding launch_cmprlb_wtv used; wv = K^-1 W'r.
+// cf = the coefficients the preceding launch_cmprlb_wtv used (all zero, with tsum = 0, for the
+// reference's unconstrained shortcut r = -g, cmprlb :1560-1563: the general formula then gives
+// exactly -g); wv = K^-1 W'r.
 // res sum-slots: [0] = #bound hits (iword), [1] = dd_p (= g'(z-x)), [2] = dtd ; min-slot [3] =
 // stpmx candidate.  xout (= the caller's x, or nullptr): also store the first trial point of the
 // line search, x = z, when its step length is known to be 1 (:2265).
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
-                         WStore<T> w, int head, int col, double theta, const Coef &cf, int plain,
+                         WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe);
 // the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
 template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
                       const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
-                      int plain, const Coef &wv, T *ndir);
+                      const Coef &wv, T *ndir);
 // backtrack (:2836-2863): res min-slot [0] = alpha; then argmin pass:
 // res min-slot [0] = smallest global index attaining alpha (as double)
 template <typename T>

@@ -61,29 +61,27 @@ namespace lbk {
     }                                 \
   } while (0)
 
+// Two trips in flight per wave (for_rows_raw, PIPE) where a kernel's registers leave one wave
+// per SIMD anyway: the MC = 20 instantiations (MC = 32 would need a vmcnt beyond 63).
+constexpr bool pipe_for(int mc) { return mc == 20; }
+
 // physical column offset (elements) of logical column j; j >= col -> logical 0
 __device__ __forceinline__ int64_t col_off(int j, int col, int head, int m, int64_t ld) {
   const int jj = j < col ? j : 0;
   return (int64_t)((head - 1 + jj) % m) * ld;
 }
 // Unroll slots beyond the stored pairs (the kernels are unrolled to MC = 5/10/20/32 columns;
-// e.g. the update pass at col - 1 = 9 old columns runs the MC = 10 code).  col_off sends such a
-// slot to column 0 again, and with nontemporal loads that second request goes to HBM like the
-// first (PMC: +1.3 GB per launch at n = 1e8).  The fp64 kernels therefore skip the load; the
-// fp32 kernels, which already live at the register limit, lose 2x to the guarded form and keep
-// the duplicate load.
+// e.g. the update pass at col - 1 = 9 old columns runs the MC = 10 code) read a small zero
+// buffer instead (`zero`: the same 16 bytes for every lane -- a cache hit, no HBM traffic).
+// Selecting the ADDRESS keeps the load unconditional: a branch around each load cuts the loop
+// body into basic blocks, the compiler then waits for the first loads of a trip (s_waitcnt
+// vmcnt(0) behind the iwhere unpack) before it has issued the column loads, and a wave that runs
+// alone on its SIMD (fp32, m = 20: > 256 registers) pays two memory latencies per trip -- round
+// 1's 3.7 TB/s for that kernel against 6.4 TB/s for the same arithmetic in straight-line form
+// (profiles/scripts/r32m20_variants.hip).
 template <typename T, int W, bool NT>
-__device__ __forceinline__ void ld_col(bool live, const T *p, double (&o)[W]) {
-  if constexpr (sizeof(T) == 8) {
-    if (live) {
-      ldx<W, NT>(p, o);
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; ++k) o[k] = 0.0;
-    }
-  } else {
-    ldx<W, NT>(p, o);
-  }
+__device__ __forceinline__ void ld_col(bool live, const T *p, const T *zero, double (&o)[W]) {
+  ldx<W, NT>(live ? p : zero, o);
 }
 
 // ---- pending pair ----
@@ -101,39 +99,177 @@ template <typename T>
 __device__ __forceinline__ double pend_s(double dk, double stp) {
   return stp != 1.0 ? (double)(T)(stp * dk) : dk;
 }
-// columns j = 0..MC-1 of one row group; the pending column is read from (r, d) instead
-template <typename T, int MC, int W, bool NT>
+// columns j = 0..MC-1 of one row group; the pending column is read from (r, d) instead.
+// PSPEC: the caller guarantees pe.on && col == MC (every iteration once the memory is full):
+// the pending column is then the compile-time slot MC - 1 and no select is needed.
+template <typename T, int MC, int W, bool NT, bool PSPEC = false>
 __device__ __forceinline__ void load_cols(const T *__restrict__ wy, const T *__restrict__ ws,
-                                          const T *pr, const T *pd, int64_t i, int col, int head,
-                                          int m, int64_t ldw, Pend pe, double (&a)[MC][W],
-                                          double (&b)[MC][W]) {
-  // one base pointer per matrix and a selected element offset (selecting between two base
-  // pointers per column makes the compiler keep a table of addresses in scratch memory);
-  // all buffers are allocations of T, so the distances are whole elements
-  const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
-  const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
+                                          const T *pr, const T *pd, const T *zero, int64_t i,
+                                          int col, int head, int m, int64_t ldw, Pend pe,
+                                          double (&a)[MC][W], double (&b)[MC][W]) {
+  if constexpr (PSPEC) {
 #pragma unroll
-  for (int j = 0; j < MC; ++j) {
-    const int64_t off = col_off(j, col, head, m, ldw);
-    const bool pj = pe.on && j == col - 1;
-    ld_col<T, W, NT>(j < col, wy + ((pj ? dy : off) + i), a[j]);
-    ld_col<T, W, NT>(j < col, ws + ((pj ? ds : off) + i), b[j]);
+    for (int j = 0; j < MC - 1; ++j) {
+      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
+      ldx<W, NT>(wy + off, a[j]);
+      ldx<W, NT>(ws + off, b[j]);
+    }
+    ldx<W, NT>(pr + i, a[MC - 1]);
+    ldx<W, NT>(pd + i, b[MC - 1]);
+  } else {
+    // one base pointer per matrix and a selected element offset (selecting between two base
+    // pointers per column makes the compiler keep a table of addresses in scratch memory);
+    // all buffers are allocations of T, so the distances are whole elements
+    const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
+    const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw);
+      const bool pj = pe.on && j == col - 1;
+      ld_col<T, W, NT>(j < col, wy + ((pj ? dy : off) + i), zero, a[j]);
+      ld_col<T, W, NT>(j < col, ws + ((pj ? ds : off) + i), zero, b[j]);
+    }
+  }
+}
+template <typename T, int MC, int W, bool PSPEC = false>
+__device__ __forceinline__ void fix_pending(int col, Pend pe, const double (&gv)[W],
+                                            double (&a)[MC][W], double (&b)[MC][W]) {
+  if constexpr (PSPEC) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      a[MC - 1][k] = pend_y<T>(gv[k], a[MC - 1][k]);
+      b[MC - 1][k] = pend_s<T>(b[MC - 1][k], pe.stp);
+    }
+  } else {
+    // branch-free selects: a predicated write a[col-1][k] = ... would turn the register arrays
+    // into dynamically indexed ones (scratch memory)
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const bool pj = pe.on && j == col - 1;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const double yk = pend_y<T>(gv[k], a[j][k]);
+        const double sk = pend_s<T>(b[j][k], pe.stp);
+        a[j][k] = pj ? yk : a[j][k];
+        b[j][k] = pj ? sk : b[j][k];
+      }
+    }
+  }
+}
+// The same in two phases for the kernels that schedule their loads themselves (device_util.hpp,
+// "raw" loads): issue_cols starts every column load of the trip, get_cols reads the landed
+// registers.
+template <typename T, int MC, int W, bool NT, bool PSPEC = false>
+__device__ __forceinline__ void issue_cols(const T *__restrict__ wy, const T *__restrict__ ws,
+                                           const T *pr, const T *pd, const T *zero, int64_t i,
+                                           int col, int head, int m, int64_t ldw, Pend pe,
+                                           RawOf<T, W> (&ra)[MC], RawOf<T, W> (&rb)[MC]) {
+  constexpr int B = (int)sizeof(T) * W;
+  if constexpr (PSPEC) {
+#pragma unroll
+    for (int j = 0; j < MC - 1; ++j) {
+      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
+      raw_issue<B, NT>(ra[j], wy + off);
+      raw_issue<B, NT>(rb[j], ws + off);
+    }
+    raw_issue<B, NT>(ra[MC - 1], pr + i);
+    raw_issue<B, NT>(rb[MC - 1], pd + i);
+  } else {
+    // (one base pointer per matrix and a selected element offset, as in load_cols)
+    const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
+    const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw);
+      const bool live = j < col, pj = pe.on && j == col - 1;
+      const T *py = wy + ((pj ? dy : off) + i), *ps = ws + ((pj ? ds : off) + i);
+      raw_issue<B, NT>(ra[j], live ? py : zero);
+      raw_issue<B, NT>(rb[j], live ? ps : zero);
+    }
   }
 }
 template <typename T, int MC, int W>
-__device__ __forceinline__ void fix_pending(int col, Pend pe, const double (&gv)[W],
-                                            double (&a)[MC][W], double (&b)[MC][W]) {
-  // branch-free selects: a predicated write a[col-1][k] = ... would turn the register arrays
-  // into dynamically indexed ones (scratch memory)
+__device__ __forceinline__ void land_cols(RawOf<T, W> (&ra)[MC], RawOf<T, W> (&rb)[MC]) {
 #pragma unroll
   for (int j = 0; j < MC; ++j) {
-    const bool pj = pe.on && j == col - 1;
+    raw_land(ra[j]);
+    raw_land(rb[j]);
+  }
+}
+template <typename T, int MC, int W>
+__device__ __forceinline__ void get_cols(const RawOf<T, W> (&ra)[MC], const RawOf<T, W> (&rb)[MC],
+                                         double (&a)[MC][W], double (&b)[MC][W]) {
+#pragma unroll
+  for (int j = 0; j < MC; ++j) {
+    raw_get<W>(ra[j], (const T *)nullptr, a[j]);
+    raw_get<W>(rb[j], (const T *)nullptr, b[j]);
+  }
+}
+// One column pair (logical column j) of a landed trip as doubles, the pending pair already in
+// its stored form.  For the kernels that must not keep all 2*MC operands widened at once (fp32
+// with many accumulators): they read each column where they use it, twice if need be -- OPAQUE
+// hides the second conversion from the optimiser, which would otherwise keep the doubles of the
+// first use alive (and spill).
+__device__ __forceinline__ double cvt_opaque(double v) { return v; }
+__device__ __forceinline__ double cvt_opaque(float v) {
+  double d;
+  asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(v));
+  return d;
+}
+template <int W, bool OPAQUE>
+__device__ __forceinline__ void raw_get_col(const RawReg<8 * W> &r, const double *, double (&o)[W]) {
+  raw_get<W>(r, (const double *)nullptr, o);
+}
+template <int W, bool OPAQUE>
+__device__ __forceinline__ void raw_get_col(const RawReg<4 * W> &r, const float *, double (&o)[W]) {
+  if constexpr (!OPAQUE) {
+    raw_get<W>(r, (const float *)nullptr, o);
+  } else if constexpr (W == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_bit_cast(f4, r.v);
+    o[0] = cvt_opaque(v.x), o[1] = cvt_opaque(v.y), o[2] = cvt_opaque(v.z), o[3] = cvt_opaque(v.w);
+  } else if constexpr (W == 2) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = __builtin_bit_cast(f2, r.v);
+    o[0] = cvt_opaque(v.x), o[1] = cvt_opaque(v.y);
+  } else {
+    o[0] = cvt_opaque(__builtin_bit_cast(float, r.v));
+  }
+}
+template <typename T, int MC, int W, bool PSPEC, bool OPAQUE>
+__device__ __forceinline__ void col_pair(const RawOf<T, W> (&ra)[MC], const RawOf<T, W> (&rb)[MC], int j,
+                                         int col, Pend pe, const double (&gv)[W], double (&aj)[W],
+                                         double (&bj)[W]) {
+  raw_get_col<W, OPAQUE>(ra[j], (const T *)nullptr, aj);
+  raw_get_col<W, OPAQUE>(rb[j], (const T *)nullptr, bj);
+  const bool pj = PSPEC ? j == MC - 1 : (pe.on && j == col - 1);
+  if (PSPEC ? j == MC - 1 : true) {  // (compile-time false for the other columns of PSPEC)
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      const double yk = pend_y<T>(gv[k], a[j][k]);
-      const double sk = pend_s<T>(b[j][k], pe.stp);
-      a[j][k] = pj ? yk : a[j][k];
-      b[j][k] = pj ? sk : b[j][k];
+      const double yk = pend_y<T>(gv[k], aj[k]);
+      const double sk = pend_s<T>(bj[k], pe.stp);
+      aj[k] = pj ? yk : aj[k];
+      bj[k] = pj ? sk : bj[k];
+    }
+  }
+}
+
+// the newest pair (logical column col - 1) of one row group, from the registers
+template <int MC, int W, bool PSPEC = false>
+__device__ __forceinline__ void newest_cols(int col, const double (&a)[MC][W], const double (&b)[MC][W],
+                                            double (&yn)[W], double (&sn)[W]) {
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    if constexpr (PSPEC) {
+      yn[k] = a[MC - 1][k], sn[k] = b[MC - 1][k];
+    } else {
+      yn[k] = 0.0, sn[k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < MC; ++j)
+        if (j == col - 1) {
+          yn[k] = a[j][k];
+          sn[k] = b[j][k];
+        }
     }
   }
 }

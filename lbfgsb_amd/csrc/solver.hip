@@ -32,7 +32,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/lbfgsb_hip.h"
@@ -78,8 +80,13 @@ struct Rccl {
                             hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false;  // every symbol resolved
   bool load() {
-    if (h) return true;
+    if (ok) return true;
+    if (h) {  // an earlier attempt found a library without the symbols: try again from scratch
+      dlclose(h);
+      h = nullptr;
+    }
     // LBFGSB_RCCL_LIBRARY: a specific build of the library (tests point it at a small
     // shared-memory stand-in so that the communicator code path runs with several ranks on one GPU)
     const char *names[] = {std::getenv("LBFGSB_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
@@ -99,7 +106,12 @@ struct Rccl {
     SYM(GroupStart, "ncclGroupStart");
     SYM(GroupEnd, "ncclGroupEnd");
 #undef SYM
-    return GetUniqueId && CommInitRank && AllReduce && AllGather && GroupStart && GroupEnd;
+    ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather && GroupStart && GroupEnd;
+    if (!ok) {
+      dlclose(h);
+      h = nullptr;
+    }
+    return ok;
   }
 };
 Rccl g_rccl;
@@ -135,6 +147,7 @@ struct lbfgsb_hip_ctx {
   int m = 0, flags = 0, device = 0;
   int rank = 0, nranks = 1;
   int64_t nsync = 0, nfullsort = 0;
+  int64_t ntiesplit = 0;  // walks that ended inside a group of equal breakpoints
   double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
   // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
   // the next setulb_dev call fetches it together with the sums of its own first pass
@@ -148,6 +161,7 @@ struct lbfgsb_hip_ctx {
   double clk_ms[3] = {0.0, 0.0, 0.0};
   int64_t clk_n[3] = {0, 0, 0};
   hipStream_t clk_stream = nullptr;
+  hipEvent_t order_ev = nullptr;  // lbfgsb_hip_wait_stream
   void clk_begin(int k) {
     if (!clock_on) return;
     if (!clk_ev[k][0]) {
@@ -183,7 +197,7 @@ template <typename T>
 class Solver final : public lbfgsb_hip_ctx {
  public:
   // ---- device state ----
-  T *ws = nullptr, *wy = nullptr;
+  T *ws = nullptr, *wy = nullptr, *zero_buf = nullptr;
   int64_t ld = 0;
   T *z = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *xp = nullptr, *tbrk = nullptr;
   lbk::iw_t *iwhere = nullptr;  // one byte per row (the reference's int32 only in export/import)
@@ -239,7 +253,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (p) (void)hipFree(p);
       p = nullptr;
     };
-    F(ws), F(wy), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
+    F(ws), F(wy), F(zero_buf), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
         F(d_fix), F(pg_buf), F(pg_tmp);
@@ -251,6 +265,8 @@ class Solver final : public lbfgsb_hip_ctx {
     H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix);
     if (pf_ev) (void)hipEventDestroy(pf_ev);
     pf_ev = nullptr;
+    if (order_ev) (void)hipEventDestroy(order_ev);
+    order_ev = nullptr;
     for (auto &pair : clk_ev)
       for (auto &e : pair) {
         if (e) (void)hipEventDestroy(e);
@@ -287,6 +303,8 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&wy, wbytes));
     HIPCHK(hipMemsetAsync(ws, 0, wbytes, stream));
     HIPCHK(hipMemsetAsync(wy, 0, wbytes, stream));
+    HIPCHK(hipMalloc(&zero_buf, 256));  // read by the unroll slots beyond the stored pairs
+    HIPCHK(hipMemsetAsync(zero_buf, 0, 256, stream));
     const size_t vb = (size_t)(n + 32) * sizeof(T);
     for (T **p : {&z, &r, &d, &t, &xp, &tbrk}) {
       HIPCHK(hipMalloc(p, vb));
@@ -400,7 +418,7 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
-  lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m}; }
+  lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m, zero_buf}; }
 
   // =================================================================== cauchy
   // Breakpoint provider: hands the replicated host walk the breakpoints of ALL ranks in
@@ -428,6 +446,14 @@ class Solver final : public lbfgsb_hip_ctx {
     std::vector<uint32_t> taken;
     uint32_t next_chunk = 64;
     int grow = 0;
+    // LBFGSB_F_EXACT_TIES: the reference's own pop order (bkmin first, then hpsolb's heap),
+    // replayed on the host over ALL breakpoints; records are gathered in that order
+    bool exact = false;
+    std::vector<double> ht;       // heap keys   (t of hpsolb, 0-based)
+    std::vector<uint32_t> hio;    // heap values (iorder: local rows)
+    int64_t hleft = 0;            // nleft of the reference's walk for the NEXT pop
+    bool hbuilt = false;
+    int64_t hibkmin = -1;
   };
 
   // every rank contributes d_msg[0..count) (device); all of it lands in h_msg_all (rank-major)
@@ -600,8 +626,98 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
+  // ---- LBFGSB_F_EXACT_TIES: breakpoints in the reference's own order ----
+  // cauchy takes the smallest breakpoint from the scan (first minimum in variable order, :1384-
+  // 1389), then moves the last list entry into its slot, builds hpsolb's heap over the rest and
+  // pops one breakpoint per segment (:1391-1403).  Among EQUAL breakpoints that order is a
+  // property of the heap, not of the variables; it matters only when the walk ends inside a
+  // group of equal breakpoints (then it decides which of them are fixed).  Replaying it needs the
+  // whole list on the host: O(n) transfer + heap build, so it is opt-in and runs only for a call
+  // whose walk did end inside such a group (or from the start under iprint >= 99).
+  int exact_init(Provider &pv) {
+    CHK(ensure_tbrk());
+    std::vector<T> tb((size_t)n);
+    HIPCHK(hipMemcpyAsync(tb.data(), tbrk, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    nsync++;
+    pv = Provider{};
+    pv.exact = true;
+    pv.ht.clear(), pv.hio.clear();
+    const double inf = std::numeric_limits<double>::infinity();
+    double bk = 0.0;
+    for (int64_t i = 0; i < n; ++i) {  // the list of :1306-1322: variables with a finite breakpoint
+      const double t = (double)tb[(size_t)i];
+      if (!(t >= 0.0) || t == inf) continue;
+      pv.ht.push_back(t);
+      pv.hio.push_back((uint32_t)i);
+      if (pv.ht.size() == 1 || t < bk) bk = t, pv.hibkmin = (int64_t)pv.ht.size() - 1;
+    }
+    pv.hleft = (int64_t)pv.ht.size();
+    pv.hbuilt = false;
+    pv.have = true, pv.full = true;
+    pv.win_hi = inf;
+    pv.M.clear();
+    pv.mpos = pv.safe_end = 0;
+    pv.more_anywhere = pv.hleft > 0;
+    pv.taken.assign(1, 0);
+    pv.next_chunk = 1;  // the first record is the scan's minimum itself
+    return 0;
+  }
+  int refill_exact(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
+    const int recl = 2 * col + 4;
+    const uint32_t chunk_cap = (uint32_t)std::min<size_t>((msg_len - 2) / (size_t)recl, CHUNK_MAX);
+    const uint32_t want = std::min<uint32_t>(pv.next_chunk, chunk_cap);
+    pv.next_chunk = std::min<uint32_t>(std::max<uint32_t>(pv.next_chunk, 16) * 4, chunk_cap);
+    std::vector<uint64_t> hk;
+    std::vector<uint32_t> hi;
+    const int64_t nbreak = (int64_t)pv.ht.size();
+    while (hk.size() < want && pv.hleft > 0) {
+      double tj;
+      uint32_t row;
+      if (pv.hleft == nbreak) {  // iter == 1 (:1384-1389)
+        tj = pv.ht[(size_t)pv.hibkmin], row = pv.hio[(size_t)pv.hibkmin];
+      } else {
+        if (!pv.hbuilt) {  // iter == 2: the last entry replaces the used one (:1391-1398)
+          if (pv.hibkmin != nbreak - 1) {
+            pv.ht[(size_t)pv.hibkmin] = pv.ht[(size_t)nbreak - 1];
+            pv.hio[(size_t)pv.hibkmin] = pv.hio[(size_t)nbreak - 1];
+          }
+        }
+        lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio.data(), pv.hbuilt ? 1 : 0);
+        pv.hbuilt = true;
+        tj = pv.ht[(size_t)pv.hleft - 1], row = pv.hio[(size_t)pv.hleft - 1];
+      }
+      pv.hleft--;
+      uint64_t bits;
+      std::memcpy(&bits, &tj, 8);
+      hk.push_back(bits);
+      hi.push_back(row);
+    }
+    const uint32_t len = (uint32_t)hk.size();
+    pv.M.clear();
+    pv.mpos = pv.safe_end = 0;
+    pv.more_anywhere = pv.hleft > 0;
+    pv.taken.assign(1, 0);
+    pv.raw = nullptr;
+    if (len == 0) return 0;
+    HIPCHK(hipMemcpyAsync(keys[0], hk.data(), (size_t)len * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(idx[0], hi.data(), (size_t)len * 4, hipMemcpyHostToDevice, stream));
+    lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], len, row0, x, l, u, g, W(), head, col, r, d, pend,
+                                 d_msg + 2);
+    CHK(put_header((double)len, (double)pv.hleft));
+    CHK(exchange(2 + (size_t)len * recl));  // (also orders the pageable uploads above)
+    pv.M.resize(len);
+    for (uint32_t k = 0; k < len; ++k) {
+      const double *rec = h_msg_all + 2 + (size_t)k * recl;
+      pv.M[k] = MRec{rec[0], (int64_t)rec[1], 0, rec};
+    }
+    pv.safe_end = len;
+    return 0;
+  }
+
   // all-gather the next chunk of every rank's local list and merge
   int refill(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
+    if (pv.exact) return refill_exact(pv, x, l, u, g, head, col);
     const int recl = 2 * col + 4;
     const uint32_t chunk = pv.next_chunk;
     // the message buffer holds CHUNK_MAX records of the widest kind (col = m); narrower records
@@ -739,11 +855,14 @@ class Solver final : public lbfgsb_hip_ctx {
       lbk::launch_cauchy_finish<T>(q, n, row0, (const T *)cx, (const T *)cl, (const T *)cu,
                                    (const T *)cg, tbrk, iwhere, z, tsum, last_t, last_i);
       z_valid = true;
-    } else if (!fixlist.empty()) {
-      std::memcpy(h_fix, fixlist.data(), fixlist.size() * sizeof(int64_t));
-      HIPCHK(hipMemcpyAsync(d_fix, h_fix, fixlist.size() * sizeof(int64_t), hipMemcpyHostToDevice,
-                            stream));
-      lbk::launch_cauchy_fix(q, d_fix, (int)fixlist.size(), row0, n, iwhere);
+    } else {
+      for (size_t at = 0; at < fixlist.size(); at += FIX_CAP) {  // (one piece unless exact order)
+        const size_t cnt = std::min(FIX_CAP, fixlist.size() - at);
+        if (at) HIPCHK(hipStreamSynchronize(stream));  // h_fix is reused
+        std::memcpy(h_fix, fixlist.data() + at, cnt * sizeof(int64_t));
+        HIPCHK(hipMemcpyAsync(d_fix, h_fix, cnt * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        lbk::launch_cauchy_fix(q, d_fix, (int)cnt, row0, n, iwhere);
+      }
     }
     return 0;
   }
@@ -957,11 +1076,22 @@ class Solver final : public lbfgsb_hip_ctx {
       return 0;
     }
 
+    // Equal breakpoints are delivered in index order, the reference pops them in heap order
+    // (hpsolb :2079); the two differ in effect only if the walk ends INSIDE such a group.  That
+    // is detected (tie_split) and counted; with LBFGSB_F_EXACT_TIES the walk is then replayed from
+    // its start in the reference's own order (exact_init / refill_exact).
+    const bool can_exact = (flags & LBFGSB_F_EXACT_TIES) && nranks == 1 && !comm;
+    bool exact_run = can_exact && print_level >= 99;  // (a replay would print the walk twice)
+    std::vector<double> p_start(p, p + col2);
+    const double f1_start = f1, f2_start = f2, dtm_start = dtm;
+    for (;;) {  // at most two trips: the second one in exact order
+    bool tie_split = false;
     if (nbreak != 0) {
       int64_t nleft = nbreak;
       int64_t iter = 1;
       double tj = 0.0;
       Provider pv;
+      if (exact_run) CHK(exact_init(pv));
       const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
       for (;;) {
         const double tj0 = tj;
@@ -983,11 +1113,13 @@ class Solver final : public lbfgsb_hip_ctx {
             const double *rec = pv.raw ? pv.raw + pos * 4 : M[pos].rec;
             const double mt = rec[0];
             if (!(mt <= (tj + dtm) * INFL && mt < inf)) {  // beyond reach: dtm < dt
+              tie_split = last_t >= 0.0 && mt == last_t;
               stop = true;
               break;
             }
             const double dt = mt - tj;
             if (dtm < dt) {  // :1416
+              tie_split = last_t >= 0.0 && mt == last_t;
               stop = true;
               break;
             }
@@ -1002,7 +1134,7 @@ class Solver final : public lbfgsb_hip_ctx {
             last_t = mt;
             last_i = (int64_t)rec[1];
             if (!fix_overflow) {
-              if (fixlist.size() < FIX_CAP)
+              if (pv.exact || fixlist.size() < FIX_CAP)  // (exact order: no cursor describes the set)
                 fixlist.push_back(last_i * 2 + (dibp > 0.0 ? 1 : 0));
               else
                 fix_overflow = true;
@@ -1085,7 +1217,10 @@ class Solver final : public lbfgsb_hip_ctx {
           }
         }
         if (to_tight_loop) continue;
-        if (!rec) break;  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
+        if (!rec) {  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
+          tie_split = last_t >= 0.0 && pv.have && pv.mpos < pv.safe_end && pv.M[pv.mpos].t == last_t;
+          break;
+        }
         tj = rec[0];
         const double dt = tj - tj0;
         if (dt != 0.0 && ipr >= 100) {  // :1408-1412
@@ -1094,7 +1229,10 @@ class Solver final : public lbfgsb_hip_ctx {
           std::fprintf(rep.out, "Distance to the next break point =  %s\n", lbr::fD(dt, 11, 4).c_str());
           std::fprintf(rep.out, "Distance to the stationary point =  %s\n", lbr::fD(dtm, 11, 4).c_str());
         }
-        if (dtm < dt) break;  // :1416
+        if (dtm < dt) {  // :1416
+          tie_split = last_t >= 0.0 && tj == last_t;
+          break;
+        }
 
         // fix this variable (:1421-1434)
         pv.taken[pv.M[pv.mpos].rank]++;
@@ -1106,7 +1244,7 @@ class Solver final : public lbfgsb_hip_ctx {
         const double zibp = rec[3];
         last_t = tj;
         last_i = rec_gi;
-        if (fixlist.size() < FIX_CAP)
+        if (pv.exact || fixlist.size() < FIX_CAP)
           fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
         else
           fix_overflow = true;
@@ -1152,6 +1290,21 @@ class Solver final : public lbfgsb_hip_ctx {
           break;
         }
       }
+    }
+    if (tie_split && !exact_run) {
+      ntiesplit++;
+      if (can_exact) {  // replay from the start of the walk, in the reference's order
+        exact_run = true;
+        std::copy(p_start.begin(), p_start.end(), p);
+        for (int j = 0; j < col2; ++j) c[j] = 0.0;
+        f1 = f1_start, f2 = f2_start, dtm = dtm_start, tsum = 0.0, nseg = 1;
+        last_t = -1.0, last_i = -1;
+        fixlist.clear();
+        fix_overflow = false;
+        continue;
+      }
+    }
+    break;
     }
     if (debug_walk)
       std::fprintf(stderr, "[cauchy] nseg=%d tsum=%g dtm=%g last=(%.17g,%lld)\n", nseg, tsum, dtm,
@@ -1323,7 +1476,7 @@ class Solver final : public lbfgsb_hip_ctx {
       }
       clk_begin(0);
       lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
-                                plain ? 1 : 0, newrow ? 1 : 0, r, d, pend);
+                                newrow ? 1 : 0, r, d, pend);
       clk_end(0);
       CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
       res = h_res;
@@ -1359,8 +1512,8 @@ class Solver final : public lbfgsb_hip_ctx {
     if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
     clk_begin(2);
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, z, r, l, u, nbd, iwhere, x, g, W(), head, col, theta,
-                                cm_cf, cm_plain ? 1 : 0, cw, d, t, ls_unit_step ? xmut : nullptr,
-                                ls_do_stpmx ? 1 : 0, pend);
+                                cm_cf, cw, d, t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
+                                pend);
     clk_end(2);
     pend.on = 0;  // the pass stored the pair into its W slot
     z_valid = true;
@@ -1388,8 +1541,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // xp = xcp and the Newton direction as vectors (the direction goes to tbrk, which the
     // cursor-based cauchy_finish_kernel has read by then)
     if (!(flags & LBFGSB_F_MIRROR_INDEX)) CHK(write_xcp(xp, x, l, u, g));
-    lbk::launch_subsm_dir<T>(q, n, xp, iwhere, x, g, W(), head, col, theta, cm_cf, cm_plain ? 1 : 0,
-                             cw, tbrk);
+    lbk::launch_subsm_dir<T>(q, n, xp, iwhere, x, g, W(), head, col, theta, cm_cf, cw, tbrk);
     tbrk_valid = false;
     lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
     CHK(fetch(0, 1, 0));
@@ -1482,6 +1634,7 @@ class Solver final : public lbfgsb_hip_ctx {
       stpmx = 0, sbgnrm = 0, stp = 0, gdold = 0, dtd = 0, iter = 0, nfgv = 0, nseg = 0;
       nintol = 0, nskip = 0, ifun = 0, cachyt = 0, sbtime = 0, lnscht = 0, info = 0;
       nfree_g = nglob, nenter_g = 0, ileave_g = 0;
+      index_valid = false;
       tol = factr * epsmch;
       std::memcpy(word, "---", 4);
       prjctd = cnstnd = false, boxed = true;
@@ -1663,6 +1816,7 @@ class Solver final : public lbfgsb_hip_ctx {
             HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
           const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
           lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
+          index_valid = true;
           if (track)
             HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
           // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
@@ -1677,7 +1831,7 @@ class Solver final : public lbfgsb_hip_ctx {
               q.res_off = 3;
               clk_begin(0);
               lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
-                                        plain ? 1 : 0, newrow ? 1 : 0, r, d, pend);
+                                        newrow ? 1 : 0, r, d, pend);
               clk_end(0);
               q.res_off = 0;
               npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
@@ -1992,6 +2146,7 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
+  bool index_valid = false;  // a freev has run: wasfree is the membership of Index(1:nfree)
 
   // ============================================================ state exchange
   int export_state(void *wa_, int32_t *iwa) override {
@@ -2024,6 +2179,26 @@ class Solver final : public lbfgsb_hip_ctx {
       std::vector<lbk::iw_t> h((size_t)n);
       HIPCHK(hipMemcpy(h.data(), iwhere, (size_t)n * sizeof(lbk::iw_t), hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < n; ++i) iwa[n + i] = h[(size_t)i];
+      if (!index) {
+        // Contexts that do not mirror the reference's lists keep only the MEMBERSHIP of the free
+        // set as of the last freev (wasfree): Index is rebuilt from it in freev's order (:2044-
+        // 2054: free variables ascending from the front, active ones from the back).  The
+        // enter/leave segments of Indx2 are dead outside the call that made them (formk reads
+        // them in the same call, the next freev overwrites them): exported as zeros.
+        std::memset(iwa, 0, (size_t)n * 4);
+        std::memset(iwa + 2 * n, 0, (size_t)n * 4);
+        if (index_valid) {
+          std::vector<int8_t> wf((size_t)n);
+          HIPCHK(hipMemcpy(wf.data(), wasfree, (size_t)n, hipMemcpyDeviceToHost));
+          int64_t nf = 0, ia = n;
+          for (int64_t i = 0; i < n; ++i) {
+            if (wf[(size_t)i])
+              iwa[nf++] = (int32_t)(i + 1);
+            else
+              iwa[--ia] = (int32_t)(i + 1);
+          }
+        }
+      }
     }
     return 0;
   }
@@ -2055,16 +2230,20 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     // free-set membership as of the last freev: Index(1:nfree)
     std::vector<int8_t> wf((size_t)n, 0);
-    const int iter = isave_user[29];
     const int64_t nfree = isave_user[37];
     bool have_index = false;
     for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
-    if (!have_index) {
+    if (!have_index) {  // state from before the first freev (START / FG_START)
       std::fill(wf.begin(), wf.end(), (int8_t)1);
     } else {
-      for (int64_t i = 0; i < nfree; ++i) wf[iwa[i] - 1] = 1;
+      if (nfree < 0 || nfree > n) return fail(LBFGSB_E_STATE, "import_state: isave(38) (nfree) out of range");
+      for (int64_t i = 0; i < nfree; ++i) {
+        const int64_t k = iwa[i];
+        if (k < 1 || k > n) return fail(LBFGSB_E_STATE, "import_state: Index entry out of range");
+        wf[(size_t)(k - 1)] = 1;
+      }
     }
-    (void)iter;
+    index_valid = have_index;
     HIPCHK(hipMemcpyAsync(wasfree, wf.data(), (size_t)n, hipMemcpyHostToDevice, stream));
     if (index) {
       HIPCHK(hipMemcpyAsync(index, iwa, (size_t)n * 4, hipMemcpyHostToDevice, stream));
@@ -2108,7 +2287,7 @@ class Solver final : public lbfgsb_hip_ctx {
     std::memset(&cf, 0, sizeof cf);
     if (which == 0 || which == 2)
       lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
-                                cf, 0, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5});
+                                cf, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5});
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     else if (which == 3 || which == 4) {
@@ -2116,7 +2295,7 @@ class Solver final : public lbfgsb_hip_ctx {
       const T *l = (const T *)cl, *u = (const T *)cu;
       if (which == 3)  // with a pending pair: the variant every iteration after an update runs
         lbk::launch_subsm_update<T>(q, n, 0.5, z, r, l, u, cnbd, iwhere, (const T *)x, (const T *)g,
-                                    W(), head, col, 1.0, cf, 0, cf, d, t, (T *)nullptr, 1,
+                                    W(), head, col, 1.0, cf, cf, d, t, (T *)nullptr, 1,
                                     lbk::Pend{1, 0.5});
       else             // as the evaluation of a trial point: reduces only
         lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, d, 0.5, iwhere,
@@ -2227,12 +2406,31 @@ int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, 
   ncclComm_t comm = nullptr;
   if (g_rccl.CommInitRank(&comm, nranks, id, rank) != ncclSuccess)
     return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
-  if (ctx->flags & LBFGSB_F_REAL32) {
-    as<float>(ctx)->comm = comm;
-    return as<float>(ctx)->set_ranks(rank, nranks);
-  }
-  as<double>(ctx)->comm = comm;
-  return as<double>(ctx)->set_ranks(rank, nranks);
+  auto attach = [&](auto *s) -> int {
+    if (s->comm) g_rccl.CommDestroy(s->comm);  // (a second init replaces the communicator)
+    s->comm = nullptr;
+    const int rc = s->set_ranks(rank, nranks);
+    if (rc) {
+      g_rccl.CommDestroy(comm);
+      return rc;
+    }
+    s->comm = comm;
+    return 0;
+  };
+  if (ctx->flags & LBFGSB_F_REAL32) return attach(as<float>(ctx));
+  return attach(as<double>(ctx));
+}
+
+void *lbfgsb_hip_get_stream(lbfgsb_hip_ctx *ctx) { return ctx ? (void *)ctx->q.stream : nullptr; }
+
+int lbfgsb_hip_wait_stream(lbfgsb_hip_ctx *ctx, void *producer_stream) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if ((hipStream_t)producer_stream == ctx->q.stream) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->order_ev) HIPCHK(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ctx->order_ev, (hipStream_t)producer_stream));
+  HIPCHK(hipStreamWaitEvent(ctx->q.stream, ctx->order_ev, 0));
+  return 0;
 }
 
 int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag,
@@ -2277,7 +2475,10 @@ int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void 
       if (fg) {
         rc = ctx->sync();  // a callback may run on any stream
         if (rc) return rc;
+        // (the callback must leave g complete or ordered before the context's stream:
+        //  lbfgsb_hip_wait_stream / lbfgsb_hip_get_stream, include/lbfgsb_hip.h)
         *f = fg(user, x, g);
+        if (std::isnan(*f)) lbh::str60_set(task, "STOP: THE OBJECTIVE CALLBACK RETURNED NaN");
       } else {
         rc = ctx->k_objective(builtin_kind, x, g, nullptr);  // f comes back with the next call
         if (rc) return rc;
@@ -2378,6 +2579,12 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
   return 0;
 }
 
+int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count) {
+  if (!ctx || !count) return fail(LBFGSB_E_ARG, "tie_splits: NULL argument");
+  *count = ctx->ntiesplit;
+  return 0;
+}
+
 int lbfgsb_hip_pass_clock(lbfgsb_hip_ctx *ctx, int enable, double *ms_total, int64_t *count) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   HIPCHK(hipSetDevice(ctx->device));
@@ -2398,7 +2605,53 @@ int lbfgsb_hip_pass_clock(lbfgsb_hip_ctx *ctx, int enable, double *ms_total, int
 }
 
 // ----------------------------------------------------------- host-pointer form
-// The exact reference signature (src/lbfgsb.f90:88-89) plus real_bytes/mirror.
+// The exact reference signature (src/lbfgsb.f90:88-89) plus real_bytes/mirror.  The context of a
+// run is kept in a process-wide registry; isave(17:18) hold {id, tag} -- slots the reference
+// never writes (:250-284) -- never a raw pointer.
+namespace {
+constexpr int32_t HOST_TAG = 0x4C424642;  // "LBFB"
+struct HostRegistry {
+  std::mutex mu;
+  std::unordered_map<int32_t, lbfgsb_hip_ctx *> live;
+  int32_t next_id = 1;
+  ~HostRegistry() {  // contexts of runs that were abandoned without lbfgsb_hip_release_host
+    for (auto &kv : live) delete kv.second;
+  }
+  int32_t add(lbfgsb_hip_ctx *c) {
+    std::lock_guard<std::mutex> lk(mu);
+    while (live.count(next_id) || next_id <= 0) next_id = next_id == INT32_MAX ? 1 : next_id + 1;
+    live[next_id] = c;
+    return next_id;
+  }
+  lbfgsb_hip_ctx *find(const int32_t *isave) {
+    if (isave[17] != HOST_TAG) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(isave[16]);
+    return it == live.end() ? nullptr : it->second;
+  }
+  void drop(int32_t *isave) {
+    lbfgsb_hip_ctx *c = nullptr;
+    if (isave[17] == HOST_TAG) {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = live.find(isave[16]);
+      if (it != live.end()) {
+        c = it->second;
+        live.erase(it);
+      }
+    }
+    delete c;
+    isave[16] = isave[17] = 0;
+  }
+};
+HostRegistry g_host;
+}  // namespace
+
+int lbfgsb_hip_release_host(int32_t *isave) {
+  if (!isave) return fail(LBFGSB_E_ARG, "isave == NULL");
+  g_host.drop(isave);
+  return 0;
+}
+
 int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
                            const int32_t *nbd, void *f, void *g, double factr, double pgtol,
                            void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
@@ -2410,6 +2663,7 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
   lbfgsb_hip_ctx *ctx = nullptr;
   const bool start = lbh::str60_eq(task, "START");
   if (start) {
+    g_host.drop(isave);  // a START over the isave of a run that is still registered
     // the reference's own argument checks that do not need a context (:1618-1620)
     if (n <= 0 || m <= 0) {
       if (n <= 0) lbh::str60_set(task, "ERROR: N <= 0");
@@ -2421,36 +2675,55 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
     if (rc) return rc;
     if (iteration_file && iteration_file[0]) ctx->itfile_name = iteration_file;
     const size_t vb = ((size_t)n + 32) * rb;
-    HIPCHK(hipMalloc(&ctx->hx, vb));
-    HIPCHK(hipMalloc(&ctx->hg, vb));
-    HIPCHK(hipMalloc(&ctx->hl, vb));
-    HIPCHK(hipMalloc(&ctx->hu, vb));
-    HIPCHK(hipMalloc(&ctx->hnbd, ((size_t)n + 32) * 4));
-    HIPCHK(hipMemset(ctx->hg, 0, vb));
-    HIPCHK(hipMemcpy(ctx->hx, x, (size_t)n * rb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->hl, l, (size_t)n * rb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->hu, u, (size_t)n * rb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->hnbd, nbd, (size_t)n * 4, hipMemcpyHostToDevice));
+    auto stage = [&]() -> int {
+      HIPCHK(hipMalloc(&ctx->hx, vb));
+      HIPCHK(hipMalloc(&ctx->hg, vb));
+      HIPCHK(hipMalloc(&ctx->hl, vb));
+      HIPCHK(hipMalloc(&ctx->hu, vb));
+      HIPCHK(hipMalloc(&ctx->hnbd, ((size_t)n + 32) * 4));
+      HIPCHK(hipMemset(ctx->hg, 0, vb));
+      HIPCHK(hipMemcpy(ctx->hx, x, (size_t)n * rb, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ctx->hl, l, (size_t)n * rb, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ctx->hu, u, (size_t)n * rb, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(ctx->hnbd, nbd, (size_t)n * 4, hipMemcpyHostToDevice));
+      return 0;
+    };
+    rc = stage();
+    if (rc) {
+      lbfgsb_hip_destroy(ctx);
+      return rc;
+    }
     std::memset(isave, 0, 44 * sizeof(int32_t));
-    uint64_t hbits = (uint64_t)(uintptr_t)ctx;
-    std::memcpy(&isave[16], &hbits, 8);  // isave(17:18): never written by the reference
-    // offsets the reference documents in isave(1:16) (:250-265), saturated instead of wrapped
-    const int64_t off[16] = {(int64_t)m * n, (int64_t)m * m, 4ll * m * m};
-    (void)off;
+    // the wa offsets the reference persists in isave(4:16) (:250-265: lws, lwy, lsy, lss, lwt, lwn,
+    // lsnd, lz, lr, ld, lt, lxp, lwa; isave(1:3) = m*n, m^2, 4m^2), 1-based, computed in 64 bits
+    // and saturated (the reference's default-integer arithmetic wraps at n = 1e8, m = 10)
+    {
+      const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
+      const int64_t lws = 1, lwy = lws + mn, lsy = lwy + mn, lss = lsy + mm, lwt = lss + mm,
+                    lwn = lwt + mm, lsnd = lwn + 4 * mm, lz = lsnd + 4 * mm, lr = lz + n, ld_ = lr + n,
+                    lt = ld_ + n, lxp = lt + n, lwa = lxp + n;
+      const int64_t v[16] = {mn, mm, 4 * mm, lws, lwy, lsy, lss, lwt, lwn, lsnd, lz, lr, ld_, lt, lxp, lwa};
+      for (int k = 0; k < 16; ++k) isave[k] = (int32_t)std::min<int64_t>(v[k], INT32_MAX);
+    }
+    isave[16] = g_host.add(ctx);
+    isave[17] = HOST_TAG;
   } else {
-    uint64_t hbits = 0;
-    std::memcpy(&hbits, &isave[16], 8);
-    ctx = (lbfgsb_hip_ctx *)(uintptr_t)hbits;
+    ctx = g_host.find(isave);
     if (!ctx || ctx->n != n || ctx->m != m)
       return fail(LBFGSB_E_STATE, "setulb called without a live context (task must be START first)");
     if (lbh::str60_pre(task, "FG"))
       HIPCHK(hipMemcpy(ctx->hg, g, (size_t)n * rb, hipMemcpyHostToDevice));
   }
+  const int32_t keep_id = isave[16], keep_tag = isave[17];
+  int32_t keep16[16];
+  std::memcpy(keep16, isave, sizeof keep16);
   double fd = r32 ? (double)*(float *)f : *(double *)f;
   double ds[29];
   for (int i = 0; i < 29; ++i) ds[i] = r32 ? (double)((float *)dsave)[i] : ((double *)dsave)[i];
   int rc = ctx->setulb_dev(ctx->hx, ctx->hl, ctx->hu, ctx->hnbd, &fd, ctx->hg, factr, pgtol, task,
                            iprint, csave, lsave, isave, ds);
+  std::memcpy(isave, keep16, sizeof keep16);
+  isave[16] = keep_id, isave[17] = keep_tag;
   if (iprint >= 0) std::fflush(stdout);
   if (rc) return rc;
   for (int i = 0; i < 29; ++i) {
@@ -2474,10 +2747,8 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
     void *src = r32 ? (void *)as<float>(ctx)->t : (void *)as<double>(ctx)->t;
     HIPCHK(hipMemcpy((char *)wa + (size_t)off_t * rb, src, (size_t)n * rb, hipMemcpyDeviceToHost));
   }
-  if (!lbh::str60_pre(task, "FG") && !lbh::str60_pre(task, "NEW_X")) {
-    lbfgsb_hip_destroy(ctx);  // terminal task: CONVERGENCE / ABNORMAL / ERROR / STOP
-    isave[16] = isave[17] = 0;
-  }
+  if (!lbh::str60_pre(task, "FG") && !lbh::str60_pre(task, "NEW_X"))
+    g_host.drop(isave);  // terminal task: CONVERGENCE / ABNORMAL / ERROR / STOP
   return 0;
 }
 

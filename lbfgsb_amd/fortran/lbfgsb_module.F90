@@ -27,6 +27,9 @@
       integer,parameter,public :: lbfgsp_wp = wp
 
       public :: setulb
+      public :: lbfgsb_release   ! extension: frees the GPU context of a run that was stopped
+                                 ! by the caller (task = 'STOP...' without another setulb call,
+                                 ! as test/driver2.f90:174-195 does); harmless otherwise
 
       interface
          function lbfgsb_hip_setulb_host(n,m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,iprint,  &
@@ -42,6 +45,11 @@
             type(c_ptr),value :: iteration_file
             integer(c_int32_t) :: rc
          end function lbfgsb_hip_setulb_host
+         function lbfgsb_hip_release_host(isave) bind(C,name='lbfgsb_hip_release_host') result(rc)
+            import :: c_int32_t
+            integer(c_int32_t) :: isave(*)
+            integer(c_int32_t) :: rc
+         end function lbfgsb_hip_release_host
          function lbfgsb_hip_last_error() bind(C,name='lbfgsb_hip_last_error') result(p)
             import :: c_ptr
             type(c_ptr) :: p
@@ -119,5 +127,11 @@
       end if
 
       end subroutine setulb
+
+      subroutine lbfgsb_release(Isave)
+      integer :: Isave(44)
+      integer(c_int32_t) :: rc
+      rc = lbfgsb_hip_release_host(Isave)
+      end subroutine lbfgsb_release
 
       end module lbfgsb_module

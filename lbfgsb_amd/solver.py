@@ -60,8 +60,10 @@ class DeviceSolver:
 
     def __init__(self, n_local: int, m: int, n_global: Optional[int] = None, row0: int = 0,
                  real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None,
-                 same_stream_objective: bool = False, parallel_gcp: bool = False):
+                 same_stream_objective: bool = False, parallel_gcp: bool = False,
+                 exact_ties: bool = False):
         self.lib = load_library()
+        self.same_stream_objective = bool(same_stream_objective)
         self.n, self.m = int(n_local), int(m)
         self.n_global = int(n_global if n_global is not None else n_local)
         self.row0 = int(row0)
@@ -69,6 +71,7 @@ class DeviceSolver:
         flags = (capi.F_REAL32 if real32 else 0) | (capi.F_MIRROR_INDEX if mirror_index else 0)
         flags |= capi.F_NO_RETURN_SYNC if same_stream_objective else 0
         flags |= capi.F_PARALLEL_GCP if parallel_gcp else 0  # opt-in, see include/lbfgsb_hip.h
+        flags |= capi.F_EXACT_TIES if exact_ties else 0      # opt-in, see include/lbfgsb_hip.h
         h = C.c_void_p()
         sp = C.c_void_p(int(stream)) if stream else None
         check(self.lib.lbfgsb_hip_create(self.n, self.n_global, self.row0, self.m, flags, device,
@@ -144,11 +147,30 @@ class DeviceSolver:
     def set_task(self, s: str):
         self.task[:] = pad60(s)
 
-    def setulb(self, x, l, u, nbd, g, factr: float, pgtol: float, iprint: int = -1) -> str:
-        if self.task_s == "START" and not isinstance(x, np.ndarray):
-            # the solver runs on its own stream: make sure the caller's tensors are materialised
+    def wait_stream(self, stream=None):
+        """Order the solver's stream after everything queued so far on `stream` (default: torch's
+        current stream) without blocking the host (lbfgsb_hip_wait_stream)."""
+        if stream is None:
             import torch
-            torch.cuda.synchronize()
+            stream = torch.cuda.current_stream().cuda_stream
+        check(self.lib.lbfgsb_hip_wait_stream(self.h, C.c_void_p(int(stream))))
+
+    @property
+    def stream(self) -> int:
+        """the hipStream_t every kernel of this context runs on"""
+        return int(self.lib.lbfgsb_hip_get_stream(self.h) or 0)
+
+    def setulb(self, x, l, u, nbd, g, factr: float, pgtol: float, iprint: int = -1) -> str:
+        if not isinstance(x, np.ndarray):
+            t = self.task_s
+            if t == "START":
+                # the solver runs on its own stream: make sure the caller's tensors are materialised
+                import torch
+                torch.cuda.synchronize()
+            elif t.startswith("FG") and not self.same_stream_objective:
+                # g (and x) were produced on torch's current stream: the solver's stream must not
+                # read them before that work is done (include/lbfgsb_hip.h, "Stream ordering")
+                self.wait_stream()
         check(self.lib.lbfgsb_hip_setulb_dev(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(self.f),
                                              _p(g), float(factr), float(pgtol), _p(self.task),
                                              int(iprint), _p(self.csave), _p(self.lsave),
@@ -164,14 +186,32 @@ class DeviceSolver:
             import torch
             torch.cuda.synchronize()
         cb = C.cast(None, capi.FG_FN)
+        failure = []
         if fg is not None:
-            cb = capi.FG_FN(lambda user, xp, gp: float(fg(xp, gp)))
+            def _fg(user, xp, gp):
+                # the callback must leave g complete, or ordered before the solver's stream
+                # (self.wait_stream() / evaluate on self.stream); a Python exception cannot cross
+                # the C frame: it is kept, the evaluation reports NaN -- the line search then
+                # fails and the loop ends -- and it is raised again below
+                if failure:
+                    return float("nan")
+                try:
+                    val = float(fg(xp, gp))
+                    if not self.same_stream_objective:
+                        self.wait_stream()
+                    return val
+                except BaseException as e:   # noqa: BLE001
+                    failure.append(e)
+                    return float("nan")
+            cb = capi.FG_FN(_fg)
             self._keep.append(cb)
         check(self.lib.lbfgsb_hip_minimize(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g),
                                            float(factr), float(pgtol), int(max_iter), int(max_fg),
                                            int(iprint), cb, None, int(builtin), _p(self.f),
                                            _p(self.task), _p(self.lsave), _p(self.isave),
                                            _p(self.dsave)))
+        if failure:
+            raise failure[0]
         return self.task_s
 
     # ---- state exchange / kernels ----
@@ -241,6 +281,12 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_pass_clock(self.h, int(enable), ms, cnt))
         names = ("cmprlb_wtv", "update_scan", "subsm_update")
         return {nm: (ms[k], cnt[k]) for k, nm in enumerate(names)}
+
+    def tie_splits(self) -> int:
+        """setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints"""
+        c = C.c_int64()
+        check(self.lib.lbfgsb_hip_tie_splits(self.h, C.byref(c)))
+        return int(c.value)
 
     def stats(self):
         a, b, c, w = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()

@@ -1,0 +1,154 @@
+"""Boundary behaviour of the C ABI that the parity tests do not touch: stream ordering of the
+caller's f,g evaluation, the registry behind the host-pointer form (the reference's own
+argument list, src/lbfgsb.f90:88-89), error propagation out of the minimize wrapper."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(oracle_built):
+    import torch
+    import lbfgsb_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    lbfgsb_amd.load_library()
+    return dict(po=oracle_built, torch=torch, la=lbfgsb_amd)
+
+
+def test_fg_produced_on_another_stream_is_ordered(env):
+    """include/lbfgsb_hip.h "Stream ordering": g written by work that is still QUEUED on another
+    stream when setulb is re-entered (no host synchronisation in between) must be what the
+    solver reads -- DeviceSolver.setulb orders the solver's stream behind torch's current stream
+    (lbfgsb_hip_wait_stream).  Same trajectory as the fully synchronised loop."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 200_003, 5, 6
+    p = po.problem_quadratic(n, m, mixed_nbd=True)
+    i = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    a = 1.0 + 99.0 * ((7919 * i) % 10007).double() / 10006.0
+    c = -2.0 + 4.0 * ((104729 * i) % 100003).double() / 100002.0
+
+    def run(async_side):
+        sol = la.DeviceSolver(n, m)
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        side = torch.cuda.Stream()
+        rows = []
+        while True:
+            if async_side and sol.task_s.startswith("FG"):
+                with torch.cuda.stream(side):
+                    t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            else:
+                t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if t.startswith("FG"):
+                if async_side:
+                    # the FG return synchronised the solver's stream: x is complete.  f is taken
+                    # synchronously; g is written on a side stream behind a long spin, so that it
+                    # is still being produced when setulb is called again
+                    d = x - c
+                    sol.f[0] = float(0.5 * torch.sum(a * d * d))
+                    with torch.cuda.stream(side):
+                        torch.cuda._sleep(20_000_000)
+                        g.copy_(a * (x - c))
+                else:
+                    d = x - c
+                    g.copy_(a * d)
+                    sol.f[0] = float(0.5 * torch.sum(a * d * d))
+                    torch.cuda.synchronize()
+            elif t.startswith("NEW_X"):
+                rows.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                             float(sol.f[0])))
+                if sol.isave[29] >= iters:
+                    break
+            else:
+                break
+        torch.cuda.synchronize()
+        sol.close()
+        return rows
+    ref = run(False)
+    got = run(True)
+    assert [r[:4] for r in got] == [r[:4] for r in ref]
+    for a_, b_ in zip(got, ref):
+        assert a_[4] == pytest.approx(b_[4], rel=1e-12)
+
+
+def test_host_form_registry_and_offsets(env):
+    """The host-pointer form keeps its context in a registry keyed by isave(17:18): stale or
+    garbage handles are refused, a caller that stops by itself releases the context with
+    lbfgsb_hip_release_host, START over a live run frees the old one, and isave(1:16) carry the
+    wa offsets the reference persists there (src/lbfgsb.f90:250-265)."""
+    po, la = env["po"], env["la"]
+    lib = la.load_library()
+    p = po.problem_quadratic(300, 4, mixed_nbd=True)
+    nbd = p.nbd.astype(np.int32)
+
+    def call(s):
+        la.setulb(p.n, p.m, s.x, p.l, p.u, nbd, s.f, s.g, 0.0, 0.0, s.wa, s.iwa, s.task, -1, s.csave,
+                  s.lsave, s.isave, s.dsave)
+        if s.task_s.startswith("FG"):
+            s.f[0] = p.fg(s.x, s.g)
+    s = po.State.fresh(p)
+    for _ in range(6):
+        call(s)
+    n, m = p.n, p.m
+    mn, mm = m * n, m * m
+    want = [mn, mm, 4 * mm, 1, 1 + mn, 1 + 2 * mn, 1 + 2 * mn + mm, 1 + 2 * mn + 2 * mm, 1 + 2 * mn + 3 * mm,
+            1 + 2 * mn + 7 * mm, 1 + 2 * mn + 11 * mm]
+    assert s.isave[:11].tolist() == want
+    assert s.isave[11] == want[10] + n and s.isave[15] == want[10] + 5 * n       # lr ... lwa
+    # the caller stops by itself (driver2 style) and releases the context
+    assert lib.lbfgsb_hip_release_host(s.isave.ctypes.data_as(C.c_void_p)) == 0
+    assert s.isave[16] == 0 and s.isave[17] == 0
+    with pytest.raises(la.LbfgsbError):
+        call(s)                                   # the run is gone: refused, not dereferenced
+    # garbage in the handle slots
+    s2 = po.State.fresh(p)
+    call(s2)
+    bad = s2.copy()
+    bad.isave[16] = 123456
+    with pytest.raises(la.LbfgsbError):
+        call(bad)
+    bad = s2.copy()
+    bad.isave[17] = 77
+    with pytest.raises(la.LbfgsbError):
+        call(bad)
+    # START over the isave of a live run: the old context is freed, the new run is independent
+    old_id = int(s2.isave[16])
+    s2.task[:] = po.pad60("START")
+    s2.x[:] = p.x0
+    call(s2)
+    assert s2.task_s.startswith("FG_START") and int(s2.isave[16]) != 0
+    stale = s2.copy()
+    stale.isave[16] = old_id if old_id != int(s2.isave[16]) else old_id + 1000
+    with pytest.raises(la.LbfgsbError):
+        call(stale)
+    lib.lbfgsb_hip_release_host(s2.isave.ctypes.data_as(C.c_void_p))
+
+
+def test_minimize_callback_exception_is_raised(env):
+    """A Python exception inside the fg callback of DeviceSolver.minimize must not be swallowed
+    by the C frame: the loop ends and the exception is raised to the caller."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m = 1001, 4
+    p = po.problem_quadratic(n, m)
+    sol = la.DeviceSolver(n, m)
+    x = torch.from_numpy(p.x0.copy()).cuda()
+    g = torch.zeros_like(x)
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+    calls = []
+
+    def fg(xp, gp):
+        calls.append(1)
+        if len(calls) == 3:
+            raise ValueError("objective blew up")
+        return sol.objective(0, x, g)
+    with pytest.raises(ValueError, match="objective blew up"):
+        sol.minimize(x, l, u, nbd, g, fg=fg, factr=0.0, pgtol=0.0, max_iter=50)
+    assert sol.task_s.startswith("STOP: THE OBJECTIVE CALLBACK RETURNED NaN")
+    assert len(calls) == 3
+    sol.close()
