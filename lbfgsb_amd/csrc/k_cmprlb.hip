@@ -306,10 +306,11 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
     const bool spec = pe.on && col == mc;
 #define LB_CMPRLB(NEWROWV, PSPECV)                                                                  \
   DISPATCH_MAXC_NT(col, q.nt,                                                                       \
-                   hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, pipe_for(MC)>),\
-                                      dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum, iwhere,    \
-                                      w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta, a, pr, pd,   \
-                                      pe, q.d_part))
+                   DISPATCH_PIPE(MC, hipLaunchKernelGGL(                                            \
+                                         (cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, PIPEV>),   \
+                                         dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum, iwhere, \
+                                         w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta, a, pr,    \
+                                         pd, pe, q.d_part)))
     if (newrow) {
       if (spec)
         LB_CMPRLB(true, true);

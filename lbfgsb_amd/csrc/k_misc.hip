@@ -20,16 +20,28 @@ int grid_for(int64_t n, int vec) {
 // The passes over W keep 2-3 workgroups resident per CU (132-250 VGPRs): a grid of about that
 // many workgroups, each striding over more rows, reads 3-6 % faster than 2048 of them (sweep at
 // n = 1e8: 512 and 768 workgroups are equal, 1024+ slower).  LBFGSB_WGRID overrides.
-// (fp32, m = 10 measured the other way round -- 2048: 150 it/s, 768: 144 -- and keeps 2048.)
+// (Round 1 kept 2048 for fp32; with the straight-line trips 768 is the better grid there too:
+//  fp32 m = 20 94 -> 99.7 it/s, m = 10 158.9 -> 159.9.)
 int grid_for_w(int64_t n, int vec, int elem_bytes) {
   static const int env_cap = [] {
     const char *e = std::getenv("LBFGSB_WGRID");
     const int v = e ? std::atoi(e) : 0;
     return v >= 1 && v <= MAX_BLOCKS ? v : 0;
   }();
-  const int cap = env_cap ? env_cap : (elem_bytes == 8 ? 768 : MAX_BLOCKS);
+  (void)elem_bytes;
+  const int cap = env_cap ? env_cap : 768;
   const int g = grid_for(n, vec);
   return g > cap ? cap : g;
+}
+
+bool pipe_on(int mc, int elem_bytes) {
+  static const int e = [] {
+    const char *v = std::getenv("LBFGSB_PIPE");
+    return v ? std::atoi(v) : -1;
+  }();
+  if (e == 0) return false;
+  if (e == 1) return mc <= 20;
+  return mc == 20 || (mc == 10 && elem_bytes == 4);
 }
 
 int maxc_for(int col) { return col <= 5 ? 5 : (col <= 10 ? 10 : (col <= 20 ? 20 : 32)); }

@@ -175,11 +175,12 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
   const bool spec = pe.on && col == maxc_for(col);
 #define LB_SUBSM(PSPECV)                                                                            \
   DISPATCH_MAXC_NT(col, q.nt,                                                                       \
-                   hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV, PSPECV, pipe_for(MC)>),      \
-                                      dim3(gr), dim3(BLOCK), 0, q.stream, n, tsum, zout, r, l, u, nbd, \
-                                      iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head, col,     \
-                                      theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, w.wy + slot,   \
-                                      w.ws + slot, q.d_part))
+                   DISPATCH_PIPE(MC, hipLaunchKernelGGL(                                            \
+                                         (subsm_update_kernel<T, MC, NTV, PSPECV, PIPEV>), dim3(gr),\
+                                         dim3(BLOCK), 0, q.stream, n, tsum, zout, r, l, u, nbd,     \
+                                         iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head, col,  \
+                                         theta, cf, wv, dvec, tvec, xout, do_stpmx, pe,             \
+                                         w.wy + slot, w.ws + slot, q.d_part)))
   if (spec)
     LB_SUBSM(true);
   else

@@ -219,10 +219,11 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         WStore<T> w, int head, int col, int itail, int store_pair, int store_iw) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
-  DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, pipe_for(MC)>), dim3(gr), dim3(BLOCK), 0,
-                                         q.stream, n, x, l, u, nbd, g, r, d, stp, iwhere, tbrk, w.ws,
-                                         w.wy, w.zero, w.ld, w.m, head, nold, itail, store_pair,
-                                         store_iw, q.d_part));
+  DISPATCH_MAXC_NT(nold, q.nt,
+                   DISPATCH_PIPE(MC, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PIPEV>), dim3(gr),
+                                                        dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d,
+                                                        stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m,
+                                                        head, nold, itail, store_pair, store_iw, q.d_part)));
   q.launches++;
   launch_finalize(q, gr, 4 * maxc_for(nold) + 9, 1, 1);
 }

@@ -818,3 +818,185 @@ def test_parallel_gcp_with_pairs_stored(env):
         assert abs(a_[2] - b_[2]) <= 2 and abs(a_[3] - b_[3]) <= 2, (a_, b_)
         assert a_[5] == pytest.approx(b_[5], rel=1e-9)
     assert st["cauchy_fullsorts"] >= 2
+
+
+# ---------------------------------------------------------------------------------------------
+# Equal breakpoints (src/lbfgsb.f90:1384-1403, hpsolb :2079-2157)
+# ---------------------------------------------------------------------------------------------
+def _craft_tie_split(po, want_non_prefix=True):
+    """A one-step input whose Cauchy walk ENDS INSIDE a group of equal breakpoints, found with
+    the oracle: at a NEW_X state of a quadratic run, K interior free variables get the same
+    distance to their lower bound (delta, exactly) and the same gradient entry (gamma), hence
+    bit-identical breakpoints t* = delta / gamma, while their rows of W differ -- the jumps of
+    f' at t* differ per variable and f' changes sign part-way through the group.
+    -> (problem, state, group, oracle's next state)."""
+    n, m = 600, 5
+    p = po.problem_quadratic(n, m)
+    eng = po.Engine("oracle")
+    snaps = []
+    po.run(eng, p, max_calls=60, snapshot=lambda k, s: snaps.append(s.copy()))
+    off = po.wa_offsets(n, m)
+    rng = np.random.default_rng(1)
+
+    def step(prob, s):
+        s = s.copy()
+        po.call(eng, prob, s)
+        return s
+    for k, s in enumerate(snaps):
+        if not s.task_s.startswith("NEW_X") or s.isave[27] < 2:
+            continue
+        nxt = step(p, s)
+        x, d = s.x, -s.g
+        o, ln = off["xp"]
+        iw = nxt.iwa[n:2 * n]
+        free = (iw == 0) & (np.abs(d) > 1e-8)
+        if free.sum() < 50:
+            continue
+        ts = float(np.median((nxt.wa[o:o + ln][free] - x[free]) / d[free]))
+        rest = float(np.sum(s.g[free] ** 2))
+        interior = np.nonzero(free & (x > p.l + 0.3) & (x < p.u - 0.05))[0]
+        for K in (8, 16):
+            for _ in range(3):
+                cand = np.sort(rng.choice(interior, K, replace=False))
+                for mult in (0.25, 0.5, 1, 2, 4):
+                    for c in (0.6, 0.9, 1.2):
+                        gam = float(np.sqrt(rest * mult / K))
+                        delta = float(np.round(c * ts * gam * 1024) / 1024)
+                        if not 0 < delta <= 0.25:
+                            continue
+                        q = po.Problem(p.name, n, m, p.x0, p.l.copy(), p.u.copy(), p.nbd.copy(), p.factr,
+                                       p.pgtol, p.fg, p.real)
+                        s2 = s.copy()
+                        if any(x[i] - (x[i] - delta) != delta for i in cand):
+                            continue
+                        q.l[cand] = x[cand] - delta
+                        s2.g[cand] = gam
+                        out = step(q, s2)
+                        fixed = out.iwa[n:2 * n][cand] > 0
+                        nfix = int(fixed.sum())
+                        if not (0 < nfix < K and out.task_s.startswith("FG")):
+                            continue
+                        prefix = bool(np.all(fixed[:nfix]))
+                        if want_non_prefix and prefix:
+                            continue
+                        return q, s2, cand, out
+    raise AssertionError("no tie-split construction found")
+
+
+def _one_call(env, p, s_in, **ctx_flags):
+    po, torch, la = env["po"], env["torch"], env["la"]
+    s = s_in.copy()
+    sol = la.DeviceSolver(p.n, p.m, mirror_index=True, **ctx_flags)
+    try:
+        x, g = _dev(torch, s.x), _dev(torch, s.g)
+        l, u, nbd = _dev(torch, p.l), _dev(torch, p.u), _dev(torch, p.nbd.astype(np.int32))
+        sol.import_state(s.wa, s.iwa, s.isave)
+        for name in ("task", "csave", "lsave", "isave", "dsave"):
+            getattr(sol, name)[:] = getattr(s, name)
+        sol.f[0] = s.f[0]
+        sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+        torch.cuda.synchronize()
+        wa, iwa = sol.export_state()
+        out = po.State(p.n, p.m, x.cpu().numpy(), g.cpu().numpy(), sol.f.copy(), wa, iwa, sol.task.copy(),
+                       sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(), sol.dsave.copy())
+        return out, sol.tie_splits()
+    finally:
+        sol.close()
+
+
+def test_walk_ending_inside_a_tie_group(env):
+    """The case VERDICT r1 asked for: a walk that ends INSIDE a group of equal breakpoints, where
+    the reference's heap order (hpsolb :2079) -- not the variable order -- decides which members
+    are fixed (here a non-prefix subset of the group).
+      * default context: the call is detected (tie_splits == 1); the generalized Cauchy POINT is
+        the reference's (every member of the group reaches its bound at t* whether it is labelled
+        fixed or not: xp to 1e-12), iwhere differs from the reference's only inside the group;
+      * LBFGSB_F_EXACT_TIES: the walk is replayed in the reference's own order and the whole state
+        equals the oracle's as in every other one-step test (iwhere, Index, counters exactly)."""
+    po = env["po"]
+    q, s, group, want = _craft_tie_split(po)
+    n, m = q.n, q.m
+    fixed_ref = want.iwa[n:2 * n][group] > 0
+    assert 0 < fixed_ref.sum() < len(group) and not np.all(fixed_ref[:fixed_ref.sum()])
+    # exact order: full one-step parity
+    got, splits = _one_call(env, q, s, exact_ties=True)
+    assert splits == 1
+    compare_states(got, want, n, m, po)
+    # default order
+    got, splits = _one_call(env, q, s)
+    assert splits == 1
+    off = po.wa_offsets(n, m)
+    o, ln = off["xp"]
+    assert np.max(np.abs(got.wa[o:o + ln] - want.wa[o:o + ln])) <= 1e-12
+    diff = np.nonzero(got.iwa[n:2 * n] != want.iwa[n:2 * n])[0]
+    assert set(diff.tolist()) <= set(group.tolist())
+    fixed_got = got.iwa[n:2 * n][group] > 0
+    assert np.all(fixed_got[:fixed_got.sum()])            # variable order: a prefix of the group
+
+
+def test_tie_groups_of_identical_variables_trajectory(env):
+    """Problems with EXACT symmetries (copies of the same variable) keep whole groups of equal
+    breakpoints alive over many iterations.  A walk that ends inside such a group fixes the same
+    NUMBER of copies in either order (identical jumps), so the default path and the reference
+    stay equal in every scalar -- iteration, nfg, nseg, nfree, f -- and in x up to a permutation
+    inside the groups; with LBFGSB_F_EXACT_TIES also x itself is equal."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    base, copies, m, iters = 257, 8, 5, 40
+    n = base * copies
+    b = np.arange(n) % base
+    a = 1.0 + 99.0 * ((7919 * (b + 1)) % 10007) / 10006.0
+    c = -2.0 + 4.0 * ((104729 * (b + 1)) % 100003) / 100002.0
+
+    def fg(x, g):
+        d = x - c
+        g[:] = a * d
+        return float(0.5 * np.sum(a * d * d))
+    p = po.Problem("sym_quadratic", n, m, np.zeros(n), -np.ones(n), np.ones(n), np.full(n, 2, np.int32),
+                   0.0, 0.0, fg, np.float64)
+    rows_o, xs_o = [], []
+
+    def snap(k, s):
+        if s.task_s.startswith("NEW_X"):
+            rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]), int(s.isave[37]), float(s.f[0])))
+            xs_o.append(s.x.copy())
+    po.run(po.Engine("oracle"), p, max_iter=iters, snapshot=snap)
+
+    def run_gpu(**flags):
+        sol = la.DeviceSolver(n, m, **flags)
+        x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        g = torch.zeros_like(x)
+        l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+        nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+        rows, xs = [], []
+        while True:
+            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+            elif t.startswith("NEW_X"):
+                rows.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                             float(sol.f[0])))
+                xs.append(x.cpu().numpy())
+                if sol.isave[29] >= iters:
+                    break
+            else:
+                break
+        splits = sol.tie_splits()
+        sol.close()
+        return rows, xs, splits
+    rows_g, xs_g, splits = run_gpu()
+    assert len(rows_g) == len(rows_o)
+    for ra, rb in zip(rows_g, rows_o):
+        assert ra[:4] == rb[:4], (ra, rb)
+        assert ra[4] == pytest.approx(rb[4], rel=1e-10)
+    for xa, xb in zip(xs_g, xs_o):
+        ga = np.sort(xa.reshape(copies, base), axis=0)
+        gb = np.sort(xb.reshape(copies, base), axis=0)
+        assert np.max(np.abs(ga - gb)) <= 1e-9
+    rows_e, xs_e, splits_e = run_gpu(exact_ties=True)
+    assert [r[:4] for r in rows_e] == [r[:4] for r in rows_o]
+    for xa, xb in zip(xs_e, xs_o):
+        assert np.max(np.abs(xa - xb)) <= 1e-9
+    print("tie splits on this trajectory: %d (default), %d (exact ties)" % (splits, splits_e))
