@@ -216,6 +216,15 @@ int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double
 /* load host column-major W (n x m each, leading dimension n) into the context */
 int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy);
 
+/* formk's inner products from scratch (src/lbfgsb.f90:1756-1851): one masked Gram pass over W
+ * with the context's current iwhere (free = iwhere <= 0).  h_out receives 2 col^2 + col sums:
+ *   [i(i+1)/2 + j]        i >= j : sum_free Wy_i Wy_j
+ *   [T + i(i+1)/2 + j]    i >= j : sum_act  Ws_i Ws_j          (T = col (col+1) / 2)
+ *   [2T + i col + j]      all    : sum over (i > j ? active : free) rows of Ws_i Wy_j
+ * lbfgsb_hip_set_iwhere loads iwhere (host int32[n_local], the reference's values). */
+int lbfgsb_hip_set_iwhere(lbfgsb_hip_ctx *ctx, const int32_t *h_iwhere);
+int lbfgsb_hip_formk_gram(lbfgsb_hip_ctx *ctx, int col, int head, double *h_out);
+
 /* bare streaming kernel launches, and the same bracketed by hipEvents on the
  * context's stream: *h_ms_per_launch = average duration of `reps` launches. */
 int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head);

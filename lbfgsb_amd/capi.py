@@ -38,6 +38,8 @@ PROTOTYPES = {
     "lbfgsb_hip_projgr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_wtv": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "lbfgsb_hip_set_w": (C.c_int, [_vp, _vp, _vp]),
+    "lbfgsb_hip_set_iwhere": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_formk_gram": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "lbfgsb_hip_wtv_launch_only": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "lbfgsb_hip_wtv_time": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "lbfgsb_hip_kernel_time": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

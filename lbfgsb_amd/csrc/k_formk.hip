@@ -134,7 +134,10 @@ __device__ __forceinline__ void gram_role(const double2 (*__restrict__ sl)[64], 
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
         const double2 aj = sl[C0 + j][lane];
-        acc[k++] += ax * aj.x + ay * aj.y;
+        // (a reduction, summed in another order than the reference's anyway: fused multiply-adds
+        //  halve the fp64 issue slots of this compute-heavy pass -- 420 flops per row)
+        acc[k] = __builtin_fma(ax, aj.x, __builtin_fma(ay, aj.y, acc[k]));
+        ++k;
       }
     }
   } else if constexpr (MT == 2) {  // R_z: Ws_i . Wy_j, free rows, i <= j, outer j in [LO,HI)
@@ -146,7 +149,8 @@ __device__ __forceinline__ void gram_role(const double2 (*__restrict__ sl)[64], 
 #pragma unroll
       for (int i = 0; i <= j; ++i) {
         const double2 sv = sl[MC + i][lane];
-        acc[k++] += sv.x * yx + sv.y * yy;
+        acc[k] = __builtin_fma(sv.x, yx, __builtin_fma(sv.y, yy, acc[k]));
+        ++k;
       }
     }
   } else {  // L_a: Ws_i . Wy_j, active rows, i > j, outer i in [max(LO,1),HI)
@@ -158,7 +162,8 @@ __device__ __forceinline__ void gram_role(const double2 (*__restrict__ sl)[64], 
 #pragma unroll
       for (int j = 0; j < i; ++j) {
         const double2 y = sl[j][lane];
-        acc[k++] += sx * y.x + sy * y.y;
+        acc[k] = __builtin_fma(sx, y.x, __builtin_fma(sy, y.y, acc[k]));
+        ++k;
       }
     }
   }
@@ -294,19 +299,186 @@ __global__ __launch_bounds__(512) void formk_gram_rows_kernel(
   }
 }
 
+// Quad variant (col <= 10): no LDS, no barriers.  The four lanes of a quad share the rows of all
+// four: lane q = lane & 3 owns ONE of the four masked triangles of WN1 --
+//   q = 0: Y'ZZ'Y (free rows), q = 1: S'AA'S (active rows),
+//   q = 2: R_z = sum_free S_i Y_j for i <= j, q = 3: L_a = sum_active S_i Y_j for i > j --
+// MC(MC+1)/2 fp64 sums per lane instead of 2 MC^2 + MC, and sees every row of its quad through
+// DPP quad permutes (a VALU move, no LDS).  All four triangles have the shape
+// acc[a, b] += U_a V_b for a >= b with U, V in {Y, S} of the row, so one instruction stream
+// serves the four roles: U and V are selected per lane.  Loads are 8 bytes per lane and column
+// (one fp64 row / two fp32 rows), straight to registers; the whole trip is issued before its
+// first use.  HBM traffic: one pass over W plus iwhere.
+template <typename T>
+struct GramQuad {
+  static constexpr int W = sizeof(T) == 8 ? 1 : 2;  // rows per lane
+};
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = dpp_i<CTRL>((int)b), hi = dpp_i<CTRL>((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(float v) {  // the fp32 operand travels, widened on arrival
+  return (double)__builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <typename T, int MC>
+__global__ __launch_bounds__(BLOCK) void formk_gram_quad_kernel(
+    int64_t n, const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero,
+    int64_t ldw, int m, int head, int col, const iw_t *__restrict__ iwhere, double *gpart) {
+  constexpr int W = GramQuad<T>::W, TRI = MC * (MC + 1) / 2;
+  double acc[TRI];
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) acc[k] = 0.0;
+  const int lane = threadIdx.x & 63, q = lane & 3;
+  const bool u_is_s = q & 1, v_is_s = q == 1 || q == 2, want_free = (q & 1) == 0;
+  // every lane of a quad must run the same number of trips: groups of 4 * W rows, the ragged
+  // end is padded with rows that read the zero buffer and count as neither free nor active
+  const int64_t ngroups = (n + 4 * W - 1) / (4 * W);
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x / 4);
+  for (int64_t gq = (int64_t)blockIdx.x * (blockDim.x / 4) + (threadIdx.x >> 2); gq < ngroups; gq += stride) {
+    const int64_t i0 = (gq * 4 + q) * W;  // this lane's first row
+    T y[MC][W], sv[MC][W];
+    int fl[W];
+    const bool in = i0 + W <= n;  // (partial groups: element-wise below)
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, col, head, m, ldw) + i0;
+      const bool live = j < col && in;
+      if constexpr (W == 1) {
+        y[j][0] = __builtin_nontemporal_load(live ? wy + off : zero);
+        sv[j][0] = __builtin_nontemporal_load(live ? ws + off : zero);
+      } else {
+        typedef T t2 __attribute__((ext_vector_type(2)));
+        const t2 a = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(live ? wy + off : zero));
+        const t2 b = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(live ? ws + off : zero));
+        y[j][0] = a.x, y[j][1] = a.y, sv[j][0] = b.x, sv[j][1] = b.y;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) fl[k] = in ? (iwhere[i0 + k] <= 0 ? 1 : 0) : 2;
+    if (!in) {  // ragged end: the rows that exist, one by one
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (i0 + k < n) {
+          fl[k] = iwhere[i0 + k] <= 0 ? 1 : 0;
+#pragma unroll
+          for (int j = 0; j < MC; ++j) {
+            if (j < col) {
+              const int64_t off = col_off(j, col, head, m, ldw) + i0 + k;
+              y[j][k] = wy[off], sv[j][k] = ws[off];
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto add_row = [&](const double (&Y)[MC], const double (&S)[MC], int f) {
+      const double mk = (f == (want_free ? 1 : 0)) ? 1.0 : 0.0;
+      double U[MC], V[MC];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        U[c] = (u_is_s ? S[c] : Y[c]) * mk;
+        V[c] = v_is_s ? S[c] : Y[c];
+      }
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          acc[t] = __builtin_fma(U[a], V[b], acc[t]);
+          ++t;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      double Y[MC], S[MC];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) Y[c] = (double)y[c][k], S[c] = (double)sv[c][k];
+      add_row(Y, S, fl[k]);
+#define LB_MATE(CTRL)                                                     \
+      {                                                                   \
+        _Pragma("unroll") for (int c = 0; c < MC; ++c) {                  \
+          Y[c] = dpp_d<CTRL>(y[c][k]);                                    \
+          S[c] = dpp_d<CTRL>(sv[c][k]);                                   \
+        }                                                                 \
+        add_row(Y, S, dpp_i<CTRL>(fl[k]));                                \
+      }
+      LB_MATE(0xB1)  // lane ^ 1
+      LB_MATE(0x4E)  // lane ^ 2
+      LB_MATE(0x1B)  // lane ^ 3
+#undef LB_MATE
+    }
+  }
+  // lanes with equal q hold the same triangle: reduce over them, then across the 4 waves
+  __shared__ double sm[4][4][TRI];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+    if (lane < 4) sm[w][lane][k] = v;
+  }
+  __syncthreads();
+  const int tri = col * (col + 1) / 2;
+  for (int e = threadIdx.x; e < 4 * TRI; e += blockDim.x) {
+    const int role = e / TRI, k = e % TRI;
+    int a = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > k) --a;
+    while ((a + 1) * (a + 2) / 2 <= k) ++a;
+    const int b = k - a * (a + 1) / 2;
+    if (a >= col) continue;
+    const double sum = ((sm[0][role][k] + sm[1][role][k]) + sm[2][role][k]) + sm[3][role][k];
+    int slot;
+    if (role == 0)
+      slot = a * (a + 1) / 2 + b;             // Y'ZZ'Y (i = a, j = b)
+    else if (role == 1)
+      slot = tri + a * (a + 1) / 2 + b;       // S'AA'S
+    else if (role == 2)
+      slot = 2 * tri + b * col + a;           // R_z: is = b <= jy = a
+    else {
+      if (a == b) continue;                   // L_a has no diagonal
+      slot = 2 * tri + a * col + b;           // L_a: is = a > jy = b
+    }
+    gpart[(size_t)slot * GRAM_BLOCKS + blockIdx.x] = sum;
+  }
+}
+
 template <typename T>
 void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
                        const iw_t *iwhere) {
   int gr = 0;
   if (col <= 10) {
-    const int64_t nslab = (n + 127) / 128;
-    gr = (int)(nslab < GRAM_BLOCKS ? nslab : GRAM_BLOCKS);
-    if (col <= 5)
-      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 5>), dim3(gr), dim3(512), 0, q.stream, n, w.ws,
-                         w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
-    else
-      hipLaunchKernelGGL((formk_gram_rows_kernel<T, 10>), dim3(gr), dim3(512), 0, q.stream, n,
-                         w.ws, w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
+    static const int variant = [] {  // LBFGSB_GRAM = rows: the LDS-slab kernel (A/B timing)
+      const char *e = std::getenv("LBFGSB_GRAM");
+      return e && e[0] == 'r' ? 1 : 0;
+    }();
+    if (variant == 1) {
+      const int64_t nslab = (n + 127) / 128;
+      gr = (int)(nslab < GRAM_BLOCKS ? nslab : GRAM_BLOCKS);
+      if (col <= 5)
+        hipLaunchKernelGGL((formk_gram_rows_kernel<T, 5>), dim3(gr), dim3(512), 0, q.stream, n, w.ws,
+                           w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
+      else
+        hipLaunchKernelGGL((formk_gram_rows_kernel<T, 10>), dim3(gr), dim3(512), 0, q.stream, n,
+                           w.ws, w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
+    } else {
+      const int64_t ngroups = (n + 4 * GramQuad<T>::W - 1) / (4 * GramQuad<T>::W);
+      const int64_t want = (ngroups + BLOCK / 4 - 1) / (BLOCK / 4);
+      gr = (int)(want < GRAM_BLOCKS ? want : GRAM_BLOCKS);
+      if (col <= 5)
+        hipLaunchKernelGGL((formk_gram_quad_kernel<T, 5>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
+                           w.wy, w.zero, w.ld, w.m, head, col, iwhere, q.d_gpart);
+      else
+        hipLaunchKernelGGL((formk_gram_quad_kernel<T, 10>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
+                           w.wy, w.zero, w.ld, w.m, head, col, iwhere, q.d_gpart);
+    }
     q.launches++;
     finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
     return;

@@ -135,6 +135,8 @@ struct lbfgsb_hip_ctx {
                        const void *g, double *out) = 0;
   virtual int k_wtv(const void *v, int col, int head, double *out, bool launch_only) = 0;
   virtual int k_set_w(const void *hws, const void *hwy) = 0;
+  virtual int k_set_iwhere(const int32_t *h_iw) = 0;
+  virtual int k_formk_gram(int col, int head, double *out) = 0;
   virtual int k_launch(int which, const void *x, const void *g, int col, int head) = 0;
   virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
   virtual int sync() = 0;
@@ -2313,6 +2315,22 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
+  int k_set_iwhere(const int32_t *h_iw) override {
+    HIPCHK(hipSetDevice(device));
+    std::vector<lbk::iw_t> h((size_t)n);
+    for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)h_iw[i];
+    HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int k_formk_gram(int col, int head, double *out) override {
+    HIPCHK(hipSetDevice(device));
+    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "formk_gram: bad col/head");
+    lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
+    const int E = 2 * col * col + col;
+    CHK(fetch(E, 0, 0));
+    std::memcpy(out, h_res, sizeof(double) * E);
+    return 0;
+  }
   int k_objective(int kind, const void *x, void *g, double *f) override {
     HIPCHK(hipSetDevice(device));
     if (kind == 0) {
@@ -2560,6 +2578,14 @@ int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const 
 int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   return ctx->k_set_w(h_ws, h_wy);
+}
+int lbfgsb_hip_set_iwhere(lbfgsb_hip_ctx *ctx, const int32_t *h_iwhere) {
+  if (!ctx || !h_iwhere) return fail(LBFGSB_E_ARG, "set_iwhere: NULL argument");
+  return ctx->k_set_iwhere(h_iwhere);
+}
+int lbfgsb_hip_formk_gram(lbfgsb_hip_ctx *ctx, int col, int head, double *h_out) {
+  if (!ctx || !h_out) return fail(LBFGSB_E_ARG, "formk_gram: NULL argument");
+  return ctx->k_formk_gram(col, head, h_out);
 }
 int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");

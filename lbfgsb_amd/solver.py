@@ -239,6 +239,17 @@ class DeviceSolver:
         assert ws.shape == (self.m, self.n) and wy.shape == (self.m, self.n)
         check(self.lib.lbfgsb_hip_set_w(self.h, _p(ws), _p(wy)))
 
+    def set_iwhere(self, iwhere: np.ndarray):
+        iw = np.ascontiguousarray(iwhere, np.int32)
+        assert iw.shape == (self.n,)
+        check(self.lib.lbfgsb_hip_set_iwhere(self.h, _p(iw)))
+
+    def formk_gram(self, col: int, head: int = 1) -> np.ndarray:
+        """formk's inner products from scratch (layout: include/lbfgsb_hip.h)"""
+        out = np.zeros(2 * col * col + col)
+        check(self.lib.lbfgsb_hip_formk_gram(self.h, col, head, _p(out)))
+        return out
+
     def wtv(self, v, col: int, head: int = 1) -> np.ndarray:
         out = np.zeros(2 * col)
         check(self.lib.lbfgsb_hip_wtv(self.h, _p(v), col, head, _p(out)))

@@ -451,6 +451,48 @@ def test_kernel_wtv_against_float128(env):
         sol.close()
 
 
+@pytest.mark.parametrize("real32", [False, True], ids=["fp64", "fp32"])
+def test_kernel_formk_gram_against_numpy(env, real32):
+    """formk's inner products from scratch (src/lbfgsb.f90:1756-1851: Y'ZZ'Y over the free rows,
+    S'AA'S over the active rows, L_a + R_z mixed) for every column count / circular head / ragged
+    n, both the quad kernel (col <= 10) and the LDS-tile kernel (col > 10), against numpy in
+    extended precision."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    rng = np.random.default_rng(23)
+    real = np.float32 if real32 else np.float64
+    for n, m in ((1, 3), (7, 5), (1000, 5), (4099, 10), (30001, 10), (2049, 20)):
+        ws = rng.standard_normal((m, n)).astype(real)
+        wy = rng.standard_normal((m, n)).astype(real)
+        iw = rng.integers(-3, 4, n).astype(np.int32)
+        sol = la.DeviceSolver(n, m, real32=real32)
+        sol.set_w(ws, wy)
+        sol.set_iwhere(iw)
+        free = (iw <= 0)
+        for col in sorted({1, 2, m // 2 + 1, m}):
+            for head in (1, m):
+                got = sol.formk_gram(col, head)
+                cols = [(head - 1 + j) % m for j in range(col)]
+                Y = wy[cols].astype(np.longdouble)
+                S = ws[cols].astype(np.longdouble)
+                Yf, Sa, Sf = Y * free, S * (~free), S * free
+                tri = col * (col + 1) // 2
+                want = np.zeros(2 * col * col + col, np.longdouble)
+                bound = np.zeros_like(want)
+                for i in range(col):
+                    for j in range(i + 1):
+                        want[i * (i + 1) // 2 + j] = Yf[i] @ Y[j]
+                        bound[i * (i + 1) // 2 + j] = np.abs(Yf[i]) @ np.abs(Y[j])
+                        want[tri + i * (i + 1) // 2 + j] = Sa[i] @ S[j]
+                        bound[tri + i * (i + 1) // 2 + j] = np.abs(Sa[i]) @ np.abs(S[j])
+                    for j in range(col):
+                        a = Sa[i] if i > j else Sf[i]
+                        want[2 * tri + i * col + j] = a @ Y[j]
+                        bound[2 * tri + i * col + j] = np.abs(a) @ np.abs(Y[j])
+                assert np.all(np.abs(got - want.astype(np.float64)) <= 1e-13 * bound.astype(np.float64) + 1e-300), \
+                    (n, m, col, head)
+        sol.close()
+
+
 def test_edge_cases(env):
     """n=1, unconstrained (cauchy skipped after the first update), all variables fixed,
     zero gradient at start, invalid nbd and l>u."""
