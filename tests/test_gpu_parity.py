@@ -630,6 +630,51 @@ def test_full_size_rosenbrock_n1e6_against_oracle(env):
         assert a[4] == pytest.approx(b[4], rel=1e-8)
 
 
+def test_config3_rosenbrock_n1e7_against_reference_anchors(env):
+    """BASELINE.json configs[2] at its stated size: extended Rosenbrock with box bounds (driver3
+    formulas), n = 1e7, m = 10, fp64, on-device objective -- against per-iteration anchors that the
+    REAL reference produced in the build container (tests/golden/rosenbrock_n1e7_anchors.json,
+    made by tests/golden/make_anchors_n1e7.py).  Iteration 1 fixes 9,999,999 variables in two
+    tie groups; iterations 10 -> 11, 12 -> 13 and 15 -> 16 move ~5e6 variables between the free and
+    the active set (SURVEY.md appendix C's stress pattern: formk's from-scratch Gram path)."""
+    import json
+    po, torch, la = env["po"], env["torch"], env["la"]
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       "rosenbrock_n1e7_anchors.json")))
+    n, m = gold["n"], gold["m"]
+    rows_o = [(r["iter"], r["nfg"], r["nseg"], r["nfree"], r["f"]) for r in gold["rows"]]
+    iters = len(rows_o)
+    assert n == 10_000_000 and rows_o[0][2] == n and rows_o[0][3] == 1
+    assert any(abs(a[3] - b[3]) > 4_000_000 for a, b in zip(rows_o, rows_o[1:]))
+    sol = la.DeviceSolver(n, m)
+    x = torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+    g = torch.zeros_like(x)
+    l = torch.empty_like(x)
+    l[0::2] = 1.0
+    l[1::2] = -100.0
+    u = torch.full_like(x, 100.0)
+    nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    rows_g = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(1, x, g)
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                           float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    sol.close()
+    del x, g, l, u, nbd
+    torch.cuda.empty_cache()
+    assert len(rows_g) == iters
+    for a, b in zip(rows_g, rows_o):
+        assert a[:4] == b[:4], (a, b)                 # iter, nfg, nseg, nfree
+        assert a[4] == pytest.approx(b[4], rel=1e-7)
+
+
 def _random_box_rosenbrock(po, seed):
     """Extended Rosenbrock with a random start, random boxes around it and all four bound
     types: small problems that reach the rarely taken branches of the reference."""
