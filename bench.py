@@ -324,27 +324,13 @@ def main():
         ms, cnt = clocks[name]
         return (ms / cnt, cnt) if cnt else (None, 0)
 
-    # average launch duration over the timed region (in-run hipEvents); the same kernel launched
-    # back to back after the run is kept beside it as a cross-check
-    ms_iso = sol.kernel_time(2, x, g, col, head, a.roofline_reps)  # the variant the iteration runs
-    ms_fused, n_fused = in_run("cmprlb_wtv")
-    if ms_fused is None:
-        ms_fused = ms_iso
-    alg_fused = ((2 * col + 2) * rbytes + 1) * n_loc
-    ach_fused = alg_fused / (ms_fused * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "cmprlb_wtv_kernel<%s, %d, true, %s>" % ("float" if a.real32 else "double", mc, nts),
-                "achieved": ach_fused, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach_fused / HBM_PEAK_GBS, "traffic": traffic_of("cmprlb_wtv_traffic.json", n_loc),
-                "traffic_source": "profiles/cmprlb_wtv_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes of the same kernel at n=1e8, bytes per row x rows; "
-                                  "not re-measured in this run)",
-                "algorithmic_bytes_per_launch": alg_fused, "avg_launch_ms": ms_fused,
-                "launches_timed": n_fused, "timing": "hipEvents around each launch inside the timed region",
-                "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col}
-    # the other two passes over W of an iteration, for the whole picture: the update/scan pass
-    # (read-only: W old columns + x, l, u, g, r, d + nbd, iwhere) and the subspace pass (the one
-    # pass that stores vectors: z, d, t, r, the trial x and the new W column pair)
-    others = []
+    # Average launch duration over the timed region (in-run hipEvents); the same kernel launched
+    # back to back after the run is kept beside it as a cross-check.  Passes over W of one
+    # iteration: update_scan_kernel (read-only: the WS/WY matvecs W'd of cauchy and S'y, S's of
+    # matupd, + formk's new row), subsm_update_kernel (W wv; the one pass that stores) and -- only
+    # where the closed form for W'Z r does not apply (m > 10, few free variables, long walks) --
+    # cmprlb_wtv_kernel (r of cmprlb + W'r of subsm).
+    tname = "float" if a.real32 else "double"
 
     def pass_traffic(key, rows):
         tf = os.path.join(ROOT, "profiles", "w_pass_traffic.json")
@@ -354,33 +340,40 @@ def main():
             except Exception:
                 return None
         return None
-    try:
-        ms_us_iso = sol.kernel_time(4, x, g, col, head, a.roofline_reps)
-        ms_us = in_run("update_scan")[0] or ms_us_iso
-        by_us = ((2 * (col - 1) + 6) * rbytes + 5) * n_loc   # + nbd (int32) + iwhere (int8)
-        others.append({"kernel": "update_scan_kernel<%s, %d, %s> (as trial-point evaluation)"
-                       % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
-                       "achieved": by_us / (ms_us * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": by_us / (ms_us * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_us,
-                       "avg_launch_ms_back_to_back": ms_us_iso,
-                       "algorithmic_bytes_per_launch": by_us, "stores": "none",
-                       "traffic": pass_traffic("update_scan", n_loc)})
-        ms_su_iso = sol.kernel_time(3, x, g, col, head, a.roofline_reps)
-        ms_su = in_run("subsm_update")[0] or ms_su_iso
-        # in the run the pass also stores the first trial point x (one more vector)
-        by_su = ((2 * col + 4 + 6 + (1 if in_run("subsm_update")[0] else 0)) * rbytes + 5) * n_loc
-        others.append({"kernel": "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
-                       % ("float" if a.real32 else "double", mc, nts), "bound": "hbm",
-                       "achieved": by_su / (ms_su * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": by_su / (ms_su * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms_su,
-                       "avg_launch_ms_back_to_back": ms_su_iso,
-                       "algorithmic_bytes_per_launch": by_su,
-                       "stores": "z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11),
-                       "traffic": pass_traffic("subsm_update", n_loc),
-                       "traffic_note": "PMC pass of the back-to-back variant, which does not store the "
-                                       "trial x (one vector less than in the run)"})
-    except Exception as e:
-        others.append({"error": repr(e)})
+
+    def pass_record(key, which, label, alg_bytes, stores, traffic_key):
+        ms_iso = sol.kernel_time(which, x, g, col, head, a.roofline_reps)
+        ms_run, cnt = in_run(key)
+        ms = ms_run if ms_run is not None else ms_iso
+        ach = alg_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": pass_traffic(traffic_key, n_loc),
+                "traffic_source": "profiles/w_pass_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes of the same kernel at n=1e8, bytes per row x rows; "
+                                  "not re-measured in this run)",
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
+                "launches_timed": cnt,
+                "timing": ("hipEvents around each launch inside the timed region" if cnt else
+                           "not launched inside the timed region: back-to-back launches after it"),
+                "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col,
+                "stores": stores}
+    n_sub = in_run("subsm_update")[1]
+    rec_us = pass_record("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
+                         "first trial point)" % (tname, mc, nts),
+                         ((2 * (col - 1) + 6) * rbytes + 5) * n_loc, "none", "update_scan")
+    # (in the run the subspace pass also stores the first trial point x: one more vector)
+    rec_su = pass_record("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
+                         % (tname, mc, nts), ((2 * col + 4 + 6 + (1 if n_sub else 0)) * rbytes + 5) * n_loc,
+                         "z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11),
+                         "subsm_update")
+    rec_cw = pass_record("cmprlb_wtv", 2, "cmprlb_wtv_kernel<%s, %d, true, %s>" % (tname, mc, nts),
+                         ((2 * col + 2) * rbytes + 1) * n_loc, "none", "cmprlb_wtv")
+    closed_steps, three_steps = sol.path_counts()
+    if rec_cw["launches_timed"]:      # three-pass iteration: cmprlb_wtv carries W'r inside it
+        roofline, others = rec_cw, [rec_us, rec_su]
+    else:                             # two-pass iteration: the update pass carries the matvecs
+        rec_cw["note"] = "not part of this run's iteration (W'Z r in closed form); timed back to back"
+        roofline, others = rec_us, [rec_su, rec_cw]
     ms_kernel = sol.wtv_time(g, col, head, a.roofline_reps)
     alg_bytes = (2 * col + 1) * n_loc * rbytes
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
@@ -422,6 +415,8 @@ def main():
         "kernel_launches_per_iter": (stats["launches"] - st0["launches"]) / a.steps,
         "host_blocked_ms_per_iter": (stats["wait_seconds"] - st0["wait_seconds"]) / a.steps * 1e3,
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
+        "subspace_steps_closed_form": closed_steps,
+        "subspace_steps_three_pass": three_steps,
         "roofline": roofline,
         "roofline_wtv": roofline_wtv,
         "roofline_other_w_passes": others,

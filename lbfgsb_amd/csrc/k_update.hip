@@ -112,19 +112,30 @@ struct UpdScanTrip {
     land_cols<T, MC, W>(ra, rb);
   }
 };
-template <typename T, int MC, bool NT, bool PIPE>
+// NEWROW: the pass also yields the new row/column of formk's WN1 (:1756-1793) for the pair being
+// formed here -- with the free/active split of the rows as cauchy's n-loop leaves it, i.e.
+// BEFORE the breakpoint walk (the host corrects the sums for the few rows the walk fixes, from
+// the records it gathers for them anyway).  With them and the walk's own p = W'd the host has
+// W'Z r in closed form (solver.hip, subspace_closed_form), and the iteration needs no third pass
+// over W.  Extra sum slots, X = 4 MC + 9:  [X, X+MC) sum_free y Wy_j | [X+MC, ..) sum_act s Ws_j |
+// [X+2MC, ..) sum_act s Wy_j | [X+3MC, ..) sum_free Ws_j y | [X+4MC ..+4) sum_free y y,
+// sum_act s s, sum_act s y, sum_free s y   (y, s in their stored form); min and max follow.
+template <typename T, int MC, bool NT, bool PIPE, bool NEWROW>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
     const T *__restrict__ d, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
     int store_iw, double *part) {
-  constexpr int NA = 4 * MC + 11;
+  constexpr int NX = NEWROW ? 4 * MC + 4 : 0;  // extra sums
+  constexpr int X = 4 * MC + 9;                // first extra slot
+  constexpr int NA = 4 * MC + 11 + NX;
+  constexpr int IMIN = X + NX, IMAX = X + NX + 1;  // bkmin, |proj g|
   constexpr int V = RowsPerAcc<T, MC, NA>::V;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
-  acc[4 * MC + 9] = LB_INF;
+  acc[IMIN] = LB_INF;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
   const UpdScanCtx<T> ctx{x, l, u, g, r, d, ws, wy, zero, nbd, iwhere, ldw, m, head, nold};
   for_rows_raw<UpdScanTrip<T, MC, V, NT>, UpdScanTrip<T, MC, 1, NT>, V, PIPE, 0>(
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     for (int k = 0; k < W; ++k) {
       // ---- the line search's own sums at this trial point: g'd (:2244), |proj g| (:781) ----
       acc[4 * MC + 7] = acc[4 * MC + 7] + gv[k] * dv[k];
-      acc[4 * MC + 10] = fmax(acc[4 * MC + 10], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
+      acc[IMAX] = fmax(acc[IMAX], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
       rv[k] = gv[k] - rv[k];                              // y (:813-815)
       acc[2 * MC] = acc[2 * MC] + rv[k] * rv[k];          // rr (:816)
       if (stp != 1.0) dv[k] = stp * dv[k];                // s (:822)
@@ -179,11 +190,11 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         if (nb[k] <= 2 && nb[k] != 0 && neggi < 0.0) {
           tb[k] = tl / (-neggi);
           acc[4 * MC + 4] += 1.0;
-          acc[4 * MC + 9] = fmin(acc[4 * MC + 9], tb[k]);
+          acc[IMIN] = fmin(acc[IMIN], tb[k]);
         } else if (nb[k] >= 2 && neggi > 0.0) {
           tb[k] = tu / neggi;
           acc[4 * MC + 4] += 1.0;
-          acc[4 * MC + 9] = fmin(acc[4 * MC + 9], tb[k]);
+          acc[IMIN] = fmin(acc[IMIN], tb[k]);
         } else {
           tb[k] = LB_INF;
           acc[4 * MC + 5] += 1.0;
@@ -203,6 +214,30 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         acc[3 * MC + 2 + j] += b[j][k] * ng[k];  // p_{col+j}  (:1302)
       }
     }
+    if constexpr (NEWROW) {
+      double yf[W], sa[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const double yst = (double)(T)rv[k], sst = (double)(T)dv[k];  // as stored in W
+        const bool fr = iw[k] <= 0;                                   // after the n-loop's update
+        yf[k] = fr ? yst : 0.0;
+        sa[k] = fr ? 0.0 : sst;
+        acc[X + 4 * MC + 0] = __builtin_fma(yf[k], yst, acc[X + 4 * MC + 0]);
+        acc[X + 4 * MC + 1] = __builtin_fma(sa[k], sst, acc[X + 4 * MC + 1]);
+        acc[X + 4 * MC + 2] = __builtin_fma(sa[k], yst, acc[X + 4 * MC + 2]);
+        acc[X + 4 * MC + 3] = __builtin_fma(fr ? sst : 0.0, yst, acc[X + 4 * MC + 3]);
+      }
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          acc[X + j] = __builtin_fma(yf[k], a[j][k], acc[X + j]);
+          acc[X + MC + j] = __builtin_fma(sa[k], b[j][k], acc[X + MC + j]);
+          acc[X + 2 * MC + j] = __builtin_fma(sa[k], a[j][k], acc[X + 2 * MC + j]);
+          acc[X + 3 * MC + j] = __builtin_fma(b[j][k], yf[k], acc[X + 3 * MC + j]);
+        }
+      }
+    }
     if (store_pair) {  // else the pair stays pending (see Pend)
       st<W>(ws + offn + i, dv);
       st<W>(wy + offn + i, rv);
@@ -211,27 +246,40 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
     if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
   });
-  block_reduce_store<NA>(acc, 4 * MC + 9, 1, 1, part, MAX_BLOCKS);
+  block_reduce_store<NA>(acc, X + NX, 1, 1, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
                         const T *g, const T *r, const T *d, double stp, iw_t *iwhere, T *tbrk,
-                        WStore<T> w, int head, int col, int itail, int store_pair, int store_iw) {
+                        WStore<T> w, int head, int col, int itail, int store_pair, int store_iw,
+                        int newrow) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
-  DISPATCH_MAXC_NT(nold, q.nt,
-                   DISPATCH_PIPE(MC, hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PIPEV>), dim3(gr),
-                                                        dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d,
-                                                        stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m,
-                                                        head, nold, itail, store_pair, store_iw, q.d_part)));
+#define LB_UPDSCAN(NEWROWV)                                                                          \
+  DISPATCH_MAXC_NT(nold, q.nt, DISPATCH_PIPE(MC, {                                                   \
+                     constexpr bool NRV = NEWROWV && MC <= 10;                                       \
+                     constexpr bool PPV = (PIPEV || NRV) && MC <= 20;                                \
+                     hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PPV, NRV>), dim3(gr),        \
+                                        dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d, stp,     \
+                                        iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, nold,     \
+                                        itail, store_pair, store_iw, q.d_part);                      \
+                   }))
+  // (MC = 20 with the 84 extra sums does not fit the register file: those shapes keep the
+  //  three-pass iteration)
+  const int mc = maxc_for(nold);
+  if (update_scan_extra(nold, newrow))
+    LB_UPDSCAN(true);
+  else
+    LB_UPDSCAN(false);
+#undef LB_UPDSCAN
   q.launches++;
-  launch_finalize(q, gr, 4 * maxc_for(nold) + 9, 1, 1);
+  launch_finalize(q, gr, 4 * mc + 9 + update_scan_extra(nold, newrow), 1, 1);
 }
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
   template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double, WStore<T>, int, int, int); \
-  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, double, iw_t *, T *, WStore<T>, int, int, int, int, int);
+  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

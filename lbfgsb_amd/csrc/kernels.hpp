@@ -14,7 +14,7 @@ constexpr int BLOCK = 256;        // 4 wave64 per workgroup
 constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 workgroups, grid-stride beyond that
 constexpr int GRAM_BLOCKS = 1024;
 constexpr int MAXM = 32;          // LBFGSB_MAX_M
-constexpr int RES_MAX = 6 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 4*MC+8 of update_scan
+constexpr int RES_MAX = 6 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 8*20+15 of update_scan(newrow)
 
 // launch queue + reduction scratch owned by the context
 struct Queue {
@@ -278,7 +278,11 @@ template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
                         iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
-                        int store_pair, int store_iw);
+                        int store_pair, int store_iw, int newrow = 0);
+// newrow (col - 1 <= 10): 4 MC + 4 more sum slots in front of the min / max slots -- the new
+// row/column of formk's WN1 with the PRE-walk free set (layout: update_scan_kernel in
+// k_update.hip); min slot = 4 MC + 9 + (newrow ? 4 MC + 4 : 0), max slot behind it
+inline int update_scan_extra(int nold, int newrow);
 // Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
 template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
@@ -293,6 +297,11 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, con
                            double xl, double xr);
 template <typename T>
 void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out);
+
+inline int update_scan_extra(int nold, int newrow) {
+  const int mc = maxc_for(nold);
+  return newrow && mc <= 10 ? 4 * mc + 4 : 0;
+}
 
 // finalize: d_part -> d_res (nsum sums, then nmin mins, then nmax maxes)
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax);

@@ -1002,6 +1002,8 @@ class Solver final : public lbfgsb_hip_ctx {
     pf_valid = false;
     fixlist.clear();
     fix_overflow = false;
+    closed_ok = false;
+    std::memset(nrc, 0, sizeof nrc);
     const int ipr = quiet ? -1 : print_level;
     if (sbgnrm <= 0.0) {  // :1245-1249
       scan.ready = false;
@@ -1039,6 +1041,8 @@ class Solver final : public lbfgsb_hip_ctx {
     const double bkmin = scan.bkmin;
     if (theta != 1.0)
       for (int j = 0; j < col; ++j) p[col + j] = theta * p[col + j];  // :1337
+    p_ini_max = 0.0;
+    for (int j = 0; j < 2 * col; ++j) p_ini_max = std::max(p_ini_max, std::fabs(p[j]));
 
     double last_t = -1.0;
     int64_t last_i = -1;
@@ -1250,6 +1254,17 @@ class Solver final : public lbfgsb_hip_ctx {
           fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
         else
           fix_overflow = true;
+        if (col > 0 && col <= 10) {
+          // this row leaves the free set: its share of formk's new row/column moves from the
+          // free sums to the active ones (the update pass summed with the pre-walk split)
+          const double yk = rec[4 + col - 1], sk = rec[4 + 2 * col - 1];
+          for (int j = 0; j < col; ++j) {
+            nrc[0][j] += yk * rec[4 + j];        // - sum_free y_new Wy_j
+            nrc[1][j] += sk * rec[4 + col + j];  // + sum_act  s_new Ws_j
+            nrc[2][j] += sk * rec[4 + j];        // + sum_act  s_new Wy_j
+            nrc[3][j] += rec[4 + col + j] * yk;  // - sum_free Ws_j y_new
+          }
+        }
         if (ipr >= 100)  // :1435
           std::fprintf(rep.out, " Variable  %11lld   is fixed.\n", (long long)rec_gi + 1);
         if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
@@ -1303,6 +1318,7 @@ class Solver final : public lbfgsb_hip_ctx {
         last_t = -1.0, last_i = -1;
         fixlist.clear();
         fix_overflow = false;
+        std::memset(nrc, 0, sizeof nrc);
         continue;
       }
     }
@@ -1320,6 +1336,14 @@ class Solver final : public lbfgsb_hip_ctx {
     tsum = tsum + dtm;
     if (col > 0 && dtm != 0.0)
       for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
+    if (col > 0) {
+      // p = W'd over the variables that still move = the free variables: with it W'Z r needs no
+      // pass over W (subspace_closed_form).  Not after a long walk (its rounding accumulates in
+      // p and in the corrections) and not when p is what little is left of a much larger p.
+      double pm = 0.0;
+      for (int j = 0; j < col2; ++j) p_fin[j] = p[j], pm = std::max(pm, std::fabs(p[j]));
+      closed_ok = nseg <= 4096 && pm >= 1e-3 * p_ini_max && p_ini_max > 0.0;
+    }
     return leave(tsum, last_t, last_i);
   }
 
@@ -1456,18 +1480,63 @@ class Solver final : public lbfgsb_hip_ctx {
     return true;
   }
 
+  // W'Z r without a pass over W (cmprlb :1565-1583 folded into subsm :2742-2754).  On the free
+  // rows the Cauchy point is x + tsum d with d = -g, so
+  //     r = (1 - theta tsum) d + W (M c)   on the free rows Z,   and
+  //     W'Z r = (1 - theta tsum) W'Z d + (W'ZZ'W) (M c).
+  // W'Z d is the p the walk ends with (it carries W'd over the variables that still move,
+  // :1300-1304, :1463-1470); W'ZZ'W is in WN1 and in matupd's matrices:  Y'ZZ'Y = WN1(1:col,1:col),
+  // S'ZZ'S = S'S - S'AA'S = Ss - WN1(m+1:,m+1:),  S'ZZ'Y = R_z above the diagonal (WN1), Sy - L_a
+  // below it (:1756-1793).  Equal to the sums over the rows up to reassociation -- and to the
+  // rounding of z - x, which the row form carries at 1 ulp of x per row: the caller uses this
+  // form only when neither the free set nor p is a small remainder of something much larger.
+  void subspace_closed_form(int col, double theta, double *wv) {
+    const int m2 = 2 * m;
+    lbh::Mat WN1{snd.data(), m2}, SY{sy.data(), m}, SS{ss.data(), m};
+    const double k1 = 1.0 - theta * gcp.tsum;
+    auto YYf = [&](int i, int j) { return i >= j ? WN1(i, j) : WN1(j, i); };
+    auto SSf = [&](int i, int j) {
+      const double tot = i <= j ? SS(i, j) : SS(j, i);
+      const double act = i >= j ? WN1(m + i, m + j) : WN1(m + j, m + i);
+      return tot - act;
+    };
+    auto SYf = [&](int is, int jy) {  // sum_free s_is y_jy
+      return is <= jy ? WN1(m + is, jy) : SY(is, jy) - WN1(m + is, jy);
+    };
+    const double *a1 = cm_cf.a, *a2 = cm_cf.a + lbk::MAXM;  // (M c)_j, theta (M c)_{col+j}
+    for (int i = 0; i < col; ++i) {
+      double ay = k1 * p_fin[i], as = k1 * (p_fin[col + i] / theta);
+      for (int j = 0; j < col; ++j) {
+        ay = ay + YYf(i, j) * a1[j] + SYf(j, i) * a2[j];
+        as = as + SYf(i, j) * a1[j] + SSf(i, j) * a2[j];
+      }
+      wv[i] = ay;
+      wv[col + i] = theta * as;
+    }
+  }
+
   // do_formk: formk is pending for this iteration and col <= 10: its new row/column sums ride
   // along in the cmprlb_wtv pass and the status changes are patched sparsely.
+  // closed: no cmprlb pass at all -- new row from the update pass (nrpre, corrected by the
+  // walk), W'Z r in closed form.
   int subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
                int col, int head, bool cnstnd, int &iword, int &info, bool do_formk, bool updatd,
-               int iupdat, const double *pre) {
+               int iupdat, const double *pre, bool closed = false) {
     // cmprlb :1548-1586 (+ W'r of subsm).  `pre` != nullptr: the pass was already launched
     // together with freev's counts (one fetch for both) and its sums are in pre[].
     const int MC = lbk::maxc_for(col);
     const bool newrow = do_formk && updatd;
     const double *res = pre;
     const int ipr = quiet ? -1 : print_level;
-    if (!pre) {
+    if (closed) {
+      lbk::Coef cf;
+      bool plain;
+      if (!cmprlb_coef(col, theta, cnstnd, cf, plain)) {
+        info = -8;
+        return 0;
+      }
+      nclosed++;
+    } else if (!pre) {
       lbk::Coef cf;
       bool plain;
       if (!cmprlb_coef(col, theta, cnstnd, cf, plain)) {
@@ -1484,17 +1553,32 @@ class Solver final : public lbfgsb_hip_ctx {
       res = h_res;
     }
     double *wv = &wa8m[0];
-    for (int i = 0; i < col; ++i) {
-      wv[i] = res[i];
-      wv[col + i] = theta * res[MC + i];
+    if (!closed) {
+      nthreepass++;
+      for (int i = 0; i < col; ++i) {
+        wv[i] = res[i];
+        wv[col + i] = theta * res[MC + i];
+      }
     }
     if (do_formk) {
       double nr[4 * lbk::MAXM];
-      if (newrow) std::memcpy(nr, res + 2 * MC, sizeof(double) * 4 * MC);
+      if (closed) {
+        if (newrow) {
+          for (int j = 0; j < col; ++j) {
+            nr[0 * MC + j] = nrpre.t[0][j] - nrc[0][j];
+            nr[1 * MC + j] = nrpre.t[1][j] + nrc[1][j];
+            nr[2 * MC + j] = nrpre.t[2][j] + nrc[2][j];
+            nr[3 * MC + j] = nrpre.t[3][j] - nrc[3][j];
+          }
+        }
+      } else if (newrow) {
+        std::memcpy(nr, res + 2 * MC, sizeof(double) * 4 * MC);
+      }
       CHK(formk_incremental(col, head, updatd, iupdat, nr, MC));
       formk_factor(col, theta, info);
       if (info != 0) return 0;
     }
+    if (closed) subspace_closed_form(col, theta, wv);
     if (ipr >= 99) std::fprintf(rep.out, "\n----------------SUBSM entered-----------------\n\n");  // :2738
     lbh::Mat WN{wn.data(), 2 * m};
     const int col2 = 2 * col;
@@ -1571,6 +1655,22 @@ class Solver final : public lbfgsb_hip_ctx {
   // sums of a cmprlb_wtv pass that was launched together with freev's counts
   double pre_res[6 * lbk::MAXM];
   bool pre_valid = false;
+  // ---- two-pass iteration (col <= 10): formk's new row rides in the update pass with the
+  //      pre-walk free set, the walk corrects it for the rows it fixes, and W'Z r follows in
+  //      closed form from the walk's p and WN1 (subspace_closed_form) -- no cmprlb pass ----
+  const bool two_pass = [] {
+    const char *e = std::getenv("LBFGSB_TWO_PASS");
+    return !(e && e[0] == '0');
+  }();
+  struct NewRow {
+    bool valid = false;
+    int col = 0;
+    double t[4][lbk::MAXM];  // logical columns 0..col-1: Y'ZZ'Y row, S'AA'S row, L_a row, R_z column
+  } nrpre;
+  double nrc[4][lbk::MAXM];  // what the walk's fixed rows take from / add to them
+  double p_fin[2 * lbk::MAXM], p_ini_max = 0.0;
+  bool closed_ok = false;    // this call's cauchy left everything the closed form needs
+  int64_t nclosed = 0, nthreepass = 0;
 
   int print_level = -1;
 
@@ -1698,6 +1798,7 @@ class Solver final : public lbfgsb_hip_ctx {
 
     bool compute_pg = true, prelims = true, linesearch = true;
     double spec_sbgnrm = 0.0;
+    nrpre.valid = false;
     // value of a deferred built-in objective: one more sum in front of this call's first fetch
     int fo = 0;
     if (f_pending) {
@@ -1726,18 +1827,19 @@ class Solver final : public lbfgsb_hip_ctx {
           c2 = col, it2 = itail % m + 1, h2 = head % m + 1;
         }
         const int MCo = lbk::maxc_for(c2 - 1);
+        const int NX = lbk::update_scan_extra(c2 - 1, two_pass ? 1 : 0);
         clk_begin(1);
         q.res_off = fo;
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
-                                   it2, 0, store_iw);
+                                   it2, 0, store_iw, two_pass ? 1 : 0);
         q.res_off = 0;
         clk_end(1);
-        CHK(fetch(fo + 4 * MCo + 9, 1, 1));
+        CHK(fetch(fo + 4 * MCo + 9 + NX, 1, 1));
         if (fo) *f = f_scale * h_res[0];
         const double *R = h_res + fo;
         gd = R[4 * MCo + 7];
-        spec_sbgnrm = R[4 * MCo + 10];
-        std::memcpy(spec.res, R, sizeof(double) * (4 * MCo + 11));
+        spec_sbgnrm = R[4 * MCo + 10 + NX];
+        std::memcpy(spec.res, R, sizeof(double) * (4 * MCo + 11 + NX));
         spec.valid = true;  // dropped below unless dcsrch accepts this point
         spec.x = x, spec.g = g, spec.stp = stp, spec.head = h2, spec.col = c2, spec.itail = it2;
         tbrk_valid = false;
@@ -1825,7 +1927,11 @@ class Solver final : public lbfgsb_hip_ctx {
           // sets of sums with ONE host sync (it is wasted only if no variable is free)
           pre_valid = false;
           int npre = 0;
-          if (col > 0) {
+          // (two-pass iteration: no cmprlb pass if the closed form applies -- decided for good
+          //  once nfree is known, below)
+          const bool closed_cand = two_pass && closed_ok && cnstnd && col > 0 && col <= 10 &&
+                                   (!updatd || (nrpre.valid && nrpre.col == col));
+          if (col > 0 && !closed_cand) {
             lbk::Coef cf;
             bool plain;
             if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
@@ -1905,8 +2011,13 @@ class Solver final : public lbfgsb_hip_ctx {
             sbtime += now_s() - cpu1;
             continue;
           }
+          // closed form: only while the free variables are not a small remainder (S'ZZ'S comes
+          // as S'S - S'AA'S)
+          const bool closed = two_pass && closed_ok && cnstnd && col <= 10 && !pre_valid &&
+                              (!updatd || (nrpre.valid && nrpre.col == col)) &&
+                              nfree_g * 16 >= nglob;
           CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
-                       pre_valid ? pre_res : nullptr));
+                       pre_valid ? pre_res : nullptr, closed));
           pre_valid = false;
           if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
             if (ipr >= 1)
@@ -2090,16 +2201,26 @@ class Solver final : public lbfgsb_hip_ctx {
         // unless that pass already ran as the evaluation of the accepted trial point
         const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
                            spec.head == head && spec.col == col && spec.itail == itail;
+        const int NX = lbk::update_scan_extra(col - 1, two_pass ? 1 : 0);
         if (reuse) {
-          std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11));
+          std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
           if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
             lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
         } else {
           clk_begin(1);
           lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
-                                     col, itail, 0, 1);
+                                     col, itail, 0, 1, two_pass ? 1 : 0);
           clk_end(1);
-          CHK(fetch(4 * MCo + 9, 1, 1));
+          CHK(fetch(4 * MCo + 9 + NX, 1, 1));
+        }
+        nrpre.valid = false;
+        if (NX) {  // formk's new row/column with the pre-walk free set (update_scan_kernel NEWROW)
+          const int X0 = 4 * MCo + 9, nold_ = col - 1;
+          for (int k = 0; k < 4; ++k) {
+            for (int j = 0; j < nold_; ++j) nrpre.t[k][j] = h_res[X0 + k * MCo + j];
+            nrpre.t[k][nold_] = h_res[X0 + 4 * MCo + k];
+          }
+          nrpre.valid = true, nrpre.col = col;
         }
         spec.valid = false;
         tbrk_valid = false;
@@ -2114,7 +2235,7 @@ class Solver final : public lbfgsb_hip_ctx {
         scan.p[2 * col - 1] = h_res[4 * MCo + 2];
         scan.f1 = h_res[4 * MCo + 3], scan.nbreak = h_res[4 * MCo + 4];
         scan.nunb = h_res[4 * MCo + 5], scan.nunbnz = h_res[4 * MCo + 6];
-        scan.bkmin = h_res[4 * MCo + 9];
+        scan.bkmin = h_res[4 * MCo + 9 + NX];
         scan.ready = true;
       } else {
         lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
@@ -2301,7 +2422,8 @@ class Solver final : public lbfgsb_hip_ctx {
                                     lbk::Pend{1, 0.5});
       else             // as the evaluation of a trial point: reduces only
         lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, d, 0.5, iwhere,
-                                   (T *)nullptr, W(), head, col, (head + col - 2) % m + 1, 0, 0);
+                                   (T *)nullptr, W(), head, col, (head + col - 2) % m + 1, 0, 0,
+                                   two_pass ? 1 : 0);  // (the variant the iteration launches)
     } else
       return fail(LBFGSB_E_ARG, "unknown kernel");
     return 0;
@@ -2602,6 +2724,18 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
   if (syncs) *syncs = ctx->nsync;
   if (cauchy_fullsorts) *cauchy_fullsorts = ctx->nfullsort;
   if (wait_seconds) *wait_seconds = ctx->t_wait;
+  return 0;
+}
+
+int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  int64_t a, b;
+  if (ctx->flags & LBFGSB_F_REAL32)
+    a = as<float>(ctx)->nclosed, b = as<float>(ctx)->nthreepass;
+  else
+    a = as<double>(ctx)->nclosed, b = as<double>(ctx)->nthreepass;
+  if (closed_form) *closed_form = a;
+  if (three_pass) *three_pass = b;
   return 0;
 }
 

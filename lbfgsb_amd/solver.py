@@ -293,6 +293,12 @@ class DeviceSolver:
         names = ("cmprlb_wtv", "update_scan", "subsm_update")
         return {nm: (ms[k], cnt[k]) for k, nm in enumerate(names)}
 
+    def path_counts(self):
+        """(subspace steps by the two-pass closed form, by the three-pass route)"""
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.lbfgsb_hip_path_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def tie_splits(self) -> int:
         """setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints"""
         c = C.c_int64()
