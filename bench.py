@@ -368,7 +368,7 @@ def main():
                          "subsm_update")
     rec_cw = pass_record("cmprlb_wtv", 2, "cmprlb_wtv_kernel<%s, %d, true, %s>" % (tname, mc, nts),
                          ((2 * col + 2) * rbytes + 1) * n_loc, "none", "cmprlb_wtv")
-    closed_steps, three_steps = sol.path_counts()
+    closed_steps, three_steps, handed_windows = sol.path_counts()
     if rec_cw["launches_timed"]:      # three-pass iteration: cmprlb_wtv carries W'r inside it
         roofline, others = rec_cw, [rec_us, rec_su]
     else:                             # two-pass iteration: the update pass carries the matvecs
@@ -417,6 +417,7 @@ def main():
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
         "subspace_steps_closed_form": closed_steps,
         "subspace_steps_three_pass": three_steps,
+        "cauchy_walks_served_by_update_pass": handed_windows,
         "roofline": roofline,
         "roofline_wtv": roofline_wtv,
         "roofline_other_w_passes": others,

@@ -260,8 +260,10 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
 
 /* how many subspace minimisations so far took the two-pass route (W'Z r in closed form, no
  * cmprlb pass over W: col <= 10, bounded problem, short walk, >= 1/16 of the variables free) and
- * how many the three-pass route (cmprlb_wtv_kernel) */
-int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass);
+ * how many the three-pass route (cmprlb_wtv_kernel); handed_windows = Cauchy walks whose
+ * breakpoints came with the update pass itself (no window pass, no host sync of their own) */
+int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass,
+                           int64_t *handed_windows);
 
 /* number of setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints
  * (see LBFGSB_F_EXACT_TIES) */

@@ -31,7 +31,7 @@ PROTOTYPES = {
     "lbfgsb_hip_wait_stream": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_release_host": (C.c_int, [_vp]),
     "lbfgsb_hip_tie_splits": (C.c_int, [_vp, _vp]),
-    "lbfgsb_hip_path_counts": (C.c_int, [_vp, _vp, _vp]),
+    "lbfgsb_hip_path_counts": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lbfgsb_hip_minimize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_export_state": (C.c_int, [_vp, _vp, _vp]),

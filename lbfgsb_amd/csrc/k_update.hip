@@ -126,7 +126,8 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
     const T *__restrict__ d, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
-    int store_iw, double *part) {
+    int store_iw, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap, uint32_t *ccount,
+    double *part) {
   constexpr int NX = NEWROW ? 4 * MC + 4 : 0;  // extra sums
   constexpr int X = 4 * MC + 9;                // first extra slot
   constexpr int NA = 4 * MC + 11 + NX;
@@ -242,6 +243,40 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
       st<W>(ws + offn + i, dv);
       st<W>(wy + offn + i, rv);
     }
+    // Breakpoints up to cand_hi -- where the NEXT walk is expected to end, the caller's guess from
+    // the previous one -- are handed over with this pass (appended, unordered, like the window
+    // kernels do): the usual short walk then needs no window pass and no host sync of its own.
+    if (cand_hi >= 0.0) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const double tr_ = (double)(T)tb[k];  // as brk_time / tbrk hold it
+        bits |= (tr_ >= 0.0 && tr_ <= cand_hi) ? (1u << k) : 0u;
+      }
+      // (once the list is full nothing more is appended: a guess that was far too wide -- the
+      //  host then falls back to the window pass -- must not turn this pass into an atomics
+      //  benchmark; the count is then only a lower bound, which is all the host needs)
+      if (__ballot(bits != 0) != 0ull && __builtin_nontemporal_load(ccount) <= ccap) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          const bool pred = (bits >> k) & 1u;
+          const unsigned long long mask = __ballot(pred);
+          if (mask == 0ull) continue;
+          const int leader = __ffsll((long long)mask) - 1;
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(ccount, (uint32_t)__popcll(mask));
+          base = __shfl(base, leader);
+          if (pred) {
+            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < ccap) {
+              ckeys[pos] = key_of((double)(T)tb[k]);
+              cidx[pos] = (uint32_t)(i + k);
+            }
+          }
+        }
+      }
+    }
     // iwhere settles after the first iterations: store only from waves that changed a row
     if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
     if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
@@ -252,7 +287,9 @@ template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
                         const T *g, const T *r, const T *d, double stp, iw_t *iwhere, T *tbrk,
                         WStore<T> w, int head, int col, int itail, int store_pair, int store_iw,
-                        int newrow) {
+                        int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap,
+                        uint32_t *ccount) {
+  if (cand_hi >= 0.0) (void)hipMemsetAsync(ccount, 0, sizeof(uint32_t), q.stream);
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
 #define LB_UPDSCAN(NEWROWV)                                                                          \
@@ -262,7 +299,8 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                      hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PPV, NRV>), dim3(gr),        \
                                         dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d, stp,     \
                                         iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, nold,     \
-                                        itail, store_pair, store_iw, q.d_part);                      \
+                                        itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap,     \
+                                        ccount, q.d_part);                                           \
                    }))
   // (MC = 20 with the 84 extra sums does not fit the register file: those shapes keep the
   //  three-pass iteration)
@@ -279,7 +317,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
   template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double, WStore<T>, int, int, int); \
-  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int);
+  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int, double, uint64_t *, uint32_t *, uint32_t, uint32_t *);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

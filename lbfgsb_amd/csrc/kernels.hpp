@@ -278,7 +278,11 @@ template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
                         iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
-                        int store_pair, int store_iw, int newrow = 0);
+                        int store_pair, int store_iw, int newrow = 0, double cand_hi = -1.0,
+                        uint64_t *ckeys = nullptr, uint32_t *cidx = nullptr, uint32_t ccap = 0,
+                        uint32_t *ccount = nullptr);
+// cand_hi >= 0: rows whose breakpoint t lies in [0, cand_hi] are appended (unordered) to
+// ckeys / cidx (capacity ccap), *ccount = how many there are (zeroed by the launch)
 // newrow (col - 1 <= 10): 4 MC + 4 more sum slots in front of the min / max slots -- the new
 // row/column of formk's WN1 with the PRE-walk free set (layout: update_scan_kernel in
 // k_update.hip); min slot = 4 MC + 9 + (newrow ? 4 MC + 4 : 0), max slot behind it

@@ -150,6 +150,7 @@ struct lbfgsb_hip_ctx {
   int rank = 0, nranks = 1;
   int64_t nsync = 0, nfullsort = 0;
   int64_t ntiesplit = 0;  // walks that ended inside a group of equal breakpoints
+  int64_t nspecwin = 0;   // walks served by the candidates the update pass handed over
   double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
   // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
   // the next setulb_dev call fetches it together with the sums of its own first pass
@@ -258,13 +259,13 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(d_fix), F(pg_buf), F(pg_tmp);
+        F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
       p = nullptr;
     };
-    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix);
+    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix), H(h_sp_all), H(h_sp_loc);
     if (pf_ev) (void)hipEventDestroy(pf_ev);
     pf_ev = nullptr;
     if (order_ev) (void)hipEventDestroy(order_ev);
@@ -343,6 +344,10 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&d_msg2, msg_len * sizeof(double)));
     HIPCHK(hipEventCreateWithFlags(&pf_ev, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(&h_hdr, 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&sp_keys, SPEC_CAP * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&sp_idx, SPEC_CAP * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&sp_count, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&sp_msg, (2 + (size_t)SPEC_CAP * (2 * m_ + 4)) * sizeof(double)));
     HIPCHK(hipMalloc(&d_fix, FIX_CAP * sizeof(int64_t)));
     HIPCHK(hipHostMalloc(&h_fix, FIX_CAP * sizeof(int64_t)));
     CHK(set_ranks(0, 1));
@@ -366,6 +371,14 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&d_msg_all, (size_t)nr * msg_len * sizeof(double)));
     HIPCHK(hipHostMalloc(&h_msg_all, (size_t)nr * msg_len * sizeof(double)));
     HIPCHK(hipHostMalloc(&h_msg_loc, msg_len * sizeof(double)));
+    if (sp_msg_all) (void)hipFree(sp_msg_all);
+    if (h_sp_all) (void)hipHostFree(h_sp_all);
+    if (h_sp_loc) (void)hipHostFree(h_sp_loc);
+    sp_msg_all = h_sp_all = h_sp_loc = nullptr;
+    HIPCHK(hipMalloc(&sp_msg_all, (size_t)nr * sp_len() * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_sp_all, ((size_t)nr * sp_len() + nr) * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_sp_loc, sp_len() * sizeof(double)));
+    spcand.valid = false;
     return 0;
   }
 
@@ -537,6 +550,66 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   static constexpr uint32_t FAST_CAP = 256;  // candidates delivered by the one-sync fast path
+  // ---- candidates handed over by the update pass itself (update_scan_kernel, cand_hi) ----
+  static constexpr uint32_t SPEC_CAP = 128;
+  uint64_t *sp_keys = nullptr;
+  uint32_t *sp_idx = nullptr, *sp_count = nullptr;
+  double *sp_msg = nullptr, *sp_msg_all = nullptr, *h_sp_all = nullptr, *h_sp_loc = nullptr;
+  struct SpecCand {
+    bool valid = false, fresh = false;
+    double hi = -1.0;
+    int col = 0;
+  } spcand;
+  double last_tsum = 0.0, last_dtm0 = 0.0;  // where the previous walk ended / first aimed
+  size_t sp_len() const { return 2 + (size_t)SPEC_CAP * (2 * m + 4); }
+  double spec_factor = 2.0;
+  const bool spec_on = [] {  // LBFGSB_SPEC_CAPTURE=0 switches the hand-over off (measurement)
+    const char *e = std::getenv("LBFGSB_SPEC_CAPTURE");
+    return !(e && e[0] == '0');
+  }();
+  double spec_hi(bool cnstnd) const {  // the guess: a little beyond where the previous walk ended
+    if (!spec_on || !cnstnd || iter_seen < 3) return -1.0;  // (the first walks cross most breakpoints)
+    return last_tsum > 0.0 && std::isfinite(last_tsum) ? spec_factor * last_tsum : -1.0;
+  }
+  int iter_seen = 0;
+  // queue the gather of the candidates' records and their way to the host (all ranks') behind the
+  // update pass; spec_land() completes it after the phase's one host sync
+  int spec_queue(const T *x, const T *l, const T *u, const T *g, int head, int col, double stp) {
+    lbk::launch_cauchy_gather_dyn<T>(q, sp_idx, sp_keys, sp_count, SPEC_CAP, row0, x, l, u, g, W(), head,
+                                     col, r, d, lbk::Pend{1, stp}, sp_msg);
+    const size_t cnt = 2 + (size_t)SPEC_CAP * (2 * col + 4);
+    if (nranks == 1 && !comm) {
+      HIPCHK(hipMemcpyAsync(h_sp_all, sp_msg, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+    } else if (comm) {
+      if (g_rccl.AllGather(sp_msg, sp_msg_all, cnt, ncclDouble, comm, stream) != ncclSuccess)
+        return fail(LBFGSB_E_COMM, "ncclAllGather failed");
+      HIPCHK(hipMemcpyAsync(h_sp_all, sp_msg_all, (size_t)nranks * cnt * sizeof(double),
+                            hipMemcpyDeviceToHost, stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(h_sp_loc, sp_msg, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
+    return 0;
+  }
+  size_t sp_stride = 0;  // doubles per rank in h_sp_all
+  int spec_land(int col, double hi) {
+    const int recl = 2 * col + 4;
+    sp_stride = 2 + (size_t)SPEC_CAP * recl;
+    if (nranks > 1 && !comm) {
+      // host all-gather: first the counts, then only as many records as the fullest rank has
+      if (!cb_ag) return fail(LBFGSB_E_COMM, "multi-rank context without an all-gather");
+      double *cnts = h_sp_all + (size_t)nranks * sp_len() - nranks;  // (tail of the buffer)
+      if (cb_ag(cb_user, h_sp_loc, cnts, (int64_t)sizeof(double)) != 0)
+        return fail(LBFGSB_E_COMM, "host all-gather callback failed");
+      double mx = 0.0;
+      for (int rk = 0; rk < nranks; ++rk) mx = std::max(mx, cnts[rk]);
+      const size_t keep = (size_t)std::min<double>(mx, (double)SPEC_CAP);
+      sp_stride = 2 + keep * recl;
+      if (cb_ag(cb_user, h_sp_loc, h_sp_all, (int64_t)(sp_stride * sizeof(double))) != 0)
+        return fail(LBFGSB_E_COMM, "host all-gather callback failed");
+    }
+    spcand.valid = true, spcand.fresh = true, spcand.hi = hi, spcand.col = col;
+    return 0;
+  }
 
   // *big != nullptr: if more than PG_MIN candidates lie in the window, only report their number
   // (the caller switches to the parallel search) instead of ordering them
@@ -546,6 +619,53 @@ class Solver final : public lbfgsb_hip_ctx {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
     const int recl = 2 * col + 4;
     pf_valid = false;  // (new candidate lists: a prefetched chunk of the old ones is void)
+    if (spcand.valid && spcand.fresh && lo_t < 0.0 && hi > spcand.hi)
+      spec_factor = std::min(4.0, spec_factor * 1.5);  // the guess was short: aim further next time
+    if (spcand.valid && spcand.fresh && lo_t < 0.0 && hi <= spcand.hi && spcand.col == col) {
+      // the update pass already delivered every breakpoint up to spcand.hi with its record
+      spcand.fresh = false;
+      const size_t scount = sp_stride;
+      double gsum = 0.0;
+      bool all_in = true;
+      for (int rk = 0; rk < nranks; ++rk) {
+        const double c = h_sp_all[(size_t)rk * scount];
+        gsum += c;
+        if (c > (double)SPEC_CAP) all_in = false;
+      }
+      // adapt the guess: too many candidates -> aim closer next time, few -> a little wider
+      if (!all_in)
+        spec_factor = std::max(1.05, 0.5 * (spec_factor + 1.0));
+      else if (gsum < 0.25 * SPEC_CAP)
+        spec_factor = std::min(4.0, spec_factor * 1.25);
+      if (all_in) {
+        if (big) *big = gsum;
+        pv.have = true, pv.full = false;
+        pv.win_hi = spcand.hi;
+        pv.Cl = (uint32_t)h_sp_all[(size_t)rank * scount];
+        pv.pl = pv.Cl;  // everything is already on the host
+        pv.cur = 0;
+        pv.M.clear();
+        pv.raw = nullptr;
+        for (int rk = 0; rk < nranks; ++rk) {
+          const double *base = h_sp_all + (size_t)rk * scount;
+          const uint32_t lr = (uint32_t)base[0];
+          for (uint32_t k = 0; k < lr; ++k) {
+            const double *rec = base + 2 + (size_t)k * recl;
+            pv.M.push_back(MRec{rec[0], (int64_t)rec[1], rk, rec});
+          }
+        }
+        std::sort(pv.M.begin(), pv.M.end(), [](const MRec &a, const MRec &b) {
+          return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
+        });
+        pv.mpos = 0;
+        pv.safe_end = pv.M.size();
+        pv.more_anywhere = false;
+        pv.taken.assign(nranks, 0);
+        pv.next_chunk = 64;
+        nspecwin++;
+        return 0;
+      }
+    }
     if (tbrk_valid)
       lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
                                    d_count);
@@ -1062,6 +1182,7 @@ class Solver final : public lbfgsb_hip_ctx {
     double dtm = -f1 / f2;
     double tsum = 0.0;
     nseg = 1;
+    last_dtm0 = dtm;
     if (ipr >= 99) std::fprintf(rep.out, " There are %11lld   breakpoints \n", (long long)nbreak);  // :1367
 
     if (col == 0 && nbreak != 0 && (flags & LBFGSB_F_PARALLEL_GCP) && dtm >= bkmin) {
@@ -1336,6 +1457,8 @@ class Solver final : public lbfgsb_hip_ctx {
     tsum = tsum + dtm;
     if (col > 0 && dtm != 0.0)
       for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
+    last_tsum = tsum;
+    iter_seen++;
     if (col > 0) {
       // p = W'd over the variables that still move = the free variables: with it W'Z r needs no
       // pass over W (subspace_closed_form).  Not after a long walk (its rounding accumulates in
@@ -1728,6 +1851,7 @@ class Solver final : public lbfgsb_hip_ctx {
 
     if (lbh::str60_eq(task, "START")) {  // :430-507
       spec.valid = false, pend.on = 0, scan.ready = false;
+      spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
       epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
                               : std::numeric_limits<double>::epsilon();
       time1 = now_s();
@@ -1813,6 +1937,7 @@ class Solver final : public lbfgsb_hip_ctx {
     if (lbh::str60_pre(task, "FG_LN")) {
       compute_pg = false, prelims = false;
       spec.valid = false;
+      spcand.valid = false;
       // First trial of a line search on a bounded problem: it is accepted far more often than
       // not, so evaluate it with the pass that matupd + the next cauchy scan would run anyway
       // (read-only with the pair pending); g'd and |proj g| are two of its sums.  Contexts
@@ -1830,11 +1955,16 @@ class Solver final : public lbfgsb_hip_ctx {
         const int NX = lbk::update_scan_extra(c2 - 1, two_pass ? 1 : 0);
         clk_begin(1);
         q.res_off = fo;
+        const double chi = spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
-                                   it2, 0, store_iw, two_pass ? 1 : 0);
+                                   it2, 0, store_iw, two_pass ? 1 : 0, chi, sp_keys, sp_idx, SPEC_CAP,
+                                   sp_count);
         q.res_off = 0;
         clk_end(1);
+        spcand.valid = false;
+        if (chi >= 0.0) CHK(spec_queue(x, l, u, g, h2, c2, stp));
         CHK(fetch(fo + 4 * MCo + 9 + NX, 1, 1));
+        if (chi >= 0.0) CHK(spec_land(c2, chi));
         if (fo) *f = f_scale * h_res[0];
         const double *R = h_res + fo;
         gd = R[4 * MCo + 7];
@@ -2087,11 +2217,13 @@ class Solver final : public lbfgsb_hip_ctx {
               lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
             ls.x_is_z = false;
             spec.valid = false;  // the trial point was not accepted
+            spcand.valid = false;
           } else {
             lbh::str60_set(task, "NEW_X");
           }
         } else {
           spec.valid = false;
+          spcand.valid = false;
         }
 
         if (info != 0 || iback >= 20) {  // :734-769
@@ -2177,6 +2309,7 @@ class Solver final : public lbfgsb_hip_ctx {
         nskip++;
         updatd = false;
         spec.valid = false;
+        spcand.valid = false;
         if (ipr >= 1)
           std::fprintf(rep.out, "  ys=%s  -gs=%s BFGS update SKIPPED\n", lbr::fE(dr, 10, 3).c_str(),
                        lbr::fE(ddum, 10, 3).c_str());
@@ -2208,10 +2341,15 @@ class Solver final : public lbfgsb_hip_ctx {
             lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
         } else {
           clk_begin(1);
+          const double chi = spec_hi(cnstnd);
           lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
-                                     col, itail, 0, 1, two_pass ? 1 : 0);
+                                     col, itail, 0, 1, two_pass ? 1 : 0, chi, sp_keys, sp_idx, SPEC_CAP,
+                                     sp_count);
           clk_end(1);
+          spcand.valid = false;
+          if (chi >= 0.0) CHK(spec_queue(x, l, u, g, head, col, stp));
           CHK(fetch(4 * MCo + 9 + NX, 1, 1));
+          if (chi >= 0.0) CHK(spec_land(col, chi));
         }
         nrpre.valid = false;
         if (NX) {  // formk's new row/column with the pre-walk free set (update_scan_kernel NEWROW)
@@ -2346,6 +2484,7 @@ class Solver final : public lbfgsb_hip_ctx {
     get(wa8m);
     z_valid = true;  // z as imported
     spec.valid = false, pend.on = 0, tbrk_valid = false, scan.ready = false;
+    spcand.valid = false;
     {
       std::vector<lbk::iw_t> h((size_t)n);
       for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)iwa[n + i];
@@ -2727,8 +2866,10 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
   return 0;
 }
 
-int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass) {
+int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass,
+                           int64_t *handed_windows) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (handed_windows) *handed_windows = ctx->nspecwin;
   int64_t a, b;
   if (ctx->flags & LBFGSB_F_REAL32)
     a = as<float>(ctx)->nclosed, b = as<float>(ctx)->nthreepass;

@@ -294,10 +294,11 @@ class DeviceSolver:
         return {nm: (ms[k], cnt[k]) for k, nm in enumerate(names)}
 
     def path_counts(self):
-        """(subspace steps by the two-pass closed form, by the three-pass route)"""
-        a, b = C.c_int64(), C.c_int64()
-        check(self.lib.lbfgsb_hip_path_counts(self.h, C.byref(a), C.byref(b)))
-        return int(a.value), int(b.value)
+        """(subspace steps by the two-pass closed form, by the three-pass route, Cauchy walks
+        served by the breakpoints the update pass handed over)"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.lbfgsb_hip_path_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def tie_splits(self) -> int:
         """setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints"""
