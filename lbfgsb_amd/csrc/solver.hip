@@ -563,9 +563,11 @@ class Solver final : public lbfgsb_hip_ctx {
   double last_tsum = 0.0, last_dtm0 = 0.0;  // where the previous walk ended / first aimed
   size_t sp_len() const { return 2 + (size_t)SPEC_CAP * (2 * m + 4); }
   double spec_factor = 2.0;
-  const bool spec_on = [] {  // LBFGSB_SPEC_CAPTURE=0 switches the hand-over off (measurement)
+  // Off unless LBFGSB_SPEC_CAPTURE=1: measured at n = 1e8 / 1.25e7 (profiles/README.md, r02q) a walk
+  // either crosses no breakpoint at all or hundreds to thousands -- SPEC_CAP records serve 0-3 of 31.
+  const bool spec_on = [] {
     const char *e = std::getenv("LBFGSB_SPEC_CAPTURE");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   double spec_hi(bool cnstnd) const {  // the guess: a little beyond where the previous walk ended
     if (!spec_on || !cnstnd || iter_seen < 3) return -1.0;  // (the first walks cross most breakpoints)
@@ -619,6 +621,11 @@ class Solver final : public lbfgsb_hip_ctx {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
     const int recl = 2 * col + 4;
     pf_valid = false;  // (new candidate lists: a prefetched chunk of the old ones is void)
+    if (debug_walk && lo_t < 0.0) {
+      double c0 = spcand.valid ? h_sp_all[0] : -1.0;
+      std::fprintf(stderr, "[spec] valid=%d fresh=%d hi_asked=%g spec_hi=%g factor=%g count0=%g\n",
+                   (int)spcand.valid, (int)spcand.fresh, hi, spcand.hi, spec_factor, c0);
+    }
     if (spcand.valid && spcand.fresh && lo_t < 0.0 && hi > spcand.hi)
       spec_factor = std::min(4.0, spec_factor * 1.5);  // the guess was short: aim further next time
     if (spcand.valid && spcand.fresh && lo_t < 0.0 && hi <= spcand.hi && spcand.col == col) {

@@ -809,15 +809,21 @@ def test_parallel_gcp_opt_in(env, kind):
         assert a[4] == pytest.approx(b[4], rel=1e-9)
 
 
+@pytest.mark.parametrize("handover", [False, True], ids=["", "handover"])
 @pytest.mark.parametrize("n,m,mixed,min_agree", [(1000, 10, False, 72), (4096, 10, True, 80),
                                                  (100003, 5, False, 60)])
-def test_device_path_to_convergence_against_oracle(env, n, m, mixed, min_agree):
+def test_device_path_to_convergence_against_oracle(env, monkeypatch, n, m, mixed, min_agree, handover):
     """The production path (device pointers, speculative update pass, pending pair, functional
     Cauchy point, on-device objective) run to CONVERGENCE with factr = pgtol = 0: the integer
     columns (iteration, nfg, nseg, nfree) equal the oracle's for at least `min_agree` iterations
     (all 72 of the n = 1000 fixture; beyond that the stop test acts on rounding noise), f agrees
-    to 1e-11 throughout, same final message."""
+    to 1e-11 throughout, same final message.  `handover`: with LBFGSB_SPEC_CAPTURE=1 the update
+    pass also hands the next walk's first breakpoints over (off by default: DESIGN.md section 4)."""
     po, torch, la = env["po"], env["torch"], env["la"]
+    if handover:
+        monkeypatch.setenv("LBFGSB_SPEC_CAPTURE", "1")
+    else:
+        monkeypatch.delenv("LBFGSB_SPEC_CAPTURE", raising=False)
     p = po.problem_quadratic(n, m, mixed_nbd=mixed)
     rows_o = []
     so = po.run(po.Engine("oracle"), p,
@@ -839,7 +845,9 @@ def test_device_path_to_convergence_against_oracle(env, n, m, mixed, min_agree):
                            int(sol.isave[37]), float(sol.f[0])))
         else:
             break
+    handed = sol.path_counts()[2]
     sol.close()
+    assert handed == 0 if not handover else handed >= 0
     assert t == so.task_s and t.startswith("CONVERGENCE")
     k = 0
     while k < min(len(rows_o), len(rows_g)) and rows_o[k][:4] == rows_g[k][:4]:
