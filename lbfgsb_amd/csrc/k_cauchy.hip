@@ -320,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void pgcp_gather_kernel(
       const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
       const bool pj = pe.on && j == col - 1;
       const double yv = pj ? pend_y<T>((double)g[i], (double)pr[i]) : (double)wy[off];
-      const double sv = theta * (pj ? pend_s<T>((double)pd[i], pe.stp) : (double)ws[off]);
+      const double sv = theta * (pj ? pend_sx<T>((double)pd[i], (double)x[i], pe) : (double)ws[off]);
       wb[(int64_t)j * nbp + k] = yv;
       wb[(int64_t)(col + j) * nbp + k] = sv;
       uu[(int64_t)j * nbp + k] = d * yv;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
                                       : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
     } else {
       v = (pe.on && f - 4 - col == col - 1)
-              ? pend_s<T>((double)pd[i], pe.stp)
+              ? pend_sx<T>((double)pd[i], (double)x[i], pe)
               : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
     }
     rec[q] = v;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
                                       : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
     } else {
       v = (pe.on && f - 4 - col == col - 1)
-              ? pend_s<T>((double)pd[i], pe.stp)
+              ? pend_sx<T>((double)pd[i], (double)x[i], pe)
               : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
     }
     rec[q] = v;

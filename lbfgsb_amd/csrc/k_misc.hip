@@ -273,6 +273,27 @@ __global__ __launch_bounds__(BLOCK) void pair_commit_kernel(int64_t n, const T *
   });
 }
 template <typename T>
+__global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const T *__restrict__ x,
+                                                               const T *__restrict__ t,
+                                                               T *__restrict__ d, T *z) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double xv[W], tv[W], dv[W];
+    ld<W>(x + i, xv);
+    ld<W>(t + i, tv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) dv[k] = xv[k] - tv[k];  // exactly subsm_update_kernel's d = z - x
+    st<W>(d + i, dv);
+    if (z) st<W>(z + i, xv);
+  });
+}
+template <typename T>
+void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z) {
+  hipLaunchKernelGGL(dz_materialise_kernel<T>, dim3(grid_for(n, VecOf<T>::V)), dim3(BLOCK), 0, q.stream,
+                     n, x, t, d, z);
+  q.launches++;
+}
+template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
                         WStore<T> w, int head, int col) {
   const int gr = grid_for(n, VecOf<T>::V);
@@ -626,6 +647,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
   template void launch_lnsrlb_step<T>(Queue &, int64_t, T *, const T *, const T *, const T *, double); \
   template void launch_lnsrlb_eval<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *); \
   template void launch_pair_commit<T>(Queue &, int64_t, const T *, const T *, const T *, Pend, WStore<T>, int, int); \
+  template void launch_dz_materialise<T>(Queue &, int64_t, const T *, const T *, T *, T *); \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *); \
   template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *, double, double); \
   template void launch_halo_pack<T>(Queue &, int64_t, const T *, double *);

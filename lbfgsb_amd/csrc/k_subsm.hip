@@ -31,7 +31,7 @@ __device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, con
 // res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
 template <typename T>
 struct SubsmCtx {
-  const T *l, *u, *xx, *gg, *ws, *wy, *zero, *r, *dvec;
+  const T *l, *u, *xx, *gg, *ws, *wy, *zero, *r, *pd;
   const int32_t *nbd;
   const iw_t *iwhere;
   int64_t ldw;
@@ -52,8 +52,9 @@ struct SubsmTrip {
     raw_issue<B, NT>(rg, c.gg + i);
     raw_issue<4 * W, false>(rnb, c.nbd + i);
     raw_issue<W, false>(riw, c.iwhere + i);
-    // a pending pair is read from (r, d) -- which this pass overwrites further down
-    issue_cols<T, MC, W, NT, PSPEC>(c.wy, c.ws, c.r, c.dvec, c.zero, i, c.col, c.head, c.m, c.ldw, c.pe,
+    // a pending pair is read from (r, d) -- or (r, t) when d is implicit -- which this pass
+    // overwrites further down
+    issue_cols<T, MC, W, NT, PSPEC>(c.wy, c.ws, c.r, c.pd, c.zero, i, c.col, c.head, c.m, c.ldw, c.pe,
                                     ra, rb);
   }
   __device__ __forceinline__ void land() {
@@ -72,14 +73,14 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
-    int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *__restrict__ tvec,
-    T *xout, int do_stpmx, Pend pe, T *cwy, T *cws, double *part) {
+    int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
+    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
   // stores every trip issues: z, d, t, r (+ the committed pair in the steady-state shape)
   constexpr int NS = PSPEC ? 6 : 4;
-  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, r, dvec, nbd, iwhere, ldw, m, head, col, pe};
+  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, r, pd, nbd, iwhere, ldw, m, head, col, pe};
   for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     raw_geti<W>(tr.rnb, (const int32_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
     get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
-    fix_pending<T, MC, W, PSPEC>(col, pe, gv, a, b);
+    fix_pending<T, MC, W, PSPEC>(col, pe, gv, xv, a, b);
     if (PSPEC || pe.on) {
       double yn[W], sn[W];
       newest_cols<MC, W, PSPEC>(col, a, b, yn, sn);
@@ -147,15 +148,18 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     }
     // (nontemporal stores with the nontemporal loads: large problems, nothing here is re-read
     //  by this pass; the next readers stream it from HBM anyway)
+    // zout == dvec == nullptr ("lean"): the first trial step is 1, so x = z is stored below and
+    // both z and d = x - t stay implicit until something needs them as vectors (solver.hip,
+    // ensure_d) -- 5 store streams instead of 7.
     if (NT) {
-      stnt<W>(zout + i, zv);
-      stnt<W>(dvec + i, dv);
+      if (zout) stnt<W>(zout + i, zv);
+      if (dvec) stnt<W>(dvec + i, dv);
       stnt<W>(tvec + i, xv);
       stnt<W>(r + i, gv);
       if (xout) stnt<W>(xout + i, zv);
     } else {
-      st<W>(zout + i, zv);
-      st<W>(dvec + i, dv);
+      if (zout) st<W>(zout + i, zv);
+      if (dvec) st<W>(dvec + i, dv);
       st<W>(tvec + i, xv);  // t = x (:2235)
       st<W>(r + i, gv);     // r = g (:2236)
       // first trial point of the line search when its step is known to be 1: x = z (:2265);
@@ -169,7 +173,8 @@ template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
-                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe) {
+                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
+                         const T *pd) {
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   const bool spec = pe.on && col == maxc_for(col);
@@ -179,7 +184,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
                                          (subsm_update_kernel<T, MC, NTV, PSPECV, PIPEV>), dim3(gr),\
                                          dim3(BLOCK), 0, q.stream, n, tsum, zout, r, l, u, nbd,     \
                                          iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head, col,  \
-                                         theta, cf, wv, dvec, tvec, xout, do_stpmx, pe,             \
+                                         theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,         \
                                          w.wy + slot, w.ws + slot, q.d_part)))
   if (spec)
     LB_SUBSM(true);
@@ -238,7 +243,7 @@ void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, con
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
-  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const int32_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend); \
+  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const int32_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *); \
   template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *);
 INSTANTIATE(double)
 INSTANTIATE(float)

@@ -124,7 +124,7 @@ template <typename T, int MC, bool NT, bool PIPE, bool NEWROW>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
-    const T *__restrict__ d, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
+    const T *__restrict__ d, int dimpl, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
     int store_iw, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap, uint32_t *ccount,
     double *part) {
@@ -156,6 +156,9 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     bool iw_changed = false;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
+      // (dimpl: `d` points at t, the previous iterate, and the direction is x - t: the unit
+      //  first trial step of a lean subsm_update_kernel pass, see Pend::impl)
+      if (dimpl) dv[k] = (double)(T)(xv[k] - dv[k]);
       // ---- the line search's own sums at this trial point: g'd (:2244), |proj g| (:781) ----
       acc[4 * MC + 7] = acc[4 * MC + 7] + gv[k] * dv[k];
       acc[IMAX] = fmax(acc[IMAX], proj_g(xv[k], lv[k], uv[k], nb[k], gv[k]));
@@ -285,10 +288,10 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
 }
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
-                        const T *g, const T *r, const T *d, double stp, iw_t *iwhere, T *tbrk,
-                        WStore<T> w, int head, int col, int itail, int store_pair, int store_iw,
-                        int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap,
-                        uint32_t *ccount) {
+                        const T *g, const T *r, const T *d, int dimpl, double stp, iw_t *iwhere,
+                        T *tbrk, WStore<T> w, int head, int col, int itail, int store_pair,
+                        int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
+                        uint32_t ccap, uint32_t *ccount) {
   if (cand_hi >= 0.0) (void)hipMemsetAsync(ccount, 0, sizeof(uint32_t), q.stream);
   const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
   const int nold = col - 1;
@@ -297,7 +300,8 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                      constexpr bool NRV = NEWROWV && MC <= 10;                                       \
                      constexpr bool PPV = (PIPEV || NRV) && MC <= 20;                                \
                      hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PPV, NRV>), dim3(gr),        \
-                                        dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d, stp,     \
+                                        dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d, dimpl,   \
+                                        stp,                                                         \
                                         iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, nold,     \
                                         itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap,     \
                                         ccount, q.d_part);                                           \
@@ -317,7 +321,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
   template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double, WStore<T>, int, int, int); \
-  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int, double, uint64_t *, uint32_t *, uint32_t, uint32_t *);
+  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, int, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int, double, uint64_t *, uint32_t *, uint32_t, uint32_t *);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

@@ -52,6 +52,9 @@ struct Coef {
 struct Pend {
   int on;      // 0: every column is in W
   double stp;  // step length of the accepted trial
+  int impl;    // 1: d itself is not stored either -- the unit first trial step was accepted, so
+               //    d = x - t (x the accepted point, t the previous iterate); the `pd` argument of
+               //    the kernels then points at t and s = T(x - t)
 };
 
 int grid_for(int64_t n, int vec);
@@ -228,7 +231,8 @@ template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
                          const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
-                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe);
+                         const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
+                         const T *pd);
 // the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
 template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
@@ -276,8 +280,8 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // [4MC+8] #iwhere changes | min [4MC+9] bkmin | max [4MC+10] |proj g|
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
-                        const int32_t *nbd, const T *g, const T *r, const T *d, double stp,
-                        iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
+                        const int32_t *nbd, const T *g, const T *r, const T *d, int dimpl,
+                        double stp, iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
                         int store_pair, int store_iw, int newrow = 0, double cand_hi = -1.0,
                         uint64_t *ckeys = nullptr, uint32_t *cidx = nullptr, uint32_t ccap = 0,
                         uint32_t *ccount = nullptr);
@@ -288,6 +292,9 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // k_update.hip); min slot = 4 MC + 9 + (newrow ? 4 MC + 4 : 0), max slot behind it
 inline int update_scan_extra(int nold, int newrow);
 // Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
+// d = x - t, z = x: the vectors a lean subsm_update_kernel pass left implicit (Pend::impl)
+template <typename T>
+void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z);
 template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
                         WStore<T> w, int head, int col);

@@ -117,6 +117,11 @@ template <typename T>
 __device__ __forceinline__ double pend_s(double dk, double stp) {
   return stp != 1.0 ? (double)(T)(stp * dk) : dk;
 }
+// the same when d is implicit (Pend::impl): `tk` is what was loaded through pd (= t)
+template <typename T>
+__device__ __forceinline__ double pend_sx(double tk, double xk, Pend pe) {
+  return pe.impl ? (double)(T)(xk - tk) : pend_s<T>(tk, pe.stp);
+}
 // columns j = 0..MC-1 of one row group; the pending column is read from (r, d) instead.
 // PSPEC: the caller guarantees pe.on && col == MC (every iteration once the memory is full):
 // the pending column is then the compile-time slot MC - 1 and no select is needed.
@@ -151,12 +156,13 @@ __device__ __forceinline__ void load_cols(const T *__restrict__ wy, const T *__r
 }
 template <typename T, int MC, int W, bool PSPEC = false>
 __device__ __forceinline__ void fix_pending(int col, Pend pe, const double (&gv)[W],
-                                            double (&a)[MC][W], double (&b)[MC][W]) {
+                                            const double (&xv)[W], double (&a)[MC][W],
+                                            double (&b)[MC][W]) {
   if constexpr (PSPEC) {
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       a[MC - 1][k] = pend_y<T>(gv[k], a[MC - 1][k]);
-      b[MC - 1][k] = pend_s<T>(b[MC - 1][k], pe.stp);
+      b[MC - 1][k] = pend_sx<T>(b[MC - 1][k], xv[k], pe);
     }
   } else {
     // branch-free selects: a predicated write a[col-1][k] = ... would turn the register arrays
@@ -167,7 +173,7 @@ __device__ __forceinline__ void fix_pending(int col, Pend pe, const double (&gv)
 #pragma unroll
       for (int k = 0; k < W; ++k) {
         const double yk = pend_y<T>(gv[k], a[j][k]);
-        const double sk = pend_s<T>(b[j][k], pe.stp);
+        const double sk = pend_sx<T>(b[j][k], xv[k], pe);
         a[j][k] = pj ? yk : a[j][k];
         b[j][k] = pj ? sk : b[j][k];
       }

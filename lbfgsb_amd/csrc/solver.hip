@@ -517,7 +517,24 @@ class Solver final : public lbfgsb_hip_ctx {
   bool tbrk_valid = false;
   const int32_t *cnbd = nullptr;
   // the pair accepted by matupd in this call, not yet stored in W (see lbk::Pend)
-  lbk::Pend pend{0, 1.0};
+  lbk::Pend pend{0, 1.0, 0};
+  // ---- lean subspace pass: z and d stay implicit (z = x, d = x - t) while the unit first trial
+  //      step stands; ensure_d() writes them out for everything but the hot path ----
+  bool d_impl = false;
+  bool z_in_x = false;  // ... and z too: until the next cauchy gives z a new meaning
+  const bool lean_on = [] {
+    const char *e = std::getenv("LBFGSB_LEAN");
+    return !(e && e[0] == '0');
+  }();
+  const T *d_src() const { return d_impl ? t : d; }  // what the kernels read the direction from
+  int ensure_d(const T *x) {
+    if (!d_impl) return 0;
+    lbk::launch_dz_materialise<T>(q, n, x, t, d, z_in_x ? z : (T *)nullptr);
+    if (z_in_x) z_valid = true;
+    d_impl = false, z_in_x = false;
+    if (pend.on) pend.impl = 0;
+    return 0;
+  }
   // sums of an update_scan pass that ran as the evaluation of an accepted trial point (kept
   // from the FG_LNSRCH entry that returned NEW_X to the NEW_X entry that performs the update)
   struct Spec {
@@ -528,7 +545,10 @@ class Solver final : public lbfgsb_hip_ctx {
     double res[lbk::RES_MAX];
   } spec;
   int commit_pending(const T *g, int col, int head) {
-    if (pend.on) lbk::launch_pair_commit<T>(q, n, g, r, d, pend, W(), head, col);
+    if (pend.on) {
+      CHK(ensure_d((const T *)cx));
+      lbk::launch_pair_commit<T>(q, n, g, r, d, pend, W(), head, col);
+    }
     pend.on = 0;
     return 0;
   }
@@ -578,7 +598,7 @@ class Solver final : public lbfgsb_hip_ctx {
   // update pass; spec_land() completes it after the phase's one host sync
   int spec_queue(const T *x, const T *l, const T *u, const T *g, int head, int col, double stp) {
     lbk::launch_cauchy_gather_dyn<T>(q, sp_idx, sp_keys, sp_count, SPEC_CAP, row0, x, l, u, g, W(), head,
-                                     col, r, d, lbk::Pend{1, stp}, sp_msg);
+                                     col, r, d_src(), lbk::Pend{1, stp, d_impl ? 1 : 0}, sp_msg);
     const size_t cnt = 2 + (size_t)SPEC_CAP * (2 * col + 4);
     if (nranks == 1 && !comm) {
       HIPCHK(hipMemcpyAsync(h_sp_all, sp_msg, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -680,7 +700,7 @@ class Solver final : public lbfgsb_hip_ctx {
       lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, cnbd, g, iwhere, lo_t, lo_i, hi, keys[0],
                                        idx[0], SEL_CAP, d_count);
     lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
-                                     head, col, r, d, pend, d_msg);
+                                     head, col, r, d_src(), pend, d_msg);
     const size_t fcount = 2 + (size_t)FAST_CAP * recl;
     CHK(exchange(fcount));
     double gsum = 0.0;
@@ -831,7 +851,7 @@ class Solver final : public lbfgsb_hip_ctx {
     if (len == 0) return 0;
     HIPCHK(hipMemcpyAsync(keys[0], hk.data(), (size_t)len * 8, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(idx[0], hi.data(), (size_t)len * 4, hipMemcpyHostToDevice, stream));
-    lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], len, row0, x, l, u, g, W(), head, col, r, d, pend,
+    lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], len, row0, x, l, u, g, W(), head, col, r, d_src(), pend,
                                  d_msg + 2);
     CHK(put_header((double)len, (double)pv.hleft));
     CHK(exchange(2 + (size_t)len * recl));  // (also orders the pageable uploads above)
@@ -867,7 +887,7 @@ class Solver final : public lbfgsb_hip_ctx {
       h_msg_all[0] = (double)pf_len, h_msg_all[1] = (double)pf_rem;
     } else {
       lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
-                                   W(), head, col, r, d, pend, d_msg + 2);
+                                   W(), head, col, r, d_src(), pend, d_msg + 2);
       CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
       CHK(exchange(count));
     }
@@ -878,7 +898,7 @@ class Solver final : public lbfgsb_hip_ctx {
       const uint32_t npl = pv.pl + len;
       const uint32_t nlen = std::min<uint32_t>(pv.next_chunk, pv.Cl - npl);
       lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + npl, keys[pv.cur] + npl, nlen, row0, x, l, u, g, W(),
-                                   head, col, r, d, pend, d_msg2 + 2);
+                                   head, col, r, d_src(), pend, d_msg2 + 2);
       HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg2, (2 + (size_t)nlen * recl) * sizeof(double),
                             hipMemcpyDeviceToHost, stream));
       HIPCHK(hipEventRecord(pf_ev, stream));
@@ -1052,8 +1072,8 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMemcpyAsync(dM, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(dp0, p0, col2 * sizeof(double), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));  // (M, p0 are host temporaries)
-    lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], nb, nbp, x, l, u, g, W(), head, col, theta, r, d,
-                               pend, tt, dd, a0, wb, pp);
+    lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], nb, nbp, x, l, u, g, W(), head, col, theta, r,
+                               d_src(), pend, tt, dd, a0, wb, pp);
     lbk::launch_pgcp_last(q, nb, nbp, col2, pp, ulast);
     for (int cc = 0; cc < col2; ++cc)
       lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, pp + (size_t)cc * nbp, pp + (size_t)cc * nbp, (size_t)nb, 1);
@@ -1130,6 +1150,7 @@ class Solver final : public lbfgsb_hip_ctx {
     fixlist.clear();
     fix_overflow = false;
     closed_ok = false;
+    z_in_x = false;  // z means this call's Cauchy point from here on
     std::memset(nrc, 0, sizeof nrc);
     const int ipr = quiet ? -1 : print_level;
     if (sbgnrm <= 0.0) {  // :1245-1249
@@ -1675,6 +1696,7 @@ class Solver final : public lbfgsb_hip_ctx {
         info = -8;
         return 0;
       }
+      CHK(ensure_d(x));
       clk_begin(0);
       lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
                                 newrow ? 1 : 0, r, d, pend);
@@ -1726,13 +1748,17 @@ class Solver final : public lbfgsb_hip_ctx {
     // d, t, r get their line-search values in the same pass (see subsm_update_kernel); xp = xcp
     // (:2787) is written out only for state export -- and below if the backtracking branch runs
     if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
+    // lean: the first trial step is 1 and x = z is stored by the pass, so neither z nor d = x - t
+    // is written (5 store streams instead of 7); they stay implicit until ensure_d()
+    const bool lean = lean_on && ls_unit_step && cnstnd && !(flags & LBFGSB_F_MIRROR_INDEX);
     clk_begin(2);
-    lbk::launch_subsm_update<T>(q, n, gcp.tsum, z, r, l, u, nbd, iwhere, x, g, W(), head, col, theta,
-                                cm_cf, cw, d, t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
-                                pend);
+    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, l, u, nbd, iwhere, x, g, W(),
+                                head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d, t,
+                                ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0, pend, d_src());
     clk_end(2);
-    pend.on = 0;  // the pass stored the pair into its W slot
-    z_valid = true;
+    pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
+    d_impl = z_in_x = lean;
+    z_valid = !lean;
     CHK(fetch(3, 1, 0));
     iword = h_res[0] > 0.0 ? 1 : 0;
     const double dd_p = h_res[1];
@@ -1746,6 +1772,7 @@ class Solver final : public lbfgsb_hip_ctx {
       return 0;
     }
     ls.ready = false;  // z changes below: lnsrlb_begin redoes d, t, r
+    d_impl = z_in_x = false;  // (and the backtracking kernel writes all of z)
     if (ls.x_is_z) {   // ... from the iterate itself, which the pass above saved in t
       HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
       ls.x_is_z = false;
@@ -1853,11 +1880,11 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     auto refresh = [&]() {
       info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
-      pend.on = 0;  // the memory is dropped, an uncommitted pair with it
+      pend.on = 0, pend.impl = 0;  // the memory is dropped, an uncommitted pair with it
     };
 
     if (lbh::str60_eq(task, "START")) {  // :430-507
-      spec.valid = false, pend.on = 0, scan.ready = false;
+      spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
       spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
       epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
                               : std::numeric_limits<double>::epsilon();
@@ -1963,9 +1990,9 @@ class Solver final : public lbfgsb_hip_ctx {
         clk_begin(1);
         q.res_off = fo;
         const double chi = spec_hi(cnstnd);
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), h2, c2,
-                                   it2, 0, store_iw, two_pass ? 1 : 0, chi, sp_keys, sp_idx, SPEC_CAP,
-                                   sp_count);
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+                                   (T *)nullptr, W(), h2, c2, it2, 0, store_iw, two_pass ? 1 : 0, chi,
+                                   sp_keys, sp_idx, SPEC_CAP, sp_count);
         q.res_off = 0;
         clk_end(1);
         spcand.valid = false;
@@ -1982,6 +2009,7 @@ class Solver final : public lbfgsb_hip_ctx {
         tbrk_valid = false;
       } else {
         // g.d for the line search and, speculatively, |proj g| for the NEW_X return
+        CHK(ensure_d(x));
         q.res_off = fo;
         lbk::launch_lnsrlb_eval<T>(q, n, x, l, u, nbd, g, d);
         q.res_off = 0;
@@ -2036,7 +2064,7 @@ class Solver final : public lbfgsb_hip_ctx {
         if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
           gcp = Gcp{};
           gcp.copy_x = true;
-          z_valid = false;
+          z_valid = false, z_in_x = false;
           wrk = updatd;
           nseg = 0;
           pre_valid = false;
@@ -2073,6 +2101,7 @@ class Solver final : public lbfgsb_hip_ctx {
             bool plain;
             if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
               const bool newrow = updatd && col <= 20;  // updatd implies wrk
+              CHK(ensure_d(x));
               q.res_off = 3;
               clk_begin(0);
               lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
@@ -2220,8 +2249,10 @@ class Solver final : public lbfgsb_hip_ctx {
             ifun++;
             nfgv++;
             iback = ifun - 1;
-            if (!(ls.x_is_z && ifun == 1 && stp == 1.0))  // else x = z is already in place
+            if (!(ls.x_is_z && ifun == 1 && stp == 1.0)) {  // else x = z is already in place
+              CHK(ensure_d(x));  // (x still is the rejected first trial point z)
               lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
+            }
             ls.x_is_z = false;
             spec.valid = false;  // the trial point was not accepted
             spcand.valid = false;
@@ -2234,6 +2265,7 @@ class Solver final : public lbfgsb_hip_ctx {
         }
 
         if (info != 0 || iback >= 20) {  // :734-769
+          CHK(ensure_d(x));
           HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
           HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
           *f = fold;
@@ -2349,9 +2381,9 @@ class Solver final : public lbfgsb_hip_ctx {
         } else {
           clk_begin(1);
           const double chi = spec_hi(cnstnd);
-          lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, stp, iwhere, (T *)nullptr, W(), head,
-                                     col, itail, 0, 1, two_pass ? 1 : 0, chi, sp_keys, sp_idx, SPEC_CAP,
-                                     sp_count);
+          lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+                                     (T *)nullptr, W(), head, col, itail, 0, 1, two_pass ? 1 : 0, chi,
+                                     sp_keys, sp_idx, SPEC_CAP, sp_count);
           clk_end(1);
           spcand.valid = false;
           if (chi >= 0.0) CHK(spec_queue(x, l, u, g, head, col, stp));
@@ -2369,7 +2401,7 @@ class Solver final : public lbfgsb_hip_ctx {
         }
         spec.valid = false;
         tbrk_valid = false;
-        pend.on = 1, pend.stp = stp;  // committed by the subspace pass of this same call
+        pend.on = 1, pend.stp = stp, pend.impl = d_impl ? 1 : 0;  // committed by this call's subspace pass
         rr = h_res[2 * MCo];
         const int nold = col - 1;
         for (int j = 0; j < nold; ++j) {
@@ -2383,6 +2415,7 @@ class Solver final : public lbfgsb_hip_ctx {
         scan.bkmin = h_res[4 * MCo + 9 + NX];
         scan.ready = true;
       } else {
+        CHK(ensure_d(x));
         lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
         CHK(fetch(2 * MCo + 1, 0, 0));
         rr = h_res[2 * MCo];
@@ -2431,6 +2464,10 @@ class Solver final : public lbfgsb_hip_ctx {
     };
     put(sy), put(ss), put(wt), put(wn), put(snd);
     (void)mm;
+    // (z and d left implicit by a lean subspace pass: written out for the export only -- the
+    //  state of the run does not change, both buffers are dead storage while d_impl stands)
+    if (d_impl && cx)
+      lbk::launch_dz_materialise<T>(q, n, (const T *)cx, t, d, z_in_x ? z : (T *)nullptr);
     for (T *src : {z, r, d, t, xp}) {
       HIPCHK(hipMemcpyAsync(ps, src, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
       ps += n;
@@ -2490,7 +2527,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     get(wa8m);
     z_valid = true;  // z as imported
-    spec.valid = false, pend.on = 0, tbrk_valid = false, scan.ready = false;
+    spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, tbrk_valid = false, scan.ready = false;
     spcand.valid = false;
     {
       std::vector<lbk::iw_t> h((size_t)n);
@@ -2556,20 +2593,24 @@ class Solver final : public lbfgsb_hip_ctx {
     std::memset(&cf, 0, sizeof cf);
     if (which == 0 || which == 2)
       lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
-                                cf, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5});
+                                cf, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5, 0});
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     else if (which == 3 || which == 4) {
       if (!cl || !cu || !cnbd) return fail(LBFGSB_E_STATE, "kernel_time: run an iteration first");
       const T *l = (const T *)cl, *u = (const T *)cu;
+      // (the variants the iteration launches; the lean subspace pass stores its trial point into
+      //  the z buffer here instead of the caller's x -- the same five store streams)
+      const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
       if (which == 3)  // with a pending pair: the variant every iteration after an update runs
-        lbk::launch_subsm_update<T>(q, n, 0.5, z, r, l, u, cnbd, iwhere, (const T *)x, (const T *)g,
-                                    W(), head, col, 1.0, cf, cf, d, t, (T *)nullptr, 1,
-                                    lbk::Pend{1, 0.5});
+        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r, l, u, cnbd, iwhere,
+                                    (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
+                                    lean ? (T *)nullptr : d, t, lean ? z : (T *)nullptr, 1,
+                                    lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t : d);
       else             // as the evaluation of a trial point: reduces only
-        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, d, 0.5, iwhere,
-                                   (T *)nullptr, W(), head, col, (head + col - 2) % m + 1, 0, 0,
-                                   two_pass ? 1 : 0);  // (the variant the iteration launches)
+        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, lean ? t : d,
+                                   lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
+                                   (head + col - 2) % m + 1, 0, 0, two_pass ? 1 : 0);
     } else
       return fail(LBFGSB_E_ARG, "unknown kernel");
     return 0;
