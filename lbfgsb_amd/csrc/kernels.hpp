@@ -152,7 +152,16 @@ template <typename T>
 void launch_pgcp_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, int64_t nb, int64_t nbp,
                         const T *x, const T *l, const T *u, const T *g, WStore<T> w, int head, int col,
                         double theta, const T *pr, const T *pd, Pend pe, double *tt, double *dd,
-                        double *a0, double *wb, double *uu);
+                        double *a0, double *wb, double *uu, double *gi, int64_t row0);
+void launch_pgcp_mergekeys(Queue &q, int nranks, int64_t nbp, int narr, const double *counts,
+                           const double *G, uint64_t *keys, uint32_t *vals);
+void launch_pgcp_permute(Queue &q, int64_t NB, int64_t NBp, int64_t nbp, int narr, const uint32_t *vals,
+                         const double *G, double *out, const int *map);
+size_t f2scan_temp_bytes(size_t count);
+void launch_pgcp_f2(Queue &q, void *d_temp, size_t temp_bytes, int64_t nb, double f2_0, double cl,
+                    const double *df2, double *maps, double *F2);
+template <typename T>
+void launch_gcp_rest_mass(Queue &q, int64_t n, const T *g, const T *tbrk, double tstar);
 void launch_pgcp_last(Queue &q, int64_t nb, int64_t nbp, int col2, const double *uu, double *uu_last);
 void launch_pgcp_dtp(Queue &q, int64_t nb, int64_t nbp, int col2, const double *tt, const double *pp,
                      double *qq);
@@ -165,7 +174,8 @@ void launch_pgcp_find(Queue &q, int64_t nb, double f1_0, double f2_0, const doub
                       const double *sf1, const double *sf2);  // res min-slot [0] = k* (or +inf)
 void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, double f1_0, double f2_0,
                       const double *tt, const double *sf1, const double *sf2, const double *pp,
-                      const double *uu_last, const double *sq, const uint32_t *idx, double *out);
+                      const double *uu_last, const double *sq, const uint32_t *idx, const double *gi,
+                      double *out);
 // tbrk as a vector from (x, l, u, nbd, g, iwhere-after-the-scan, BEFORE the walk fixes rows)
 template <typename T>
 void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,

@@ -29,7 +29,7 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     dev = torch.device("cuda", 0)
     row0, n_loc = lbfgsb_amd.block_partition(n, world, rank)
     sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=0,
-                                  parallel_gcp=(variant == "pgcp"))
+                                  parallel_gcp=(variant in ("pgcp", "pgcp2")))
     if mode == "gloo":
         lbfgsb_amd.attach_host_group(sol, rank, world)
     elif mode == "rccl1":
@@ -42,7 +42,10 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
         dist.broadcast_object_list(ids, 0)
         sol.init_rccl(ids[0], rank, world)
         assert "libfake_rccl" in open("/proc/self/maps").read()   # (not the real library)
-    if variant == "rosen":
+    two_scale = None
+    if variant == "pgcp2":
+        p, two_scale = two_scale_problem(po, n, m)
+    elif variant == "rosen":
         p = po.problem_rosenbrock(n, m, factr=0.0, pgtol=0.0)
     else:
         p = po.problem_quadratic(n, m, mixed_nbd=(variant == "1"))
@@ -56,7 +59,15 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     rows = []
     for _ in range(100000):
         t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
-        if t.startswith("FG"):
+        if t.startswith("FG") and two_scale is not None:
+            # host objective on this rank's rows, f summed over the ranks
+            xh = x.cpu().numpy()
+            gh = np.empty_like(xh)
+            ft = torch.tensor([two_scale(xh, gh, row0, row0 + n_loc)], dtype=torch.float64)
+            dist.all_reduce(ft)
+            sol.f[0] = float(ft[0])
+            g.copy_(torch.from_numpy(gh))
+        elif t.startswith("FG"):
             sol.objective(kind, x, g, deferred=True)   # global f: fetched by the next setulb call
         elif t.startswith("NEW_X"):
             rows.append([int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
@@ -75,6 +86,25 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     sol.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+def two_scale_problem(po, n, m):
+    """Separable quadratic with two curvature scales: iterations 2 and 6 cross ~ n/2 breakpoints
+    with pairs stored (the col > 0 case of the parallel GCP search)."""
+    rng = np.random.default_rng(7)
+    a = 1.0 + 99.0 * rng.random(n)
+    a[n // 2:] *= 1e-4
+    c = rng.choice([-1.0, 1.0], n) * 5.0 * (1.0 + rng.random(n))
+    eps = 1e-3
+
+    def fg(x, g, lo=0, hi=None):
+        hi = n if hi is None else hi
+        d = x - c[lo:hi]
+        g[:] = eps * a[lo:hi] * d
+        return float(0.5 * eps * np.sum(a[lo:hi] * d * d))
+    p = po.Problem("two_scale", n, m, np.zeros(n), -np.ones(n), np.ones(n), np.full(n, 2, np.int32),
+                   0.0, 0.0, fg, np.float64)
+    return p, fg
 
 
 def fuzz_problem(po, seed):

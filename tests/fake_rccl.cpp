@@ -19,7 +19,7 @@
 #include <vector>
 
 namespace {
-constexpr size_t SLOT = (size_t)8 << 20;  // bytes per rank
+constexpr size_t SLOT = (size_t)64 << 20;  // bytes per rank
 struct Shared {
   std::atomic<int> arrived;
   std::atomic<int> generation;

@@ -99,6 +99,38 @@ def test_sharded_parallel_gcp(oracle_built, tmp_path):
     assert res["stats"]["cauchy_fullsorts"] == 0
 
 
+@pytest.mark.parametrize("world,mode", [(3, "gloo"), (2, "fakerccl")])
+def test_sharded_parallel_gcp_with_pairs_stored(oracle_built, tmp_path, monkeypatch, world, mode):
+    """The parallel GCP search with pairs stored (col > 0) over several ranks: every rank sorts and
+    gathers the records of its own breakpoints, the records are all-gathered (host callback / the
+    library's ncclAllGather path), merged by (t, global index), and each rank runs the scans on
+    all of them.  Same two-scale problem as the single-rank test: iterations 2 and 6 cross
+    ~ 91 000 breakpoints with col = 1 and col = 5; nseg / nfree within 2 of the oracle's
+    sequential walk, f to 1e-9, two full sorts per rank."""
+    po = oracle_built
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mr_worker", os.path.join(HERE, "_mr_worker.py"))
+    wk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wk)
+    n, m, iters = 200_000, 5, 8
+    if mode == "fakerccl":
+        monkeypatch.setenv("LBFGSB_RCCL_LIBRARY", _fake_rccl())
+    res = launch(world, mode, n, m, iters, "pgcp2", str(tmp_path / "out.json"))
+    p, _ = wk.two_scale_problem(po, n, m)
+    rows = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows.append([int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                              int(s.isave[37]), float(s.f[0])])
+           if s.task_s.startswith("NEW_X") else None)
+    assert sum(1 for r in rows if r[2] > 50_000) >= 2
+    assert len(res["rows"]) == len(rows) == iters
+    for a, b in zip(res["rows"], rows):
+        assert a[:2] == b[:2], (a, b)
+        assert abs(a[2] - b[2]) <= 2 and abs(a[3] - b[3]) <= 2, (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
+    assert res["stats"]["cauchy_fullsorts"] >= 2
+
+
 @pytest.mark.parametrize("world,first,count", [(2, 100, 25), (3, 200, 25)])
 def test_sharded_random_problems_match_oracle(oracle_built, tmp_path, world, first, count):
     """Random separable problems (n < 2000, m < 13, all bound types) with the rows cut over 2 and

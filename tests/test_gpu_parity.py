@@ -802,6 +802,21 @@ def test_parallel_gcp_opt_in(env, kind):
     sol.close()
     assert rows_o[0][2] > n // 4            # iteration 1 really is the nseg ~ n case
     assert st1["cauchy_fullsorts"] == 0      # and it was done without sorting or walking
+    # index work of the closed form, stated independently: with no pair stored (theta = 1) the
+    # walk crosses exactly the breakpoints t_j <= 1/theta (src/lbfgsb.f90:1270-1330 for t_j, the
+    # exit test "dtm < dt" of :1416 for the <=): nseg of iteration 1 must EQUAL 1 + their number
+    g0 = np.empty(n)
+    p.fg(p.x0, g0)
+    neg = -g0
+    tl, tu = p.x0 - p.l, p.u - p.x0
+    has_l, has_u = (p.nbd == 1) | (p.nbd == 2), (p.nbd == 2) | (p.nbd == 3)
+    stuck = (has_l & (tl <= 0) & (neg <= 0)) | (has_u & ~(has_l & (tl <= 0)) & (tu <= 0) & (neg >= 0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tb = np.where(has_l & (neg < 0), tl / -neg, np.where(has_u & (neg > 0), tu / neg, np.inf))
+    tb[stuck | (neg == 0)] = np.inf
+    crossed = int(np.sum(tb <= 1.0))
+    assert crossed < n                       # (else the last crossing counts no segment, :1436)
+    assert rows_g[0][2] == 1 + crossed, (rows_g[0], crossed)
     assert len(rows_g) == len(rows_o) == iters
     for a, b in zip(rows_g, rows_o):
         assert a[:2] == b[:2], (a, b)
