@@ -57,14 +57,17 @@ enum {
                                 elementwise kernel instead of the ordered walk of
                                 src/lbfgsb.f90:1378-1497.  Equal to the reference in exact arithmetic;
                                 in floating point the reference's f1/f2 recurrence carries its own
-                                rounding noise, so tsum (and nseg by a few units) may differ.  Also
-                                ignores the clamp f2 >= epsmch*f2_org (:1483), which only acts once
-                                the remaining gradient mass is below epsmch of the total.
+                                rounding noise, so tsum (and nseg by a few units) may differ.  The
+                                clamp f2 >= epsmch*f2_org (:1483) acts only once the gradient mass
+                                still moving is below epsmch of the total: that is checked first and
+                                such calls take the exact walk.
                                 With pairs stored (col > 0) the flag replaces LONG walks (more than
-                                32768 breakpoints within reach; single rank) by a full sort + prefix
-                                scans of the walk's state on the device -- again the reference's
-                                result in exact arithmetic, without the clamp.  Short walks and
-                                multi-rank contexts always replay the walk exactly. */
+                                32768 breakpoints within reach) by a full sort + prefix scans of the
+                                walk's state on the device, the clamp included (a scan over the maps
+                                x -> max(B, x + A)) -- again the reference's result in exact
+                                arithmetic.  With several ranks the records of all breakpoints are
+                                all-gathered and every rank runs the same (bitwise-reproducible)
+                                scans.  Short walks always replay the walk exactly. */
   LBFGSB_F_EXACT_TIES = 16   /* Breakpoints with EQUAL t are handed to the walk in variable order; the
                                 reference pops them in the order of hpsolb's heap (src/lbfgsb.f90:2079,
                                 used at :1384-1403).  Sums over a whole group of equal breakpoints
