@@ -1925,116 +1925,157 @@ class Solver final : public lbfgsb_hip_ctx {
   int print_level = -1;
 
   // =================================================================== mainlb
-  int setulb_dev(void *x_, const void *l_, const void *u_, const int32_t *nbd, double *f,
-                 void *g_, double factr, double pgtol, char *task, int iprint, char *csave,
-                 int32_t *lsave, int32_t *isave_user, double *dsave) override {
-    T *x = (T *)x_;
-    T *g = (T *)g_;
-    const T *l = (const T *)l_;
-    const T *u = (const T *)u_;
-    int32_t *isave = isave_user + 21;  // mainlb's Isave(1:23) = user isave(22:44)
-    HIPCHK(hipSetDevice(device));
-    print_level = iprint;
-    quiet = rank != 0;
-    const int ipr = quiet ? -1 : iprint;
-    for (const void *p : {(const void *)x, (const void *)l, (const void *)u, (const void *)g})
-      if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
+  // The reference keeps mainlb's locals in lsave/isave/dsave between calls (:904-947); one call's
+  // view of them, plus the call's arguments, travels through the phases below in this struct.
+  struct Mainlb {
+    T *x, *g;
+    const T *l, *u;
+    const int32_t *nbd;
+    double *f;
+    double factr, pgtol;
+    char *task, *csave;
+    int32_t *lsave, *isave;  // isave = mainlb's Isave(1:23) = the user's isave(22:44)
+    double *dsave;
+    int ipr;
+    bool prjctd = false, cnstnd = false, boxed = false, updatd = false, wrk = false;
+    int nintol = 0, iback = 0, nskip = 0, head = 0, col = 0, iter = 0, itail = 0, iupdat = 0, nseg = 0,
+        nfgv = 0, info = 0, ifun = 0, iword = 0, nfree = 0, nact = 0, ileave = 0, nenter = 0;
+    double theta = 0, fold = 0, tol = 0, dnorm = 0, epsmch = 0, cpu1 = 0, cachyt = 0, sbtime = 0,
+           lnscht = 0, time1 = 0, gd = 0, stpmx = 0, sbgnrm = 0, stp = 0, gdold = 0, dtd = 0, xstep = 0.0;
+    // this call's route through the loop, and what the entry phase found
+    bool compute_pg = true, prelims = true, linesearch = true;
+    double spec_sbgnrm = 0.0;
+    int fo = 0;  // 1: the value of a deferred built-in objective rides in front of the first fetch
+  };
+  // what a phase tells the driver loop: go on with the next phase | start the loop trip again
+  // (memory refreshed, update skipped) | the call is over
+  enum Flow { NEXT, AGAIN, DONE };
+  static int again(Flow &fl) { return fl = AGAIN, 0; }
+  static int done(Flow &fl) { return fl = DONE, 0; }
+#define MAINLB_VIEW(L)                                                                             \
+  [[maybe_unused]] T *const x = L.x;                                                              \
+  [[maybe_unused]] T *const g = L.g;                                                              \
+  [[maybe_unused]] const T *const l = L.l;                                                        \
+  [[maybe_unused]] const T *const u = L.u;                                                        \
+  [[maybe_unused]] const int32_t *const nbd = L.nbd;                                              \
+  [[maybe_unused]] double *const f = L.f;                                                         \
+  [[maybe_unused]] char *const task = L.task;                                                     \
+  [[maybe_unused]] char *const csave = L.csave;                                                   \
+  [[maybe_unused]] int32_t *const lsave = L.lsave;                                                \
+  [[maybe_unused]] int32_t *const isave = L.isave;                                                \
+  [[maybe_unused]] double *const dsave = L.dsave;                                                 \
+  [[maybe_unused]] const double factr = L.factr, pgtol = L.pgtol;                                 \
+  [[maybe_unused]] const int ipr = L.ipr;                                                         \
+  [[maybe_unused]] bool &prjctd = L.prjctd, &cnstnd = L.cnstnd, &boxed = L.boxed,                 \
+                        &updatd = L.updatd, &wrk = L.wrk, &compute_pg = L.compute_pg,            \
+                        &prelims = L.prelims, &linesearch = L.linesearch;                         \
+  [[maybe_unused]] int &nintol = L.nintol, &iback = L.iback, &nskip = L.nskip, &head = L.head,    \
+                       &col = L.col, &iter = L.iter, &itail = L.itail, &iupdat = L.iupdat,        \
+                       &nseg = L.nseg, &nfgv = L.nfgv, &info = L.info, &ifun = L.ifun,            \
+                       &iword = L.iword, &nfree = L.nfree, &nact = L.nact, &ileave = L.ileave,    \
+                       &nenter = L.nenter, &fo = L.fo;                                            \
+  [[maybe_unused]] double &theta = L.theta, &fold = L.fold, &tol = L.tol, &dnorm = L.dnorm,       \
+                          &epsmch = L.epsmch, &cpu1 = L.cpu1, &cachyt = L.cachyt,                 \
+                          &sbtime = L.sbtime, &lnscht = L.lnscht, &time1 = L.time1, &gd = L.gd,   \
+                          &stpmx = L.stpmx, &sbgnrm = L.sbgnrm, &stp = L.stp, &gdold = L.gdold,   \
+                          &dtd = L.dtd, &xstep = L.xstep, &spec_sbgnrm = L.spec_sbgnrm
 
-    bool prjctd, cnstnd, boxed, updatd, wrk = false;
-    int nintol, iback, nskip, head, col, iter, itail, iupdat, nseg, nfgv, info, ifun, iword,
-        nfree, nact, ileave, nenter;
-    double theta, fold, tol, dnorm, epsmch, cpu1, cachyt, sbtime, lnscht, time1, gd, stpmx,
-        sbgnrm, stp, gdold, dtd, xstep = 0.0;
+  void save_locals(Mainlb &L) {  // :904-947
+    MAINLB_VIEW(L);
+    lsave[0] = prjctd, lsave[1] = cnstnd, lsave[2] = boxed, lsave[3] = updatd;
+    isave[0] = nintol, isave[2] = 0, isave[3] = iback, isave[4] = nskip, isave[5] = head;
+    isave[6] = col, isave[7] = itail, isave[8] = iter, isave[9] = iupdat, isave[11] = nseg;
+    isave[12] = nfgv, isave[13] = info, isave[14] = ifun, isave[15] = iword;
+    isave[16] = (int32_t)std::min<int64_t>(nfree_g, INT32_MAX);
+    isave[17] = (int32_t)std::min<int64_t>(nglob - nfree_g, INT32_MAX);
+    isave[18] = (int32_t)std::min<int64_t>(ileave_g, INT32_MAX);
+    isave[19] = (int32_t)std::min<int64_t>(nenter_g, INT32_MAX);
+    dsave[0] = theta, dsave[1] = fold, dsave[2] = tol, dsave[3] = dnorm, dsave[4] = epsmch;
+    dsave[5] = cpu1, dsave[6] = cachyt, dsave[7] = sbtime, dsave[8] = lnscht, dsave[9] = time1;
+    dsave[10] = gd, dsave[11] = stpmx, dsave[12] = sbgnrm, dsave[13] = stp, dsave[14] = gdold;
+    dsave[15] = dtd;
+  }
+  void finish(Mainlb &L) {  // :892-902
+    MAINLB_VIEW(L);
+    const double time = now_s() - time1;
+    if (!quiet) {
+      std::vector<double> xf;
+      if (ipr >= 100 && !lbh::str60_pre(task, "ERROR")) xf = host_vec(x);
+      rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip,
+                 (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm, time, nseg, word,
+                 iback, stp, xstep, err_k, cachyt, sbtime, lnscht, xf.empty() ? nullptr : xf.data());
+    }
+    save_locals(L);
+  }
+  void refresh(Mainlb &L) {
+    MAINLB_VIEW(L);
+    info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
+    pend.on = 0, pend.impl = 0;  // the memory is dropped, an uncommitted pair with it
+  }
 
-    auto save_locals = [&]() {  // :904-947
-      lsave[0] = prjctd, lsave[1] = cnstnd, lsave[2] = boxed, lsave[3] = updatd;
-      isave[0] = nintol, isave[2] = 0, isave[3] = iback, isave[4] = nskip, isave[5] = head;
-      isave[6] = col, isave[7] = itail, isave[8] = iter, isave[9] = iupdat, isave[11] = nseg;
-      isave[12] = nfgv, isave[13] = info, isave[14] = ifun, isave[15] = iword;
-      isave[16] = (int32_t)std::min<int64_t>(nfree_g, INT32_MAX);
-      isave[17] = (int32_t)std::min<int64_t>(nglob - nfree_g, INT32_MAX);
-      isave[18] = (int32_t)std::min<int64_t>(ileave_g, INT32_MAX);
-      isave[19] = (int32_t)std::min<int64_t>(nenter_g, INT32_MAX);
-      dsave[0] = theta, dsave[1] = fold, dsave[2] = tol, dsave[3] = dnorm, dsave[4] = epsmch;
-      dsave[5] = cpu1, dsave[6] = cachyt, dsave[7] = sbtime, dsave[8] = lnscht, dsave[9] = time1;
-      dsave[10] = gd, dsave[11] = stpmx, dsave[12] = sbgnrm, dsave[13] = stp, dsave[14] = gdold;
-      dsave[15] = dtd;
-    };
-    auto finish = [&]() {  // :892-902
-      const double time = now_s() - time1;
-      if (!quiet) {
-        std::vector<double> xf;
-        if (ipr >= 100 && !lbh::str60_pre(task, "ERROR")) xf = host_vec(x);
-        rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip,
-                   (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm, time, nseg, word,
-                   iback, stp, xstep, err_k, cachyt, sbtime, lnscht, xf.empty() ? nullptr : xf.data());
-      }
-      save_locals();
-    };
-    auto refresh = [&]() {
-      info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
-      pend.on = 0, pend.impl = 0;  // the memory is dropped, an uncommitted pair with it
-    };
-
-    if (lbh::str60_eq(task, "START")) {  // :430-507
-      spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
-      spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
-      epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
-                              : std::numeric_limits<double>::epsilon();
-      time1 = now_s();
-      col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false, iback = 0, itail = 0;
-      iword = 0, nact = 0, ileave = 0, nenter = 0, fold = 0, dnorm = 0, cpu1 = 0, gd = 0;
-      stpmx = 0, sbgnrm = 0, stp = 0, gdold = 0, dtd = 0, iter = 0, nfgv = 0, nseg = 0;
-      nintol = 0, nskip = 0, ifun = 0, cachyt = 0, sbtime = 0, lnscht = 0, info = 0;
-      nfree_g = nglob, nenter_g = 0, ileave_g = 0;
-      index_valid = false;
-      tol = factr * epsmch;
-      std::memcpy(word, "---", 4);
-      prjctd = cnstnd = false, boxed = true;
-      if (ipr >= 1 && !rep.itf) rep.itf = std::fopen(itfile_name.c_str(), "w");
-      // errclb :1601-1643
-      err_k = 0;
-      if (nglob <= 0) lbh::str60_set(task, "ERROR: N <= 0");
-      if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
-      if (factr < 0.0) lbh::str60_set(task, "ERROR: FACTR < 0");
-      lbk::launch_errclb<T>(q, n, row0, l, u, nbd);
-      CHK(fetch(0, 0, 2));
-      {
-        const int64_t k6 = (int64_t)h_res[0], k7 = (int64_t)h_res[1];
-        if (k6 > 0 || k7 > 0) {
-          if (k6 > k7) {
-            lbh::str60_set(task, "ERROR: INVALID NBD");
-            info = -6, err_k = k6;
-          } else {
-            lbh::str60_set(task, "ERROR: NO FEASIBLE SOLUTION");
-            info = -7, err_k = k7;
-          }
+  // task = 'START' (:430-507): errclb, active, the first f,g request
+  int phase_start(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
+    spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
+    epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
+                            : std::numeric_limits<double>::epsilon();
+    time1 = now_s();
+    col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false, iback = 0, itail = 0;
+    iword = 0, nact = 0, ileave = 0, nenter = 0, fold = 0, dnorm = 0, cpu1 = 0, gd = 0;
+    stpmx = 0, sbgnrm = 0, stp = 0, gdold = 0, dtd = 0, iter = 0, nfgv = 0, nseg = 0;
+    nintol = 0, nskip = 0, ifun = 0, cachyt = 0, sbtime = 0, lnscht = 0, info = 0;
+    nfree_g = nglob, nenter_g = 0, ileave_g = 0;
+    index_valid = false;
+    tol = factr * epsmch;
+    std::memcpy(word, "---", 4);
+    prjctd = cnstnd = false, boxed = true;
+    if (ipr >= 1 && !rep.itf) rep.itf = std::fopen(itfile_name.c_str(), "w");
+    // errclb :1601-1643
+    err_k = 0;
+    if (nglob <= 0) lbh::str60_set(task, "ERROR: N <= 0");
+    if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
+    if (factr < 0.0) lbh::str60_set(task, "ERROR: FACTR < 0");
+    lbk::launch_errclb<T>(q, n, row0, l, u, nbd);
+    CHK(fetch(0, 0, 2));
+    {
+      const int64_t k6 = (int64_t)h_res[0], k7 = (int64_t)h_res[1];
+      if (k6 > 0 || k7 > 0) {
+        if (k6 > k7) {
+          lbh::str60_set(task, "ERROR: INVALID NBD");
+          info = -6, err_k = k6;
+        } else {
+          lbh::str60_set(task, "ERROR: NO FEASIBLE SOLUTION");
+          info = -7, err_k = k7;
         }
       }
-      if (lbh::str60_pre(task, "ERROR")) {
-        if (!quiet)
-          rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip, nact, sbgnrm, 0.0,
-                     nseg, word, iback, stp, xstep, err_k, cachyt, sbtime, lnscht);
-        return 0;
-      }
-      if (!quiet) rep.prn1lb(nglob, m, ipr, epsmch);
-      if (ipr > 100) {  // :2404-2408
-        rep.vec_a4("L =", host_vec(l).data(), n);
-        rep.vec_a4("X0 =", host_vec(x).data(), n);
-        rep.vec_a4("U =", host_vec(u).data(), n);
-      }
-      lbk::launch_active<T>(q, n, x, l, u, nbd, iwhere, wasfree);  // :965-1040
-      CHK(fetch(4, 0, 0));
-      prjctd = h_res[0] > 0.0;
-      cnstnd = h_res[1] > 0.0;
-      boxed = h_res[2] == 0.0;
-      if (!quiet) rep.active_msgs(ipr, prjctd, cnstnd, (long long)h_res[3]);
-      if (prevfree) HIPCHK(hipMemsetAsync(prevfree, 1, (size_t)n, stream));
-      lbh::str60_set(task, "FG_START");
-      save_locals();
-      return 0;
     }
+    if (lbh::str60_pre(task, "ERROR")) {
+      if (!quiet)
+        rep.prn3lb(nglob, *f, task, ipr, info, iter, nfgv, nintol, nskip, nact, sbgnrm, 0.0,
+                   nseg, word, iback, stp, xstep, err_k, cachyt, sbtime, lnscht);
+      return done(flow);
+    }
+    if (!quiet) rep.prn1lb(nglob, m, ipr, epsmch);
+    if (ipr > 100) {  // :2404-2408
+      rep.vec_a4("L =", host_vec(l).data(), n);
+      rep.vec_a4("X0 =", host_vec(x).data(), n);
+      rep.vec_a4("U =", host_vec(u).data(), n);
+    }
+    lbk::launch_active<T>(q, n, x, l, u, nbd, iwhere, wasfree);  // :965-1040
+    CHK(fetch(4, 0, 0));
+    prjctd = h_res[0] > 0.0;
+    cnstnd = h_res[1] > 0.0;
+    boxed = h_res[2] == 0.0;
+    if (!quiet) rep.active_msgs(ipr, prjctd, cnstnd, (long long)h_res[3]);
+    if (prevfree) HIPCHK(hipMemsetAsync(prevfree, 1, (size_t)n, stream));
+    lbh::str60_set(task, "FG_START");
+    save_locals(L);
+    return done(flow);
+  }
 
+  void phase_restore(Mainlb &L) {
+    MAINLB_VIEW(L);
     // restore :511-550
     prjctd = lsave[0], cnstnd = lsave[1], boxed = lsave[2], updatd = lsave[3];
     nintol = isave[0], iback = isave[3], nskip = isave[4], head = isave[5], col = isave[6];
@@ -2046,12 +2087,14 @@ class Solver final : public lbfgsb_hip_ctx {
     cpu1 = dsave[5], cachyt = dsave[6], sbtime = dsave[7], lnscht = dsave[8], time1 = dsave[9];
     gd = dsave[10], stpmx = dsave[11], sbgnrm = dsave[12], stp = dsave[13], gdold = dsave[14];
     dtd = dsave[15];
+  }
 
-    bool compute_pg = true, prelims = true, linesearch = true;
-    double spec_sbgnrm = 0.0;
+  // where the call re-enters mainlb (:552-577); for the first trial point of a line search this
+  // is also its evaluation (update_scan_kernel run speculatively)
+  int phase_entry(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
     nrpre.valid = false;
     // value of a deferred built-in objective: one more sum in front of this call's first fetch
-    int fo = 0;
     if (f_pending) {
       f_pending = false;
       if (lbh::str60_pre(task, "FG")) {
@@ -2121,422 +2164,490 @@ class Solver final : public lbfgsb_hip_ctx {
           HIPCHK(hipStreamSynchronize(stream));
           *f = fold;
         }
-        finish();
+        finish(L);
       } else {
         lbh::str60_set(task, "FG_START");
-        save_locals();
+        save_locals(L);
       }
-      return 0;
+      return done(flow);
     }
+    return 0;
+  }
 
-    if (compute_pg) {  // :579-596
-      nfgv = 1;
-      q.res_off = fo;
-      lbk::launch_projgr<T>(q, n, x, l, u, nbd, g);
-      q.res_off = 0;
-      CHK(fetch(fo, 0, 1));
-      if (fo) *f = f_scale * h_res[0];
-      sbgnrm = h_res[fo];
-      if (!quiet) rep.iterate0(ipr, iter, nfgv, *f, sbgnrm);
-      if (sbgnrm <= pgtol) {
-        lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
-        finish();
-        return 0;
-      }
+  // first projected gradient (:579-596)
+  int phase_first_projgr(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    nfgv = 1;
+    q.res_off = fo;
+    lbk::launch_projgr<T>(q, n, x, l, u, nbd, g);
+    q.res_off = 0;
+    CHK(fetch(fo, 0, 1));
+    if (fo) *f = f_scale * h_res[0];
+    sbgnrm = h_res[fo];
+    if (!quiet) rep.iterate0(ipr, iter, nfgv, *f, sbgnrm);
+    if (sbgnrm <= pgtol) {
+      lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
+      finish(L);
+      return done(flow);
     }
+    return 0;
+  }
 
-    for (;;) {  // main_loop :599
-      if (prelims) {
-        if (ipr >= 99) std::fprintf(rep.out, "\n\nITERATION %5d\n", iter + 1);
-        iword = -1;
-        ls.ready = false;
-        ls.x_is_z = false;
-        ls_do_stpmx = cnstnd && iter != 0;
-        ls_unit_step = !(iter == 0 && !boxed);  // lnsrlb :2228-2232
-        xmut = x;
-        if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
-          gcp = Gcp{};
-          gcp.copy_x = true;
-          z_valid = false, z_in_x = false;
-          wrk = updatd;
-          nseg = 0;
-          pre_valid = false;
-        } else {
-          cpu1 = now_s();
-          CHK(cauchy(x, l, u, nbd, g, theta, col, head, sbgnrm, epsmch, nseg, info));
-          if (info != 0) {  // :620-635
-            if (ipr >= 1)
-              std::fprintf(rep.out,
-                           "\n Singular triangular system detected;\n   refresh the lbfgs "
-                           "memory and restart the iteration.\n");
-            refresh();
-            cachyt += now_s() - cpu1;
-            continue;
-          }
-          // freev :1980-2059 (counts; the lists only when mirroring Index)
-          if (prevfree)
-            HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
-          const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
-          lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
-          index_valid = true;
-          if (track)
-            HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-          // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
-          // sets of sums with ONE host sync (it is wasted only if no variable is free)
-          pre_valid = false;
-          int npre = 0;
-          // (two-pass iteration: no cmprlb pass if the closed form applies -- decided for good
-          //  once nfree is known, below)
-          const bool closed_cand = two_pass && closed_ok && cnstnd && col > 0 && col <= 10 &&
-                                   (!updatd || (nrpre.valid && nrpre.col == col));
-          if (col > 0 && !closed_cand) {
-            lbk::Coef cf;
-            bool plain;
-            if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
-              const bool newrow = updatd && col <= 20;  // updatd implies wrk
-              CHK(ensure_d(x));
-              q.res_off = 3;
-              clk_begin(0);
-              lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
-                                        newrow ? 1 : 0, r, d, pend);
-              clk_end(0);
-              q.res_off = 0;
-              npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
-            }
-          }
-          CHK(fetch(3 + npre, 0, 0));
-          if (npre) {
-            std::memcpy(pre_res, h_res + 3, sizeof(double) * npre);
-            pre_valid = true;
-          }
-          chg_local = track ? *h_count : 0;
-          cachyt += now_s() - cpu1;
-          nintol += nseg;
-          nfree_g = (int64_t)h_res[0];
-          if (iter > 0 && cnstnd) {
-            nenter_g = (int64_t)h_res[1];
-            ileave_g = nglob + 1 - (int64_t)h_res[2];
-          } else {
-            nenter_g = 0;
-            ileave_g = nglob + 1;
-          }
-          wrk = (ileave_g < nglob + 1) || (nenter_g > 0) || updatd;
-          if (ipr >= 99) {  // :2023-2057
-            if (iter > 0 && cnstnd) {
-              if (ipr >= 100 && chg_local > 0 && chg_local <= CHG_CAP) {
-                // this rank's rows that changed status: leaving rows in ascending order (the scan
-                // of Index(1:nfree)), entering rows in descending order (the active part of Index
-                // is filled from the back)
-                std::vector<uint32_t> ch(chg_local);
-                (void)hipMemcpyAsync(ch.data(), d_chg, chg_local * sizeof(uint32_t),
-                                     hipMemcpyDeviceToHost, stream);
-                (void)hipStreamSynchronize(stream);
-                std::vector<int64_t> lv, en;
-                for (uint32_t e : ch) ((e & 0x80000000u) ? lv : en).push_back((int64_t)(e & 0x7fffffffu));
-                std::sort(lv.begin(), lv.end());
-                std::sort(en.begin(), en.end(), std::greater<int64_t>());
-                for (int64_t k : lv)
-                  std::fprintf(rep.out, " Variable %11lld  leaves the set of free variables\n",
-                               (long long)(row0 + k + 1));
-                for (int64_t k : en)
-                  std::fprintf(rep.out, " Variable %11lld  enters the set of free variables\n",
-                               (long long)(row0 + k + 1));
-              }
-              std::fprintf(rep.out, " %11lld  variables leave; %11lld  variables enter\n",
-                           (long long)(nglob + 1 - ileave_g), (long long)nenter_g);
-            }
-            std::fprintf(rep.out, " %11lld  variables are free at GCP %11d\n", (long long)nfree_g,
-                         iter + 1);
-          }
-          if (index)
-            lbk::launch_freev_lists(q, n, iwhere, prevfree, (iter > 0 && cnstnd) ? 1 : 0, index,
-                                    indx2, scan_tmp);
-        }
-
-        if (nfree_g == 0 || col == 0) {
-          // skip the subspace minimization :648-651: the line search starts from z = xcp
-          CHK(commit_pending(g, col, head));
-          CHK(ensure_z(x, l, u, g));
-        } else {
-          cpu1 = now_s();
-          const bool incr = wrk && col <= 20;  // incremental WN1, fused into the cmprlb pass
-          if (wrk && !incr) CHK(formk(col, head, theta, info));
-          if (info != 0) {  // :666-682
-            if (ipr >= 1)
-              std::fprintf(rep.out,
-                           "\n Nonpositive definiteness in Cholesky factorization in formk;\n   "
-                           "refresh the lbfgs memory and restart the iteration.\n");
-            refresh();
-            sbtime += now_s() - cpu1;
-            continue;
-          }
-          // closed form: only while the free variables are not a small remainder (S'ZZ'S comes
-          // as S'S - S'AA'S)
-          const bool closed = two_pass && closed_ok && cnstnd && col <= 10 && !pre_valid &&
-                              (!updatd || (nrpre.valid && nrpre.col == col)) &&
-                              nfree_g * 16 >= nglob;
-          CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
-                       pre_valid ? pre_res : nullptr, closed));
-          pre_valid = false;
-          if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
-            if (ipr >= 1)
-              std::fprintf(rep.out,
-                           "\n Nonpositive definiteness in Cholesky factorization in formk;\n   "
-                           "refresh the lbfgs memory and restart the iteration.\n");
-            refresh();
-            sbtime += now_s() - cpu1;
-            continue;
-          }
-          if (info != 0) {  // :694-710
-            if (ipr >= 1)
-              std::fprintf(rep.out,
-                           "\n Singular triangular system detected;\n   refresh the lbfgs "
-                           "memory and restart the iteration.\n");
-            refresh();
-            sbtime += now_s() - cpu1;
-            continue;
-          }
-          sbtime += now_s() - cpu1;
-        }
-        cpu1 = now_s();
-      }
-
-      if (linesearch) {  // lnsrlb :2174-2275
-        const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
-        bool ls_abort = false;
-        if (!lbh::str60_pre(task, "FG_LN")) {
-          const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
-          double stpmx_cand;
-          if (ls.ready) {  // d, t, r, dtd, g'd came out of the subsm pass
-            dtd = ls.dtd, gd = ls.gd, stpmx_cand = ls.stpmx;
-          } else {
-            lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, t, r, do_stpmx);
-            CHK(fetch(2, 1, 0));
-            dtd = h_res[0], gd = h_res[1], stpmx_cand = h_res[2];
-          }
-          ls.ready = false;
-          dnorm = std::sqrt(dtd);
-          stpmx = big;
-          if (cnstnd) stpmx = iter == 0 ? 1.0 : std::min(big, stpmx_cand);
-          stp = (iter == 0 && !boxed) ? std::min(1.0 / dnorm, stpmx) : 1.0;
-          fold = *f;
-          ifun = 0;
-          iback = 0;
-          lbh::str60_set(csave, "START");
-        }
-        if (ifun == 0) {
-          gdold = gd;
-          if (gd >= 0.0) {  // :2247-2253
-            if (!quiet)  // the reference prints this regardless of iprint (:2250)
-              std::fprintf(rep.out, "  ascent direction in projection gd = %s\n",
-                           lbr::flist(gd).c_str());
-            info = -4;
-            ls_abort = true;
-          }
-        }
-        if (!ls_abort) {
-          lbh::dcsrch(*f, gd, stp, ftol, gtol, xtol, 0.0, stpmx, csave, isave + 21, dsave + 16);
-          xstep = stp * dnorm;
-          if (!lbh::str60_pre(csave, "CONV") && !lbh::str60_pre(csave, "WARN")) {
-            lbh::str60_set(task, "FG_LNSRCH");
-            ifun++;
-            nfgv++;
-            iback = ifun - 1;
-            if (!(ls.x_is_z && ifun == 1 && stp == 1.0)) {  // else x = z is already in place
-              CHK(ensure_d(x));  // (x still is the rejected first trial point z)
-              lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
-            }
-            ls.x_is_z = false;
-            spec.valid = false;  // the trial point was not accepted
-            spcand.valid = false;
-          } else {
-            lbh::str60_set(task, "NEW_X");
-          }
-        } else {
-          spec.valid = false;
-          spcand.valid = false;
-        }
-
-        if (info != 0 || iback >= 20) {  // :734-769
-          CHK(ensure_d(x));
-          HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-          HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-          *f = fold;
-          if (col == 0) {
-            if (info == 0) {
-              info = -9;
-              nfgv--, ifun--, iback--;
-            }
-            lbh::str60_set(task, "ABNORMAL_TERMINATION_IN_LNSRCH");
-            iter++;
-            HIPCHK(hipStreamSynchronize(stream));
-            finish();
-            return 0;
-          }
-          if (ipr >= 1)
-            std::fprintf(rep.out,
-                         "\n Bad direction in the line search;\n   refresh the lbfgs memory and "
-                         "restart the iteration.\n");
-          if (info == 0) nfgv--;
-          refresh();
-          lbh::str60_set(task, "RESTART_FROM_LNSRCH");
-          lnscht += now_s() - cpu1;
-          prelims = linesearch = true;
-          continue;
-        } else if (lbh::str60_pre(task, "FG_LN")) {
-          save_locals();
-          if (!(flags & LBFGSB_F_NO_RETURN_SYNC)) {
-            const double t0 = now_s();
-            HIPCHK(hipStreamSynchronize(stream));  // x is ready for the caller's f,g evaluation
-            t_wait += now_s() - t0;
-            nsync++;
-          }
-          return 0;
-        } else {
-          lnscht += now_s() - cpu1;
-          iter++;
-          sbgnrm = spec_sbgnrm;  // projgr (:781) was evaluated with g.d: x, g unchanged since
-          switch (iword) {       // prn2lb :2438-2443
-            case 0: std::memcpy(word, "con", 4); break;
-            case 1: std::memcpy(word, "bnd", 4); break;
-            case 5: std::memcpy(word, "TNT", 4); break;
-            default: std::memcpy(word, "---", 4);
-          }
-          if (!quiet)
-            rep.prn2lb(ipr, iter, nfgv, (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm,
-                       nseg, word, iback, stp, xstep, *f);
-          if (ipr > 100) {  // :2449-2452
-            rep.vec_a4("X =", host_vec(x).data(), n);
-            rep.vec_a4("G =", host_vec(g).data(), n);
-          }
-          save_locals();
-          return 0;
-        }
-      }
-
-      // ---- NEW_X re-entry: termination tests :794-810 ----
-      if (sbgnrm <= pgtol) {
-        lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
-        finish();
-        return 0;
-      }
-      double ddum = std::max(std::max(std::fabs(fold), std::fabs(*f)), 1.0);
-      if ((fold - *f) <= tol * ddum) {
-        lbh::str60_set(task, "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH");
-        if (iback >= 10) info = -5;
-        finish();
-        return 0;
-      }
-
-      // ---- :812-834 ----
-      double dr;
-      if (stp == 1.0) {
-        dr = gd - gdold;
-        ddum = -gdold;
-      } else {
-        dr = (gd - gdold) * stp;
-        ddum = -gdold * stp;
-      }
-      if (dr <= epsmch * ddum) {
-        nskip++;
-        updatd = false;
-        spec.valid = false;
-        spcand.valid = false;
-        if (ipr >= 1)
-          std::fprintf(rep.out, "  ys=%s  -gs=%s BFGS update SKIPPED\n", lbr::fE(dr, 10, 3).c_str(),
-                       lbr::fE(ddum, 10, 3).c_str());
-        prelims = linesearch = true;
-        continue;
-      }
-
-      // ---- matupd :2291-2346 (pointer bookkeeping on the host) ----
-      updatd = true;
-      iupdat++;
-      if (iupdat <= m) {
-        col = iupdat;
-        itail = (head + iupdat - 2) % m + 1;
-      } else {
-        itail = itail % m + 1;
-        head = head % m + 1;
-      }
-      const int MCo = lbk::maxc_for(col - 1);
-      double rr;
-      if (cnstnd) {
-        // the next loop trip starts with cauchy: do its n-loop in the same pass over W --
-        // unless that pass already ran as the evaluation of the accepted trial point
-        const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
-                           spec.head == head && spec.col == col && spec.itail == itail;
-        const int NX = lbk::update_scan_extra(col - 1, two_pass ? 1 : 0);
-        if (reuse) {
-          std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
-          if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
-            lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
-        } else {
-          clk_begin(1);
-          const double chi = spec_hi(cnstnd);
-          lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
-                                     (T *)nullptr, W(), head, col, itail, 0, 1, two_pass ? 1 : 0, chi,
-                                     sp_keys, sp_idx, SPEC_CAP, sp_count);
-          clk_end(1);
-          spcand.valid = false;
-          if (chi >= 0.0) CHK(spec_queue(x, l, u, g, head, col, stp));
-          CHK(fetch(4 * MCo + 9 + NX, 1, 1));
-          if (chi >= 0.0) CHK(spec_land(col, chi));
-        }
-        nrpre.valid = false;
-        if (NX) {  // formk's new row/column with the pre-walk free set (update_scan_kernel NEWROW)
-          const int X0 = 4 * MCo + 9, nold_ = col - 1;
-          for (int k = 0; k < 4; ++k) {
-            for (int j = 0; j < nold_; ++j) nrpre.t[k][j] = h_res[X0 + k * MCo + j];
-            nrpre.t[k][nold_] = h_res[X0 + 4 * MCo + k];
-          }
-          nrpre.valid = true, nrpre.col = col;
-        }
-        spec.valid = false;
-        tbrk_valid = false;
-        pend.on = 1, pend.stp = stp, pend.impl = d_impl ? 1 : 0;  // committed by this call's subspace pass
-        rr = h_res[2 * MCo];
-        const int nold = col - 1;
-        for (int j = 0; j < nold; ++j) {
-          scan.p[j] = h_res[2 * MCo + 1 + j];
-          scan.p[col + j] = h_res[3 * MCo + 2 + j];
-        }
-        scan.p[col - 1] = h_res[3 * MCo + 1];
-        scan.p[2 * col - 1] = h_res[4 * MCo + 2];
-        scan.f1 = h_res[4 * MCo + 3], scan.nbreak = h_res[4 * MCo + 4];
-        scan.nunb = h_res[4 * MCo + 5], scan.nunbnz = h_res[4 * MCo + 6];
-        scan.bkmin = h_res[4 * MCo + 9 + NX];
-        scan.ready = true;
-      } else {
-        CHK(ensure_d(x));
-        lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
-        CHK(fetch(2 * MCo + 1, 0, 0));
-        rr = h_res[2 * MCo];
-      }
-      theta = rr / dr;
-      lbh::Mat SY{sy.data(), m}, SS{ss.data(), m};
-      if (iupdat > m) {  // :2324-2330
-        for (int j = 0; j < col - 1; ++j) {
-          for (int i = 0; i <= j; ++i) SS(i, j) = SS(i + 1, j + 1);
-          for (int i = j; i < col - 1; ++i) SY(i, j) = SY(i + 1, j + 1);
-        }
-      }
-      for (int j = 0; j < col - 1; ++j) {
-        SY(col - 1, j) = h_res[j];
-        SS(j, col - 1) = h_res[MCo + j];
-      }
-      SS(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
-      SY(col - 1, col - 1) = dr;
-      info = lbh::formt(m, wt.data(), sy.data(), ss.data(), col, theta);  // :849
-      if (info != 0) {
+  // generalized Cauchy point + freev (:599-646)
+  int phase_cauchy_freev(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    if (ipr >= 99) std::fprintf(rep.out, "\n\nITERATION %5d\n", iter + 1);
+    iword = -1;
+    ls.ready = false;
+    ls.x_is_z = false;
+    ls_do_stpmx = cnstnd && iter != 0;
+    ls_unit_step = !(iter == 0 && !boxed);  // lnsrlb :2228-2232
+    xmut = x;
+    if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
+      gcp = Gcp{};
+      gcp.copy_x = true;
+      z_valid = false, z_in_x = false;
+      wrk = updatd;
+      nseg = 0;
+      pre_valid = false;
+    } else {
+      cpu1 = now_s();
+      CHK(cauchy(x, l, u, nbd, g, theta, col, head, sbgnrm, epsmch, nseg, info));
+      if (info != 0) {  // :620-635
         if (ipr >= 1)
           std::fprintf(rep.out,
-                       "\n Nonpositive definiteness in Cholesky factorization in formt;\n   "
-                       "refresh the lbfgs memory and restart the iteration.\n");
-        refresh();
+                       "\n Singular triangular system detected;\n   refresh the lbfgs "
+                       "memory and restart the iteration.\n");
+        refresh(L);
+        cachyt += now_s() - cpu1;
+        return again(flow);
       }
-      prelims = linesearch = true;
+      // freev :1980-2059 (counts; the lists only when mirroring Index)
+      if (prevfree)
+        HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
+      const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
+      lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
+      index_valid = true;
+      if (track)
+        HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
+      // sets of sums with ONE host sync (it is wasted only if no variable is free)
+      pre_valid = false;
+      int npre = 0;
+      // (two-pass iteration: no cmprlb pass if the closed form applies -- decided for good
+      //  once nfree is known, below)
+      const bool closed_cand = two_pass && closed_ok && cnstnd && col > 0 && col <= 10 &&
+                               (!updatd || (nrpre.valid && nrpre.col == col));
+      if (col > 0 && !closed_cand) {
+        lbk::Coef cf;
+        bool plain;
+        if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
+          const bool newrow = updatd && col <= 20;  // updatd implies wrk
+          CHK(ensure_d(x));
+          q.res_off = 3;
+          clk_begin(0);
+          lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
+                                    newrow ? 1 : 0, r, d, pend);
+          clk_end(0);
+          q.res_off = 0;
+          npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
+        }
+      }
+      CHK(fetch(3 + npre, 0, 0));
+      if (npre) {
+        std::memcpy(pre_res, h_res + 3, sizeof(double) * npre);
+        pre_valid = true;
+      }
+      chg_local = track ? *h_count : 0;
+      cachyt += now_s() - cpu1;
+      nintol += nseg;
+      nfree_g = (int64_t)h_res[0];
+      if (iter > 0 && cnstnd) {
+        nenter_g = (int64_t)h_res[1];
+        ileave_g = nglob + 1 - (int64_t)h_res[2];
+      } else {
+        nenter_g = 0;
+        ileave_g = nglob + 1;
+      }
+      wrk = (ileave_g < nglob + 1) || (nenter_g > 0) || updatd;
+      if (ipr >= 99) {  // :2023-2057
+        if (iter > 0 && cnstnd) {
+          if (ipr >= 100 && chg_local > 0 && chg_local <= CHG_CAP) {
+            // this rank's rows that changed status: leaving rows in ascending order (the scan
+            // of Index(1:nfree)), entering rows in descending order (the active part of Index
+            // is filled from the back)
+            std::vector<uint32_t> ch(chg_local);
+            (void)hipMemcpyAsync(ch.data(), d_chg, chg_local * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
+            std::vector<int64_t> lv, en;
+            for (uint32_t e : ch) ((e & 0x80000000u) ? lv : en).push_back((int64_t)(e & 0x7fffffffu));
+            std::sort(lv.begin(), lv.end());
+            std::sort(en.begin(), en.end(), std::greater<int64_t>());
+            for (int64_t k : lv)
+              std::fprintf(rep.out, " Variable %11lld  leaves the set of free variables\n",
+                           (long long)(row0 + k + 1));
+            for (int64_t k : en)
+              std::fprintf(rep.out, " Variable %11lld  enters the set of free variables\n",
+                           (long long)(row0 + k + 1));
+          }
+          std::fprintf(rep.out, " %11lld  variables leave; %11lld  variables enter\n",
+                       (long long)(nglob + 1 - ileave_g), (long long)nenter_g);
+        }
+        std::fprintf(rep.out, " %11lld  variables are free at GCP %11d\n", (long long)nfree_g,
+                     iter + 1);
+      }
+      if (index)
+        lbk::launch_freev_lists(q, n, iwhere, prevfree, (iter > 0 && cnstnd) ? 1 : 0, index,
+                                indx2, scan_tmp);
     }
+    return 0;
+  }
+
+  // formk + cmprlb + subsm (:648-712)
+  int phase_subspace(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    if (nfree_g == 0 || col == 0) {
+      // skip the subspace minimization :648-651: the line search starts from z = xcp
+      CHK(commit_pending(g, col, head));
+      CHK(ensure_z(x, l, u, g));
+    } else {
+      cpu1 = now_s();
+      const bool incr = wrk && col <= 20;  // incremental WN1, fused into the cmprlb pass
+      if (wrk && !incr) CHK(formk(col, head, theta, info));
+      if (info != 0) {  // :666-682
+        if (ipr >= 1)
+          std::fprintf(rep.out,
+                       "\n Nonpositive definiteness in Cholesky factorization in formk;\n   "
+                       "refresh the lbfgs memory and restart the iteration.\n");
+        refresh(L);
+        sbtime += now_s() - cpu1;
+        return again(flow);
+      }
+      // closed form: only while the free variables are not a small remainder (S'ZZ'S comes
+      // as S'S - S'AA'S)
+      const bool closed = two_pass && closed_ok && cnstnd && col <= 10 && !pre_valid &&
+                          (!updatd || (nrpre.valid && nrpre.col == col)) &&
+                          nfree_g * 16 >= nglob;
+      CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
+                   pre_valid ? pre_res : nullptr, closed));
+      pre_valid = false;
+      if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
+        if (ipr >= 1)
+          std::fprintf(rep.out,
+                       "\n Nonpositive definiteness in Cholesky factorization in formk;\n   "
+                       "refresh the lbfgs memory and restart the iteration.\n");
+        refresh(L);
+        sbtime += now_s() - cpu1;
+        return again(flow);
+      }
+      if (info != 0) {  // :694-710
+        if (ipr >= 1)
+          std::fprintf(rep.out,
+                       "\n Singular triangular system detected;\n   refresh the lbfgs "
+                       "memory and restart the iteration.\n");
+        refresh(L);
+        sbtime += now_s() - cpu1;
+        return again(flow);
+      }
+      sbtime += now_s() - cpu1;
+    }
+    cpu1 = now_s();
+    return 0;
+  }
+
+  // lnsrlb (:714-792): set-up, dcsrch, the next trial point or the accepted one
+  int phase_linesearch(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
+    bool ls_abort = false;
+    if (!lbh::str60_pre(task, "FG_LN")) {
+      const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
+      double stpmx_cand;
+      if (ls.ready) {  // d, t, r, dtd, g'd came out of the subsm pass
+        dtd = ls.dtd, gd = ls.gd, stpmx_cand = ls.stpmx;
+      } else {
+        lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, t, r, do_stpmx);
+        CHK(fetch(2, 1, 0));
+        dtd = h_res[0], gd = h_res[1], stpmx_cand = h_res[2];
+      }
+      ls.ready = false;
+      dnorm = std::sqrt(dtd);
+      stpmx = big;
+      if (cnstnd) stpmx = iter == 0 ? 1.0 : std::min(big, stpmx_cand);
+      stp = (iter == 0 && !boxed) ? std::min(1.0 / dnorm, stpmx) : 1.0;
+      fold = *f;
+      ifun = 0;
+      iback = 0;
+      lbh::str60_set(csave, "START");
+    }
+    if (ifun == 0) {
+      gdold = gd;
+      if (gd >= 0.0) {  // :2247-2253
+        if (!quiet)  // the reference prints this regardless of iprint (:2250)
+          std::fprintf(rep.out, "  ascent direction in projection gd = %s\n",
+                       lbr::flist(gd).c_str());
+        info = -4;
+        ls_abort = true;
+      }
+    }
+    if (!ls_abort) {
+      lbh::dcsrch(*f, gd, stp, ftol, gtol, xtol, 0.0, stpmx, csave, isave + 21, dsave + 16);
+      xstep = stp * dnorm;
+      if (!lbh::str60_pre(csave, "CONV") && !lbh::str60_pre(csave, "WARN")) {
+        lbh::str60_set(task, "FG_LNSRCH");
+        ifun++;
+        nfgv++;
+        iback = ifun - 1;
+        if (!(ls.x_is_z && ifun == 1 && stp == 1.0)) {  // else x = z is already in place
+          CHK(ensure_d(x));  // (x still is the rejected first trial point z)
+          lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
+        }
+        ls.x_is_z = false;
+        spec.valid = false;  // the trial point was not accepted
+        spcand.valid = false;
+      } else {
+        lbh::str60_set(task, "NEW_X");
+      }
+    } else {
+      spec.valid = false;
+      spcand.valid = false;
+    }
+
+    if (info != 0 || iback >= 20) {  // :734-769
+      CHK(ensure_d(x));
+      HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      *f = fold;
+      if (col == 0) {
+        if (info == 0) {
+          info = -9;
+          nfgv--, ifun--, iback--;
+        }
+        lbh::str60_set(task, "ABNORMAL_TERMINATION_IN_LNSRCH");
+        iter++;
+        HIPCHK(hipStreamSynchronize(stream));
+        finish(L);
+        return done(flow);
+      }
+      if (ipr >= 1)
+        std::fprintf(rep.out,
+                     "\n Bad direction in the line search;\n   refresh the lbfgs memory and "
+                     "restart the iteration.\n");
+      if (info == 0) nfgv--;
+      refresh(L);
+      lbh::str60_set(task, "RESTART_FROM_LNSRCH");
+      lnscht += now_s() - cpu1;
+      prelims = linesearch = true;
+      return again(flow);
+    } else if (lbh::str60_pre(task, "FG_LN")) {
+      save_locals(L);
+      if (!(flags & LBFGSB_F_NO_RETURN_SYNC)) {
+        const double t0 = now_s();
+        HIPCHK(hipStreamSynchronize(stream));  // x is ready for the caller's f,g evaluation
+        t_wait += now_s() - t0;
+        nsync++;
+      }
+      return done(flow);
+    } else {
+      lnscht += now_s() - cpu1;
+      iter++;
+      sbgnrm = spec_sbgnrm;  // projgr (:781) was evaluated with g.d: x, g unchanged since
+      switch (iword) {       // prn2lb :2438-2443
+        case 0: std::memcpy(word, "con", 4); break;
+        case 1: std::memcpy(word, "bnd", 4); break;
+        case 5: std::memcpy(word, "TNT", 4); break;
+        default: std::memcpy(word, "---", 4);
+      }
+      if (!quiet)
+        rep.prn2lb(ipr, iter, nfgv, (int)std::min<int64_t>(nglob - nfree_g, INT32_MAX), sbgnrm,
+                   nseg, word, iback, stp, xstep, *f);
+      if (ipr > 100) {  // :2449-2452
+        rep.vec_a4("X =", host_vec(x).data(), n);
+        rep.vec_a4("G =", host_vec(g).data(), n);
+      }
+      save_locals(L);
+      return done(flow);
+    }
+    return 0;
+  }
+
+  // NEW_X re-entry: termination tests (:794-810)
+  int phase_termination(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    // ---- NEW_X re-entry: termination tests :794-810 ----
+    if (sbgnrm <= pgtol) {
+      lbh::str60_set(task, "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL");
+      finish(L);
+      return done(flow);
+    }
+    double ddum = std::max(std::max(std::fabs(fold), std::fabs(*f)), 1.0);
+    if ((fold - *f) <= tol * ddum) {
+      lbh::str60_set(task, "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH");
+      if (iback >= 10) info = -5;
+      finish(L);
+      return done(flow);
+    }
+    return 0;
+  }
+
+  // y, s and matupd (:812-857)
+  int phase_update(Mainlb &L, Flow &flow) {
+    MAINLB_VIEW(L);
+    // ---- :812-834 ----
+    double dr, ddum;
+    if (stp == 1.0) {
+      dr = gd - gdold;
+      ddum = -gdold;
+    } else {
+      dr = (gd - gdold) * stp;
+      ddum = -gdold * stp;
+    }
+    if (dr <= epsmch * ddum) {
+      nskip++;
+      updatd = false;
+      spec.valid = false;
+      spcand.valid = false;
+      if (ipr >= 1)
+        std::fprintf(rep.out, "  ys=%s  -gs=%s BFGS update SKIPPED\n", lbr::fE(dr, 10, 3).c_str(),
+                     lbr::fE(ddum, 10, 3).c_str());
+      prelims = linesearch = true;
+      return again(flow);
+    }
+
+    // ---- matupd :2291-2346 (pointer bookkeeping on the host) ----
+    updatd = true;
+    iupdat++;
+    if (iupdat <= m) {
+      col = iupdat;
+      itail = (head + iupdat - 2) % m + 1;
+    } else {
+      itail = itail % m + 1;
+      head = head % m + 1;
+    }
+    const int MCo = lbk::maxc_for(col - 1);
+    double rr;
+    if (cnstnd) {
+      // the next loop trip starts with cauchy: do its n-loop in the same pass over W --
+      // unless that pass already ran as the evaluation of the accepted trial point
+      const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
+                         spec.head == head && spec.col == col && spec.itail == itail;
+      const int NX = lbk::update_scan_extra(col - 1, two_pass ? 1 : 0);
+      if (reuse) {
+        std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
+        if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
+          lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
+      } else {
+        clk_begin(1);
+        const double chi = spec_hi(cnstnd);
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+                                   (T *)nullptr, W(), head, col, itail, 0, 1, two_pass ? 1 : 0, chi,
+                                   sp_keys, sp_idx, SPEC_CAP, sp_count);
+        clk_end(1);
+        spcand.valid = false;
+        if (chi >= 0.0) CHK(spec_queue(x, l, u, g, head, col, stp));
+        CHK(fetch(4 * MCo + 9 + NX, 1, 1));
+        if (chi >= 0.0) CHK(spec_land(col, chi));
+      }
+      nrpre.valid = false;
+      if (NX) {  // formk's new row/column with the pre-walk free set (update_scan_kernel NEWROW)
+        const int X0 = 4 * MCo + 9, nold_ = col - 1;
+        for (int k = 0; k < 4; ++k) {
+          for (int j = 0; j < nold_; ++j) nrpre.t[k][j] = h_res[X0 + k * MCo + j];
+          nrpre.t[k][nold_] = h_res[X0 + 4 * MCo + k];
+        }
+        nrpre.valid = true, nrpre.col = col;
+      }
+      spec.valid = false;
+      tbrk_valid = false;
+      pend.on = 1, pend.stp = stp, pend.impl = d_impl ? 1 : 0;  // committed by this call's subspace pass
+      rr = h_res[2 * MCo];
+      const int nold = col - 1;
+      for (int j = 0; j < nold; ++j) {
+        scan.p[j] = h_res[2 * MCo + 1 + j];
+        scan.p[col + j] = h_res[3 * MCo + 2 + j];
+      }
+      scan.p[col - 1] = h_res[3 * MCo + 1];
+      scan.p[2 * col - 1] = h_res[4 * MCo + 2];
+      scan.f1 = h_res[4 * MCo + 3], scan.nbreak = h_res[4 * MCo + 4];
+      scan.nunb = h_res[4 * MCo + 5], scan.nunbnz = h_res[4 * MCo + 6];
+      scan.bkmin = h_res[4 * MCo + 9 + NX];
+      scan.ready = true;
+    } else {
+      CHK(ensure_d(x));
+      lbk::launch_update_pairs<T>(q, n, g, r, d, stp, W(), head, col, itail);
+      CHK(fetch(2 * MCo + 1, 0, 0));
+      rr = h_res[2 * MCo];
+    }
+    theta = rr / dr;
+    lbh::Mat SY{sy.data(), m}, SS{ss.data(), m};
+    if (iupdat > m) {  // :2324-2330
+      for (int j = 0; j < col - 1; ++j) {
+        for (int i = 0; i <= j; ++i) SS(i, j) = SS(i + 1, j + 1);
+        for (int i = j; i < col - 1; ++i) SY(i, j) = SY(i + 1, j + 1);
+      }
+    }
+    for (int j = 0; j < col - 1; ++j) {
+      SY(col - 1, j) = h_res[j];
+      SS(j, col - 1) = h_res[MCo + j];
+    }
+    SS(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
+    SY(col - 1, col - 1) = dr;
+    info = lbh::formt(m, wt.data(), sy.data(), ss.data(), col, theta);  // :849
+    if (info != 0) {
+      if (ipr >= 1)
+        std::fprintf(rep.out,
+                     "\n Nonpositive definiteness in Cholesky factorization in formt;\n   "
+                     "refresh the lbfgs memory and restart the iteration.\n");
+      refresh(L);
+    }
+    prelims = linesearch = true;
+    return 0;
+  }
+#undef MAINLB_VIEW
+
+  int setulb_dev(void *x_, const void *l_, const void *u_, const int32_t *nbd, double *f,
+                 void *g_, double factr, double pgtol, char *task, int iprint, char *csave,
+                 int32_t *lsave, int32_t *isave_user, double *dsave) override {
+    HIPCHK(hipSetDevice(device));
+    print_level = iprint;
+    quiet = rank != 0;
+    Mainlb L;
+    L.x = (T *)x_, L.g = (T *)g_, L.l = (const T *)l_, L.u = (const T *)u_, L.nbd = nbd, L.f = f;
+    L.factr = factr, L.pgtol = pgtol, L.task = task, L.csave = csave, L.lsave = lsave;
+    L.isave = isave_user + 21, L.dsave = dsave, L.ipr = quiet ? -1 : iprint;
+    for (const void *p : {(const void *)L.x, (const void *)L.l, (const void *)L.u, (const void *)L.g})
+      if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
+    Flow flow = NEXT;
+#define PHASE(call)               \
+  {                               \
+    flow = NEXT;                  \
+    CHK(call);                    \
+    if (flow == DONE) return 0;   \
+  }
+    if (lbh::str60_eq(task, "START")) {
+      PHASE(phase_start(L, flow));
+      return 0;
+    }
+    phase_restore(L);
+    PHASE(phase_entry(L, flow));
+    if (L.compute_pg) PHASE(phase_first_projgr(L, flow));
+    for (;;) {  // main_loop :599
+      if (L.prelims) {
+        PHASE(phase_cauchy_freev(L, flow));
+        if (flow == AGAIN) continue;
+        PHASE(phase_subspace(L, flow));
+        if (flow == AGAIN) continue;
+      }
+      if (L.linesearch) {
+        PHASE(phase_linesearch(L, flow));
+        if (flow == AGAIN) continue;
+      }
+      PHASE(phase_termination(L, flow));
+      PHASE(phase_update(L, flow));
+      // (AGAIN and NEXT alike: the next loop trip)
+    }
+#undef PHASE
   }
 
   int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
