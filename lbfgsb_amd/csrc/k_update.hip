@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   for_rows_raw<UpdScanTrip<T, MC, V, NT>, UpdScanTrip<T, MC, 1, NT>, V, PIPE, 0>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
-    double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W], a[MC][W], b[MC][W];
+    double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W];
     int nb[W], iw[W];
     raw_get<W>(tr.rx, (const T *)nullptr, xv);
     raw_get<W>(tr.rl, (const T *)nullptr, lv);
@@ -152,7 +152,6 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     raw_get<W>(tr.rd, (const T *)nullptr, dv);
     raw_geti<W>(tr.rnb, (const int32_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
-    get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     bool iw_changed = false;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -208,18 +207,10 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
       acc[3 * MC + 1] += rv[k] * ng[k];  // new Wy column . d
       acc[4 * MC + 2] += dv[k] * ng[k];  // new Ws column . d
     }
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        acc[j] += dv[k] * a[j][k];               // Sy(col,j) (:2335)
-        acc[MC + j] += b[j][k] * dv[k];          // Ss(j,col) (:2336)
-        acc[2 * MC + 1 + j] += a[j][k] * ng[k];  // p_j        (:1301)
-        acc[3 * MC + 2 + j] += b[j][k] * ng[k];  // p_{col+j}  (:1302)
-      }
-    }
+    // (columns are widened one pair at a time, where they are used: the fp32 instantiations with
+    //  many accumulators cannot keep all 2 MC operands of a trip as doubles)
+    double yf[W], sa[W];
     if constexpr (NEWROW) {
-      double yf[W], sa[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) {
         const double yst = (double)(T)rv[k], sst = (double)(T)dv[k];  // as stored in W
@@ -231,14 +222,26 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         acc[X + 4 * MC + 2] = __builtin_fma(sa[k], yst, acc[X + 4 * MC + 2]);
         acc[X + 4 * MC + 3] = __builtin_fma(fr ? sst : 0.0, yst, acc[X + 4 * MC + 3]);
       }
+    }
 #pragma unroll
-      for (int j = 0; j < MC; ++j) {
+    for (int j = 0; j < MC; ++j) {
+      double aj[W], bj[W];
+      raw_get_col<W, false>(tr.ra[j], (const T *)nullptr, aj);
+      raw_get_col<W, false>(tr.rb[j], (const T *)nullptr, bj);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[j] += dv[k] * aj[k];               // Sy(col,j) (:2335)
+        acc[MC + j] += bj[k] * dv[k];          // Ss(j,col) (:2336)
+        acc[2 * MC + 1 + j] += aj[k] * ng[k];  // p_j        (:1301)
+        acc[3 * MC + 2 + j] += bj[k] * ng[k];  // p_{col+j}  (:1302)
+      }
+      if constexpr (NEWROW) {
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-          acc[X + j] = __builtin_fma(yf[k], a[j][k], acc[X + j]);
-          acc[X + MC + j] = __builtin_fma(sa[k], b[j][k], acc[X + MC + j]);
-          acc[X + 2 * MC + j] = __builtin_fma(sa[k], a[j][k], acc[X + 2 * MC + j]);
-          acc[X + 3 * MC + j] = __builtin_fma(b[j][k], yf[k], acc[X + 3 * MC + j]);
+          acc[X + j] = __builtin_fma(yf[k], aj[k], acc[X + j]);
+          acc[X + MC + j] = __builtin_fma(sa[k], bj[k], acc[X + MC + j]);
+          acc[X + 2 * MC + j] = __builtin_fma(sa[k], aj[k], acc[X + 2 * MC + j]);
+          acc[X + 3 * MC + j] = __builtin_fma(bj[k], yf[k], acc[X + 3 * MC + j]);
         }
       }
     }
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     // Breakpoints up to cand_hi -- where the NEXT walk is expected to end, the caller's guess from
     // the previous one -- are handed over with this pass (appended, unordered, like the window
     // kernels do): the usual short walk then needs no window pass and no host sync of its own.
-    if (cand_hi >= 0.0) {
+    // (not in the instantiation that has no register to spare for it: NEWROW at MC = 20)
+    if (!(NEWROW && MC > 10) && cand_hi >= 0.0) {
       unsigned bits = 0;
 #pragma unroll
       for (int k = 0; k < W; ++k) {
@@ -297,8 +301,8 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   const int nold = col - 1;
 #define LB_UPDSCAN(NEWROWV)                                                                          \
   DISPATCH_MAXC_NT(nold, q.nt, DISPATCH_PIPE(MC, {                                                   \
-                     constexpr bool NRV = NEWROWV && MC <= 10;                                       \
-                     constexpr bool PPV = (PIPEV || NRV) && MC <= 20;                                \
+                     constexpr bool NRV = NEWROWV && MC <= 20;                                       \
+                     constexpr bool PPV = MC <= 10 ? (PIPEV || NRV) : (PIPEV && !NRV && MC <= 20);   \
                      hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PPV, NRV>), dim3(gr),        \
                                         dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d, dimpl,   \
                                         stp,                                                         \

@@ -321,7 +321,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out);
 
 inline int update_scan_extra(int nold, int newrow) {
   const int mc = maxc_for(nold);
-  return newrow && mc <= 10 ? 4 * mc + 4 : 0;
+  return newrow && mc <= 20 ? 4 * mc + 4 : 0;
 }
 
 // finalize: d_part -> d_res (nsum sums, then nmin mins, then nmax maxes)

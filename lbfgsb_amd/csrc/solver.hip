@@ -1496,7 +1496,7 @@ class Solver final : public lbfgsb_hip_ctx {
           fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
         else
           fix_overflow = true;
-        if (col > 0 && col <= 10) {
+        if (col > 0 && col <= two_pass_maxcol) {
           // this row leaves the free set: its share of formk's new row/column moves from the
           // free sums to the active ones (the update pass summed with the pre-walk split)
           const double yk = rec[4 + col - 1], sk = rec[4 + 2 * col - 1];
@@ -1912,6 +1912,15 @@ class Solver final : public lbfgsb_hip_ctx {
     const char *e = std::getenv("LBFGSB_TWO_PASS");
     return !(e && e[0] == '0');
   }();
+  // (col <= 20: beyond that the update pass has no registers for the 4 col + 4 extra sums;
+  //  LBFGSB_TWO_PASS_MAXCOL lowers the limit, for measurements)
+  const int two_pass_maxcol = [] {
+    const char *e = std::getenv("LBFGSB_TWO_PASS_MAXCOL");
+    const int v = e ? std::atoi(e) : 20;
+    return v < 0 ? 0 : (v > 20 ? 20 : v);
+  }();
+  // update_scan_kernel's NEWROW flag for the pass that forms pair number `colnew`
+  int nr_flag(int colnew) const { return two_pass && colnew <= two_pass_maxcol ? 1 : 0; }
   struct NewRow {
     bool valid = false;
     int col = 0;
@@ -2122,12 +2131,12 @@ class Solver final : public lbfgsb_hip_ctx {
           c2 = col, it2 = itail % m + 1, h2 = head % m + 1;
         }
         const int MCo = lbk::maxc_for(c2 - 1);
-        const int NX = lbk::update_scan_extra(c2 - 1, two_pass ? 1 : 0);
+        const int NX = lbk::update_scan_extra(c2 - 1, nr_flag(c2));
         clk_begin(1);
         q.res_off = fo;
         const double chi = spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
-                                   (T *)nullptr, W(), h2, c2, it2, 0, store_iw, two_pass ? 1 : 0, chi,
+                                   (T *)nullptr, W(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count);
         q.res_off = 0;
         clk_end(1);
@@ -2236,7 +2245,7 @@ class Solver final : public lbfgsb_hip_ctx {
       int npre = 0;
       // (two-pass iteration: no cmprlb pass if the closed form applies -- decided for good
       //  once nfree is known, below)
-      const bool closed_cand = two_pass && closed_ok && cnstnd && col > 0 && col <= 10 &&
+      const bool closed_cand = two_pass && closed_ok && cnstnd && col > 0 && col <= two_pass_maxcol &&
                                (!updatd || (nrpre.valid && nrpre.col == col));
       if (col > 0 && !closed_cand) {
         lbk::Coef cf;
@@ -2326,7 +2335,7 @@ class Solver final : public lbfgsb_hip_ctx {
       }
       // closed form: only while the free variables are not a small remainder (S'ZZ'S comes
       // as S'S - S'AA'S)
-      const bool closed = two_pass && closed_ok && cnstnd && col <= 10 && !pre_valid &&
+      const bool closed = two_pass && closed_ok && cnstnd && col <= two_pass_maxcol && !pre_valid &&
                           (!updatd || (nrpre.valid && nrpre.col == col)) &&
                           nfree_g * 16 >= nglob;
       CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
@@ -2532,7 +2541,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // unless that pass already ran as the evaluation of the accepted trial point
       const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
                          spec.head == head && spec.col == col && spec.itail == itail;
-      const int NX = lbk::update_scan_extra(col - 1, two_pass ? 1 : 0);
+      const int NX = lbk::update_scan_extra(col - 1, nr_flag(col));
       if (reuse) {
         std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
         if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
@@ -2541,7 +2550,7 @@ class Solver final : public lbfgsb_hip_ctx {
         clk_begin(1);
         const double chi = spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
-                                   (T *)nullptr, W(), head, col, itail, 0, 1, two_pass ? 1 : 0, chi,
+                                   (T *)nullptr, W(), head, col, itail, 0, 1, nr_flag(col), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count);
         clk_end(1);
         spcand.valid = false;
@@ -2814,7 +2823,7 @@ class Solver final : public lbfgsb_hip_ctx {
       else             // as the evaluation of a trial point: reduces only
         lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, lean ? t : d,
                                    lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
-                                   (head + col - 2) % m + 1, 0, 0, two_pass ? 1 : 0);
+                                   (head + col - 2) % m + 1, 0, 0, nr_flag(col));
     } else
       return fail(LBFGSB_E_ARG, "unknown kernel");
     return 0;
