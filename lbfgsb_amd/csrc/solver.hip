@@ -20,180 +20,7 @@
 // formk_gram, update_pairs, lnsrlb_begin/step, pair_commit, xcp_fill, subsm_dir/backtrack.
 //
 // There is no CPU fallback anywhere in this file.
-#include <dlfcn.h>
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-
-#include <algorithm>
-#include <functional>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <mutex>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "../../include/lbfgsb_hip.h"
-#include "host_dense.hpp"
-#include "kernels.hpp"
-#include "report.hpp"
-
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) {
-  g_err = msg;
-  return code;
-}
-
-#define HIPCHK(expr)                                                                    \
-  do {                                                                                  \
-    hipError_t e_ = (expr);                                                             \
-    if (e_ != hipSuccess)                                                               \
-      return fail(LBFGSB_E_NOGPU, std::string(#expr) + ": " + hipGetErrorString(e_));   \
-  } while (0)
-#define CHK(expr)          \
-  do {                     \
-    int rc_ = (expr);      \
-    if (rc_ != 0) return rc_; \
-  } while (0)
-
-double now_s() {
-  using namespace std::chrono;
-  return duration<double>(steady_clock::now().time_since_epoch()).count();
-}
-
-// ---------------------------------------------------------------- RCCL (dlopen)
-struct Rccl {
-  void *h = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
-                            hipStream_t) = nullptr;
-  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
-                            hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  bool ok = false;  // every symbol resolved
-  bool load() {
-    if (ok) return true;
-    if (h) {  // an earlier attempt found a library without the symbols: try again from scratch
-      dlclose(h);
-      h = nullptr;
-    }
-    // LBFGSB_RCCL_LIBRARY: a specific build of the library (tests point it at a small
-    // shared-memory stand-in so that the communicator code path runs with several ranks on one GPU)
-    const char *names[] = {std::getenv("LBFGSB_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
-                           "/opt/rocm/lib/librccl.so.1"};
-    for (const char *nm : names) {
-      if (!nm || !*nm) continue;
-      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-      if (h) break;
-    }
-    if (!h) return false;
-#define SYM(f, name) f = reinterpret_cast<decltype(f)>(dlsym(h, name))
-    SYM(GetUniqueId, "ncclGetUniqueId");
-    SYM(CommInitRank, "ncclCommInitRank");
-    SYM(CommDestroy, "ncclCommDestroy");
-    SYM(AllReduce, "ncclAllReduce");
-    SYM(AllGather, "ncclAllGather");
-    SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd");
-#undef SYM
-    ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather && GroupStart && GroupEnd;
-    if (!ok) {
-      dlclose(h);
-      h = nullptr;
-    }
-    return ok;
-  }
-};
-Rccl g_rccl;
-
-struct Rec {  // one breakpoint as the host walk needs it
-  double t;
-  int64_t gidx;
-};
-
-}  // namespace
-
-// ===================================================================== context
-struct lbfgsb_hip_ctx {
-  virtual ~lbfgsb_hip_ctx() {}
-  virtual int setulb_dev(void *x, const void *l, const void *u, const int32_t *nbd, double *f,
-                         void *g, double factr, double pgtol, char *task, int iprint, char *csave,
-                         int32_t *lsave, int32_t *isave, double *dsave) = 0;
-  virtual int export_state(void *wa, int32_t *iwa) = 0;
-  virtual int import_state(const void *wa, const int32_t *iwa, const int32_t *isave) = 0;
-  virtual int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd,
-                       const void *g, double *out) = 0;
-  virtual int k_wtv(const void *v, int col, int head, double *out, bool launch_only) = 0;
-  virtual int k_set_w(const void *hws, const void *hwy) = 0;
-  virtual int k_set_iwhere(const int32_t *h_iw) = 0;
-  virtual int k_formk_gram(int col, int head, double *out) = 0;
-  virtual int k_launch(int which, const void *x, const void *g, int col, int head) = 0;
-  virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
-  virtual int sync() = 0;
-
-  // host-entry staging (setulb_host)
-  void *hx = nullptr, *hg = nullptr, *hl = nullptr, *hu = nullptr;
-  int32_t *hnbd = nullptr;
-  std::string itfile_name = "iterate.dat";
-  int64_t n = 0, nglob = 0, row0 = 0;
-  int m = 0, flags = 0, device = 0;
-  int rank = 0, nranks = 1;
-  int64_t nsync = 0, nfullsort = 0;
-  int64_t ntiesplit = 0;  // walks that ended inside a group of equal breakpoints
-  int64_t ngcp_clamped = 0;  // closed-form GCPs declined because the f2 clamp would have acted
-  int64_t nspecwin = 0;   // walks served by the candidates the update pass handed over
-  double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
-  // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
-  // the next setulb_dev call fetches it together with the sums of its own first pass
-  bool f_pending = false;
-  double f_scale = 1.0;
-  // in-run clocks of the three passes over W (hipEvents on the solver's stream around each
-  // launch, read at the next host sync): 0 cmprlb_wtv, 1 update_scan, 2 subsm_update
-  bool clock_on = false;
-  hipEvent_t clk_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  bool clk_pending[3] = {false, false, false};
-  double clk_ms[3] = {0.0, 0.0, 0.0};
-  int64_t clk_n[3] = {0, 0, 0};
-  hipStream_t clk_stream = nullptr;
-  hipEvent_t order_ev = nullptr;  // lbfgsb_hip_wait_stream
-  void clk_begin(int k) {
-    if (!clock_on) return;
-    if (!clk_ev[k][0]) {
-      (void)hipEventCreate(&clk_ev[k][0]);
-      (void)hipEventCreate(&clk_ev[k][1]);
-    }
-    clk_collect();  // (a pass launched twice between two syncs: keep the first reading)
-    (void)hipEventRecord(clk_ev[k][0], clk_stream);
-  }
-  void clk_end(int k) {
-    if (!clock_on) return;
-    (void)hipEventRecord(clk_ev[k][1], clk_stream);
-    clk_pending[k] = true;
-  }
-  void clk_collect() {  // call after a stream sync (or when the events are known complete)
-    for (int k = 0; k < 3; ++k) {
-      if (!clk_pending[k]) continue;
-      if (hipEventQuery(clk_ev[k][1]) != hipSuccess) continue;
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, clk_ev[k][0], clk_ev[k][1]) == hipSuccess) {
-        clk_ms[k] += ms;
-        clk_n[k]++;
-      }
-      clk_pending[k] = false;
-    }
-  }
-  lbk::Queue q{};
-};
+#include "solver_base.hpp"
 
 namespace {
 
@@ -2883,435 +2710,36 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
-};
-
-template <typename T>
-Solver<T> *as(lbfgsb_hip_ctx *c) {
-  return static_cast<Solver<T> *>(c);
-}
-
-}  // namespace
-
-// ====================================================================== C ABI
-extern "C" {
-
-const char *lbfgsb_hip_last_error(void) { return g_err.c_str(); }
-
-int lbfgsb_hip_create(int64_t n_local, int64_t n_global, int64_t row0, int m, int flags,
-                      int device, void *stream, lbfgsb_hip_ctx **out) {
-  if (!out) return fail(LBFGSB_E_ARG, "out == NULL");
-  *out = nullptr;
-  if (n_local <= 0 || n_global < n_local || row0 < 0 || row0 + n_local > n_global)
-    return fail(LBFGSB_E_ARG, "bad n_local / n_global / row0");
-  if (m <= 0 || m > LBFGSB_MAX_M) return fail(LBFGSB_E_ARG, "m must be in 1..LBFGSB_MAX_M");
-  if (n_local > 0xFFFFFFF0ll) return fail(LBFGSB_E_ARG, "n_local must fit 32 bits");
-  int rc;
-  if (flags & LBFGSB_F_REAL32) {
-    auto *s = new Solver<float>();
-    rc = s->init(n_local, n_global, row0, m, flags, device, stream);
-    if (rc) {
-      delete s;
-      return rc;
-    }
-    *out = s;
-  } else {
-    auto *s = new Solver<double>();
-    rc = s->init(n_local, n_global, row0, m, flags, device, stream);
-    if (rc) {
-      delete s;
-      return rc;
-    }
-    *out = s;
-  }
-  return LBFGSB_OK;
-}
-
-void lbfgsb_hip_destroy(lbfgsb_hip_ctx *ctx) { delete ctx; }
-
-int lbfgsb_hip_rccl_unique_id(void *id128) {
-  if (!g_rccl.load()) return fail(LBFGSB_E_COMM, "cannot load librccl");
-  ncclUniqueId id;
-  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclGetUniqueId");
-  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-  std::memcpy(id128, &id, 128);
-  return 0;
-}
-
-int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, int nranks) {
-  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return fail(LBFGSB_E_ARG, "bad rank");
-  if (!g_rccl.load()) return fail(LBFGSB_E_COMM, "cannot load librccl");
-  HIPCHK(hipSetDevice(ctx->device));
-  ncclUniqueId id;
-  std::memcpy(&id, id128, 128);
-  ncclComm_t comm = nullptr;
-  if (g_rccl.CommInitRank(&comm, nranks, id, rank) != ncclSuccess)
-    return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
-  auto attach = [&](auto *s) -> int {
-    if (s->comm) g_rccl.CommDestroy(s->comm);  // (a second init replaces the communicator)
-    s->comm = nullptr;
-    const int rc = s->set_ranks(rank, nranks);
-    if (rc) {
-      g_rccl.CommDestroy(comm);
-      return rc;
-    }
-    s->comm = comm;
+  int attach_rccl(ncclComm_t c, int rank_, int nranks_) override {
+    if (comm) g_rccl.CommDestroy(comm);  // (a second init replaces the communicator)
+    comm = nullptr;
+    CHK(set_ranks(rank_, nranks_));
+    comm = c;
     return 0;
-  };
-  if (ctx->flags & LBFGSB_F_REAL32) return attach(as<float>(ctx));
-  return attach(as<double>(ctx));
-}
-
-void *lbfgsb_hip_get_stream(lbfgsb_hip_ctx *ctx) { return ctx ? (void *)ctx->q.stream : nullptr; }
-
-int lbfgsb_hip_wait_stream(lbfgsb_hip_ctx *ctx, void *producer_stream) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  if ((hipStream_t)producer_stream == ctx->q.stream) return 0;
-  HIPCHK(hipSetDevice(ctx->device));
-  if (!ctx->order_ev) HIPCHK(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ctx->order_ev, (hipStream_t)producer_stream));
-  HIPCHK(hipStreamWaitEvent(ctx->q.stream, ctx->order_ev, 0));
-  return 0;
-}
-
-int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag,
-                              void *user, int rank, int nranks) {
-  if (!ctx || !ar || nranks < 1 || rank < 0 || rank >= nranks)
-    return fail(LBFGSB_E_ARG, "bad host reducer arguments");
-  if (ctx->flags & LBFGSB_F_REAL32) {
-    auto *s = as<float>(ctx);
-    s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
-    return s->set_ranks(rank, nranks);
   }
-  auto *s = as<double>(ctx);
-  s->cb_ar = ar, s->cb_ag = ag, s->cb_user = user;
-  return s->set_ranks(rank, nranks);
-}
-
-int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
-                          const int32_t *nbd, double *f, void *g, double factr, double pgtol,
-                          char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave,
-                          double *dsave) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  const int rc = ctx->setulb_dev(x, l, u, nbd, f, g, factr, pgtol, task, iprint, csave, lsave,
-                                 isave, dsave);
-  if (iprint >= 0) std::fflush(stdout);
-  return rc;
-}
-
-int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
-                        const int32_t *nbd, void *g, double factr, double pgtol, int max_iter,
-                        int max_fg, int iprint, lbfgsb_fg_fn fg, void *user, int builtin_kind,
-                        double *f, char *task, int32_t *lsave, int32_t *isave, double *dsave) {
-  if (!ctx || !f || !task || !lsave || !isave || !dsave)
-    return fail(LBFGSB_E_ARG, "minimize: NULL argument");
-  char csave[60];
-  std::memset(csave, ' ', 60);
-  lbh::str60_set(task, "START");
-  for (;;) {
-    int rc = ctx->setulb_dev(x, l, u, nbd, f, g, factr, pgtol, task, iprint, csave, lsave, isave,
-                             dsave);
-    if (rc) return rc;
-    if (lbh::str60_pre(task, "FG")) {
-      if (fg) {
-        rc = ctx->sync();  // a callback may run on any stream
-        if (rc) return rc;
-        // (the callback must leave g complete or ordered before the context's stream:
-        //  lbfgsb_hip_wait_stream / lbfgsb_hip_get_stream, include/lbfgsb_hip.h)
-        *f = fg(user, x, g);
-        if (std::isnan(*f)) lbh::str60_set(task, "STOP: THE OBJECTIVE CALLBACK RETURNED NaN");
-      } else {
-        rc = ctx->k_objective(builtin_kind, x, g, nullptr);  // f comes back with the next call
-        if (rc) return rc;
-      }
-    } else if (lbh::str60_pre(task, "NEW_X")) {
-      if (max_iter > 0 && isave[29] >= max_iter)
-        lbh::str60_set(task, "STOP: MAXIMUM NUMBER OF ITERATIONS REACHED");
-      else if (max_fg > 0 && isave[33] >= max_fg)
-        lbh::str60_set(task, "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT");
-    } else {
-      break;
-    }
+  int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank_,
+                  int nranks_) override {
+    cb_ar = ar, cb_ag = ag, cb_user = user;
+    return set_ranks(rank_, nranks_);
   }
-  if (iprint >= 0) std::fflush(stdout);
-  return ctx->sync();
-}
-
-int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->export_state(wa, iwa);
-}
-int lbfgsb_hip_import_state(lbfgsb_hip_ctx *ctx, const void *wa, const int32_t *iwa,
-                            const int32_t *isave) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->import_state(wa, iwa, isave);
-}
-
-int lbfgsb_hip_projgr(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u,
-                      const int32_t *nbd, const void *g, double *h_sbgnrm) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->k_projgr(x, l, u, nbd, g, h_sbgnrm);
-}
-int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double *h_out) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->k_wtv(v, col, head, h_out, false);
-}
-int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->k_wtv(v, col, head, nullptr, true);
-}
-int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, int reps,
-                        double *h_ms_per_launch) {
-  if (!ctx || reps < 1) return fail(LBFGSB_E_ARG, "wtv_time: bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
-  for (int k = 0; k < 3; ++k) CHK(ctx->k_wtv(v, col, head, nullptr, true));
-  HIPCHK(hipEventRecord(e0, ctx->q.stream));
-  for (int k = 0; k < reps; ++k) CHK(ctx->k_wtv(v, col, head, nullptr, true));
-  HIPCHK(hipEventRecord(e1, ctx->q.stream));
-  HIPCHK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *h_ms_per_launch = (double)ms / reps;
-  return 0;
-}
-int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const void *g, int col,
-                           int head, int reps, double *h_ms_per_launch) {
-  if (!ctx || reps < 1) return fail(LBFGSB_E_ARG, "kernel_time: bad arguments");
-  HIPCHK(hipSetDevice(ctx->device));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
-  for (int k = 0; k < 2; ++k) CHK(ctx->k_launch(which, x, g, col, head));
-  HIPCHK(hipEventRecord(e0, ctx->q.stream));
-  for (int k = 0; k < reps; ++k) CHK(ctx->k_launch(which, x, g, col, head));
-  HIPCHK(hipEventRecord(e1, ctx->q.stream));
-  HIPCHK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *h_ms_per_launch = (double)ms / reps;
-  return 0;
-}
-int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->k_set_w(h_ws, h_wy);
-}
-int lbfgsb_hip_set_iwhere(lbfgsb_hip_ctx *ctx, const int32_t *h_iwhere) {
-  if (!ctx || !h_iwhere) return fail(LBFGSB_E_ARG, "set_iwhere: NULL argument");
-  return ctx->k_set_iwhere(h_iwhere);
-}
-int lbfgsb_hip_formk_gram(lbfgsb_hip_ctx *ctx, int col, int head, double *h_out) {
-  if (!ctx || !h_out) return fail(LBFGSB_E_ARG, "formk_gram: NULL argument");
-  return ctx->k_formk_gram(col, head, h_out);
-}
-int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->sync();
-}
-int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  return ctx->k_objective(kind, x, g, h_f);
-}
-int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
-                     int64_t *cauchy_fullsorts, double *wait_seconds) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  if (launches) *launches = ctx->q.launches;
-  if (syncs) *syncs = ctx->nsync;
-  if (cauchy_fullsorts) *cauchy_fullsorts = ctx->nfullsort;
-  if (wait_seconds) *wait_seconds = ctx->t_wait;
-  return 0;
-}
-
-int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass,
-                           int64_t *handed_windows) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  if (handed_windows) *handed_windows = ctx->nspecwin;
-  int64_t a, b;
-  if (ctx->flags & LBFGSB_F_REAL32)
-    a = as<float>(ctx)->nclosed, b = as<float>(ctx)->nthreepass;
-  else
-    a = as<double>(ctx)->nclosed, b = as<double>(ctx)->nthreepass;
-  if (closed_form) *closed_form = a;
-  if (three_pass) *three_pass = b;
-  return 0;
-}
-
-int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count) {
-  if (!ctx || !count) return fail(LBFGSB_E_ARG, "tie_splits: NULL argument");
-  *count = ctx->ntiesplit;
-  return 0;
-}
-
-int lbfgsb_hip_pass_clock(lbfgsb_hip_ctx *ctx, int enable, double *ms_total, int64_t *count) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
-  HIPCHK(hipSetDevice(ctx->device));
-  ctx->clk_stream = ctx->q.stream;
-  if (enable == 1) {
-    for (int k = 0; k < 3; ++k) ctx->clk_ms[k] = 0.0, ctx->clk_n[k] = 0, ctx->clk_pending[k] = false;
-    ctx->clock_on = true;
-  } else {
-    HIPCHK(hipStreamSynchronize(ctx->q.stream));
-    ctx->clk_collect();
-    if (enable == 0) ctx->clock_on = false;
+  void path_counts(int64_t &closed_form, int64_t &three_pass) const override {
+    closed_form = nclosed, three_pass = nthreepass;
   }
-  for (int k = 0; k < 3; ++k) {
-    if (ms_total) ms_total[k] = ctx->clk_ms[k];
-    if (count) count[k] = ctx->clk_n[k];
-  }
-  return 0;
-}
-
-// ----------------------------------------------------------- host-pointer form
-// The exact reference signature (src/lbfgsb.f90:88-89) plus real_bytes/mirror.  The context of a
-// run is kept in a process-wide registry; isave(17:18) hold {id, tag} -- slots the reference
-// never writes (:250-284) -- never a raw pointer.
-namespace {
-constexpr int32_t HOST_TAG = 0x4C424642;  // "LBFB"
-struct HostRegistry {
-  std::mutex mu;
-  std::unordered_map<int32_t, lbfgsb_hip_ctx *> live;
-  int32_t next_id = 1;
-  ~HostRegistry() {  // contexts of runs that were abandoned without lbfgsb_hip_release_host
-    for (auto &kv : live) delete kv.second;
-  }
-  int32_t add(lbfgsb_hip_ctx *c) {
-    std::lock_guard<std::mutex> lk(mu);
-    while (live.count(next_id) || next_id <= 0) next_id = next_id == INT32_MAX ? 1 : next_id + 1;
-    live[next_id] = c;
-    return next_id;
-  }
-  lbfgsb_hip_ctx *find(const int32_t *isave) {
-    if (isave[17] != HOST_TAG) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = live.find(isave[16]);
-    return it == live.end() ? nullptr : it->second;
-  }
-  void drop(int32_t *isave) {
-    lbfgsb_hip_ctx *c = nullptr;
-    if (isave[17] == HOST_TAG) {
-      std::lock_guard<std::mutex> lk(mu);
-      auto it = live.find(isave[16]);
-      if (it != live.end()) {
-        c = it->second;
-        live.erase(it);
-      }
-    }
-    delete c;
-    isave[16] = isave[17] = 0;
-  }
+  const void *prev_iterate() const override { return t; }
 };
-HostRegistry g_host;
+
 }  // namespace
 
-int lbfgsb_hip_release_host(int32_t *isave) {
-  if (!isave) return fail(LBFGSB_E_ARG, "isave == NULL");
-  g_host.drop(isave);
-  return 0;
+lbfgsb_hip_ctx *lbfgsb_make_solver(int64_t n_local, int64_t n_global, int64_t row0, int m, int flags,
+                                   int device, void *stream, int *rc) {
+  auto make = [&](auto *s) -> lbfgsb_hip_ctx * {
+    *rc = s->init(n_local, n_global, row0, m, flags, device, stream);
+    if (*rc) {
+      delete s;
+      return nullptr;
+    }
+    return s;
+  };
+  if (flags & LBFGSB_F_REAL32) return make(new Solver<float>());
+  return make(new Solver<double>());
 }
-
-int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
-                           const int32_t *nbd, void *f, void *g, double factr, double pgtol,
-                           void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
-                           int32_t *lsave, int32_t *isave, void *dsave, const char *iteration_file,
-                           int32_t real_bytes, int32_t mirror) {
-  const bool r32 = real_bytes == 4;
-  if (real_bytes != 4 && real_bytes != 8) return fail(LBFGSB_E_ARG, "real_bytes must be 4 or 8");
-  const size_t rb = (size_t)real_bytes;
-  lbfgsb_hip_ctx *ctx = nullptr;
-  const bool start = lbh::str60_eq(task, "START");
-  if (start) {
-    g_host.drop(isave);  // a START over the isave of a run that is still registered
-    // the reference's own argument checks that do not need a context (:1618-1620)
-    if (n <= 0 || m <= 0) {
-      if (n <= 0) lbh::str60_set(task, "ERROR: N <= 0");
-      if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
-      return 0;
-    }
-    int fl = (r32 ? LBFGSB_F_REAL32 : 0) | (mirror ? LBFGSB_F_MIRROR_INDEX : 0);
-    int rc = lbfgsb_hip_create(n, n, 0, m, fl, 0, nullptr, &ctx);
-    if (rc) return rc;
-    if (iteration_file && iteration_file[0]) ctx->itfile_name = iteration_file;
-    const size_t vb = ((size_t)n + 32) * rb;
-    auto stage = [&]() -> int {
-      HIPCHK(hipMalloc(&ctx->hx, vb));
-      HIPCHK(hipMalloc(&ctx->hg, vb));
-      HIPCHK(hipMalloc(&ctx->hl, vb));
-      HIPCHK(hipMalloc(&ctx->hu, vb));
-      HIPCHK(hipMalloc(&ctx->hnbd, ((size_t)n + 32) * 4));
-      HIPCHK(hipMemset(ctx->hg, 0, vb));
-      HIPCHK(hipMemcpy(ctx->hx, x, (size_t)n * rb, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(ctx->hl, l, (size_t)n * rb, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(ctx->hu, u, (size_t)n * rb, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(ctx->hnbd, nbd, (size_t)n * 4, hipMemcpyHostToDevice));
-      return 0;
-    };
-    rc = stage();
-    if (rc) {
-      lbfgsb_hip_destroy(ctx);
-      return rc;
-    }
-    std::memset(isave, 0, 44 * sizeof(int32_t));
-    // the wa offsets the reference persists in isave(4:16) (:250-265: lws, lwy, lsy, lss, lwt, lwn,
-    // lsnd, lz, lr, ld, lt, lxp, lwa; isave(1:3) = m*n, m^2, 4m^2), 1-based, computed in 64 bits
-    // and saturated (the reference's default-integer arithmetic wraps at n = 1e8, m = 10)
-    {
-      const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
-      const int64_t lws = 1, lwy = lws + mn, lsy = lwy + mn, lss = lsy + mm, lwt = lss + mm,
-                    lwn = lwt + mm, lsnd = lwn + 4 * mm, lz = lsnd + 4 * mm, lr = lz + n, ld_ = lr + n,
-                    lt = ld_ + n, lxp = lt + n, lwa = lxp + n;
-      const int64_t v[16] = {mn, mm, 4 * mm, lws, lwy, lsy, lss, lwt, lwn, lsnd, lz, lr, ld_, lt, lxp, lwa};
-      for (int k = 0; k < 16; ++k) isave[k] = (int32_t)std::min<int64_t>(v[k], INT32_MAX);
-    }
-    isave[16] = g_host.add(ctx);
-    isave[17] = HOST_TAG;
-  } else {
-    ctx = g_host.find(isave);
-    if (!ctx || ctx->n != n || ctx->m != m)
-      return fail(LBFGSB_E_STATE, "setulb called without a live context (task must be START first)");
-    if (lbh::str60_pre(task, "FG"))
-      HIPCHK(hipMemcpy(ctx->hg, g, (size_t)n * rb, hipMemcpyHostToDevice));
-  }
-  const int32_t keep_id = isave[16], keep_tag = isave[17];
-  int32_t keep16[16];
-  std::memcpy(keep16, isave, sizeof keep16);
-  double fd = r32 ? (double)*(float *)f : *(double *)f;
-  double ds[29];
-  for (int i = 0; i < 29; ++i) ds[i] = r32 ? (double)((float *)dsave)[i] : ((double *)dsave)[i];
-  int rc = ctx->setulb_dev(ctx->hx, ctx->hl, ctx->hu, ctx->hnbd, &fd, ctx->hg, factr, pgtol, task,
-                           iprint, csave, lsave, isave, ds);
-  std::memcpy(isave, keep16, sizeof keep16);
-  isave[16] = keep_id, isave[17] = keep_tag;
-  if (iprint >= 0) std::fflush(stdout);
-  if (rc) return rc;
-  for (int i = 0; i < 29; ++i) {
-    if (r32)
-      ((float *)dsave)[i] = (float)ds[i];
-    else
-      ((double *)dsave)[i] = ds[i];
-  }
-  if (r32)
-    *(float *)f = (float)fd;
-  else
-    *(double *)f = fd;
-  HIPCHK(hipMemcpy(x, ctx->hx, (size_t)n * rb, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(g, ctx->hg, (size_t)n * rb, hipMemcpyDeviceToHost));
-  if (mirror) {
-    rc = ctx->export_state(wa, iwa);
-    if (rc) return rc;
-  } else if (wa) {
-    // previous iterate: wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175
-    const int64_t off_t = 2ll * m * n + 11ll * m * m + 3ll * n;
-    void *src = r32 ? (void *)as<float>(ctx)->t : (void *)as<double>(ctx)->t;
-    HIPCHK(hipMemcpy((char *)wa + (size_t)off_t * rb, src, (size_t)n * rb, hipMemcpyDeviceToHost));
-  }
-  if (!lbh::str60_pre(task, "FG") && !lbh::str60_pre(task, "NEW_X"))
-    g_host.drop(isave);  // terminal task: CONVERGENCE / ABNORMAL / ERROR / STOP
-  return 0;
-}
-
-}  // extern "C"

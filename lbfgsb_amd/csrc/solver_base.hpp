@@ -1,0 +1,190 @@
+// solver_base.hpp -- what solver.hip (the mainlb state machine, Solver<T>) and capi.hip (the C ABI
+// of include/lbfgsb_hip.h) share: error plumbing, the dlopen'ed RCCL entry points, and the
+// type-erased context the C ABI hands out.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <functional>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lbfgsb_hip.h"
+#include "host_dense.hpp"
+#include "kernels.hpp"
+#include "report.hpp"
+
+namespace lbs {
+
+inline thread_local std::string g_err;
+
+inline int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                    \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(LBFGSB_E_NOGPU, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+#define CHK(expr)          \
+  do {                     \
+    int rc_ = (expr);      \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+inline double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------- RCCL (dlopen)
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false;  // every symbol resolved
+  bool load() {
+    if (ok) return true;
+    if (h) {  // an earlier attempt found a library without the symbols: try again from scratch
+      dlclose(h);
+      h = nullptr;
+    }
+    // LBFGSB_RCCL_LIBRARY: a specific build of the library (tests point it at a small
+    // shared-memory stand-in so that the communicator code path runs with several ranks on one GPU)
+    const char *names[] = {std::getenv("LBFGSB_RCCL_LIBRARY"), "librccl.so.1", "librccl.so",
+                           "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      if (!nm || !*nm) continue;
+      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) return false;
+#define SYM(f, name) f = reinterpret_cast<decltype(f)>(dlsym(h, name))
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+#undef SYM
+    ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather && GroupStart && GroupEnd;
+    if (!ok) {
+      dlclose(h);
+      h = nullptr;
+    }
+    return ok;
+  }
+};
+inline Rccl g_rccl;
+
+struct Rec {  // one breakpoint as the host walk needs it
+  double t;
+  int64_t gidx;
+};
+
+}  // namespace lbs
+using namespace lbs;
+
+// ===================================================================== context
+struct lbfgsb_hip_ctx {
+  virtual ~lbfgsb_hip_ctx() {}
+  virtual int setulb_dev(void *x, const void *l, const void *u, const int32_t *nbd, double *f,
+                         void *g, double factr, double pgtol, char *task, int iprint, char *csave,
+                         int32_t *lsave, int32_t *isave, double *dsave) = 0;
+  virtual int export_state(void *wa, int32_t *iwa) = 0;
+  virtual int import_state(const void *wa, const int32_t *iwa, const int32_t *isave) = 0;
+  virtual int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd,
+                       const void *g, double *out) = 0;
+  virtual int k_wtv(const void *v, int col, int head, double *out, bool launch_only) = 0;
+  virtual int k_set_w(const void *hws, const void *hwy) = 0;
+  virtual int k_set_iwhere(const int32_t *h_iw) = 0;
+  virtual int k_formk_gram(int col, int head, double *out) = 0;
+  virtual int k_launch(int which, const void *x, const void *g, int col, int head) = 0;
+  virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
+  virtual int sync() = 0;
+  // communicators (capi.hip): an initialised RCCL communicator / a host reducer for this context
+  virtual int attach_rccl(ncclComm_t comm, int rank, int nranks) = 0;
+  virtual int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank,
+                          int nranks) = 0;
+  virtual void path_counts(int64_t &closed_form, int64_t &three_pass) const = 0;
+  virtual const void *prev_iterate() const = 0;  // t: the reference's wa(3n+2mn+11m^2+1 : +n)
+
+  // host-entry staging (setulb_host)
+  void *hx = nullptr, *hg = nullptr, *hl = nullptr, *hu = nullptr;
+  int32_t *hnbd = nullptr;
+  std::string itfile_name = "iterate.dat";
+  int64_t n = 0, nglob = 0, row0 = 0;
+  int m = 0, flags = 0, device = 0;
+  int rank = 0, nranks = 1;
+  int64_t nsync = 0, nfullsort = 0;
+  int64_t ntiesplit = 0;  // walks that ended inside a group of equal breakpoints
+  int64_t ngcp_clamped = 0;  // closed-form GCPs declined because the f2 clamp would have acted
+  int64_t nspecwin = 0;   // walks served by the candidates the update pass handed over
+  double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
+  // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
+  // the next setulb_dev call fetches it together with the sums of its own first pass
+  bool f_pending = false;
+  double f_scale = 1.0;
+  // in-run clocks of the three passes over W (hipEvents on the solver's stream around each
+  // launch, read at the next host sync): 0 cmprlb_wtv, 1 update_scan, 2 subsm_update
+  bool clock_on = false;
+  hipEvent_t clk_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool clk_pending[3] = {false, false, false};
+  double clk_ms[3] = {0.0, 0.0, 0.0};
+  int64_t clk_n[3] = {0, 0, 0};
+  hipStream_t clk_stream = nullptr;
+  hipEvent_t order_ev = nullptr;  // lbfgsb_hip_wait_stream
+  void clk_begin(int k) {
+    if (!clock_on) return;
+    if (!clk_ev[k][0]) {
+      (void)hipEventCreate(&clk_ev[k][0]);
+      (void)hipEventCreate(&clk_ev[k][1]);
+    }
+    clk_collect();  // (a pass launched twice between two syncs: keep the first reading)
+    (void)hipEventRecord(clk_ev[k][0], clk_stream);
+  }
+  void clk_end(int k) {
+    if (!clock_on) return;
+    (void)hipEventRecord(clk_ev[k][1], clk_stream);
+    clk_pending[k] = true;
+  }
+  void clk_collect() {  // call after a stream sync (or when the events are known complete)
+    for (int k = 0; k < 3; ++k) {
+      if (!clk_pending[k]) continue;
+      if (hipEventQuery(clk_ev[k][1]) != hipSuccess) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, clk_ev[k][0], clk_ev[k][1]) == hipSuccess) {
+        clk_ms[k] += ms;
+        clk_n[k]++;
+      }
+      clk_pending[k] = false;
+    }
+  }
+  lbk::Queue q{};
+};
+
+
+// the two instantiations live in solver.hip
+lbfgsb_hip_ctx *lbfgsb_make_solver(int64_t n_local, int64_t n_global, int64_t row0, int m, int flags,
+                                   int device, void *stream, int *rc);
