@@ -38,6 +38,17 @@ def nrm_close(a, b, rtol, what, floor=0.0):
     assert err <= rtol * scale + 1e-300, "%s: max|diff| %.3e > %.1e * %.3e" % (what, err, rtol, scale)
 
 
+def rel_err(a, b, floor=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(float(np.max(np.abs(b))) if b.size else 0.0, floor, 1e-300)
+    return (float(np.max(np.abs(a - b))) if b.size else 0.0) / scale
+
+
+# the largest amplification seen: error of a factor / (condition number x error of what was factored)
+COND_SEEN = {"wt": 0.0, "wn": 0.0}
+
+
 def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), check_indx2=True,
                    check_iwhere=True):
     """got / exp: pyoracle.State after the same call from the same input state."""
@@ -78,6 +89,18 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), che
         a = np.triu(seg(got, "wt").reshape(m, m, order="F")[:col, :col])
         b = np.triu(seg(exp, "wt").reshape(m, m, order="F")[:col, :col])
         nrm_close(a, b, 1e-7, "wt")
+        # why 1e-7 and not 1e-10: wt is the Cholesky factor of T = theta S'S + L D^-1 L' (formt,
+        # :1926-1966), formed from sy / ss, whose entries are n-term sums (reassociated here).
+        # A factor moves by up to ~ cond(T) x the relative change of T: check the tolerance
+        # against THAT -- the error of wt must be explained by cond(T) = cond(wt)^2 times the
+        # error of its inputs (or by rounding itself, 1e-15), with a modest constant.
+        sy_g, sy_e = (np.tril(seg(s_, "sy").reshape(m, m, order="F")[:col, :col]) for s_ in (got, exp))
+        ss_g, ss_e = (np.triu(seg(s_, "ss").reshape(m, m, order="F")[:col, :col]) for s_ in (got, exp))
+        e_in = max(rel_err(sy_g, sy_e), rel_err(ss_g, ss_e), 1e-15)
+        cond_t = float(np.linalg.cond(b)) ** 2 if col > 1 else 1.0
+        amp = rel_err(a, b) / (cond_t * e_in)
+        COND_SEEN["wt"] = max(COND_SEEN["wt"], amp)
+        assert amp <= 50.0, "wt: error %.2e, cond(T) %.2e, input error %.2e" % (rel_err(a, b), cond_t, e_in)
         # formk state: WN1 (kept incrementally, reference :1735-1851) and the factored WN
         ga = seg(got, "snd").reshape(2 * m, 2 * m, order="F")
         ea = seg(exp, "snd").reshape(2 * m, 2 * m, order="F")
@@ -89,6 +112,17 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), che
         gw = seg(got, "wn").reshape(2 * m, 2 * m, order="F")[:2 * col, :2 * col]
         ew = seg(exp, "wn").reshape(2 * m, 2 * m, order="F")[:2 * col, :2 * col]
         nrm_close(np.triu(gw), np.triu(ew), 1e-6, "wn")
+        # the same argument for the factored K of formk (:1856-1906): wn holds its triangular
+        # factor; its error against cond(K) = cond(factor)^2 times the error of WN1 (and of theta,
+        # sy through the assembly)
+        e_in = max(rel_err(np.tril(ga[:col, :col]), np.tril(ea[:col, :col]), scale),
+                   rel_err(np.tril(ga[m:m + col, m:m + col]), np.tril(ea[m:m + col, m:m + col]), scale),
+                   rel_err(ga[m:m + col, :col], ea[m:m + col, :col], scale), e_in, 1e-15)
+        cond_k = float(np.linalg.cond(np.triu(ew))) ** 2
+        amp = rel_err(np.triu(gw), np.triu(ew)) / (cond_k * e_in)
+        COND_SEEN["wn"] = max(COND_SEEN["wn"], amp)
+        assert amp <= 50.0, "wn: error %.2e, cond(K) %.2e, input error %.2e" % (
+            rel_err(np.triu(gw), np.triu(ew)), cond_k, e_in)
         # cauchy / cmprlb / subsm scratch wa(8m) (:617-619): at a first FG_LNSRCH return
         # wa(1:2m) = K^-1 W'Zr of subsm (through two triangular solves with the factored K:
         # the tolerance of wn), wa(2m+1:4m) = c = W'(xcp - x), wa(4m+1:6m) = the last wbp,
@@ -1110,3 +1144,13 @@ def test_tie_groups_of_identical_variables_trajectory(env):
     for xa, xb in zip(xs_e, xs_o):
         assert np.max(np.abs(xa - xb)) <= 1e-9
     print("tie splits on this trajectory: %d (default), %d (exact ties)" % (splits, splits_e))
+
+
+def test_zz_factor_errors_are_explained_by_conditioning(env):
+    """Runs last in this module: the one-step and production-path cases above compared wt (formt's
+    Cholesky factor) and wn (formk's factored K) with loose absolute tolerances (1e-7, 1e-6); each
+    comparison also required the error to be at most 50 x cond x (error of the factored matrix's
+    inputs).  This reports the largest such amplification seen and insists the checks really ran."""
+    assert COND_SEEN["wt"] > 0.0 and COND_SEEN["wn"] > 0.0
+    print("largest error / (cond x input error): wt %.3g, wn %.3g" % (COND_SEEN["wt"], COND_SEEN["wn"]))
+    assert COND_SEEN["wt"] <= 50.0 and COND_SEEN["wn"] <= 50.0
