@@ -360,13 +360,13 @@ def main():
     n_sub = in_run("subsm_update")[1]
     rec_us = pass_record("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
                          "first trial point)" % (tname, mc, nts),
-                         ((2 * (col - 1) + 6) * rbytes + 5) * n_loc, "none", "update_scan")
+                         ((2 * (col - 1) + 6) * rbytes + 2) * n_loc, "none", "update_scan")
     # the subspace pass stores t, r, the first trial point x and the pending Ws/Wy column; z and
     # d = x - t stay implicit while the unit first trial step stands (LBFGSB_LEAN=0: stored too)
     lean = os.environ.get("LBFGSB_LEAN", "1") != "0"
     n_st = 5 if lean else 6 + (1 if n_sub else 0)
     rec_su = pass_record("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
-                         % (tname, mc, nts), ((2 * col + 4 + n_st) * rbytes + 5) * n_loc,
+                         % (tname, mc, nts), ((2 * col + 4 + n_st) * rbytes + 2) * n_loc,
                          ("t, r, trial x + Ws/Wy column (5 of %d streams)" % (2 * col + 9)) if lean else
                          ("z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11)),
                          "subsm_update")

@@ -191,7 +191,7 @@ void launch_cauchy_window(Queue &q, int64_t n, int64_t row0, const T *tbrk, doub
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
     int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
-    const T *__restrict__ u, const int32_t *__restrict__ nbd, const T *__restrict__ g,
+    const T *__restrict__ u, const nb_t *__restrict__ nbd, const T *__restrict__ g,
     const iw_t *__restrict__ iwhere, double lo_t, int64_t lo_i, double hi_t, uint64_t *keys,
     uint32_t *idx, uint32_t cap, uint32_t *count) {
   const int lane = threadIdx.x & 63;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
 }
 template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
-                              const int32_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
+                              const nb_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
                               uint32_t *d_count) {
   (void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), q.stream);
@@ -1084,7 +1084,7 @@ void launch_freev_lists(Queue &q, int64_t n, const iw_t *iwhere, const int8_t *p
   template void launch_cauchy_allkeys<T>(Queue &, int64_t, int64_t, const T *, double, int64_t, uint64_t *, uint32_t *); \
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t, int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, const T *, const T *, Pend, double *); \
   template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint64_t *, const uint32_t *, uint32_t, int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, const T *, const T *, Pend, double *); \
-  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const iw_t *, double, int64_t, double, uint64_t *, uint32_t *, uint32_t, uint32_t *); \
+  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *, const T *, const nb_t *, const T *, const iw_t *, double, int64_t, double, uint64_t *, uint32_t *, uint32_t, uint32_t *); \
   template void launch_iwhere_update<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, iw_t *); \
   template void launch_pgcp_gather<T>(Queue &, const uint32_t *, const uint64_t *, int64_t, int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, double, const T *, const T *, Pend, double *, double *, double *, double *, double *, double *, int64_t); \
   template void launch_gcp_rest_mass<T>(Queue &, int64_t, const T *, const T *, double); \

@@ -272,6 +272,16 @@ __global__ __launch_bounds__(BLOCK) void pair_commit_kernel(int64_t n, const T *
     st<W>(cws + i, dv);
   });
 }
+__global__ __launch_bounds__(BLOCK) void nbd_pack_kernel(int64_t n, const int32_t *__restrict__ nbd,
+                                                         nb_t *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (nb_t)nbd[i];
+}
+void launch_nbd_pack(Queue &q, int64_t n, const int32_t *nbd, nb_t *out) {
+  hipLaunchKernelGGL(nbd_pack_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, nbd, out);
+  q.launches++;
+}
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const T *__restrict__ x,
                                                                const T *__restrict__ t,

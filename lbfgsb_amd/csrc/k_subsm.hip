@@ -32,7 +32,7 @@ __device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, con
 template <typename T>
 struct SubsmCtx {
   const T *l, *u, *xx, *gg, *ws, *wy, *zero, *r, *pd;
-  const int32_t *nbd;
+  const nb_t *nbd;
   const iw_t *iwhere;
   int64_t ldw;
   int m, head, col;
@@ -42,7 +42,7 @@ template <typename T, int MC, int W, bool NT, bool PSPEC>
 struct SubsmTrip {
   static constexpr int NL = 6 + 2 * MC;
   RawOf<T, W> rl, ru, rx, rg, ra[MC], rb[MC];
-  RawOf<int32_t, W> rnb;
+  RawOf<nb_t, W> rnb;
   RawOf<iw_t, W> riw;
   __device__ __forceinline__ void issue(const SubsmCtx<T> &c, int64_t i) {
     constexpr int B = (int)sizeof(T) * W;
@@ -50,7 +50,7 @@ struct SubsmTrip {
     raw_issue<B, NT>(ru, c.u + i);
     raw_issue<B, NT>(rx, c.xx + i);
     raw_issue<B, NT>(rg, c.gg + i);
-    raw_issue<4 * W, false>(rnb, c.nbd + i);
+    raw_issue<W, false>(rnb, c.nbd + i);
     raw_issue<W, false>(riw, c.iwhere + i);
     // a pending pair is read from (r, d) -- or (r, t) when d is implicit -- which this pass
     // overwrites further down
@@ -70,7 +70,7 @@ struct SubsmTrip {
 template <typename T, int MC, bool NT, bool PSPEC, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, double tsum, T *__restrict__ zout, T *r,
-    const T *__restrict__ l, const T *__restrict__ u, const int32_t *__restrict__ nbd,
+    const T *__restrict__ l, const T *__restrict__ u, const nb_t *__restrict__ nbd,
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
     int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     raw_get<W>(tr.ru, (const T *)nullptr, uv);
     raw_get<W>(tr.rx, (const T *)nullptr, xv);
     raw_get<W>(tr.rg, (const T *)nullptr, gv);
-    raw_geti<W>(tr.rnb, (const int32_t *)nullptr, nb);
+    raw_geti<W>(tr.rnb, (const nb_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
     get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     fix_pending<T, MC, W, PSPEC>(col, pe, gv, xv, a, b);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
 }
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
-                         const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
+                         const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
                          const T *pd) {
@@ -243,7 +243,7 @@ void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, con
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
-  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const int32_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *); \
+  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const nb_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *); \
   template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *);
 INSTANTIATE(double)
 INSTANTIATE(float)

@@ -76,7 +76,7 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 template <typename T>
 struct UpdScanCtx {
   const T *x, *l, *u, *g, *r, *d, *ws, *wy, *zero;
-  const int32_t *nbd;
+  const nb_t *nbd;
   const iw_t *iwhere;
   int64_t ldw;
   int m, head, nold;
@@ -85,7 +85,7 @@ template <typename T, int MC, int W, bool NT>
 struct UpdScanTrip {
   static constexpr int NL = 8 + 2 * MC;
   RawOf<T, W> rx, rl, ru, rg, rr, rd, ra[MC], rb[MC];
-  RawOf<int32_t, W> rnb;
+  RawOf<nb_t, W> rnb;
   RawOf<iw_t, W> riw;
   __device__ __forceinline__ void issue(const UpdScanCtx<T> &c, int64_t i) {
     constexpr int B = (int)sizeof(T) * W;
@@ -95,7 +95,7 @@ struct UpdScanTrip {
     raw_issue<B, NT>(rg, c.g + i);
     raw_issue<B, NT>(rr, c.r + i);
     raw_issue<B, NT>(rd, c.d + i);
-    raw_issue<4 * W, false>(rnb, c.nbd + i);
+    raw_issue<W, false>(rnb, c.nbd + i);
     raw_issue<W, false>(riw, c.iwhere + i);
     issue_cols<T, MC, W, NT>(c.wy, c.ws, (const T *)nullptr, (const T *)nullptr, c.zero, i, c.nold, c.head,
                              c.m, c.ldw, Pend{0, 1.0}, ra, rb);
@@ -123,7 +123,7 @@ struct UpdScanTrip {
 template <typename T, int MC, bool NT, bool PIPE, bool NEWROW>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
-    const int32_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
+    const nb_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
     const T *__restrict__ d, int dimpl, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
     int store_iw, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap, uint32_t *ccount,
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     raw_get<W>(tr.rg, (const T *)nullptr, gv);
     raw_get<W>(tr.rr, (const T *)nullptr, rv);
     raw_get<W>(tr.rd, (const T *)nullptr, dv);
-    raw_geti<W>(tr.rnb, (const int32_t *)nullptr, nb);
+    raw_geti<W>(tr.rnb, (const nb_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
     bool iw_changed = false;
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   block_reduce_store<NA>(acc, X + NX, 1, 1, part, MAX_BLOCKS);
 }
 template <typename T>
-void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const int32_t *nbd,
+void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const nb_t *nbd,
                         const T *g, const T *r, const T *d, int dimpl, double stp, iw_t *iwhere,
                         T *tbrk, WStore<T> w, int head, int col, int itail, int store_pair,
                         int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
@@ -325,7 +325,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
   template void launch_update_pairs<T>(Queue &, int64_t, const T *, const T *, const T *, double, WStore<T>, int, int, int); \
-  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *, const T *, int, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int, double, uint64_t *, uint32_t *, uint32_t, uint32_t *);
+  template void launch_update_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const nb_t *, const T *, const T *, const T *, int, double, iw_t *, T *, WStore<T>, int, int, int, int, int, int, double, uint64_t *, uint32_t *, uint32_t, uint32_t *);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

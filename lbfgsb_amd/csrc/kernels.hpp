@@ -41,6 +41,9 @@ struct WStore {
 // iwhere (cauchy's per-variable status, -3..3) is kept as one byte per row on the device; the
 // reference's int32 layout exists only in export_state / import_state
 using iw_t = int8_t;
+// nbd as the hot passes read it: one byte per row, a private copy of the caller's int32 array
+// (values 0..3; made by nbd_pack_kernel) -- 3 bytes per row less in each pass over W
+using nb_t = int8_t;
 
 // small coefficient vectors travel as kernel arguments (scalar loads)
 struct Coef {
@@ -133,7 +136,7 @@ void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *key
 // the window compaction with the breakpoint times recomputed per row (no stored tbrk)
 template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
-                              const int32_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
+                              const nb_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
                               uint32_t *d_count);
 // cauchy's iwhere update (:1284-1291) alone
@@ -239,7 +242,7 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 // line search, x = z, when its step length is known to be 1 (:2265).
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
-                         const int32_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
+                         const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
                          const T *pd);
@@ -290,7 +293,7 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // [4MC+8] #iwhere changes | min [4MC+9] bkmin | max [4MC+10] |proj g|
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
-                        const int32_t *nbd, const T *g, const T *r, const T *d, int dimpl,
+                        const nb_t *nbd, const T *g, const T *r, const T *d, int dimpl,
                         double stp, iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
                         int store_pair, int store_iw, int newrow = 0, double cand_hi = -1.0,
                         uint64_t *ckeys = nullptr, uint32_t *cidx = nullptr, uint32_t ccap = 0,
@@ -302,6 +305,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // k_update.hip); min slot = 4 MC + 9 + (newrow ? 4 MC + 4 : 0), max slot behind it
 inline int update_scan_extra(int nold, int newrow);
 // Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
+void launch_nbd_pack(Queue &q, int64_t n, const int32_t *nbd, nb_t *out);
 // d = x - t, z = x: the vectors a lean subsm_update_kernel pass left implicit (Pend::impl)
 template <typename T>
 void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z);

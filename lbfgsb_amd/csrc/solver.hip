@@ -84,7 +84,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (p) (void)hipFree(p);
       p = nullptr;
     };
-    F(ws), F(wy), F(zero_buf), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(index), F(indx2),
+    F(ws), F(wy), F(zero_buf), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all);
@@ -142,6 +142,7 @@ class Solver final : public lbfgsb_hip_ctx {
       HIPCHK(hipMemsetAsync(*p, 0, vb, stream));
     }
     HIPCHK(hipMalloc(&iwhere, (size_t)(n + 32) * sizeof(lbk::iw_t)));
+    HIPCHK(hipMalloc(&nbd8, (size_t)(n + 32) * sizeof(lbk::nb_t)));
     HIPCHK(hipMemsetAsync(iwhere, 0, (size_t)(n + 32) * sizeof(lbk::iw_t), stream));
     HIPCHK(hipMalloc(&wasfree, (size_t)n + 32));
     HIPCHK(hipMemsetAsync(wasfree, 1, (size_t)n + 32, stream));
@@ -344,6 +345,18 @@ class Solver final : public lbfgsb_hip_ctx {
   // of the vector (full sort, cursor-based cauchy_finish) fill it in first
   bool tbrk_valid = false;
   const int32_t *cnbd = nullptr;
+  // nbd as one byte per row for the passes over W (lbk::nb_t): packed when a run starts, when a
+  // state is imported, and whenever the caller's pointer changes.  Like l and u, nbd must not
+  // change between START and the end of a run (the reference reads it afresh on every call,
+  // but a run whose bound types change under it has no meaning there either).
+  lbk::nb_t *nbd8 = nullptr;
+  const int32_t *nbd8_src = nullptr;
+  int ensure_nbd8(const int32_t *nbd) {
+    if (nbd8_src == nbd) return 0;
+    lbk::launch_nbd_pack(q, n, nbd, nbd8);
+    nbd8_src = nbd;
+    return 0;
+  }
   // the pair accepted by matupd in this call, not yet stored in W (see lbk::Pend)
   lbk::Pend pend{0, 1.0, 0};
   // ---- lean subspace pass: z and d stay implicit (z = x, d = x - t) while the unit first trial
@@ -525,7 +538,7 @@ class Solver final : public lbfgsb_hip_ctx {
       lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
                                    d_count);
     else
-      lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, cnbd, g, iwhere, lo_t, lo_i, hi, keys[0],
+      lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, nbd8, g, iwhere, lo_t, lo_i, hi, keys[0],
                                        idx[0], SEL_CAP, d_count);
     lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
                                      head, col, r, d_src(), pend, d_msg);
@@ -1672,7 +1685,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // is written (5 store streams instead of 7); they stay implicit until ensure_d()
     const bool lean = lean_on && ls_unit_step && cnstnd && !(flags & LBFGSB_F_MIRROR_INDEX);
     clk_begin(2);
-    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, l, u, nbd, iwhere, x, g, W(),
+    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, l, u, nbd8, iwhere, x, g, W(),
                                 head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d, t,
                                 ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0, pend, d_src());
     clk_end(2);
@@ -1962,7 +1975,7 @@ class Solver final : public lbfgsb_hip_ctx {
         clk_begin(1);
         q.res_off = fo;
         const double chi = spec_hi(cnstnd);
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd8, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
                                    (T *)nullptr, W(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count);
         q.res_off = 0;
@@ -2376,7 +2389,7 @@ class Solver final : public lbfgsb_hip_ctx {
       } else {
         clk_begin(1);
         const double chi = spec_hi(cnstnd);
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+        lbk::launch_update_scan<T>(q, n, x, l, u, nbd8, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
                                    (T *)nullptr, W(), head, col, itail, 0, 1, nr_flag(col), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count);
         clk_end(1);
@@ -2454,6 +2467,8 @@ class Solver final : public lbfgsb_hip_ctx {
     L.isave = isave_user + 21, L.dsave = dsave, L.ipr = quiet ? -1 : iprint;
     for (const void *p : {(const void *)L.x, (const void *)L.l, (const void *)L.u, (const void *)L.g})
       if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
+    if (lbh::str60_eq(task, "START")) nbd8_src = nullptr;  // (a new run may reuse the buffer)
+    CHK(ensure_nbd8(nbd));
     Flow flow = NEXT;
 #define PHASE(call)               \
   {                               \
@@ -2568,6 +2583,7 @@ class Solver final : public lbfgsb_hip_ctx {
     get(wa8m);
     z_valid = true;  // z as imported
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, tbrk_valid = false, scan.ready = false;
+    nbd8_src = nullptr;
     spcand.valid = false;
     {
       std::vector<lbk::iw_t> h((size_t)n);
@@ -2643,12 +2659,12 @@ class Solver final : public lbfgsb_hip_ctx {
       //  the z buffer here instead of the caller's x -- the same five store streams)
       const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
       if (which == 3)  // with a pending pair: the variant every iteration after an update runs
-        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r, l, u, cnbd, iwhere,
+        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r, l, u, nbd8, iwhere,
                                     (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
                                     lean ? (T *)nullptr : d, t, lean ? z : (T *)nullptr, 1,
                                     lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t : d);
       else             // as the evaluation of a trial point: reduces only
-        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, cnbd, (const T *)g, r, lean ? t : d,
+        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, nbd8, (const T *)g, r, lean ? t : d,
                                    lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
                                    (head + col - 2) % m + 1, 0, 0, nr_flag(col));
     } else

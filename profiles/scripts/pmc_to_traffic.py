@@ -17,8 +17,8 @@ import statistics
 import sys
 
 KERNELS = {
-    "update_scan": ("update_scan_kernel<double, 10, true, true, true>", lambda n: 197 * n),
-    "subsm_update": ("subsm_update_kernel<double, 10, true, true, false>", lambda n: 237 * n),
+    "update_scan": ("update_scan_kernel<double, 10, true, true, true>", lambda n: 194 * n),
+    "subsm_update": ("subsm_update_kernel<double, 10, true, true, false>", lambda n: 234 * n),
     "cmprlb_wtv": ("cmprlb_wtv_kernel<double, 10, true, true, true, false>", lambda n: 177 * n),
     "wtv": ("wtv_kernel<double, 10, true>", lambda n: 168 * n),
 }
