@@ -892,36 +892,68 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
                                                             int8_t *wasfree, double *part,
                                                             uint32_t *chg, uint32_t chg_cap,
                                                             uint32_t *chg_count) {
-  // rows whose status changed are collected per workgroup in LDS and appended to the global
-  // list with ONE global atomic per flush (a same-address atomic per row would serialise:
-  // 1e5 changes x ~12 ns)
-  constexpr int LCAP = 2048;
+  // 16 rows per lane and trip (one 16-byte load of each byte array).  Rows whose status changed
+  // are collected per workgroup in LDS and appended to the global list with ONE global atomic
+  // per flush (a same-address atomic per row would serialise: 1e5 changes x ~12 ns)
+  constexpr int R = 16, LCAP = 8192;
   __shared__ uint32_t lbuf[LCAP];
   __shared__ uint32_t lcount, gbase;
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
   double acc[3] = {0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * R;
   const int64_t ntrip = (n + stride - 1) / stride;  // uniform trip count (barriers inside)
   for (int64_t trip = 0; trip < ntrip; ++trip) {
-    const int64_t i = trip * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = trip * stride + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * R;
     if (i < n) {
-      const bool fr = iwhere[i] <= 0;
-      const bool was = wasfree[i] != 0;
-      if (fr) acc[0] += 1.0;
-      if (fr && !was) acc[1] += 1.0;
-      if (!fr && was) acc[2] += 1.0;
-      if (chg && fr != was) {
-        const uint32_t pos = atomicAdd(&lcount, 1u);  // LDS atomic; pos < LCAP by the flush rule
-        lbuf[pos] = (uint32_t)i | (fr ? 0u : 0x80000000u);
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      union {
+        v4i v;
+        int8_t b[R];
+      } iw, wf;
+      const bool full = i + R <= n;  // (both arrays are allocated with 32 spare elements, but
+                                     //  rows beyond n must neither be counted nor written)
+      if (full) {
+        iw.v = *reinterpret_cast<const v4i *>(iwhere + i);
+        wf.v = *reinterpret_cast<const v4i *>(wasfree + i);
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          iw.b[k] = i + k < n ? iwhere[i + k] : (iw_t)1;
+          wf.b[k] = i + k < n ? wasfree[i + k] : (int8_t)0;
+        }
       }
-      if (fr != was) wasfree[i] = fr ? 1 : 0;  // (few rows: keeps the pass that follows free of
-                                               //  drained store traffic)
+      int nfr = 0, nen = 0, nlv = 0;
+      unsigned changed = 0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const bool fr = iw.b[k] <= 0, was = wf.b[k] != 0;
+        nfr += fr, nen += fr && !was, nlv += !fr && was;
+        changed |= (fr != was) ? (1u << k) : 0u;
+        wf.b[k] = fr ? 1 : 0;
+      }
+      acc[0] += nfr, acc[1] += nen, acc[2] += nlv;
+      if (changed) {  // (few rows: keeps the pass that follows free of drained store traffic)
+        if (chg) {
+          const uint32_t pos = atomicAdd(&lcount, (uint32_t)__builtin_popcount(changed));  // LDS atomic
+          uint32_t w = pos;
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if ((changed >> k) & 1u) lbuf[w++] = (uint32_t)(i + k) | (wf.b[k] ? 0u : 0x80000000u);
+        }
+        if (full) {
+          *reinterpret_cast<v4i *>(wasfree + i) = wf.v;
+        } else {
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if (i + k < n) wasfree[i + k] = wf.b[k];
+        }
+      }
     }
     if (chg) {
       __syncthreads();
       const uint32_t cnt = lcount;
-      if (cnt > LCAP - BLOCK || trip == ntrip - 1) {  // uniform: flush
+      if (cnt > LCAP - BLOCK * R || trip == ntrip - 1) {  // uniform: flush
         if (threadIdx.x == 0) gbase = cnt ? atomicAdd(chg_count, cnt) : 0u;
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < cnt; k += BLOCK)
@@ -936,7 +968,7 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
 }
 void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree, uint32_t *chg,
                         uint32_t chg_cap, uint32_t *chg_count) {
-  const int gr = grid_for(n, 1);
+  const int gr = grid_for(n, 16);
   if (chg) (void)hipMemsetAsync(chg_count, 0, sizeof(uint32_t), q.stream);
   hipLaunchKernelGGL(freev_count_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
                      q.d_part, chg, chg_cap, chg_count);
