@@ -350,7 +350,7 @@ def main():
                 "frac": ach / HBM_PEAK_GBS, "traffic": pass_traffic(traffic_key, n_loc),
                 "traffic_source": "profiles/w_pass_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                   "passes over this bench at n=1e8, in-iteration launches of this kernel "
-                                  "[profiles/r02p_*]: bytes per row x rows; not re-measured in this run)",
+                                  "[profiles/r03d_*]: bytes per row x rows; not re-measured in this run)",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
                 "launches_timed": cnt,
                 "timing": ("hipEvents around each launch inside the timed region" if cnt else
