@@ -584,11 +584,11 @@ def test_device_objectives_match_oracle(env):
 
 def test_full_size_quadratic_n1e6_against_oracle(env):
     """BASELINE.json configs[1]: separable bounded quadratic, n = 1e6, m = 10, on-device
-    objective.  Iteration 1 walks ~976,721 Cauchy segments (full breakpoint sort); integer
-    state must equal the oracle's, f to 1e-9.  Anchors pinned by the reference itself
+    objective, 30 iterations.  Iteration 1 walks ~976,721 Cauchy segments (full breakpoint
+    sort); integer state must equal the oracle's at every iteration, f to 1e-9.  Anchors pinned by the reference itself
     (BASELINE.md section 2): nseg(it1) = 976721, nfree(it1) = 23280, f(it1) = 8.2541454907951783E+06."""
     po, torch, la = env["po"], env["torch"], env["la"]
-    n, m, iters = 1_000_000, 10, 4
+    n, m, iters = 1_000_000, 10, 30
     p = po.problem_quadratic(n, m)
     rows_o = []
     po.run(po.Engine("oracle"), p, max_iter=iters,
@@ -612,14 +612,71 @@ def test_full_size_quadratic_n1e6_against_oracle(env):
         else:
             break
     st = sol.stats()
+    closed_steps, three_steps, _ = sol.path_counts()
     sol.close()
     assert rows_o[0][2] == 976721 and rows_o[0][3] == 23280
     assert rows_o[0][4] == pytest.approx(8.2541454907951783e06, rel=1e-13)
+    # 30 iterations: from iteration 11 on the memory is full (col = m) and the iteration is the
+    # bench's own steady state -- two passes over W, W'Z r in closed form, lean stores, pending
+    # pair.  More anchors printed by the reference itself: it 10, 20, 30
+    assert rows_o[9][2:4] == (39, 499959) and rows_o[29][1] == 32
+    for k, fref in ((1, 4.4408007558922265e06), (2, 4.2654335281014517e06), (9, 4.2089636688019084e06),
+                    (19, 4.2086430506394058e06), (29, 4.2086404848337891e06)):
+        assert rows_o[k][4] == pytest.approx(fref, rel=1e-13)
+        assert rows_g[k][4] == pytest.approx(fref, rel=1e-9)
     assert len(rows_g) == len(rows_o) == iters
     for a, b in zip(rows_g, rows_o):
         assert a[:4] == b[:4], (a, b)
         assert a[4] == pytest.approx(b[4], rel=1e-9)
     assert st["cauchy_fullsorts"] >= 1
+    assert closed_steps >= 15, (closed_steps, three_steps)   # the closed form really was the path taken
+
+
+def test_headline_config_n1e8_fp64_anchors(env):
+    """The workload bench.py times (BASELINE.json metric: n = 1e8, m = 10, fp64, on-device
+    objective) at full size, 14 iterations -- through the first full-sort walk, the filling of
+    the memory and into the steady state.  Size-independent anchors printed by the reference
+    (-fdefault-integer-8 build, SURVEY.md 8c / BASELINE.md section 2): nseg(it1) = 97,671,921,
+    nfree(it2) = 49,999,496; f must fall monotonically; the two-pass iteration (closed-form
+    W'Z r) must be the path taken once pairs are stored; and the sums over 1e8 rows must be
+    reproducible bit for bit from one run to the next (fixed-order reductions, no atomics)."""
+    torch, la = env["torch"], env["la"]
+    n, m, iters = 100_000_000, 10, 14
+    free_b, _tot = torch.cuda.mem_get_info()
+    if free_b < 40 * (1 << 30):
+        pytest.skip("needs ~30 GB of HBM")
+
+    def run():
+        sol = la.DeviceSolver(n, m)
+        x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        g = torch.zeros_like(x)
+        l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+        nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+        rows = []
+        while True:
+            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if t.startswith("FG"):
+                sol.f[0] = sol.objective(0, x, g)
+            elif t.startswith("NEW_X"):
+                rows.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                             float(sol.f[0]), float(sol.dsave[12])))
+                if sol.isave[29] >= iters:
+                    break
+            else:
+                break
+        counts = sol.path_counts()
+        sol.close()
+        del x, g, l, u, nbd
+        torch.cuda.empty_cache()
+        return rows, counts
+    rows, (closed_steps, three_steps, _) = run()
+    assert len(rows) == iters
+    assert rows[0][2] == 97_671_921, rows[0]
+    assert rows[1][3] == 49_999_496, rows[1]
+    assert all(b[4] < a[4] for a, b in zip(rows, rows[1:]))
+    assert closed_steps >= 8, (closed_steps, three_steps)
+    rows2, _ = run()
+    assert rows2 == rows       # bit for bit, f and |proj g| included
 
 
 def test_full_size_rosenbrock_n1e6_against_oracle(env):
