@@ -3,7 +3,7 @@
 // BASELINE.json north_star: "the 2m x 2m bmv middle-matrix solve and dpofa/dtrsl
 // from lbfgsb_linpack_module stay on the host".  Everything here is O(m^2) or
 // O(m^3) scalar work on matrices of order <= 2m <= 64; the n-dimensional work is
-// in kernels.hip.  Arithmetic is fp64 for both REAL64 and REAL32 contexts.
+// in the k_*.hip files.  Arithmetic is fp64 for both REAL64 and REAL32 contexts.
 //
 // Follows (operation order included, so the CPU oracle can be compared to the
 // last bit on identical inputs):

@@ -1,4 +1,4 @@
-// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+// kernels.hpp -- launch interface of the gfx950 kernels (k_*.hip).
 //
 // Every function enqueues work on `q.stream` and returns immediately; results
 // of reductions land in q.d_res (device) after the finalize kernel and are
@@ -51,7 +51,7 @@ struct Coef {
 };
 
 // A pair that matupd has accepted but that is not stored in W yet (see "pending pair" in
-// kernels.hip): logical column col-1 is  y = T(g - r), s = T(stp * d)  until it is committed.
+// kernels_common.hpp): logical column col-1 is  y = T(g - r), s = T(stp * d)  until it is committed.
 struct Pend {
   int on;      // 0: every column is in W
   double stp;  // step length of the accepted trial
@@ -147,7 +147,7 @@ void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *
 template <typename T>
 void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, const T *u,
                      const iw_t *iwhere, double tsum, T *dst);
-// ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; see kernels.hip) ----
+// ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; see k_cauchy.hip) ----
 size_t scan_temp_bytes(size_t count);
 void launch_scan(Queue &q, void *d_temp, size_t temp_bytes, const double *in, double *out,
                  size_t count, int exclusive);
@@ -220,7 +220,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
 // new row/column of formk's WN1 for the pair in logical column col-1 (ref :1756-1793):
 // [2MC..) sum_free Wy_new Wy_j, [3MC..) sum_act Ws_new Ws_j, [4MC..) sum_act Ws_new Wy_j,
 // [5MC..) sum_free Ws_j Wy_new.  r itself is not stored: launch_subsm_update recomputes it.
-// The Cauchy point is evaluated per row from (x, g, iwhere, tsum), see xcp_free in kernels.hip.
+// The Cauchy point is evaluated per row from (x, g, iwhere, tsum), see xcp_free in kernels_common.hpp.
 template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const iw_t *iwhere, WStore<T> w, int head, int col, double theta,

@@ -3,21 +3,25 @@
 // Mirrors the reverse-communication state machine of the reference `mainlb`
 // (src/lbfgsb.f90:312-949): same task protocol, same isave/dsave/lsave slots,
 // same failure/refresh branches.  Every n-dimensional operation is a kernel
-// launch from kernels.hip; every 2m x 2m operation is host code from
+// launch from the k_*.hip files; every 2m x 2m operation is host code from
 // host_dense.hpp.  One host thread per context, one HIP stream per context.
 //
-// One steady-state iteration on a bounded problem (kernels.hip has the why):
+// One steady-state iteration on a bounded problem with col <= 20 pairs stored (DESIGN.md 4a
+// has the why) -- two passes over W:
 //   FG_LNSRCH entry : update_scan as the evaluation of the first trial point  [read-only, 1 sync]
-//                     (g'd and |proj g| for dcsrch; if accepted also matupd's and the next
-//                      cauchy scan's sums) -- later trials: lnsrlb_eval
+//                     (g'd and |proj g| for dcsrch; if accepted also matupd's sums, the next
+//                      cauchy scan's sums and formk's new row) -- later trials: lnsrlb_eval
 //   NEW_X entry     : host matupd/formt from those sums (the new pair stays pending)
 //     cauchy        : host walk; window/gather only when it passes the first breakpoint
-//     freev+cmprlb  : freev_count + cmprlb_wtv (r, W'r, formk's new row)          [read-only, 1 sync]
+//     freev         : freev_count                                             [1 sync]
 //     formk         : patches for rows that changed status (sparse), host assembly + 2 Cholesky
-//     subsm+lnsrlb  : subsm_update: Newton step, projection, line-search set-up, first trial x,
-//                     commits the pending pair                                    [stores, 1 sync]
-// Other paths (col = 0, restarts, unconstrained, fallbacks): projgr, cauchy_scan, cauchy_finish,
-// formk_gram, update_pairs, lnsrlb_begin/step, pair_commit, xcp_fill, subsm_dir/backtrack.
+//     subsm+lnsrlb  : W'Z r in closed form on the host (subspace_closed_form); subsm_update:
+//                     Newton step, projection, line-search set-up, first trial x, commits the
+//                     pending pair                                            [stores, 1 sync]
+// Fallback with a third pass (cmprlb_wtv: r, W'r, formk's new row): col > 20, few free variables,
+// long walks.  Other paths (col = 0, restarts, unconstrained): projgr, cauchy_scan,
+// cauchy_finish, formk_gram, update_pairs, lnsrlb_begin/step, pair_commit, xcp_fill,
+// subsm_dir/backtrack.
 //
 // There is no CPU fallback anywhere in this file.
 #include "solver_base.hpp"
@@ -809,7 +813,7 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
-  // The Cauchy point is kept in functional form (tsum + iwhere, see xcp_row in kernels.hip)
+  // The Cauchy point is kept in functional form (tsum + iwhere, see xcp_row in kernels_common.hpp)
   // and only written out as a vector where one is needed: subsm skipped, the backtracking
   // branch of subsm, state export.
   struct Gcp {
@@ -858,7 +862,7 @@ class Solver final : public lbfgsb_hip_ctx {
   }
   const void *cx = nullptr, *cl = nullptr, *cu = nullptr, *cg = nullptr;  // this call's operands
 
-  // ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; kernels.hip "parallel GCP") ----
+  // ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; k_cauchy.hip "parallel GCP") ----
   double *pg_buf = nullptr;
   size_t pg_bytes = 0;
   void *pg_tmp = nullptr;
