@@ -480,7 +480,11 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // *big != nullptr: if more than PG_MIN candidates lie in the window, only report their number
   // (the caller switches to the parallel search) instead of ordering them
-  static constexpr double PG_MIN = 32768.0;
+  // (LBFGSB_PG_MIN lowers it so that tests can send small problems through the search)
+  const double PG_MIN = [] {
+    const char *e = std::getenv("LBFGSB_PG_MIN");
+    return e ? std::atof(e) : 32768.0;
+  }();
   int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, const T *x, const T *l,
                    const T *u, const T *g, int head, int col, double *big = nullptr) {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk

@@ -87,3 +87,61 @@ def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, m
         assert k >= 0.4 * len(ro) and abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), \
             (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
     assert late <= 0.2 * count      # the vast majority match through the last call
+
+
+def test_random_problems_parallel_gcp_search(oracle_built, monkeypatch):
+    """The opt-in parallel GCP search on random problems: LBFGSB_PG_MIN=0 sends EVERY walk that
+    passes its first breakpoint through it -- the closed form when no pair is stored, the sort +
+    scans (with the f2 clamp) when pairs are stored -- on all bound types, fixed and unbounded
+    variables, m = 1..12.  Against the oracle's sequential walk: same iteration / nfg columns,
+    nseg and nfree within 2, f to 1e-8, call by call over the first 12
+    iterations; a run may part ways late only at rounding level (final f to 1e-7)."""
+    po = oracle_built
+    import torch
+    import lbfgsb_amd as la
+    monkeypatch.setenv("LBFGSB_PG_MIN", "0")
+    searched, late, count = 0, 0, 60
+    for seed in range(9000, 9000 + count):
+        p = make(po, seed, 2500, 1, 13)
+        if not np.any(p.nbd != 0):
+            continue
+        ro = []
+        so = po.run(po.Engine("oracle"), p, max_iter=12,
+                    snapshot=lambda k, s: ro.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                     int(s.isave[37]), float(s.f[0])))
+                    if s.task_s.startswith("NEW_X") else None)
+        sol = la.DeviceSolver(p.n, p.m, parallel_gcp=True)
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        rg = []
+        for _ in range(100000):
+            t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+            elif t.startswith("NEW_X"):
+                rg.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                           float(sol.f[0])))
+                if sol.isave[29] >= 12:
+                    break
+            else:
+                break
+        searched += sol.stats()["cauchy_fullsorts"]
+        fgp = float(sol.f[0])
+        sol.close()
+        k = 0
+        while (k < min(len(ro), len(rg)) and ro[k][:2] == rg[k][:2] and abs(ro[k][2] - rg[k][2]) <= 2
+               and abs(ro[k][3] - rg[k][3]) <= 2 and abs(ro[k][4] - rg[k][4]) <= 1e-8 * max(1.0, abs(ro[k][4]))):
+            k += 1
+        if k == len(ro) == len(rg):
+            continue
+        late += 1
+        fo = float(so.f[0])
+        assert k >= 0.4 * len(ro) and abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), \
+            (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
+    assert searched >= 60           # the sort + scan path really ran (full sorts are its signature)
+    assert late <= 0.2 * count
