@@ -130,6 +130,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     q.stream = stream;
     ld = ((n + 31) / 32) * 32;
+    if (const char *e = std::getenv("LBFGSB_LD_PAD")) ld += 32 * (int64_t)std::max(0, std::atoi(e));  // (experiment)
     // streamed-once data: nontemporal loads unless W fits the 256 MiB Infinity Cache
     q.nt = (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
     if (const char *e = std::getenv("LBFGSB_NT")) q.nt = e[0] == '1';
