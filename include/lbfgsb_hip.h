@@ -76,9 +76,10 @@ enum {
                                 its variables are fixed at their bounds.  Such calls are detected
                                 and counted (lbfgsb_hip_tie_splits).  With this flag they are
                                 replayed from the start of the walk in the reference's own order:
-                                all breakpoint times travel to the host (O(n) bytes + an O(n) heap
-                                build), so the active set equals the reference's bit for bit.
-                                Single-rank contexts. */
+                                all breakpoint times travel to the host of every rank (O(n) bytes +
+                                an O(n) heap build; every rank pops the same replicated heap and
+                                gathers the records of the rows it owns), so the active set equals
+                                the reference's bit for bit.  n_global < 2^32. */
 };
 
 /* -------------------------------------------------------------------------

@@ -299,7 +299,8 @@ class Solver final : public lbfgsb_hip_ctx {
     // replayed on the host over ALL breakpoints; records are gathered in that order
     bool exact = false;
     std::vector<double> ht;       // heap keys   (t of hpsolb, 0-based)
-    std::vector<uint32_t> hio;    // heap values (iorder: local rows)
+    std::vector<uint32_t> hio;    // heap values (iorder: GLOBAL rows; < 2^32 checked by the caller)
+    std::vector<int64_t> hrow0;   // first global row of every rank (+ nglob at the end)
     int64_t hleft = 0;            // nleft of the reference's walk for the NEXT pop
     bool hbuilt = false;
     int64_t hibkmin = -1;
@@ -643,14 +644,53 @@ class Solver final : public lbfgsb_hip_ctx {
     pv.exact = true;
     pv.ht.clear(), pv.hio.clear();
     const double inf = std::numeric_limits<double>::infinity();
-    double bk = 0.0;
-    for (int64_t i = 0; i < n; ++i) {  // the list of :1306-1322: variables with a finite breakpoint
-      const double t = (double)tb[(size_t)i];
-      if (!(t >= 0.0) || t == inf) continue;
-      pv.ht.push_back(t);
-      pv.hio.push_back((uint32_t)i);
-      if (pv.ht.size() == 1 || t < bk) bk = t, pv.hibkmin = (int64_t)pv.ht.size() - 1;
+    // every rank's breakpoint times, in global variable order (ranks own ascending row blocks)
+    std::vector<double> tall;
+    std::vector<int64_t> cnt(nranks, n);
+    pv.hrow0.assign((size_t)nranks + 1, 0);
+    int64_t nmax = n;
+    if (nranks > 1) {
+      CHK(put_header((double)n, (double)row0));
+      CHK(exchange(2));
+      nmax = 0;
+      for (int rk = 0; rk < nranks; ++rk) {
+        cnt[rk] = (int64_t)h_msg_all[2 * (size_t)rk];
+        pv.hrow0[rk] = (int64_t)h_msg_all[2 * (size_t)rk + 1];
+        nmax = std::max(nmax, cnt[rk]);
+      }
+      std::vector<double> mine((size_t)nmax, -1.0);
+      for (int64_t i = 0; i < n; ++i) mine[(size_t)i] = (double)tb[(size_t)i];
+      double *dsend = nullptr, *drecv = nullptr;
+      HIPCHK(hipMalloc(&dsend, (size_t)nmax * sizeof(double)));
+      if (hipMalloc(&drecv, (size_t)nmax * nranks * sizeof(double)) != hipSuccess) {
+        (void)hipFree(dsend);
+        return fail(LBFGSB_E_NOGPU, "exact tie order: no memory for the gathered breakpoint times");
+      }
+      tall.resize((size_t)nmax * nranks);
+      int rc = 0;
+      if (hipMemcpy(dsend, mine.data(), (size_t)nmax * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(LBFGSB_E_NOGPU, "exact tie order: upload failed");
+      if (!rc) rc = allgather_big(dsend, drecv, (size_t)nmax);
+      if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = fail(LBFGSB_E_NOGPU, "exact tie order: sync");
+      if (!rc && hipMemcpy(tall.data(), drecv, tall.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(LBFGSB_E_NOGPU, "exact tie order: download failed");
+      (void)hipFree(dsend), (void)hipFree(drecv);
+      if (rc) return rc;
+    } else {
+      pv.hrow0[0] = row0;
+      tall.resize((size_t)n);
+      for (int64_t i = 0; i < n; ++i) tall[(size_t)i] = (double)tb[(size_t)i];
     }
+    pv.hrow0[nranks] = nglob;
+    double bk = 0.0;
+    for (int rk = 0; rk < nranks; ++rk)
+      for (int64_t i = 0; i < cnt[rk]; ++i) {  // the list of :1306-1322: variables with a finite breakpoint
+        const double t = tall[(size_t)rk * (size_t)nmax + (size_t)i];
+        if (!(t >= 0.0) || t == inf) continue;
+        pv.ht.push_back(t);
+        pv.hio.push_back((uint32_t)(pv.hrow0[rk] + i));
+        if (pv.ht.size() == 1 || t < bk) bk = t, pv.hibkmin = (int64_t)pv.ht.size() - 1;
+      }
     pv.hleft = (int64_t)pv.ht.size();
     pv.hbuilt = false;
     pv.have = true, pv.full = true;
@@ -658,7 +698,7 @@ class Solver final : public lbfgsb_hip_ctx {
     pv.M.clear();
     pv.mpos = pv.safe_end = 0;
     pv.more_anywhere = pv.hleft > 0;
-    pv.taken.assign(1, 0);
+    pv.taken.assign(nranks, 0);
     pv.next_chunk = 1;  // the first record is the scan's minimum itself
     return 0;
   }
@@ -667,14 +707,17 @@ class Solver final : public lbfgsb_hip_ctx {
     const uint32_t chunk_cap = (uint32_t)std::min<size_t>((msg_len - 2) / (size_t)recl, CHUNK_MAX);
     const uint32_t want = std::min<uint32_t>(pv.next_chunk, chunk_cap);
     pv.next_chunk = std::min<uint32_t>(std::max<uint32_t>(pv.next_chunk, 16) * 4, chunk_cap);
+    // the next `want` pops of the reference's walk (every rank pops the same replicated heap);
+    // each rank gathers the records of the rows it owns, in that order
     std::vector<uint64_t> hk;
     std::vector<uint32_t> hi;
+    std::vector<int> owner;
     const int64_t nbreak = (int64_t)pv.ht.size();
-    while (hk.size() < want && pv.hleft > 0) {
+    while (owner.size() < want && pv.hleft > 0) {
       double tj;
-      uint32_t row;
+      uint32_t grow;
       if (pv.hleft == nbreak) {  // iter == 1 (:1384-1389)
-        tj = pv.ht[(size_t)pv.hibkmin], row = pv.hio[(size_t)pv.hibkmin];
+        tj = pv.ht[(size_t)pv.hibkmin], grow = pv.hio[(size_t)pv.hibkmin];
       } else {
         if (!pv.hbuilt) {  // iter == 2: the last entry replaces the used one (:1391-1398)
           if (pv.hibkmin != nbreak - 1) {
@@ -684,31 +727,41 @@ class Solver final : public lbfgsb_hip_ctx {
         }
         lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio.data(), pv.hbuilt ? 1 : 0);
         pv.hbuilt = true;
-        tj = pv.ht[(size_t)pv.hleft - 1], row = pv.hio[(size_t)pv.hleft - 1];
+        tj = pv.ht[(size_t)pv.hleft - 1], grow = pv.hio[(size_t)pv.hleft - 1];
       }
       pv.hleft--;
-      uint64_t bits;
-      std::memcpy(&bits, &tj, 8);
-      hk.push_back(bits);
-      hi.push_back(row);
+      const int rk = (int)(std::upper_bound(pv.hrow0.begin(), pv.hrow0.end(), (int64_t)grow) -
+                           pv.hrow0.begin()) - 1;
+      owner.push_back(rk);
+      if (rk == rank) {
+        uint64_t bits;
+        std::memcpy(&bits, &tj, 8);
+        hk.push_back(bits);
+        hi.push_back((uint32_t)((int64_t)grow - row0));
+      }
     }
-    const uint32_t len = (uint32_t)hk.size();
+    const uint32_t len = (uint32_t)owner.size(), own = (uint32_t)hk.size();
     pv.M.clear();
     pv.mpos = pv.safe_end = 0;
     pv.more_anywhere = pv.hleft > 0;
-    pv.taken.assign(1, 0);
+    pv.taken.assign(nranks, 0);
     pv.raw = nullptr;
     if (len == 0) return 0;
-    HIPCHK(hipMemcpyAsync(keys[0], hk.data(), (size_t)len * 8, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(idx[0], hi.data(), (size_t)len * 4, hipMemcpyHostToDevice, stream));
-    lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], len, row0, x, l, u, g, W(), head, col, r, d_src(), pend,
-                                 d_msg + 2);
-    CHK(put_header((double)len, (double)pv.hleft));
-    CHK(exchange(2 + (size_t)len * recl));  // (also orders the pageable uploads above)
+    if (own) {
+      HIPCHK(hipMemcpyAsync(keys[0], hk.data(), (size_t)own * 8, hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(idx[0], hi.data(), (size_t)own * 4, hipMemcpyHostToDevice, stream));
+      lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], own, row0, x, l, u, g, W(), head, col, r, d_src(), pend,
+                                   d_msg + 2);
+    }
+    CHK(put_header((double)own, (double)pv.hleft));
+    const size_t count = 2 + (size_t)len * recl;
+    CHK(exchange(count));  // (also orders the pageable uploads above)
     pv.M.resize(len);
+    std::vector<uint32_t> cur(nranks, 0);
     for (uint32_t k = 0; k < len; ++k) {
-      const double *rec = h_msg_all + 2 + (size_t)k * recl;
-      pv.M[k] = MRec{rec[0], (int64_t)rec[1], 0, rec};
+      const int rk = owner[k];
+      const double *rec = h_msg_all + (size_t)rk * count + 2 + (size_t)cur[rk]++ * recl;
+      pv.M[k] = MRec{rec[0], (int64_t)rec[1], rk, rec};
     }
     pv.safe_end = len;
     return 0;
@@ -1176,8 +1229,13 @@ class Solver final : public lbfgsb_hip_ctx {
     // (hpsolb :2079); the two differ in effect only if the walk ends INSIDE such a group.  That
     // is detected (tie_split) and counted; with LBFGSB_F_EXACT_TIES the walk is then replayed from
     // its start in the reference's own order (exact_init / refill_exact).
-    const bool can_exact = (flags & LBFGSB_F_EXACT_TIES) && nranks == 1 && !comm;
-    bool exact_run = can_exact && print_level >= 99;  // (a replay would print the walk twice)
+    const bool can_exact = (flags & LBFGSB_F_EXACT_TIES) && nglob < 0xffffffffll;
+    // (a replay would print the walk twice; LBFGSB_EXACT_ALWAYS=1: every walk in that order, for tests)
+    static const bool exact_always = [] {
+      const char *e = std::getenv("LBFGSB_EXACT_ALWAYS");
+      return e && e[0] == '1';
+    }();
+    bool exact_run = can_exact && (print_level >= 99 || exact_always);
     std::vector<double> p_start(p, p + col2);
     const double f1_start = f1, f2_start = f2, dtm_start = dtm;
     for (;;) {  // at most two trips: the second one in exact order

@@ -29,7 +29,8 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     dev = torch.device("cuda", 0)
     row0, n_loc = lbfgsb_amd.block_partition(n, world, rank)
     sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=0,
-                                  parallel_gcp=(variant in ("pgcp", "pgcp2")))
+                                  parallel_gcp=(variant in ("pgcp", "pgcp2")),
+                                  exact_ties=(variant == "symx"))
     if mode == "gloo":
         lbfgsb_amd.attach_host_group(sol, rank, world)
     elif mode == "rccl1":
@@ -45,6 +46,8 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     two_scale = None
     if variant == "pgcp2":
         p, two_scale = two_scale_problem(po, n, m)
+    elif variant in ("sym", "symx"):
+        p, two_scale = symmetric_problem(po, n, m)
     elif variant == "rosen":
         p = po.problem_rosenbrock(n, m, factr=0.0, pgtol=0.0)
     else:
@@ -82,7 +85,7 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump({"rows": rows, "task": sol.task_s, "x": np.concatenate(xs).tolist(),
-                       "stats": sol.stats()}, fh)
+                       "stats": sol.stats(), "tie_splits": sol.tie_splits()}, fh)
     sol.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -103,6 +106,27 @@ def two_scale_problem(po, n, m):
         g[:] = eps * a[lo:hi] * d
         return float(0.5 * eps * np.sum(a[lo:hi] * d * d))
     p = po.Problem("two_scale", n, m, np.zeros(n), -np.ones(n), np.ones(n), np.full(n, 2, np.int32),
+                   0.0, 0.0, fg, np.float64)
+    return p, fg
+
+
+def symmetric_problem(po, n, m):
+    """Separable quadratic made of 8 exact copies of the same n/8 variables (copy k of variable b
+    is row k * (n/8) + b): whole groups of EQUAL breakpoints stay alive over many iterations, and
+    the members of a group sit on different ranks."""
+    copies = 8
+    base = n // copies
+    assert base * copies == n
+    b = np.arange(n) % base
+    a = 1.0 + 99.0 * ((7919 * (b + 1)) % 10007) / 10006.0
+    c = -2.0 + 4.0 * ((104729 * (b + 1)) % 100003) / 100002.0
+
+    def fg(x, g, lo=0, hi=None):
+        hi = n if hi is None else hi
+        d = x - c[lo:hi]
+        g[:] = a[lo:hi] * d
+        return float(0.5 * np.sum(a[lo:hi] * d * d))
+    p = po.Problem("sym_quadratic", n, m, np.zeros(n), -np.ones(n), np.ones(n), np.full(n, 2, np.int32),
                    0.0, 0.0, fg, np.float64)
     return p, fg
 
