@@ -132,7 +132,9 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   constexpr int X = 4 * MC + 9;                // first extra slot
   constexpr int NA = 4 * MC + 11 + NX;
   constexpr int IMIN = X + NX, IMAX = X + NX + 1;  // bkmin, |proj g|
-  constexpr int V = RowsPerAcc<T, MC, NA>::V;
+  // (fp32, MC = 10 with the new-row sums: 4 rows per lane after all -- the 16-byte loads are worth
+  //  more than the second wave the 512 registers cost: 1.88 -> 1.65 ms at n = 1e8)
+  constexpr int V = (sizeof(T) == 4 && MC == 10 && NEWROW) ? 4 : RowsPerAcc<T, MC, NA>::V;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
