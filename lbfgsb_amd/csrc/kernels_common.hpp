@@ -3,19 +3,21 @@
 //
 // Shape of every kernel: tall-skinny, HBM-bound, no reuse.  One lane owns V
 // consecutive rows (16 B per array per load, dwordx4), grid-stride over rows,
-// <= 2048 workgroups of 4 wave64.  The correction-pair matrices Ws, Wy are
-// column-major with a 256-byte aligned leading dimension, so lane i of a wave
-// reads 16 B at column_base + 16*i: every wave-instruction is one fully
-// coalesced 1 KiB request per column.  Reductions: per-lane fp64 accumulators
-// -> wave shuffle -> LDS across the 4 waves -> one partial per workgroup ->
-// fixed-order finalize kernel (deterministic; no float atomics).  2m <= 64
-// columns is far too thin for MFMA: the flop/byte ratio is <= 2 (fp64), the
-// machine balance ~10, so the roofline is HBM bandwidth.
+// <= 2048 workgroups of 4 wave64 (768 for the passes over W: what is resident).
+// The correction-pair matrices Ws, Wy are column-major with a 256-byte aligned
+// leading dimension, so lane i of a wave reads 16 B at column_base + 16*i: every
+// wave-instruction is one fully coalesced 1 KiB request per column.  Reductions:
+// per-lane fp64 accumulators -> wave shuffle -> LDS across the 4 waves -> one
+// partial per workgroup -> fixed-order finalize kernel (deterministic; no float
+// atomics).  2m <= 64 columns is far too thin for MFMA: the flop/byte ratio is
+// <= 2 (fp64), the machine balance ~10, so the roofline is HBM bandwidth.
 //
-// Column loops are unrolled to a compile-time MAXC; logical columns >= col are
-// redirected to logical column 0 (an L1/L2 hit, no HBM traffic) and their
-// results discarded, which keeps every load unconditional and in flight
-// together.
+// Column loops are unrolled to a compile-time MAXC; logical columns >= col load a
+// 256-byte zero buffer (WStore::zero: an L1/L2 hit, no HBM traffic) and contribute
+// nothing, which keeps every load unconditional and in flight together.  The two
+// passes of the steady-state iteration (k_update.hip, k_subsm.hip) and the
+// three-pass fallback (k_cmprlb.hip) schedule their loads themselves: for_rows_raw
+// in device_util.hpp, DESIGN.md section 4.
 //
 // kernels_common.hpp -- pieces shared by the kernel translation units (k_*.hip): launch-size
 // helpers, the column-count dispatch macros, the circular column addressing of W, the pending
