@@ -17,8 +17,12 @@ def libs(oracle_built):
     out = os.path.join(HERE, "_build")
     os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libhost_shim.so")
-    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
-                           os.path.join(HERE, "host_shim.cpp"), "-o", so])
+    # LBFGSB_TEST_SANITIZE=1: the same tests with UBSan on the host algebra (CPU build only; GPU
+    # sanitizers are not available on the pool)
+    san = (["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-g"]
+           if os.environ.get("LBFGSB_TEST_SANITIZE") == "1" else [])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"] + san +
+                          [os.path.join(HERE, "host_shim.cpp"), "-o", so])
     hd = C.CDLL(so)
     orc = oracle_built.Engine("oracle").lib
     return hd, orc
