@@ -127,6 +127,9 @@ int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar,
  *   - lsave[4] are int32 0/1, isave[44] int32, dsave[29] double, with the
  *     reference's meaning slot for slot (src/lbfgsb.f90:188-242).
  * The caller evaluates f,g on the device whenever task(1:2)=='FG'.
+ * l, u and nbd must not change between task='START' and the end of the run (the
+ * context keeps a packed one-byte copy of nbd for its passes over W; it is
+ * refreshed on START, after import_state and when the nbd POINTER changes).
  * ------------------------------------------------------------------------- */
 int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
                           const int32_t *nbd, double *f, void *g, double factr, double pgtol,
