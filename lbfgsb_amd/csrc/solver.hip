@@ -2041,7 +2041,8 @@ class Solver final : public lbfgsb_hip_ctx {
         const int NX = lbk::update_scan_extra(c2 - 1, nr_flag(c2));
         clk_begin(1);
         q.res_off = fo;
-        const double chi = spec_hi(cnstnd);
+        // (the MC = 20 instantiation with the new-row sums has no registers for the hand-over)
+        const double chi = (nr_flag(c2) && lbk::maxc_for(c2 - 1) > 10) ? -1.0 : spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd8, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
                                    (T *)nullptr, W(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count);
@@ -2455,7 +2456,7 @@ class Solver final : public lbfgsb_hip_ctx {
           lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
       } else {
         clk_begin(1);
-        const double chi = spec_hi(cnstnd);
+        const double chi = (nr_flag(col) && lbk::maxc_for(col - 1) > 10) ? -1.0 : spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, l, u, nbd8, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
                                    (T *)nullptr, W(), head, col, itail, 0, 1, nr_flag(col), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count);

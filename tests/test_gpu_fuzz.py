@@ -48,10 +48,17 @@ def make(po, seed, nmax, mlo, mhi):
     return po.Problem("fuzz%d" % seed, n, m, x0, l, u, nbd, factr, pgtol, fg, np.float64)
 
 
-@pytest.mark.parametrize("first,count,nmax,mlo,mhi", [(0, 120, 400, 1, 13), (5000, 40, 3000, 11, 33)])
-def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi):
+@pytest.mark.parametrize("first,count,nmax,mlo,mhi,switch", [
+    (0, 120, 400, 1, 13, None), (5000, 40, 3000, 11, 33, None),
+    # the measurement switches select fallback paths that must stay correct: the candidate
+    # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
+    (7000, 40, 1500, 1, 25, "LBFGSB_SPEC_CAPTURE=1"), (7100, 40, 1500, 1, 25, "LBFGSB_TWO_PASS=0"),
+    (7200, 40, 1500, 1, 25, "LBFGSB_LEAN=0")])
+def test_random_problems_against_oracle(oracle_built, monkeypatch, first, count, nmax, mlo, mhi, switch):
     po = oracle_built
     import lbfgsb_amd as la
+    if switch:
+        monkeypatch.setenv(*switch.split("="))
 
     def row(s):
         return (s.task_s[:12], int(s.isave[29]), int(s.isave[33]), int(s.isave[32]), int(s.isave[37]),
