@@ -152,3 +152,56 @@ def test_random_problems_parallel_gcp_search(oracle_built, monkeypatch):
             (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
     assert searched >= 60           # the sort + scan path really ran (full sorts are its signature)
     assert late <= 0.2 * count
+
+
+def test_random_problems_exact_tie_order(oracle_built, monkeypatch):
+    """LBFGSB_F_EXACT_TIES with LBFGSB_EXACT_ALWAYS=1: EVERY walk of 40 random problems is replayed
+    in the order of the reference's heap (all breakpoint times on the host, hpsolb, records
+    gathered in pop order) instead of the device's (t, index) order.  Same bar as the main
+    differential test: every NEW_X row (iteration, nfg, nseg, nfree; f to 1e-8) equals the
+    oracle's; a run may part ways late only at rounding level."""
+    po = oracle_built
+    import torch
+    import lbfgsb_amd as la
+    monkeypatch.setenv("LBFGSB_EXACT_ALWAYS", "1")
+    late, count = 0, 40
+    for seed in range(9500, 9500 + count):
+        p = make(po, seed, 1500, 1, 13)
+        ro = []
+        so = po.run(po.Engine("oracle"), p, max_iter=30,
+                    snapshot=lambda k, s: ro.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                     int(s.isave[37]), float(s.f[0])))
+                    if s.task_s.startswith("NEW_X") else None)
+        sol = la.DeviceSolver(p.n, p.m, exact_ties=True)
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        rg = []
+        for _ in range(100000):
+            t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+            elif t.startswith("NEW_X"):
+                rg.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                           float(sol.f[0])))
+                if sol.isave[29] >= 30:
+                    break
+            else:
+                break
+        fgp = float(sol.f[0])
+        sol.close()
+        k = 0
+        while (k < min(len(ro), len(rg)) and ro[k][:4] == rg[k][:4]
+               and abs(ro[k][4] - rg[k][4]) <= 1e-8 * max(1.0, abs(ro[k][4]))):
+            k += 1
+        if k == len(ro) == len(rg):
+            continue
+        late += 1
+        fo = float(so.f[0])
+        assert k >= 0.4 * len(ro) and abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), \
+            (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
+    assert late <= 0.2 * count
