@@ -86,3 +86,15 @@ def test_no_gpu_means_loud_failure_not_fallback():
         s = po.State.fresh(p)
         lbfgsb_amd.setulb(10, 3, s.x, p.l, p.u, p.nbd, s.f, s.g, 0.0, 0.0, s.wa, s.iwa, s.task, -1,
                           s.csave, s.lsave, s.isave, s.dsave)
+
+
+def test_header_and_c_example_are_plain_c():
+    """include/lbfgsb_hip.h is the boundary a C caller compiles against: it and the plain-C twin of
+    the reference's driver1 (examples/driver1.c) must be valid C99 (no C++-isms in the header)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    subprocess.check_call([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "driver1.c")])
