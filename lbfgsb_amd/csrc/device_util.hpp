@@ -315,6 +315,36 @@ __device__ __forceinline__ void raw_geti(const RawReg<W> &r, const int8_t *, int
 template <typename E, int W>
 using RawOf = RawReg<(int)sizeof(E) * W>;
 
+// ---- lane pairs (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS traffic ----
+__device__ __forceinline__ int pair_xchg(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ double pair_xchg(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)pair_xchg((int)b), hi = (unsigned)pair_xchg((int)(b >> 32));
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int BYTES>
+__device__ __forceinline__ RawReg<BYTES> raw_xchg(const RawReg<BYTES> &a) {  // the neighbour's image
+  RawReg<BYTES> o;
+  if constexpr (BYTES == 16)
+    o.v = i32x4_t{pair_xchg(a.v.x), pair_xchg(a.v.y), pair_xchg(a.v.z), pair_xchg(a.v.w)};
+  else if constexpr (BYTES == 8)
+    o.v = i32x2_t{pair_xchg(a.v.x), pair_xchg(a.v.y)};
+  else
+    o.v = pair_xchg(a.v);
+  return o;
+}
+template <int BYTES>
+__device__ __forceinline__ RawReg<BYTES> raw_sel(bool c, const RawReg<BYTES> &a, const RawReg<BYTES> &b) {
+  RawReg<BYTES> o;  // c ? a : b, word by word (static register indices on both sides)
+  if constexpr (BYTES == 16)
+    o.v = i32x4_t{c ? a.v.x : b.v.x, c ? a.v.y : b.v.y, c ? a.v.z : b.v.z, c ? a.v.w : b.v.w};
+  else if constexpr (BYTES == 8)
+    o.v = i32x2_t{c ? a.v.x : b.v.x, c ? a.v.y : b.v.y};
+  else
+    o.v = c ? a.v : b.v;
+  return o;
+}
+
 // rows per lane for kernels unrolled to MC column pairs: 16 B per lane per array, halved
 // for MC >= 20 so that the 2*MC operand values of a row group still fit the register file
 template <typename T, int MC>

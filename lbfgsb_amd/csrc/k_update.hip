@@ -120,7 +120,15 @@ struct UpdScanTrip {
 // over W.  Extra sum slots, X = 4 MC + 9:  [X, X+MC) sum_free y Wy_j | [X+MC, ..) sum_act s Ws_j |
 // [X+2MC, ..) sum_act s Wy_j | [X+3MC, ..) sum_free Ws_j y | [X+4MC ..+4) sum_free y y,
 // sum_act s s, sum_act s y, sum_free s y   (y, s in their stored form); min and max follow.
-template <typename T, int MC, bool NT, bool PIPE, bool NEWROW>
+// PAIR (MC = 20 with the new-row sums; used for fp64): the 8 sums per column are what fills the register
+// file (175 fp64 accumulators per lane), and a kernel that large runs one wave per SIMD with a
+// single trip in flight.  Neighbouring lanes therefore SHARE the per-column accumulators: the even
+// lane sums columns [0, 10), the odd lane columns [10, 20), each over the rows of BOTH lanes -- the
+// operands of the other lane's rows come over by DPP (its row scalars once per trip, its column
+// values as register images) -- which leaves room for the second trip in flight.  The caller
+// passes a row count that is a multiple of 2 V (pairs are always complete) and runs the plain
+// instantiation on the few rows that remain.
+template <typename T, int MC, bool NT, bool PIPE, bool NEWROW, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const nb_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
@@ -135,10 +143,18 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   // (fp32, MC = 10 with the new-row sums: 4 rows per lane after all -- the 16-byte loads are worth
   //  more than the second wave the 512 registers cost: 1.88 -> 1.65 ms at n = 1e8)
   constexpr int V = (sizeof(T) == 4 && MC == 10 && NEWROW) ? 4 : RowsPerAcc<T, MC, NA>::V;
+  static_assert(!PAIR || (NEWROW && MC % 2 == 0), "PAIR: the new-row instantiation, even MC");
+  constexpr int H = MC / 2;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
   acc[IMIN] = LB_INF;
+  double accp[PAIR ? 8 : 1][PAIR ? H : 1];  // PAIR: this lane's half of the columns, 8 sums each
+#pragma unroll
+  for (int a = 0; a < (PAIR ? 8 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < (PAIR ? H : 1); ++b) accp[a][b] = 0.0;
+  const bool hi = threadIdx.x & 1;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
   const UpdScanCtx<T> ctx{x, l, u, g, r, d, ws, wy, zero, nbd, iwhere, ldw, m, head, nold};
   for_rows_raw<UpdScanTrip<T, MC, V, NT>, UpdScanTrip<T, MC, 1, NT>, V, PIPE, 0>(
@@ -225,6 +241,48 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         acc[X + 4 * MC + 3] = __builtin_fma(fr ? sst : 0.0, yst, acc[X + 4 * MC + 3]);
       }
     }
+    if constexpr (PAIR) {
+      double pdv[W], png[W], pyf[W], psa[W];  // the neighbour's rows
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        pdv[k] = pair_xchg(dv[k]), png[k] = pair_xchg(ng[k]);
+        pyf[k] = pair_xchg(yf[k]), psa[k] = pair_xchg(sa[k]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < H; ++jj) {
+        // own rows: this lane's half of the columns; the half it does not sum goes to the neighbour
+        const RawOf<T, W> ma = raw_sel(hi, tr.ra[H + jj], tr.ra[jj]), mb = raw_sel(hi, tr.rb[H + jj], tr.rb[jj]);
+        const RawOf<T, W> ta = raw_xchg(raw_sel(hi, tr.ra[jj], tr.ra[H + jj]));
+        const RawOf<T, W> tb_ = raw_xchg(raw_sel(hi, tr.rb[jj], tr.rb[H + jj]));
+        double aj[W], bj[W], paj[W], pbj[W];
+        raw_get_col<W, false>(ma, (const T *)nullptr, aj);
+        raw_get_col<W, false>(mb, (const T *)nullptr, bj);
+        raw_get_col<W, false>(ta, (const T *)nullptr, paj);
+        raw_get_col<W, false>(tb_, (const T *)nullptr, pbj);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          accp[0][jj] += dv[k] * aj[k];
+          accp[1][jj] += bj[k] * dv[k];
+          accp[2][jj] += aj[k] * ng[k];
+          accp[3][jj] += bj[k] * ng[k];
+          accp[4][jj] = __builtin_fma(yf[k], aj[k], accp[4][jj]);
+          accp[5][jj] = __builtin_fma(sa[k], bj[k], accp[5][jj]);
+          accp[6][jj] = __builtin_fma(sa[k], aj[k], accp[6][jj]);
+          accp[7][jj] = __builtin_fma(bj[k], yf[k], accp[7][jj]);
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          accp[0][jj] += pdv[k] * paj[k];
+          accp[1][jj] += pbj[k] * pdv[k];
+          accp[2][jj] += paj[k] * png[k];
+          accp[3][jj] += pbj[k] * png[k];
+          accp[4][jj] = __builtin_fma(pyf[k], paj[k], accp[4][jj]);
+          accp[5][jj] = __builtin_fma(psa[k], pbj[k], accp[5][jj]);
+          accp[6][jj] = __builtin_fma(psa[k], paj[k], accp[6][jj]);
+          accp[7][jj] = __builtin_fma(pbj[k], pyf[k], accp[7][jj]);
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
       double aj[W], bj[W];
@@ -290,6 +348,22 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
     if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
   });
+  if constexpr (PAIR) {
+    // each lane holds the sums of its half of the columns: zeros for the other half, then the
+    // ordinary fixed-order reduction over all lanes
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      const double z = 0.0;
+      acc[jj] = hi ? z : accp[0][jj], acc[H + jj] = hi ? accp[0][jj] : z;
+      acc[MC + jj] = hi ? z : accp[1][jj], acc[MC + H + jj] = hi ? accp[1][jj] : z;
+      acc[2 * MC + 1 + jj] = hi ? z : accp[2][jj], acc[2 * MC + 1 + H + jj] = hi ? accp[2][jj] : z;
+      acc[3 * MC + 2 + jj] = hi ? z : accp[3][jj], acc[3 * MC + 2 + H + jj] = hi ? accp[3][jj] : z;
+      acc[X + jj] = hi ? z : accp[4][jj], acc[X + H + jj] = hi ? accp[4][jj] : z;
+      acc[X + MC + jj] = hi ? z : accp[5][jj], acc[X + MC + H + jj] = hi ? accp[5][jj] : z;
+      acc[X + 2 * MC + jj] = hi ? z : accp[6][jj], acc[X + 2 * MC + H + jj] = hi ? accp[6][jj] : z;
+      acc[X + 3 * MC + jj] = hi ? z : accp[7][jj], acc[X + 3 * MC + H + jj] = hi ? accp[7][jj] : z;
+    }
+  }
   block_reduce_store<NA>(acc, X + NX, 1, 1, part, MAX_BLOCKS);
 }
 template <typename T>
@@ -312,16 +386,56 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                                         itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap,     \
                                         ccount, q.d_part);                                           \
                    }))
-  // (MC = 20 with the 84 extra sums does not fit the register file: those shapes keep the
-  //  three-pass iteration)
   const int mc = maxc_for(nold);
-  if (update_scan_extra(nold, newrow))
+  // MC = 20 with the new-row sums: lane pairs share the per-column accumulators (PAIR), which
+  // leaves room for the second trip in flight.  Pairs must be complete: the pair kernel takes the
+  // largest multiple of 2 V rows, the plain instantiation the few rows that remain (as one more
+  // workgroup: its partials go to column `gr` of the partial-sum matrix)
+  // Measured (n = 5e7 / 1e8, m = 20): fp64 3.04 -> 2.78 ms with two trips in flight; fp32 is
+  // bound by instruction issue, not by latency (twice the rows per byte, plus the widening), and
+  // loses with the exchange on top: 3.57 -> 3.96 / 4.68 ms -- plain kernel there.
+  // LBFGSB_PAIR=0: off; 1: on, one trip in flight; 2: two trips
+  static const int pair_env = [] {
+    const char *e = std::getenv("LBFGSB_PAIR");
+    return e ? std::atoi(e) : -1;
+  }();
+  const int pair_mode = pair_env >= 0 ? pair_env : (sizeof(T) == 8 ? 2 : 0);
+  int nblocks = gr;
+  if (update_scan_extra(nold, newrow) && mc == 20 && pair_mode > 0) {
+    constexpr int MC = 20;
+    constexpr int VP = RowsPerAcc<T, MC, 4 * MC + 11 + 4 * MC + 4>::V;
+    const int64_t n_main = n / (2 * VP) * (2 * VP), n_rest = n - n_main;
+#define LB_PAIR(NTV, PIPEV)                                                                          \
+  hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PIPEV, true, true>), dim3(gr), dim3(BLOCK), 0,  \
+                     q.stream, n_main, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy,  \
+                     w.zero, w.ld, w.m, head, nold, itail, store_pair, store_iw, -1.0, ckeys, cidx,   \
+                     ccap, ccount, q.d_part)
+    if (n_main > 0) {
+      if (q.nt) {
+        if (pair_mode >= 2) LB_PAIR(true, true); else LB_PAIR(true, false);
+      } else {
+        if (pair_mode >= 2) LB_PAIR(false, true); else LB_PAIR(false, false);
+      }
+    }
+#undef LB_PAIR
+    if (n_rest > 0 || n_main == 0) {
+      const int64_t o = n_main;
+      hipLaunchKernelGGL((update_scan_kernel<T, MC, false, false, true>), dim3(1), dim3(BLOCK), 0, q.stream,
+                         n_rest, x + o, l + o, u + o, nbd + o, g + o, r + o, d + o, dimpl, stp, iwhere + o,
+                         tbrk ? tbrk + o : tbrk, w.ws + o, w.wy + o, w.zero, w.ld, w.m, head, nold, itail,
+                         store_pair, store_iw, -1.0, ckeys, cidx, ccap, ccount,
+                         q.d_part + (n_main > 0 ? gr : 0));
+      nblocks = n_main > 0 ? gr + 1 : 1;
+      q.launches++;
+    }
+  } else if (update_scan_extra(nold, newrow)) {
     LB_UPDSCAN(true);
-  else
+  } else {
     LB_UPDSCAN(false);
+  }
 #undef LB_UPDSCAN
   q.launches++;
-  launch_finalize(q, gr, 4 * mc + 9 + update_scan_extra(nold, newrow), 1, 1);
+  launch_finalize(q, nblocks, 4 * mc + 9 + update_scan_extra(nold, newrow), 1, 1);
 }
 
 // =========================== explicit instantiations =========================
