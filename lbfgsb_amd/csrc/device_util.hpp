@@ -322,6 +322,14 @@ __device__ __forceinline__ double pair_xchg(double v) {
   const unsigned lo = (unsigned)pair_xchg((int)b), hi = (unsigned)pair_xchg((int)(b >> 32));
   return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
+__device__ __forceinline__ float pair_xchg(float v) {
+  return __builtin_bit_cast(float, pair_xchg(__builtin_bit_cast(int, v)));
+}
+// a double that is known to hold a value of T exactly travels as a T (one register for fp32)
+template <typename T>
+__device__ __forceinline__ double pair_xchg_as(double v) {
+  return (double)pair_xchg((T)v);
+}
 template <int BYTES>
 __device__ __forceinline__ RawReg<BYTES> raw_xchg(const RawReg<BYTES> &a) {  // the neighbour's image
   RawReg<BYTES> o;

@@ -120,7 +120,7 @@ struct UpdScanTrip {
 // over W.  Extra sum slots, X = 4 MC + 9:  [X, X+MC) sum_free y Wy_j | [X+MC, ..) sum_act s Ws_j |
 // [X+2MC, ..) sum_act s Wy_j | [X+3MC, ..) sum_free Ws_j y | [X+4MC ..+4) sum_free y y,
 // sum_act s s, sum_act s y, sum_free s y   (y, s in their stored form); min and max follow.
-// PAIR (MC = 20 with the new-row sums; used for fp64): the 8 sums per column are what fills the register
+// PAIR (MC = 20 with the new-row sums): the 8 sums per column are what fills the register
 // file (175 fp64 accumulators per lane), and a kernel that large runs one wave per SIMD with a
 // single trip in flight.  Neighbouring lanes therefore SHARE the per-column accumulators: the even
 // lane sums columns [0, 10), the odd lane columns [10, 20), each over the rows of BOTH lanes -- the
@@ -245,8 +245,9 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
       double pdv[W], png[W], pyf[W], psa[W];  // the neighbour's rows
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        pdv[k] = pair_xchg(dv[k]), png[k] = pair_xchg(ng[k]);
-        pyf[k] = pair_xchg(yf[k]), psa[k] = pair_xchg(sa[k]);
+        pdv[k] = pair_xchg(dv[k]);
+        png[k] = pair_xchg_as<T>(ng[k]);  // (-g, y and s as stored: values of T)
+        pyf[k] = pair_xchg_as<T>(yf[k]), psa[k] = pair_xchg_as<T>(sa[k]);
       }
 #pragma unroll
       for (int jj = 0; jj < H; ++jj) {
@@ -391,15 +392,15 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   // leaves room for the second trip in flight.  Pairs must be complete: the pair kernel takes the
   // largest multiple of 2 V rows, the plain instantiation the few rows that remain (as one more
   // workgroup: its partials go to column `gr` of the partial-sum matrix)
-  // Measured (n = 5e7 / 1e8, m = 20): fp64 3.04 -> 2.78 ms with two trips in flight; fp32 is
-  // bound by instruction issue, not by latency (twice the rows per byte, plus the widening), and
-  // loses with the exchange on top: 3.57 -> 3.96 / 4.68 ms -- plain kernel there.
+  // Measured (n = 5e7 / 1e8, m = 20), two trips in flight: fp64 3.04 -> 2.78 ms, fp32 3.55 -> 3.17 ms
+  // (the fp32 instantiation sits at 509 registers: with a single spilled register its scratch
+  // reloads, which return in order behind the loads in flight, undo the pipelining -- 4.68 ms).
   // LBFGSB_PAIR=0: off; 1: on, one trip in flight; 2: two trips
   static const int pair_env = [] {
     const char *e = std::getenv("LBFGSB_PAIR");
     return e ? std::atoi(e) : -1;
   }();
-  const int pair_mode = pair_env >= 0 ? pair_env : (sizeof(T) == 8 ? 2 : 0);
+  const int pair_mode = pair_env >= 0 ? pair_env : 2;
   int nblocks = gr;
   if (update_scan_extra(nold, newrow) && mc == 20 && pair_mode > 0) {
     constexpr int MC = 20;
