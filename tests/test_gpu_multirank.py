@@ -51,6 +51,8 @@ def oracle_rows(po, n, m, iters, mixed):
     (2, "gloo", 20011, 7, 8, True),       # ragged split, all four bound types
     (3, "gloo", 300000, 10, 3, False),    # iteration 1 walks ~293k breakpoints: full sort + merged chunks
     (4, "gloo", 10007, 5, 6, True),       # four ranks on one GPU, m = 5
+    (2, "gloo", 30011, 20, 26, True),     # m = 20 until the memory is full: the pair-shared update pass,
+                                          # its leftover rows, the closed form at col = 20, on 2 ranks
     (1, "rccl1", 50021, 5, 6, True),
 ])
 def test_sharded_trajectory_matches_oracle(oracle_built, tmp_path, world, mode, n, m, iters, mixed):
