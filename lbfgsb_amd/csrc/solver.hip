@@ -1750,7 +1750,7 @@ class Solver final : public lbfgsb_hip_ctx {
     if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
     // lean: the first trial step is 1 and x = z is stored by the pass, so neither z nor d = x - t
     // is written (5 store streams instead of 7); they stay implicit until ensure_d()
-    const bool lean = lean_on && ls_unit_step && cnstnd && !(flags & LBFGSB_F_MIRROR_INDEX);
+    const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass) && !(flags & LBFGSB_F_MIRROR_INDEX);
     clk_begin(2);
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, l, u, nbd8, iwhere, x, g, W(),
                                 head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d, t,
@@ -2029,7 +2029,9 @@ class Solver final : public lbfgsb_hip_ctx {
       // (read-only with the pair pending); g'd and |proj g| are two of its sums.  Contexts
       // that mirror the reference's arrays at every return keep iwhere untouched until the
       // update is real (iwhere_update_kernel at the NEW_X entry).
-      if (cnstnd && ifun == 1) {
+      // Unconstrained problems (two_pass): the same pass -- every row is free, its p = W'd is
+      // W'Z r itself (r = -g, c = 0), and the new pair needs no copy pass of its own.
+      if ((cnstnd || two_pass) && ifun == 1) {
         const int store_iw = (flags & LBFGSB_F_MIRROR_INDEX) ? 0 : 1;
         int c2, h2, it2;  // matupd's pointer update (:2303-2309), as if this trial is accepted
         if (iupdat + 1 <= m) {
@@ -2127,6 +2129,18 @@ class Solver final : public lbfgsb_hip_ctx {
       wrk = updatd;
       nseg = 0;
       pre_valid = false;
+      // no walk: the update pass's p = W'd over all rows IS W'Z r (subspace_closed_form with
+      // tsum = 0 and no cmprlb term), its new-row sums need no correction
+      closed_ok = false;
+      std::memset(nrc, 0, sizeof nrc);
+      if (scan.ready) {
+        for (int j = 0; j < col; ++j) {
+          p_fin[j] = scan.p[j];
+          p_fin[col + j] = theta != 1.0 ? theta * scan.p[col + j] : scan.p[col + j];  // :1337
+        }
+        closed_ok = true;
+        scan.ready = false;
+      }
     } else {
       cpu1 = now_s();
       CHK(cauchy(x, l, u, nbd, g, theta, col, head, sbgnrm, epsmch, nseg, info));
@@ -2153,7 +2167,7 @@ class Solver final : public lbfgsb_hip_ctx {
       int npre = 0;
       // (two-pass iteration: no cmprlb pass if the closed form applies -- decided for good
       //  once nfree is known, below)
-      const bool closed_cand = two_pass && closed_ok && cnstnd && col > 0 && col <= two_pass_maxcol &&
+      const bool closed_cand = two_pass && closed_ok && col > 0 && col <= two_pass_maxcol &&
                                (!updatd || (nrpre.valid && nrpre.col == col));
       if (col > 0 && !closed_cand) {
         lbk::Coef cf;
@@ -2243,7 +2257,7 @@ class Solver final : public lbfgsb_hip_ctx {
       }
       // closed form: only while the free variables are not a small remainder (S'ZZ'S comes
       // as S'S - S'AA'S)
-      const bool closed = two_pass && closed_ok && cnstnd && col <= two_pass_maxcol && !pre_valid &&
+      const bool closed = two_pass && closed_ok && col <= two_pass_maxcol && !pre_valid &&
                           (!updatd || (nrpre.valid && nrpre.col == col)) &&
                           nfree_g * 16 >= nglob;
       CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
@@ -2444,7 +2458,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     const int MCo = lbk::maxc_for(col - 1);
     double rr;
-    if (cnstnd) {
+    if (cnstnd || two_pass) {
       // the next loop trip starts with cauchy: do its n-loop in the same pass over W --
       // unless that pass already ran as the evaluation of the accepted trial point
       const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&

@@ -679,6 +679,46 @@ def test_headline_config_n1e8_fp64_anchors(env):
     assert rows2 == rows       # bit for bit, f and |proj g| included
 
 
+def test_unconstrained_problem_takes_the_two_pass_iteration(env):
+    """nbd = 0 everywhere (mainlb :607-611: no Cauchy search, z = x): the update pass is run for
+    unconstrained problems too -- its p = W'd over all rows IS W'Z r, the pair stays pending and
+    is committed by the subspace pass -- so the iteration is the same two passes over W.
+    Trajectory against the oracle: integer columns exactly, f to 1e-10, the closed form taken."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 200_003, 10, 25
+    base = po.problem_quadratic(n, m)
+    p = po.Problem("quad_unconstrained", n, m, base.x0, base.l, base.u, np.zeros(n, np.int32), 0.0, 0.0,
+                   base.fg, np.float64)
+    rows_o = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                int(s.isave[37]), float(s.f[0]))) if s.task_s.startswith("NEW_X") else None)
+    sol = la.DeviceSolver(n, m)
+    x = torch.from_numpy(p.x0.copy()).cuda()
+    g = torch.zeros_like(x)
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rows_g = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(0, x, g)
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                           float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    closed_steps, three_steps, _ = sol.path_counts()
+    sol.close()
+    assert len(rows_g) == len(rows_o)
+    for a, b in zip(rows_g, rows_o):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-10)
+    assert closed_steps >= len(rows_o) - 3, (closed_steps, three_steps)
+
+
 def test_full_size_rosenbrock_n1e6_against_oracle(env):
     """BASELINE.json configs[2] shape (extended Rosenbrock with box bounds, driver3 formulas) at
     n = 1e6, m = 10, on-device objective.  Iteration 1 fixes 999,999 variables in two massive
