@@ -1641,6 +1641,19 @@ class Solver final : public lbfgsb_hip_ctx {
   // below it (:1756-1793).  Equal to the sums over the rows up to reassociation -- and to the
   // rounding of z - x, which the row form carries at 1 ulp of x per row: the caller uses this
   // form only when neither the free set nor p is a small remainder of something much larger.
+  // ... which is the case while every stored s_i keeps at least 1e-5 of its squared norm on the free
+  // rows (variables that sit at a bound do not move: their part of s is zero unless they have
+  // just arrived, so a small free SET alone does not make the free PART small)
+  bool closed_form_safe(int col) const {
+    const double *WN1 = snd.data(), *SS = ss.data();
+    const int m2 = 2 * m;
+    for (int i = 0; i < col; ++i) {
+      const double tot = SS[(size_t)i + (size_t)i * m];
+      const double act = WN1[(size_t)(m + i) + (size_t)(m + i) * m2];
+      if (!(tot - act >= 1.0e-5 * tot)) return false;
+    }
+    return true;
+  }
   void subspace_closed_form(int col, double theta, double *wv) {
     const int m2 = 2 * m;
     lbh::Mat WN1{snd.data(), m2}, SY{sy.data(), m}, SS{ss.data(), m};
@@ -1729,6 +1742,22 @@ class Solver final : public lbfgsb_hip_ctx {
       CHK(formk_incremental(col, head, updatd, iupdat, nr, MC));
       formk_factor(col, theta, info);
       if (info != 0) return 0;
+    }
+    if (closed && !closed_form_safe(col)) {
+      // the free part of some s_i is a tiny remainder of the whole column: S'ZZ'S = S'S - S'AA'S
+      // would lose it to cancellation.  W'Z r from a pass over W after all (WN1 is complete: no
+      // new-row sums)
+      CHK(ensure_d(x));
+      clk_begin(0);
+      lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cm_cf, 0, r, d, pend);
+      clk_end(0);
+      CHK(fetch(2 * MC, 0, 0));
+      for (int i = 0; i < col; ++i) {
+        wv[i] = h_res[i];
+        wv[col + i] = theta * h_res[MC + i];
+      }
+      closed = false;
+      nclosed--, nthreepass++;
     }
     if (closed) subspace_closed_form(col, theta, wv);
     if (ipr >= 99) std::fprintf(rep.out, "\n----------------SUBSM entered-----------------\n\n");  // :2738
@@ -2255,11 +2284,10 @@ class Solver final : public lbfgsb_hip_ctx {
         sbtime += now_s() - cpu1;
         return again(flow);
       }
-      // closed form: only while the free variables are not a small remainder (S'ZZ'S comes
-      // as S'S - S'AA'S)
+      // closed form (subspace() itself checks, once WN1 is up to date, that S'ZZ'S = S'S - S'AA'S
+      // does not cancel)
       const bool closed = two_pass && closed_ok && col <= two_pass_maxcol && !pre_valid &&
-                          (!updatd || (nrpre.valid && nrpre.col == col)) &&
-                          nfree_g * 16 >= nglob;
+                          (!updatd || (nrpre.valid && nrpre.col == col));
       CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
                    pre_valid ? pre_res : nullptr, closed));
       pre_valid = false;

@@ -719,6 +719,57 @@ def test_unconstrained_problem_takes_the_two_pass_iteration(env):
     assert closed_steps >= len(rows_o) - 3, (closed_steps, three_steps)
 
 
+def test_few_free_variables_still_two_passes(env):
+    """A solution with ~1 % of the variables free (the minimiser of the other 99 % lies far outside
+    the box): the closed form for W'Z r is guarded by how much of each stored s_i lives on the free
+    rows -- not by how many rows are free -- and variables that sit at a bound do not move, so the
+    iteration stays at two passes.  Trajectory against the oracle: integers exactly, f to 1e-10."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 120_000, 8, 30
+    i = np.arange(1, n + 1)
+    a = 1.0 + 99.0 * ((7919 * i) % 10007) / 10006.0
+    c = np.where(i % 100 == 0, -0.5 + ((104729 * i) % 100003) / 100002.0, 5.0 + (i % 7))
+
+    def fg(x, g):
+        d = x - c
+        g[:] = a * d
+        return float(0.5 * np.sum(a * d * d))
+    p = po.Problem("mostly_active", n, m, np.zeros(n), -np.ones(n), np.ones(n), np.full(n, 2, np.int32),
+                   0.0, 0.0, fg, np.float64)
+    rows_o = []
+    po.run(po.Engine("oracle"), p, max_iter=iters,
+           snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                int(s.isave[37]), float(s.f[0]))) if s.task_s.startswith("NEW_X") else None)
+    assert rows_o[-1][3] <= n // 50            # few free variables indeed
+    sol = la.DeviceSolver(n, m)
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    g = torch.zeros_like(x)
+    l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+    nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    rows_g = []
+    while True:
+        t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if t.startswith("FG"):
+            xh = x.cpu().numpy()
+            gh = np.empty_like(xh)
+            sol.f[0] = fg(xh, gh)
+            g.copy_(torch.from_numpy(gh))
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                           float(sol.f[0])))
+            if sol.isave[29] >= iters:
+                break
+        else:
+            break
+    closed_steps, three_steps, _ = sol.path_counts()
+    sol.close()
+    assert len(rows_g) == len(rows_o)
+    for ra, rb in zip(rows_g, rows_o):
+        assert ra[:4] == rb[:4], (ra, rb)
+        assert ra[4] == pytest.approx(rb[4], rel=1e-10)
+    assert closed_steps >= len(rows_o) // 2, (closed_steps, three_steps)
+
+
 def test_full_size_rosenbrock_n1e6_against_oracle(env):
     """BASELINE.json configs[2] shape (extended Rosenbrock with box bounds, driver3 formulas) at
     n = 1e6, m = 10, on-device objective.  Iteration 1 fixes 999,999 variables in two massive
