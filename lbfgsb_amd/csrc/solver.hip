@@ -1489,11 +1489,12 @@ class Solver final : public lbfgsb_hip_ctx {
     iter_seen++;
     if (col > 0) {
       // p = W'd over the variables that still move = the free variables: with it W'Z r needs no
-      // pass over W (subspace_closed_form).  Not after a long walk (its rounding accumulates in
-      // p and in the corrections) and not when p is what little is left of a much larger p.
+      // pass over W (subspace_closed_form).  Not when p is what little is left of a much larger p
+      // (nor after a walk of more than 2^20 segments: the host corrections of formk's new row
+      // are then no longer small change).
       double pm = 0.0;
       for (int j = 0; j < col2; ++j) p_fin[j] = p[j], pm = std::max(pm, std::fabs(p[j]));
-      closed_ok = nseg <= 4096 && pm >= 1e-3 * p_ini_max && p_ini_max > 0.0;
+      closed_ok = nseg <= (1 << 20) && pm >= 1e-3 * p_ini_max && p_ini_max > 0.0;
     }
     return leave(tsum, last_t, last_i);
   }
