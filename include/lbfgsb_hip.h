@@ -197,7 +197,11 @@ int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void 
  * export: fills every slot that has a defined meaning at a setulb return
  *   (SURVEY.md appendix B).  import: loads Ws, Wy, z, r, d, t, xp, iwhere,
  *   the free-set membership (from Index(1:nfree)), Sy, Ss, Wt, Wn, Snd, wa8m.
- * Single-rank contexts only.
+ * With several ranks every rank exports / imports ITS rows (n = n_local in the
+ * lengths above; the 2m x 2m matrices are replicated; Index is the local list and
+ * Indx2(1) carries this rank's number of free rows): checkpoint at a NEW_X return,
+ * resume with the saved task / csave / lsave / isave / dsave on the same partition.
+ * Contexts with LBFGSB_F_MIRROR_INDEX are single-rank.
  * ------------------------------------------------------------------------- */
 int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa);
 int lbfgsb_hip_import_state(lbfgsb_hip_ctx *ctx, const void *wa, const int32_t *iwa,

@@ -2617,7 +2617,11 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // ============================================================ state exchange
   int export_state(void *wa_, int32_t *iwa) override {
-    if (nranks != 1) return fail(LBFGSB_E_STATE, "export_state: single-rank contexts only");
+    // several ranks: every rank exports ITS rows in the same layout (n = n_local); the host matrices
+    // are replicated, Index is the local list and -- the global counters of isave not telling how
+    // many of THIS rank's rows are free -- Indx2(1) carries the local free count
+    if (nranks != 1 && index)
+      return fail(LBFGSB_E_STATE, "export_state: contexts that mirror Index are single-rank");
     T *wa = (T *)wa_;
     const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
     HIPCHK(hipMemcpy2DAsync(wa, (size_t)n * sizeof(T), ws, (size_t)ld * sizeof(T),
@@ -2668,6 +2672,7 @@ class Solver final : public lbfgsb_hip_ctx {
             else
               iwa[--ia] = (int32_t)(i + 1);
           }
+          if (nranks != 1) iwa[2 * n] = (int32_t)nf;
         }
       }
     }
@@ -2675,7 +2680,8 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   int import_state(const void *wa_, const int32_t *iwa, const int32_t *isave_user) override {
-    if (nranks != 1) return fail(LBFGSB_E_STATE, "import_state: single-rank contexts only");
+    if (nranks != 1 && index)
+      return fail(LBFGSB_E_STATE, "import_state: contexts that mirror Index are single-rank");
     const T *wa = (const T *)wa_;
     const int64_t mn = (int64_t)m * n;
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
@@ -2703,7 +2709,8 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     // free-set membership as of the last freev: Index(1:nfree)
     std::vector<int8_t> wf((size_t)n, 0);
-    const int64_t nfree = isave_user[37];
+    const int64_t nfree_glob = isave_user[37];
+    const int64_t nfree = nranks != 1 ? (int64_t)iwa[2 * n] : nfree_glob;  // (see export_state)
     bool have_index = false;
     for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
     if (!have_index) {  // state from before the first freev (START / FG_START)
@@ -2723,7 +2730,7 @@ class Solver final : public lbfgsb_hip_ctx {
       HIPCHK(hipMemcpyAsync(indx2, iwa + 2 * n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
     }
     HIPCHK(hipStreamSynchronize(stream));
-    nfree_g = nfree;
+    nfree_g = nfree_glob;
     nenter_g = isave_user[40];
     ileave_g = isave_user[39];
     return 0;

@@ -28,21 +28,24 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     row0, n_loc = lbfgsb_amd.block_partition(n, world, rank)
-    sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=0,
-                                  parallel_gcp=(variant in ("pgcp", "pgcp2")),
-                                  exact_ties=(variant == "symx"))
-    if mode == "gloo":
-        lbfgsb_amd.attach_host_group(sol, rank, world)
-    elif mode == "rccl1":
-        assert world == 1
-        lbfgsb_amd.attach_rccl(sol, 0, 1, dev)
-    elif mode == "fakerccl":
-        # the library's communicator code path (ncclAllReduce / ncclAllGather on the solver's
-        # stream) with several ranks on ONE GPU: LBFGSB_RCCL_LIBRARY points at tests/fake_rccl.cpp
-        ids = [lbfgsb_amd.DeviceSolver.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, 0)
-        sol.init_rccl(ids[0], rank, world)
-        assert "libfake_rccl" in open("/proc/self/maps").read()   # (not the real library)
+    def make_solver():
+        s_ = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=0,
+                                     parallel_gcp=(variant in ("pgcp", "pgcp2")),
+                                     exact_ties=(variant == "symx"))
+        if mode == "gloo":
+            lbfgsb_amd.attach_host_group(s_, rank, world)
+        elif mode == "rccl1":
+            assert world == 1
+            lbfgsb_amd.attach_rccl(s_, 0, 1, dev)
+        elif mode == "fakerccl":
+            # the library's communicator code path (ncclAllReduce / ncclAllGather on the solver's
+            # stream) with several ranks on ONE GPU: LBFGSB_RCCL_LIBRARY points at tests/fake_rccl.cpp
+            ids = [lbfgsb_amd.DeviceSolver.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, 0)
+            s_.init_rccl(ids[0], rank, world)
+            assert "libfake_rccl" in open("/proc/self/maps").read()   # (not the real library)
+        return s_
+    sol = make_solver()
     two_scale = None
     if variant == "pgcp2":
         p, two_scale = two_scale_problem(po, n, m)
@@ -77,6 +80,19 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
                          int(sol.isave[37]), float(sol.f[0]), float(sol.dsave[12])])
             if sol.isave[29] >= iters:
                 break
+            if variant == "ckpt" and sol.isave[29] == iters // 2:
+                # checkpoint / resume of a SHARDED run: every rank exports its rows in the
+                # reference's wa / iwa layout, the context is destroyed, a new one imports the
+                # state and carries on from the saved task / csave / lsave / isave / dsave
+                wa, iwa = sol.export_state()
+                saved = (sol.task.copy(), sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(),
+                         sol.dsave.copy(), sol.f.copy())
+                sol.close()
+                dist.barrier()
+                sol = make_solver()
+                sol.import_state(wa, iwa, saved[3])
+                sol.task[:], sol.csave[:], sol.lsave[:] = saved[0], saved[1], saved[2]
+                sol.isave[:], sol.dsave[:], sol.f[:] = saved[3], saved[4], saved[5]
         else:
             break
     torch.cuda.synchronize()

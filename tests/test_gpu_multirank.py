@@ -176,6 +176,25 @@ def test_sharded_exact_tie_order(oracle_built, tmp_path, monkeypatch, world, mod
     print("tie splits: %d (default order), %d (exact)" % (res_d["tie_splits"], res["tie_splits"]))
 
 
+@pytest.mark.parametrize("world,mode", [(3, "gloo"), (2, "fakerccl")])
+def test_sharded_checkpoint_and_resume(oracle_built, tmp_path, monkeypatch, world, mode):
+    """export_state / import_state on a sharded run: at iteration 7 of 14 every rank exports its rows
+    (reference wa / iwa layout with n = n_local; Indx2(1) = local free count), the contexts are
+    destroyed and rebuilt, the state is imported and the run goes on -- the trajectory must be the
+    uninterrupted one (= the single-rank oracle's): integer columns exactly, f to 1e-9."""
+    po = oracle_built
+    n, m, iters = 40_009, 6, 14
+    if mode == "fakerccl":
+        monkeypatch.setenv("LBFGSB_RCCL_LIBRARY", _fake_rccl())
+    res = launch(world, mode, n, m, iters, "ckpt", str(tmp_path / "out.json"))
+    rows, x = oracle_rows(po, n, m, iters, False)
+    assert len(res["rows"]) == len(rows) == iters
+    for a, b in zip(res["rows"], rows):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
+    assert np.max(np.abs(np.array(res["x"]) - x)) <= 1e-8 * max(1.0, np.max(np.abs(x)))
+
+
 @pytest.mark.parametrize("world,first,count", [(2, 100, 25), (3, 200, 25)])
 def test_sharded_random_problems_match_oracle(oracle_built, tmp_path, world, first, count):
     """Random separable problems (n < 2000, m < 13, all bound types) with the rows cut over 2 and
