@@ -68,18 +68,25 @@ enum {
                                 arithmetic.  With several ranks the records of all breakpoints are
                                 all-gathered and every rank runs the same (bitwise-reproducible)
                                 scans.  Short walks always replay the walk exactly. */
-  LBFGSB_F_EXACT_TIES = 16   /* Breakpoints with EQUAL t are handed to the walk in variable order; the
-                                reference pops them in the order of hpsolb's heap (src/lbfgsb.f90:2079,
-                                used at :1384-1403).  Sums over a whole group of equal breakpoints
-                                are merely reassociated; the two orders differ in effect only when
-                                the walk ends INSIDE such a group -- then the order decides which of
-                                its variables are fixed at their bounds.  Such calls are detected
-                                and counted (lbfgsb_hip_tie_splits).  With this flag they are
-                                replayed from the start of the walk in the reference's own order:
-                                all breakpoint times travel to the host of every rank (O(n) bytes +
-                                an O(n) heap build; every rank pops the same replicated heap and
-                                gathers the records of the rows it owns), so the active set equals
-                                the reference's bit for bit.  n_global < 2^32. */
+  LBFGSB_F_EXACT_TIES = 16,  /* accepted and ignored: this IS the default behaviour now (round 3).
+                                Breakpoints with EQUAL t reach the walk in variable order; the reference
+                                pops them in the order of hpsolb's heap (src/lbfgsb.f90:2079, used at
+                                :1384-1403).  Sums over a whole group of equal breakpoints are merely
+                                reassociated; the two orders differ in effect only when the walk ends
+                                INSIDE such a group -- then the order decides which of its variables are
+                                fixed at their bounds.  Such calls are detected, counted
+                                (lbfgsb_hip_tie_splits) and REPLAYED from the start of the walk in the
+                                reference's own order: all breakpoint times travel to the host of
+                                every rank (O(n) bytes + an O(n) heap build; every rank pops the same
+                                replicated heap and gathers the records of the rows it owns), so the
+                                active set equals the reference's bit for bit.  Only the calls that
+                                need it pay for it. */
+  LBFGSB_F_INDEX_TIES = 32   /* OPT-OUT of that replay: a walk that ends inside a group of equal
+                                breakpoints fixes the group's members in variable order (which members --
+                                and, when their rows of W differ, how many -- may then differ from the
+                                reference).  For callers who prefer the
+                                O(window) cost bound over the reference's tie order: the replay costs
+                                what the reference's own walk costs (heap pops over all breakpoints). */
 };
 
 /* -------------------------------------------------------------------------
@@ -102,6 +109,10 @@ const char *lbfgsb_hip_last_error(void);
  * (a) RCCL on the context's stream (librccl is dlopen'ed on first use):
  *       id = 128-byte ncclUniqueId made by lbfgsb_hip_rccl_unique_id on rank 0
  *       and distributed by the caller (e.g. torch.distributed broadcast).
+ *       ONE collective per host sync: the <= 8m+15 fp64 partials of a phase (sums,
+ *       minima, maxima together) are all-gathered and reduced on every rank's host in
+ *       rank order -- an all-reduce whose result is bit-identical on every rank and
+ *       independent of the collective algorithm RCCL picks.
  * (b) a host callback, for launchers that already own a communicator
  *     (MPI, gloo): called with the rank-local partials in host memory; must
  *     return with buf[0..nsum) summed, buf[nsum..nsum+nmin) min-reduced and
@@ -171,7 +182,8 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
  * context of the host-pointer form with this call (the Fortran module exports it as
  * lbfgsb_release).  isave(17:18) hold a registry id + tag, never a raw pointer: a stale or
  * garbage isave is refused (LBFGSB_E_STATE), a 'START' over a live id frees the old context
- * first, and whatever is still registered is freed when the process exits.  isave(1:16)
+ * first; whatever is still registered at process exit is left to the process teardown (no GPU
+ * call is made from a static destructor).  isave(1:16)
  * receive the reference's wa offsets (:250-265), saturated at INT32_MAX instead of wrapped. */
 int lbfgsb_hip_release_host(int32_t *isave);
 
@@ -264,13 +276,33 @@ int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx);
  * (one host sync and one all-reduce less per evaluation) and stores it through its f argument. */
 int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f);
 
+/* Per-context options for measurements and tests (A/B timings of fallback paths, forcing rarely
+ * taken routes).  Nothing in the library reads tuning switches from the environment: a context
+ * behaves as created unless this is called.  Names (value):
+ *   "two_pass" (0/1)        the two-pass iteration with W'Z r in closed form; 0 = always the
+ *                           cmprlb_wtv pass (three passes over W)
+ *   "two_pass_maxcol" (0..20)  largest col that takes the two-pass iteration
+ *   "lean" (0/1)            z and d = x - t left implicit by the storing pass
+ *   "spec_capture" (0/1)    the update pass hands the next walk's first breakpoints over
+ *   "pg_min" (count)        LBFGSB_F_PARALLEL_GCP: walks with more breakpoints in reach than this
+ *                           go to the sort + scans
+ *   "exact_always" (0/1)    every Cauchy walk in the reference's heap order from its start (tests)
+ *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
+ *   "wgrid" (1..2047)       workgroups of the passes over W (default 768)
+ *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule / off / on
+ *   "pair" (0/1/2)          MC = 20 update pass: lane pairs share accumulators (off / 1 trip / 2 trips)
+ *   "gram_rows" (0/1)       formk from scratch with the LDS-slab kernel instead of the quad kernel
+ * Returns LBFGSB_E_ARG for an unknown name or a value out of range. */
+int lbfgsb_hip_set_option(lbfgsb_hip_ctx *ctx, const char *name, double value);
+
 /* counters for bench/profiling: kernel launches, host syncs, full breakpoint sorts so far,
  * and the seconds the host spent blocked waiting for the stream */
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
                      int64_t *cauchy_fullsorts, double *wait_seconds);
 
 /* how many subspace minimisations so far took the two-pass route (W'Z r in closed form, no
- * cmprlb pass over W: col <= 10, bounded problem, short walk, >= 1/16 of the variables free) and
+ * cmprlb pass over W: col <= 20, walk of <= 2^20 segments, no stored s_i with its free part a
+ * tiny remainder of the column) and
  * how many the three-pass route (cmprlb_wtv_kernel); handed_windows = Cauchy walks whose
  * breakpoints came with the update pass itself (no window pass, no host sync of their own) */
 int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass,

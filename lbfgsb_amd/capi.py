@@ -47,13 +47,15 @@ PROTOTYPES = {
     "lbfgsb_hip_sync": (C.c_int, [_vp]),
     "lbfgsb_hip_objective": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lbfgsb_hip_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_set_option": (C.c_int, [_vp, _cp, C.c_double]),
 }
 
 F_REAL32 = 1
 F_MIRROR_INDEX = 2
 F_NO_RETURN_SYNC = 4
 F_PARALLEL_GCP = 8
-F_EXACT_TIES = 16
+F_EXACT_TIES = 16      # accepted and ignored: the default since round 3
+F_INDEX_TIES = 32      # opt-out: equal breakpoints in variable order, no heap-order replay
 
 
 class LbfgsbError(RuntimeError):

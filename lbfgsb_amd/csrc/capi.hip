@@ -217,6 +217,11 @@ int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *t
   return 0;
 }
 
+int lbfgsb_hip_set_option(lbfgsb_hip_ctx *ctx, const char *name, double value) {
+  if (!ctx || !name) return fail(LBFGSB_E_ARG, "set_option: NULL argument");
+  return ctx->set_option(name, value);
+}
+
 int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count) {
   if (!ctx || !count) return fail(LBFGSB_E_ARG, "tie_splits: NULL argument");
   *count = ctx->ntiesplit;
@@ -252,9 +257,11 @@ struct HostRegistry {
   std::mutex mu;
   std::unordered_map<int32_t, lbfgsb_hip_ctx *> live;
   int32_t next_id = 1;
-  ~HostRegistry() {  // contexts of runs that were abandoned without lbfgsb_hip_release_host
-    for (auto &kv : live) delete kv.second;
-  }
+  // Contexts of runs that were abandoned without lbfgsb_hip_release_host (the reference's driver2 /
+  // driver3 leave with task = 'STOP' and never re-enter setulb) are NOT destroyed from this static
+  // object's destructor: hipFree / hipStreamDestroy / ncclCommDestroy at process exit are unordered
+  // against the HIP runtime's own teardown and can fault or hang.  The process exit reclaims them.
+  ~HostRegistry() { live.clear(); }
   int32_t add(lbfgsb_hip_ctx *c) {
     std::lock_guard<std::mutex> lk(mu);
     while (live.count(next_id) || next_id <= 0) next_id = next_id == INT32_MAX ? 1 : next_id + 1;

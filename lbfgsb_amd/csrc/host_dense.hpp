@@ -367,14 +367,16 @@ inline void dcsrch(double f, double g, double &stp, double ftol, double gtol, do
 
 // hpsolb (src/lbfgsb.f90:2079-2157): t(1:n) / iorder(1:n) hold the breakpoints not yet used.
 // iheap == 0: first rearrange them into a min-heap by sifting t(2), t(3), ... up; then move the
-// least element to t(n) and restore the heap on t(1:n-1).  Used only by the opt-in exact replay of
-// the reference's pop order among EQUAL breakpoints (LBFGSB_F_EXACT_TIES); arrays are 0-based
-// here, i and j keep the reference's 1-based meaning.
-inline void hpsolb(int64_t n, double *t, uint32_t *iorder, int iheap) {
+// least element to t(n) and restore the heap on t(1:n-1).  Used by the replay of the reference's
+// pop order among EQUAL breakpoints (a walk that ends inside a tie group, solver.hip exact_init);
+// arrays are 0-based here, i and j keep the reference's 1-based meaning.  I = the type of the row
+// numbers (uint32_t while n_global < 2^32, int64_t beyond).
+template <typename I>
+inline void hpsolb(int64_t n, double *t, I *iorder, int iheap) {
   if (iheap == 0) {
     for (int64_t k = 2; k <= n; ++k) {
       const double ddum = t[k - 1];
-      const uint32_t indxin = iorder[k - 1];
+      const I indxin = iorder[k - 1];
       int64_t i = k;
       while (i > 1) {
         const int64_t j = i / 2;
@@ -390,9 +392,9 @@ inline void hpsolb(int64_t n, double *t, uint32_t *iorder, int iheap) {
   if (n > 1) {
     int64_t i = 1;
     const double out = t[0];
-    const uint32_t indxou = iorder[0];
+    const I indxou = iorder[0];
     const double ddum = t[n - 1];
-    const uint32_t indxin = iorder[n - 1];
+    const I indxin = iorder[n - 1];
     for (;;) {
       int64_t j = i + i;
       if (j > n - 1) break;

@@ -96,7 +96,7 @@ template <typename T>
 void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, iw_t *iwhere, T *tbrk, WStore<T> w,
                         int head, int col) {
-  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int gr = grid_for_w(q, n, VecOf<T>::V);
   if (col == 0) {
     hipLaunchKernelGGL((cauchy_scan_kernel<T, 0, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
                        nbd, g, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, col, q.d_part);
@@ -105,7 +105,7 @@ void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                                           q.stream, n, x, l, u, nbd, g, iwhere, tbrk, w.ws, w.wy,
                                           w.zero, w.ld, w.m, head, col, q.d_part));
   }
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 2 * (col == 0 ? 0 : maxc_for(col)) + 4, 1, 0);
 }
 
@@ -181,7 +181,7 @@ void launch_cauchy_window(Queue &q, int64_t n, int64_t row0, const T *tbrk, doub
   const int gr = grid_for(n, VecOf<T>::V * 4);
   hipLaunchKernelGGL(cauchy_window_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, tbrk,
                      lo_t, lo_i, hi_t, keys, idx, cap, d_count);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 
@@ -242,7 +242,7 @@ void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, con
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(cauchy_window_fly_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, l,
                      u, nbd, g, iwhere, lo_t, lo_i, hi_t, keys, idx, cap, d_count);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 // iwhere update of cauchy's n-loop alone (:1284-1291), for contexts whose speculative update pass
 // must leave iwhere untouched until the trial point is accepted (state mirrored at every return)
@@ -291,7 +291,7 @@ void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(iwhere_update_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
                      iwhere);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // =========================== parallel GCP search, col > 0 (opt-in) ============
@@ -493,13 +493,13 @@ void launch_pgcp_mergekeys(Queue &q, int nranks, int64_t nbp, int narr, const do
                            const double *G, uint64_t *keys, uint32_t *vals) {
   hipLaunchKernelGGL(pgcp_mergekeys_kernel, dim3(grid_for((int64_t)nranks * nbp, 1)), dim3(BLOCK), 0,
                      q.stream, nranks, nbp, narr, counts, G, keys, vals);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_pgcp_permute(Queue &q, int64_t NB, int64_t NBp, int64_t nbp, int narr, const uint32_t *vals,
                          const double *G, double *out, const int *map) {
   hipLaunchKernelGGL(pgcp_permute_kernel, dim3(grid_for(NB, 1)), dim3(BLOCK), 0, q.stream, NB, NBp, nbp,
                      narr, vals, G, out, map);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 // f2 through all breakpoints with the clamp: df2 (in) -> F2 (out, may alias df2); maps = 2 nb doubles
 size_t f2scan_temp_bytes(size_t count) {
@@ -540,7 +540,7 @@ void launch_gcp_rest_mass(Queue &q, int64_t n, const T *g, const T *tbrk, double
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(gcp_rest_mass_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, g, tbrk, tstar,
                      q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }
 
@@ -563,7 +563,7 @@ void launch_scan(Queue &q, void *d_temp, size_t temp_bytes, const double *in, do
   else
     (void)rocprim::deterministic_inclusive_scan(d_temp, temp_bytes, in, out, count, rocprim::plus<double>(),
                                                 q.stream);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 template <typename T>
 void launch_pgcp_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, int64_t nb, int64_t nbp,
@@ -574,37 +574,37 @@ void launch_pgcp_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, int
   hipLaunchKernelGGL(pgcp_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, nb, nbp, x,
                      l, u, g, w.ws, w.wy, w.ld, w.m, head, col, theta, pr, pd, pe, tt, dd, a0, wb, uu,
                      gi, row0);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_pgcp_last(Queue &q, int64_t nb, int64_t nbp, int col2, const double *uu, double *uu_last) {
   hipLaunchKernelGGL(pgcp_last_kernel, dim3(1), dim3(64), 0, q.stream, nb, nbp, col2, uu, uu_last);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_pgcp_dtp(Queue &q, int64_t nb, int64_t nbp, int col2, const double *tt, const double *pp,
                      double *qq) {
   hipLaunchKernelGGL(pgcp_dtp_kernel, dim3(grid_for(nb, 1)), dim3(BLOCK), 0, q.stream, nb, nbp, col2,
                      tt, pp, qq);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_pgcp_terms(Queue &q, int64_t nb, int64_t nbp, int col2, double theta, const double *mm,
                        const double *p0, const double *tt, const double *dd, const double *a0,
                        const double *wb, const double *pp, const double *sq, double *df2, double *a1) {
   hipLaunchKernelGGL(pgcp_terms_kernel, dim3(grid_for(nb, 1)), dim3(BLOCK), 0, q.stream, nb, nbp, col2,
                      theta, mm, p0, tt, dd, a0, wb, pp, sq, df2, a1);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_pgcp_f1(Queue &q, int64_t nb, double f2_0, const double *tt, const double *sf2,
                     const double *a1, double *df1) {
   hipLaunchKernelGGL(pgcp_f1_kernel, dim3(grid_for(nb, 1)), dim3(BLOCK), 0, q.stream, nb, f2_0, tt, sf2,
                      a1, df1);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_pgcp_find(Queue &q, int64_t nb, double f1_0, double f2_0, const double *tt,
                       const double *sf1, const double *sf2) {
   const int gr = grid_for(nb, 1);
   hipLaunchKernelGGL(pgcp_find_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, nb, f1_0, f2_0, tt, sf1, sf2,
                      q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 1, 0);
 }
 void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, double f1_0, double f2_0,
@@ -613,7 +613,7 @@ void launch_pgcp_pick(Queue &q, int64_t ks, int64_t nb, int64_t nbp, int col2, d
                       double *out) {
   hipLaunchKernelGGL(pgcp_pick_kernel, dim3(1), dim3(64), 0, q.stream, ks, nb, nbp, col2, f1_0, f2_0, tt,
                      sf1, sf2, pp, uu_last, sq, idx, gi, out);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // tbrk as a vector, for the paths that want one (full sort, cursor-based cauchy_finish)
@@ -643,7 +643,7 @@ void launch_tbrk_fill(Queue &q, int64_t n, const T *x, const T *l, const T *u, c
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(tbrk_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
                      iwhere, tbrk);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 template <typename T>
@@ -665,7 +665,7 @@ void launch_cauchy_allkeys(Queue &q, int64_t n, int64_t row0, const T *tbrk, dou
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(cauchy_allkeys_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, tbrk,
                      lo_t, lo_i, keys, idx);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 size_t sort_pairs_temp_bytes(size_t count) {
@@ -683,14 +683,14 @@ void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_
                         size_t count) {
   (void)rocprim::radix_sort_pairs(d_temp, temp_bytes, idx_in, idx_out, keys_in, keys_out, count, 0,
                                   32, q.stream);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t *keys_in,
                        uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out,
                        size_t count) {
   (void)rocprim::radix_sort_pairs(d_temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, count, 0,
                                   64, q.stream);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 template <typename T>
@@ -783,7 +783,7 @@ void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *key
   if (gr > 64) gr = 64;
   hipLaunchKernelGGL(cauchy_gather_dyn_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys,
                      d_count, cap, row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, msg);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 template <typename T>
@@ -796,7 +796,7 @@ void launch_cauchy_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, u
   if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
   hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, cnt,
                      row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, rec);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // COUNT: also return the number of rows fixed (closed-form GCP, where no walk counted them)
@@ -862,12 +862,12 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
   if (count) {
     hipLaunchKernelGGL((cauchy_finish_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, row0,
                        x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.d_part);
-    q.launches++;
+    LB_LAUNCHED(q);
     launch_finalize(q, gr, 1, 0, 0);
   } else {
     hipLaunchKernelGGL((cauchy_finish_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, row0,
                        x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.d_part);
-    q.launches++;
+    LB_LAUNCHED(q);
   }
 }
 
@@ -883,7 +883,7 @@ void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, i
                        iw_t *iwhere) {
   hipLaunchKernelGGL(cauchy_fix_kernel, dim3((count + 255) / 256), dim3(256), 0, q.stream, list, count,
                      row0, n, iwhere);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // =========================== freev (:1980-2059) ==============================
@@ -972,7 +972,7 @@ void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree
   if (chg) (void)hipMemsetAsync(chg_count, 0, sizeof(uint32_t), q.stream);
   hipLaunchKernelGGL(freev_count_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
                      q.d_part, chg, chg_cap, chg_count);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 3, 0, 0);
 }
 

@@ -279,7 +279,7 @@ template <typename T>
 void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const iw_t *iwhere, WStore<T> w, int head, int col, double theta,
                        const Coef &a, int newrow, const T *pr, const T *pd, Pend pe) {
-  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int gr = grid_for_w(q, n, VecOf<T>::V);
   const int mc = maxc_for(col);
   if (newrow && mc >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
     if (mc == 20) {
@@ -324,7 +324,7 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
     }
 #undef LB_CMPRLB
   }
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, (newrow ? 6 : 2) * mc, 0, 0);
 }
 

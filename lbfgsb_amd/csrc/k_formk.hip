@@ -455,10 +455,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
                        const iw_t *iwhere) {
   int gr = 0;
   if (col <= 10) {
-    static const int variant = [] {  // LBFGSB_GRAM = rows: the LDS-slab kernel (A/B timing)
-      const char *e = std::getenv("LBFGSB_GRAM");
-      return e && e[0] == 'r' ? 1 : 0;
-    }();
+    const int variant = q.tune.gram_rows;  // 1: the LDS-slab kernel (A/B timing)
     if (variant == 1) {
       const int64_t nslab = (n + 127) / 128;
       gr = (int)(nslab < GRAM_BLOCKS ? nslab : GRAM_BLOCKS);
@@ -479,7 +476,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
         hipLaunchKernelGGL((formk_gram_quad_kernel<T, 10>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
                            w.wy, w.zero, w.ld, w.m, head, col, iwhere, q.d_gpart);
     }
-    q.launches++;
+    LB_LAUNCHED(q);
     finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
     return;
   }
@@ -489,7 +486,7 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
     hipLaunchKernelGGL((formk_gram_kernel<T, MC>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws,
                        w.wy, w.ld, w.m, head, col, iwhere, q.d_gpart);
   });
-  q.launches++;
+  LB_LAUNCHED(q);
   finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * col * col + col, 0, 0);
 }
 
@@ -572,7 +569,7 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
   if (gr > 256) gr = 256;
   hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cnt, w.ws, w.wy,
                      w.ld, w.m, head, upcl, q.d_gpart);
-  q.launches++;
+  LB_LAUNCHED(q);
   finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * upcl * upcl + upcl, 0, 0);
 }
 

@@ -5,42 +5,29 @@
 namespace lbk {
 
 int grid_for(int64_t n, int vec) {
-  // LBFGSB_GRID: cap on the number of workgroups (<= MAX_BLOCKS), for tuning experiments
-  static const int cap = [] {
-    const char *e = std::getenv("LBFGSB_GRID");
-    const int v = e ? std::atoi(e) : 0;
-    return v >= 1 && v <= MAX_BLOCKS ? v : MAX_BLOCKS;
-  }();
   int64_t g = (n / vec + BLOCK - 1) / BLOCK;
   if (g < 1) g = 1;
-  if (g > cap) g = cap;
+  if (g > MAX_BLOCKS) g = MAX_BLOCKS;
   return (int)g;
 }
 
 // The passes over W keep 2-3 workgroups resident per CU (132-250 VGPRs): a grid of about that
 // many workgroups, each striding over more rows, reads 3-6 % faster than 2048 of them (sweep at
-// n = 1e8: 512 and 768 workgroups are equal, 1024+ slower).  LBFGSB_WGRID overrides.
+// n = 1e8: 512 and 768 workgroups are equal, 1024+ slower); Tune::wgrid, at most MAX_BLOCKS - 1
+// (the pair-shared update pass puts its leftover rows into one more column of the partial sums).
 // (Round 1 kept 2048 for fp32; with the straight-line trips 768 is the better grid there too:
 //  fp32 m = 20 94 -> 99.7 it/s, m = 10 158.9 -> 159.9.)
-int grid_for_w(int64_t n, int vec, int elem_bytes) {
-  static const int env_cap = [] {
-    const char *e = std::getenv("LBFGSB_WGRID");
-    const int v = e ? std::atoi(e) : 0;
-    return v >= 1 && v <= MAX_BLOCKS ? v : 0;
-  }();
-  (void)elem_bytes;
-  const int cap = env_cap ? env_cap : 768;
+int grid_for_w(const Queue &q, int64_t n, int vec) {
+  int cap = q.tune.wgrid;
+  if (cap < 1) cap = 1;
+  if (cap > MAX_BLOCKS - 1) cap = MAX_BLOCKS - 1;
   const int g = grid_for(n, vec);
   return g > cap ? cap : g;
 }
 
-bool pipe_on(int mc, int elem_bytes) {
-  static const int e = [] {
-    const char *v = std::getenv("LBFGSB_PIPE");
-    return v ? std::atoi(v) : -1;
-  }();
-  if (e == 0) return false;
-  if (e == 1) return mc <= 20;
+bool pipe_on(const Queue &q, int mc, int elem_bytes) {
+  if (q.tune.pipe == 0) return false;
+  if (q.tune.pipe == 1) return mc <= 20;
   return mc == 20 || (mc == 10 && elem_bytes == 4);
 }
 
@@ -77,9 +64,13 @@ void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int n
                           int nmin, int nmax) {
   const int k = nsum + nmin + nmax;
   if (k <= 0) return;
+  if (nblocks > pstride) {  // a partial-sum matrix has pstride columns per slot: never read beyond
+    if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "finalize: nblocks > pstride";
+    return;
+  }
   hipLaunchKernelGGL(finalize_kernel, dim3(k), dim3(BLOCK), 0, q.stream, part, pstride, nblocks,
                      q.d_res + q.res_off, nsum, nmin, nmax);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax) {
   finalize_from(q, q.d_part, MAX_BLOCKS, nblocks, nsum, nmin, nmax);
@@ -136,7 +127,7 @@ void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int3
   const int g = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(active_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd,
                      iwhere, wasfree, q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, g, 4, 0, 0);
 }
 
@@ -167,7 +158,7 @@ void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
   const int g = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(errclb_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, row0, l, u, nbd,
                      q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, g, 0, 0, 2);
 }
 
@@ -197,7 +188,7 @@ void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, cons
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(projgr_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
                      q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 0, 1);
 }
 
@@ -238,15 +229,15 @@ __global__ __launch_bounds__(BLOCK) void wtv_kernel(int64_t n, const T *__restri
 }
 template <typename T>
 void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
-  const int g = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int g = grid_for_w(q, n, VecOf<T>::V);
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((wtv_kernel<T, MC, NTV>), dim3(g), dim3(BLOCK), 0, q.stream, n,
                                         w.ws, w.wy, w.zero, w.ld, w.m, head, col, v, q.d_part));
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 template <typename T>
 void launch_wtv(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
   launch_wtv_nofinalize(q, n, w, head, col, v);
-  launch_finalize(q, grid_for_w(n, VecOf<T>::V, (int)sizeof(T)), 2 * maxc_for(col), 0, 0);
+  launch_finalize(q, grid_for_w(q, n, VecOf<T>::V), 2 * maxc_for(col), 0, 0);
 }
 
 
@@ -280,7 +271,7 @@ __global__ __launch_bounds__(BLOCK) void nbd_pack_kernel(int64_t n, const int32_
 }
 void launch_nbd_pack(Queue &q, int64_t n, const int32_t *nbd, nb_t *out) {
   hipLaunchKernelGGL(nbd_pack_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, nbd, out);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const T *__restrict__ x,
@@ -301,7 +292,7 @@ template <typename T>
 void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z) {
   hipLaunchKernelGGL(dz_materialise_kernel<T>, dim3(grid_for(n, VecOf<T>::V)), dim3(BLOCK), 0, q.stream,
                      n, x, t, d, z);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
@@ -310,7 +301,7 @@ void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d,
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;
   hipLaunchKernelGGL(pair_commit_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, g, r, d, pe.stp,
                      w.wy + slot, w.ws + slot);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // The Cauchy point as a vector, by the same per-row rule the fused passes use (xcp_row).
@@ -338,7 +329,7 @@ void launch_xcp_fill(Queue &q, int64_t n, const T *x, const T *g, const T *l, co
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(xcp_fill_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, l, u, iwhere,
                      tsum, dst);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // backtracking ratio of one free variable (:2842-2857); 2.0 = no restriction
@@ -382,7 +373,7 @@ void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, (int64_t)0, xp,
                      r, l, u, nbd, iwhere, 0, 0.0, q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 1, 0);
 }
 template <typename T>
@@ -391,7 +382,7 @@ void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, xp, r, l,
                      u, nbd, iwhere, 1, alpha, q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 1, 0);
 }
 template <typename T>
@@ -427,7 +418,7 @@ void launch_subsm_backtrack(Queue &q, int64_t n, int64_t row0, T *z, const T *xp
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_backtrack_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, z, xp,
                      r, l, u, iwhere, alpha, ibd);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // =========================== lnsrlb (:2174-2275) =============================
@@ -477,7 +468,7 @@ void launch_lnsrlb_begin(Queue &q, int64_t n, const T *z, const T *x, const T *g
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(lnsrlb_begin_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, z, x, g, l, u,
                      nbd, d, t, r, do_stpmx, q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 2, 1, 0);
 }
 
@@ -506,7 +497,7 @@ void launch_lnsrlb_step(Queue &q, int64_t n, T *x, const T *z, const T *d, const
                         double stp) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(lnsrlb_step_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, z, d, t, stp);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 template <typename T>
@@ -541,7 +532,7 @@ void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(lnsrlb_eval_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
                      d, q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 1);
 }
 
@@ -578,7 +569,7 @@ void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(obj_quadratic_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, g, q.nt ? 1 : 0,
                      q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }
 // rows [row0, row0+n) of the chain; xl / xr = the neighbours' boundary elements x(row0-1),
@@ -625,7 +616,7 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, con
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, nglob,
                      x, g, xl, xr, q.nt ? 1 : 0, q.d_part);
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }
 // first and last local element, as doubles, into out[0..1] (halo message)
@@ -639,7 +630,7 @@ __global__ void halo_pack_kernel(int64_t n, const T *__restrict__ x, double *out
 template <typename T>
 void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
   hipLaunchKernelGGL(halo_pack_kernel<T>, dim3(1), dim3(64), 0, q.stream, n, x, out);
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // =========================== explicit instantiations =========================

@@ -175,7 +175,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
                          const T *pd) {
-  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int gr = grid_for_w(q, n, VecOf<T>::V);
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   const bool spec = pe.on && col == maxc_for(col);
 #define LB_SUBSM(PSPECV)                                                                            \
@@ -191,7 +191,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
   else
     LB_SUBSM(false);
 #undef LB_SUBSM
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 3, 1, 0);
 }
 
@@ -234,11 +234,11 @@ template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
                       const T *gg, WStore<T> w, int head, int col, double theta, const Coef &cf,
                       const Coef &wv, T *ndir) {
-  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int gr = grid_for_w(q, n, VecOf<T>::V);
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((subsm_dir_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                         q.stream, n, xcp, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m,
                                         head, col, theta, cf, wv, ndir));
-  q.launches++;
+  LB_LAUNCHED(q);
 }
 
 // =========================== explicit instantiations =========================

@@ -52,12 +52,12 @@ __global__ __launch_bounds__(BLOCK) void update_pairs_kernel(
 template <typename T>
 void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d, double stp,
                          WStore<T> w, int head, int col, int itail) {
-  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int gr = grid_for_w(q, n, VecOf<T>::V);
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_pairs_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, g, r, d, stp, w.ws, w.wy, w.zero, w.ld, w.m,
                                          head, nold, itail, q.d_part));
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, gr, 2 * maxc_for(nold) + 1, 0, 0);
 }
 
@@ -374,7 +374,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
                         uint32_t ccap, uint32_t *ccount) {
   if (cand_hi >= 0.0) (void)hipMemsetAsync(ccount, 0, sizeof(uint32_t), q.stream);
-  const int gr = grid_for_w(n, VecOf<T>::V, (int)sizeof(T));
+  const int gr = grid_for_w(q, n, VecOf<T>::V);
   const int nold = col - 1;
 #define LB_UPDSCAN(NEWROWV)                                                                          \
   DISPATCH_MAXC_NT(nold, q.nt, DISPATCH_PIPE(MC, {                                                   \
@@ -395,12 +395,8 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   // Measured (n = 5e7 / 1e8, m = 20), two trips in flight: fp64 3.04 -> 2.78 ms, fp32 3.55 -> 3.17 ms
   // (the fp32 instantiation sits at 509 registers: with a single spilled register its scratch
   // reloads, which return in order behind the loads in flight, undo the pipelining -- 4.68 ms).
-  // LBFGSB_PAIR=0: off; 1: on, one trip in flight; 2: two trips
-  static const int pair_env = [] {
-    const char *e = std::getenv("LBFGSB_PAIR");
-    return e ? std::atoi(e) : -1;
-  }();
-  const int pair_mode = pair_env >= 0 ? pair_env : 2;
+  // Tune::pair = 0: off; 1: on, one trip in flight; 2: two trips
+  const int pair_mode = q.tune.pair;
   int nblocks = gr;
   if (update_scan_extra(nold, newrow) && mc == 20 && pair_mode > 0) {
     constexpr int MC = 20;
@@ -427,7 +423,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                          store_pair, store_iw, -1.0, ckeys, cidx, ccap, ccount,
                          q.d_part + (n_main > 0 ? gr : 0));
       nblocks = n_main > 0 ? gr + 1 : 1;
-      q.launches++;
+      LB_LAUNCHED(q);
     }
   } else if (update_scan_extra(nold, newrow)) {
     LB_UPDSCAN(true);
@@ -435,7 +431,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
     LB_UPDSCAN(false);
   }
 #undef LB_UPDSCAN
-  q.launches++;
+  LB_LAUNCHED(q);
   launch_finalize(q, nblocks, 4 * mc + 9 + update_scan_extra(nold, newrow), 1, 1);
 }
 

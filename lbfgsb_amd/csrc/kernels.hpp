@@ -16,6 +16,16 @@ constexpr int GRAM_BLOCKS = 1024;
 constexpr int MAXM = 32;          // LBFGSB_MAX_M
 constexpr int RES_MAX = 6 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 8*20+15 of update_scan(newrow)
 
+// per-context launch options (lbfgsb_hip_set_option; nothing is read from the environment)
+struct Tune {
+  int wgrid = 768;  // workgroups of the passes over W: what is resident (sweep at n = 1e8: 512 and
+                    // 768 equal, 1024+ slower)
+  int pipe = -1;    // two trips in flight per wave: -1 default rule (pipe_on), 0 off, 1 on for MC <= 20
+  int pair = 2;     // MC = 20 update pass with new-row sums: lane pairs share the per-column
+                    // accumulators; 0 off, 1 one trip in flight, 2 two trips
+  int gram_rows = 0;  // formk from scratch: 1 = the LDS-slab kernel instead of the quad kernel
+};
+
 // launch queue + reduction scratch owned by the context
 struct Queue {
   hipStream_t stream;
@@ -25,7 +35,18 @@ struct Queue {
   int64_t launches;
   int res_off = 0;  // finalize writes d_res[res_off + slot] (lets two phases share one fetch)
   bool nt = false;  // nontemporal loads in the W-pass kernels (W much larger than the Infinity Cache)
+  Tune tune{};
+  // first kernel launch that failed since the last check (hipGetLastError right behind the launch,
+  // so that the error is reported with the kernel's name and not at the next stream sync)
+  const char *launch_err_where = nullptr;
+  hipError_t launch_err = hipSuccess;
+  void launched(const char *where) {
+    launches++;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && launch_err == hipSuccess) launch_err = e, launch_err_where = where;
+  }
 };
+#define LB_LAUNCHED(q) (q).launched(__func__)
 
 // the circular correction-pair store: Ws, Wy column-major n x m, leading
 // dimension ld (multiple of 32 rows).  head is 1-based like the reference.
@@ -61,7 +82,7 @@ struct Pend {
 };
 
 int grid_for(int64_t n, int vec);
-int grid_for_w(int64_t n, int vec, int elem_bytes);  // the same for the passes over W (fewer, resident workgroups)
+int grid_for_w(const Queue &q, int64_t n, int vec);  // the same for the passes over W (fewer, resident workgroups)
 // compile-time column capacity the kernels are unrolled to for `col` pairs (5, 10, 20, 32).
 // Reduction slots that depend on col use MC = maxc_for(col) as their stride.
 int maxc_for(int col);

@@ -67,12 +67,12 @@ namespace lbk {
 // per SIMD anyway: the MC = 20 instantiations (MC = 32 would need a vmcnt beyond 63).
 // Measured (bench.py, n = 1e8): fp32 m = 20 89.7 -> 96.2 it/s, fp32 m = 10 159.5 -> 163.3, fp64
 // m = 10 no change (its kernels already run 2-3 waves per SIMD): on for MC = 20 and for fp32 MC = 10.
-// LBFGSB_PIPE = 0 / 1 forces it off / on for every MC <= 20 (tuning experiments).
-bool pipe_on(int mc, int elem_bytes);  // k_misc.hip
+// Tune::pipe = 0 / 1 forces it off / on for every MC <= 20 (tuning experiments).
+bool pipe_on(const Queue &q, int mc, int elem_bytes);  // k_misc.hip
 #define DISPATCH_PIPE(MCV, ...)        \
   do {                                 \
     if constexpr ((MCV) <= 20) {       \
-      if (pipe_on(MCV, (int)sizeof(T))) { \
+      if (pipe_on(q, MCV, (int)sizeof(T))) { \
         constexpr bool PIPEV = true;   \
         __VA_ARGS__;                   \
       } else {                         \

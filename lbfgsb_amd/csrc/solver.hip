@@ -61,8 +61,8 @@ class Solver final : public lbfgsb_hip_ctx {
   int pf_cur = 0;
   double *h_hdr = nullptr;
   size_t msg_len = 0;  // doubles per rank message
-  // reductions
-  double *h_res = nullptr;
+  // reductions (several ranks: every rank's partials, rank-major, see fetch)
+  double *h_res = nullptr, *d_res_all = nullptr, *h_res_all = nullptr;
   size_t res_len = 0;
   // streams
   hipStream_t stream = nullptr;
@@ -91,13 +91,13 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all);
+        F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
       p = nullptr;
     };
-    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix), H(h_sp_all), H(h_sp_loc);
+    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix), H(h_sp_all), H(h_sp_loc), H(h_res_all);
     if (pf_ev) (void)hipEventDestroy(pf_ev);
     pf_ev = nullptr;
     if (order_ev) (void)hipEventDestroy(order_ev);
@@ -130,10 +130,8 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     q.stream = stream;
     ld = ((n + 31) / 32) * 32;
-    if (const char *e = std::getenv("LBFGSB_LD_PAD")) ld += 32 * (int64_t)std::max(0, std::atoi(e));  // (experiment)
     // streamed-once data: nontemporal loads unless W fits the 256 MiB Infinity Cache
     q.nt = (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
-    if (const char *e = std::getenv("LBFGSB_NT")) q.nt = e[0] == '1';
     const size_t wbytes = (size_t)ld * m * sizeof(T);
     HIPCHK(hipMalloc(&ws, wbytes));
     HIPCHK(hipMalloc(&wy, wbytes));
@@ -213,6 +211,11 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipHostMalloc(&h_sp_all, ((size_t)nr * sp_len() + nr) * sizeof(double)));
     HIPCHK(hipHostMalloc(&h_sp_loc, sp_len() * sizeof(double)));
     spcand.valid = false;
+    if (d_res_all) (void)hipFree(d_res_all);
+    if (h_res_all) (void)hipHostFree(h_res_all);
+    d_res_all = h_res_all = nullptr;
+    HIPCHK(hipMalloc(&d_res_all, (size_t)nr * res_len * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_res_all, (size_t)nr * res_len * sizeof(double)));
     return 0;
   }
 
@@ -223,6 +226,7 @@ class Solver final : public lbfgsb_hip_ctx {
       p = nullptr;
     };
     F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]), F(sort_tmp);
+    sel_alloc = 0;
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipMalloc(&keys[k], count * sizeof(uint64_t)));
       HIPCHK(hipMalloc(&idx[k], count * sizeof(uint32_t)));
@@ -234,24 +238,29 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   // ---- complete a reduction across ranks and bring it to the host ----
+  // ONE collective per host sync: the k partials of every rank are all-gathered (ncclAllGather on
+  // the solver's stream, k <= 8m + 15 doubles per rank) and reduced on the host in rank order --
+  // sums | minima | maxima in one go, every rank gets bit-identical results by construction,
+  // whatever algorithm RCCL picks for the message.  (r02: up to three grouped ncclAllReduce.)
   int fetch(int nsum, int nmin, int nmax) {
     const int k = nsum + nmin + nmax;
-    if (comm) {
-      if (g_rccl.GroupStart() != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclGroupStart");
-      ncclResult_t rc = ncclSuccess;
-      if (nsum)
-        rc = g_rccl.AllReduce(q.d_res, q.d_res, nsum, ncclDouble, ncclSum, comm, stream);
-      if (rc == ncclSuccess && nmin)
-        rc = g_rccl.AllReduce(q.d_res + nsum, q.d_res + nsum, nmin, ncclDouble, ncclMin, comm,
-                              stream);
-      if (rc == ncclSuccess && nmax)
-        rc = g_rccl.AllReduce(q.d_res + nsum + nmin, q.d_res + nsum + nmin, nmax, ncclDouble,
-                              ncclMax, comm, stream);
-      if (g_rccl.GroupEnd() != ncclSuccess || rc != ncclSuccess)
-        return fail(LBFGSB_E_COMM, "ncclAllReduce failed");
+    if (q.launch_err != hipSuccess) {  // a kernel launch of this phase failed: name it
+      const hipError_t e = q.launch_err;
+      q.launch_err = hipSuccess;
+      return fail(LBFGSB_E_NOGPU, std::string("kernel launch failed in ") +
+                                      (q.launch_err_where ? q.launch_err_where : "?") + ": " +
+                                      hipGetErrorString(e));
     }
-    HIPCHK(hipMemcpyAsync(h_res, q.d_res, (size_t)k * sizeof(double), hipMemcpyDeviceToHost,
-                          stream));
+    if ((size_t)k > res_len) return fail(LBFGSB_E_STATE, "fetch: more partials than the buffer holds");
+    if (comm) {
+      if (g_rccl.AllGather(q.d_res, d_res_all, (size_t)k, ncclDouble, comm, stream) != ncclSuccess)
+        return fail(LBFGSB_E_COMM, "ncclAllGather of the partial sums failed");
+      HIPCHK(hipMemcpyAsync(h_res_all, d_res_all, (size_t)nranks * k * sizeof(double),
+                            hipMemcpyDeviceToHost, stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(h_res, q.d_res, (size_t)k * sizeof(double), hipMemcpyDeviceToHost,
+                            stream));
+    }
     {
       const double t0 = now_s();
       HIPCHK(hipStreamSynchronize(stream));
@@ -259,7 +268,16 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     nsync++;
     if (clock_on) clk_collect();
-    if (nranks > 1 && !comm) {
+    if (comm) {
+      for (int j = 0; j < k; ++j) {
+        double v = h_res_all[j];
+        for (int rk = 1; rk < nranks; ++rk) {
+          const double w = h_res_all[(size_t)rk * k + j];
+          v = j < nsum ? v + w : (j < nsum + nmin ? std::fmin(v, w) : std::fmax(v, w));
+        }
+        h_res[j] = v;
+      }
+    } else if (nranks > 1) {
       if (!cb_ar) return fail(LBFGSB_E_COMM, "multi-rank context without a reducer");
       if (cb_ar(cb_user, h_res, nsum, nmin, nmax) != 0)
         return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
@@ -295,11 +313,13 @@ class Solver final : public lbfgsb_hip_ctx {
     std::vector<uint32_t> taken;
     uint32_t next_chunk = 64;
     int grow = 0;
-    // LBFGSB_F_EXACT_TIES: the reference's own pop order (bkmin first, then hpsolb's heap),
-    // replayed on the host over ALL breakpoints; records are gathered in that order
+    // the reference's own pop order (bkmin first, then hpsolb's heap), replayed on the host over
+    // ALL breakpoints; records are gathered in that order
     bool exact = false;
     std::vector<double> ht;       // heap keys   (t of hpsolb, 0-based)
-    std::vector<uint32_t> hio;    // heap values (iorder: GLOBAL rows; < 2^32 checked by the caller)
+    std::vector<uint32_t> hio;    // heap values (iorder: GLOBAL rows), n_global < 2^32 ...
+    std::vector<int64_t> hio64;   // ... and beyond (h64)
+    bool h64 = false;
     std::vector<int64_t> hrow0;   // first global row of every rank (+ nglob at the end)
     int64_t hleft = 0;            // nleft of the reference's walk for the NEXT pop
     bool hbuilt = false;
@@ -369,10 +389,7 @@ class Solver final : public lbfgsb_hip_ctx {
   //      step stands; ensure_d() writes them out for everything but the hot path ----
   bool d_impl = false;
   bool z_in_x = false;  // ... and z too: until the next cauchy gives z a new meaning
-  const bool lean_on = [] {
-    const char *e = std::getenv("LBFGSB_LEAN");
-    return !(e && e[0] == '0');
-  }();
+  bool lean_on = true;  // (option "lean")
   const T *d_src() const { return d_impl ? t : d; }  // what the kernels read the direction from
   int ensure_d(const T *x) {
     if (!d_impl) return 0;
@@ -430,12 +447,9 @@ class Solver final : public lbfgsb_hip_ctx {
   double last_tsum = 0.0, last_dtm0 = 0.0;  // where the previous walk ended / first aimed
   size_t sp_len() const { return 2 + (size_t)SPEC_CAP * (2 * m + 4); }
   double spec_factor = 2.0;
-  // Off unless LBFGSB_SPEC_CAPTURE=1: measured at n = 1e8 / 1.25e7 (profiles/README.md, r02q) a walk
+  // Off unless option "spec_capture" = 1: measured at n = 1e8 / 1.25e7 (profiles/README.md, r02q) a walk
   // either crosses no breakpoint at all or hundreds to thousands -- SPEC_CAP records serve 0-3 of 31.
-  const bool spec_on = [] {
-    const char *e = std::getenv("LBFGSB_SPEC_CAPTURE");
-    return e && e[0] == '1';
-  }();
+  bool spec_on = false;
   double spec_hi(bool cnstnd) const {  // the guess: a little beyond where the previous walk ended
     if (!spec_on || !cnstnd || iter_seen < 3) return -1.0;  // (the first walks cross most breakpoints)
     return last_tsum > 0.0 && std::isfinite(last_tsum) ? spec_factor * last_tsum : -1.0;
@@ -482,11 +496,8 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // *big != nullptr: if more than PG_MIN candidates lie in the window, only report their number
   // (the caller switches to the parallel search) instead of ordering them
-  // (LBFGSB_PG_MIN lowers it so that tests can send small problems through the search)
-  const double PG_MIN = [] {
-    const char *e = std::getenv("LBFGSB_PG_MIN");
-    return e ? std::atof(e) : 32768.0;
-  }();
+  // (option "pg_min" lowers it so that tests can send small problems through the search)
+  double PG_MIN = 32768.0;
   int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, const T *x, const T *l,
                    const T *u, const T *g, int head, int col, double *big = nullptr) {
     // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
@@ -626,14 +637,14 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
-  // ---- LBFGSB_F_EXACT_TIES: breakpoints in the reference's own order ----
+  // ---- breakpoints in the reference's own order ----
   // cauchy takes the smallest breakpoint from the scan (first minimum in variable order, :1384-
   // 1389), then moves the last list entry into its slot, builds hpsolb's heap over the rest and
   // pops one breakpoint per segment (:1391-1403).  Among EQUAL breakpoints that order is a
   // property of the heap, not of the variables; it matters only when the walk ends inside a
   // group of equal breakpoints (then it decides which of them are fixed).  Replaying it needs the
-  // whole list on the host: O(n) transfer + heap build, so it is opt-in and runs only for a call
-  // whose walk did end inside such a group (or from the start under iprint >= 99).
+  // whole list on the host: O(n) transfer + heap build, so it runs only for a call whose walk did
+  // end inside such a group (or from the start under iprint >= 99); LBFGSB_F_INDEX_TIES opts out.
   int exact_init(Provider &pv) {
     CHK(ensure_tbrk());
     std::vector<T> tb((size_t)n);
@@ -642,7 +653,8 @@ class Solver final : public lbfgsb_hip_ctx {
     nsync++;
     pv = Provider{};
     pv.exact = true;
-    pv.ht.clear(), pv.hio.clear();
+    pv.h64 = nglob >= 0xffffffffll;
+    pv.ht.clear(), pv.hio.clear(), pv.hio64.clear();
     const double inf = std::numeric_limits<double>::infinity();
     // every rank's breakpoint times, in global variable order (ranks own ascending row blocks)
     std::vector<double> tall;
@@ -688,7 +700,10 @@ class Solver final : public lbfgsb_hip_ctx {
         const double t = tall[(size_t)rk * (size_t)nmax + (size_t)i];
         if (!(t >= 0.0) || t == inf) continue;
         pv.ht.push_back(t);
-        pv.hio.push_back((uint32_t)(pv.hrow0[rk] + i));
+        if (pv.h64)
+          pv.hio64.push_back(pv.hrow0[rk] + i);
+        else
+          pv.hio.push_back((uint32_t)(pv.hrow0[rk] + i));
         if (pv.ht.size() == 1 || t < bk) bk = t, pv.hibkmin = (int64_t)pv.ht.size() - 1;
       }
     pv.hleft = (int64_t)pv.ht.size();
@@ -713,31 +728,38 @@ class Solver final : public lbfgsb_hip_ctx {
     std::vector<uint32_t> hi;
     std::vector<int> owner;
     const int64_t nbreak = (int64_t)pv.ht.size();
+    const auto io_at = [&](size_t k) -> int64_t { return pv.h64 ? pv.hio64[k] : (int64_t)pv.hio[k]; };
     while (owner.size() < want && pv.hleft > 0) {
       double tj;
-      uint32_t grow;
+      int64_t grow;
       if (pv.hleft == nbreak) {  // iter == 1 (:1384-1389)
-        tj = pv.ht[(size_t)pv.hibkmin], grow = pv.hio[(size_t)pv.hibkmin];
+        tj = pv.ht[(size_t)pv.hibkmin], grow = io_at((size_t)pv.hibkmin);
       } else {
         if (!pv.hbuilt) {  // iter == 2: the last entry replaces the used one (:1391-1398)
           if (pv.hibkmin != nbreak - 1) {
             pv.ht[(size_t)pv.hibkmin] = pv.ht[(size_t)nbreak - 1];
-            pv.hio[(size_t)pv.hibkmin] = pv.hio[(size_t)nbreak - 1];
+            if (pv.h64)
+              pv.hio64[(size_t)pv.hibkmin] = pv.hio64[(size_t)nbreak - 1];
+            else
+              pv.hio[(size_t)pv.hibkmin] = pv.hio[(size_t)nbreak - 1];
           }
         }
-        lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio.data(), pv.hbuilt ? 1 : 0);
+        if (pv.h64)
+          lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio64.data(), pv.hbuilt ? 1 : 0);
+        else
+          lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio.data(), pv.hbuilt ? 1 : 0);
         pv.hbuilt = true;
-        tj = pv.ht[(size_t)pv.hleft - 1], grow = pv.hio[(size_t)pv.hleft - 1];
+        tj = pv.ht[(size_t)pv.hleft - 1], grow = io_at((size_t)pv.hleft - 1);
       }
       pv.hleft--;
-      const int rk = (int)(std::upper_bound(pv.hrow0.begin(), pv.hrow0.end(), (int64_t)grow) -
+      const int rk = (int)(std::upper_bound(pv.hrow0.begin(), pv.hrow0.end(), grow) -
                            pv.hrow0.begin()) - 1;
       owner.push_back(rk);
       if (rk == rank) {
         uint64_t bits;
         std::memcpy(&bits, &tj, 8);
         hk.push_back(bits);
-        hi.push_back((uint32_t)((int64_t)grow - row0));
+        hi.push_back((uint32_t)(grow - row0));
       }
     }
     const uint32_t len = (uint32_t)owner.size(), own = (uint32_t)hk.size();
@@ -983,12 +1005,26 @@ class Solver final : public lbfgsb_hip_ctx {
         pg_bytes = bytes;
       }
     }
+    // (every allocation of this search happens BEFORE the ranks vote: a rank that cannot allocate
+    //  votes "does not fit" and all of them replay the walk exactly -- none is left waiting in a
+    //  collective)
     const size_t tb = std::max(lbk::scan_temp_bytes((size_t)nb), lbk::f2scan_temp_bytes((size_t)nb)) + 256;
     if (fits && tb > pg_tmp_bytes) {
       if (pg_tmp) (void)hipFree(pg_tmp);
       pg_tmp = nullptr, pg_tmp_bytes = 0;
-      HIPCHK(hipMalloc(&pg_tmp, tb));
-      pg_tmp_bytes = tb;
+      if (hipMalloc(&pg_tmp, tb) != hipSuccess) {
+        (void)hipGetLastError();
+        pg_tmp = nullptr;
+        fits = false;
+      } else {
+        pg_tmp_bytes = tb;
+      }
+    }
+    if (fits && ensure_sel(std::max((size_t)n, (size_t)nranks * (size_t)lbp)) != 0) {
+      (void)hipGetLastError();
+      fits = false;
+      // (the window buffers of the exact replay must exist again)
+      if (sel_alloc == 0) CHK(ensure_sel(SEL_CAP));
     }
     if (multi) {  // one rank short of memory sends every rank back to the exact replay
       CHK(put_header(fits ? 1.0 : 0.0, 0.0));
@@ -996,7 +1032,6 @@ class Solver final : public lbfgsb_hip_ctx {
       for (int rk = 0; rk < nranks; ++rk) fits = fits && h_msg_all[2 * (size_t)rk] > 0.0;
     }
     if (!fits) return 0;
-    CHK(ensure_sel(std::max((size_t)n, (size_t)nranks * (size_t)lbp)));
     nfullsort++;
     lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, -1.0, -1, keys[0], idx[0]);
     lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1], (size_t)n);
@@ -1227,14 +1262,11 @@ class Solver final : public lbfgsb_hip_ctx {
 
     // Equal breakpoints are delivered in index order, the reference pops them in heap order
     // (hpsolb :2079); the two differ in effect only if the walk ends INSIDE such a group.  That
-    // is detected (tie_split) and counted; with LBFGSB_F_EXACT_TIES the walk is then replayed from
-    // its start in the reference's own order (exact_init / refill_exact).
-    const bool can_exact = (flags & LBFGSB_F_EXACT_TIES) && nglob < 0xffffffffll;
-    // (a replay would print the walk twice; LBFGSB_EXACT_ALWAYS=1: every walk in that order, for tests)
-    static const bool exact_always = [] {
-      const char *e = std::getenv("LBFGSB_EXACT_ALWAYS");
-      return e && e[0] == '1';
-    }();
+    // is detected (tie_split), counted, and the walk is then replayed from its start in the
+    // reference's own order (exact_init / refill_exact) -- unless LBFGSB_F_INDEX_TIES opts out.
+    const bool can_exact = !(flags & LBFGSB_F_INDEX_TIES);
+    // (a replay would print the walk twice: under iprint >= 99 the walk runs in that order from the
+    //  start; option "exact_always": every walk in that order, for tests)
     bool exact_run = can_exact && (print_level >= 99 || exact_always);
     std::vector<double> p_start(p, p + col2);
     const double f1_start = f1, f2_start = f2, dtm_start = dtm;
@@ -1645,13 +1677,28 @@ class Solver final : public lbfgsb_hip_ctx {
   // ... which is the case while every stored s_i keeps at least 1e-5 of its squared norm on the free
   // rows (variables that sit at a bound do not move: their part of s is zero unless they have
   // just arrived, so a small free SET alone does not make the free PART small)
+  // The same kind of difference gives sum_free s_i y_j below the diagonal: Sy(i,j) - L_a(i,j)
+  // (total minus active).  Entry by entry that difference may be small against its operands without
+  // harm -- what must not drown is its contribution to W'Z r, which is measured against the free
+  // norms |Z's_i| |Z'y_j| (Cauchy-Schwarz bounds the exact value by them): the rounding error of the
+  // difference, ~eps (|Sy| + |L_a|), has to stay below 1e-5 of that scale.
   bool closed_form_safe(int col) const {
-    const double *WN1 = snd.data(), *SS = ss.data();
+    const double *WN1 = snd.data(), *SS = ss.data(), *SY = sy.data();
     const int m2 = 2 * m;
+    const double eps = std::numeric_limits<double>::epsilon();
     for (int i = 0; i < col; ++i) {
       const double tot = SS[(size_t)i + (size_t)i * m];
       const double act = WN1[(size_t)(m + i) + (size_t)(m + i) * m2];
       if (!(tot - act >= 1.0e-5 * tot)) return false;
+    }
+    for (int i = 1; i < col; ++i) {
+      const double ssf = SS[(size_t)i + (size_t)i * m] - WN1[(size_t)(m + i) + (size_t)(m + i) * m2];
+      for (int j = 0; j < i; ++j) {
+        const double yyf = WN1[(size_t)j + (size_t)j * m2];
+        const double tot = SY[(size_t)i + (size_t)j * m], act = WN1[(size_t)(m + i) + (size_t)j * m2];
+        const double scale = std::sqrt(std::fabs(ssf) * std::fabs(yyf));
+        if (!(eps * (std::fabs(tot) + std::fabs(act)) <= 1.0e-5 * scale)) return false;
+      }
     }
     return true;
   }
@@ -1845,17 +1892,43 @@ class Solver final : public lbfgsb_hip_ctx {
   // ---- two-pass iteration (col <= 10): formk's new row rides in the update pass with the
   //      pre-walk free set, the walk corrects it for the rows it fixes, and W'Z r follows in
   //      closed form from the walk's p and WN1 (subspace_closed_form) -- no cmprlb pass ----
-  const bool two_pass = [] {
-    const char *e = std::getenv("LBFGSB_TWO_PASS");
-    return !(e && e[0] == '0');
-  }();
+  bool two_pass = true;  // (option "two_pass")
   // (col <= 20: beyond that the update pass has no registers for the 4 col + 4 extra sums;
-  //  LBFGSB_TWO_PASS_MAXCOL lowers the limit, for measurements)
-  const int two_pass_maxcol = [] {
-    const char *e = std::getenv("LBFGSB_TWO_PASS_MAXCOL");
-    const int v = e ? std::atoi(e) : 20;
-    return v < 0 ? 0 : (v > 20 ? 20 : v);
-  }();
+  //  option "two_pass_maxcol" lowers the limit, for measurements)
+  int two_pass_maxcol = 20;
+  bool exact_always = false;  // (option "exact_always": every walk in the reference's heap order)
+
+  // lbfgsb_hip_set_option: measurement / test switches of THIS context (include/lbfgsb_hip.h)
+  int set_option(const char *name, double v) override {
+    const std::string k = name ? name : "";
+    const auto flag = [&](bool &dst) -> int {
+      if (v != 0.0 && v != 1.0) return fail(LBFGSB_E_ARG, "set_option: " + k + " takes 0 or 1");
+      dst = v != 0.0;
+      return 0;
+    };
+    const auto in_range = [&](int lo, int hi, int &dst) -> int {
+      if (!(v >= lo && v <= hi) || v != std::floor(v))
+        return fail(LBFGSB_E_ARG, "set_option: " + k + " out of range");
+      dst = (int)v;
+      return 0;
+    };
+    if (k == "two_pass") return flag(two_pass);
+    if (k == "two_pass_maxcol") return in_range(0, 20, two_pass_maxcol);
+    if (k == "lean") return flag(lean_on);
+    if (k == "spec_capture") return flag(spec_on);
+    if (k == "exact_always") return flag(exact_always);
+    if (k == "nt") return flag(q.nt);
+    if (k == "pg_min") {
+      if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
+      PG_MIN = v;
+      return 0;
+    }
+    if (k == "wgrid") return in_range(1, lbk::MAX_BLOCKS - 1, q.tune.wgrid);
+    if (k == "pipe") return in_range(-1, 1, q.tune.pipe);
+    if (k == "pair") return in_range(0, 2, q.tune.pair);
+    if (k == "gram_rows") return in_range(0, 1, q.tune.gram_rows);
+    return fail(LBFGSB_E_ARG, "set_option: unknown option '" + k + "'");
+  }
   // update_scan_kernel's NEWROW flag for the pass that forms pair number `colnew`
   int nr_flag(int colnew) const { return two_pass && colnew <= two_pass_maxcol ? 1 : 0; }
   struct NewRow {
@@ -2622,6 +2695,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // many of THIS rank's rows are free -- Indx2(1) carries the local free count
     if (nranks != 1 && index)
       return fail(LBFGSB_E_STATE, "export_state: contexts that mirror Index are single-rank");
+    HIPCHK(hipSetDevice(device));
     T *wa = (T *)wa_;
     const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
     HIPCHK(hipMemcpy2DAsync(wa, (size_t)n * sizeof(T), ws, (size_t)ld * sizeof(T),
@@ -2682,6 +2756,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int import_state(const void *wa_, const int32_t *iwa, const int32_t *isave_user) override {
     if (nranks != 1 && index)
       return fail(LBFGSB_E_STATE, "import_state: contexts that mirror Index are single-rank");
+    HIPCHK(hipSetDevice(device));
     const T *wa = (const T *)wa_;
     const int64_t mn = (int64_t)m * n;
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
@@ -2763,6 +2838,7 @@ class Solver final : public lbfgsb_hip_ctx {
   }
   int k_launch(int which, const void *x, const void *g, int col, int head) override {
     if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "bad col/head");
+    HIPCHK(hipSetDevice(device));
     lbk::Coef cf;
     std::memset(&cf, 0, sizeof cf);
     if (which == 0 || which == 2)

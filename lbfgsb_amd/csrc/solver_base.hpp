@@ -56,12 +56,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
-                            hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
   bool ok = false;  // every symbol resolved
   bool load() {
     if (ok) return true;
@@ -83,12 +79,9 @@ struct Rccl {
     SYM(GetUniqueId, "ncclGetUniqueId");
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
-    SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather");
-    SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd");
 #undef SYM
-    ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather && GroupStart && GroupEnd;
+    ok = GetUniqueId && CommInitRank && CommDestroy && AllGather;
     if (!ok) {
       dlclose(h);
       h = nullptr;
@@ -128,6 +121,7 @@ struct lbfgsb_hip_ctx {
   virtual int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank,
                           int nranks) = 0;
   virtual void path_counts(int64_t &closed_form, int64_t &three_pass) const = 0;
+  virtual int set_option(const char *name, double value) = 0;  // lbfgsb_hip_set_option
   virtual const void *prev_iterate() const = 0;  // t: the reference's wa(3n+2mn+11m^2+1 : +n)
 
   // host-entry staging (setulb_host)

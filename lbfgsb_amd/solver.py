@@ -61,7 +61,7 @@ class DeviceSolver:
     def __init__(self, n_local: int, m: int, n_global: Optional[int] = None, row0: int = 0,
                  real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None,
                  same_stream_objective: bool = False, parallel_gcp: bool = False,
-                 exact_ties: bool = False):
+                 exact_ties: bool = True, index_ties: bool = False, options: Optional[dict] = None):
         self.lib = load_library()
         self.same_stream_objective = bool(same_stream_objective)
         self.n, self.m = int(n_local), int(m)
@@ -71,7 +71,9 @@ class DeviceSolver:
         flags = (capi.F_REAL32 if real32 else 0) | (capi.F_MIRROR_INDEX if mirror_index else 0)
         flags |= capi.F_NO_RETURN_SYNC if same_stream_objective else 0
         flags |= capi.F_PARALLEL_GCP if parallel_gcp else 0  # opt-in, see include/lbfgsb_hip.h
-        flags |= capi.F_EXACT_TIES if exact_ties else 0      # opt-in, see include/lbfgsb_hip.h
+        # a walk that ends inside a group of equal breakpoints is replayed in the reference's heap
+        # order by default; index_ties=True (or exact_ties=False) opts out (include/lbfgsb_hip.h)
+        flags |= capi.F_INDEX_TIES if (index_ties or not exact_ties) else 0
         h = C.c_void_p()
         sp = C.c_void_p(int(stream)) if stream else None
         check(self.lib.lbfgsb_hip_create(self.n, self.n_global, self.row0, self.m, flags, device,
@@ -84,6 +86,12 @@ class DeviceSolver:
         self.dsave = np.zeros(29, np.float64)
         self.f = np.zeros(1, np.float64)
         self._keep = []
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name: str, value: float):
+        """measurement / test switch of this context (lbfgsb_hip_set_option)"""
+        check(self.lib.lbfgsb_hip_set_option(self.h, name.encode(), float(value)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -9,8 +9,8 @@
  * iprint; the iteration-file unit slot isave(24) is left 0.
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).
- * Parity pinned by tests/test_oracle_golden.py (fixtures produced by the
- * real reference) and tests/test_oracle_vs_ref.py (oracle/_ref when built).
+ * Parity pinned by tests/test_oracle_golden.py: fixtures produced by the real
+ * reference, and live runs against oracle/_ref when it is built.
  */
 #include "lbfgsb_oracle.h"
 

@@ -31,7 +31,8 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     def make_solver():
         s_ = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=0,
                                      parallel_gcp=(variant in ("pgcp", "pgcp2")),
-                                     exact_ties=(variant == "symx"))
+                                     index_ties=(variant == "sym"),
+                                     options={"exact_always": 1} if variant == "symx" else None)
         if mode == "gloo":
             lbfgsb_amd.attach_host_group(s_, rank, world)
         elif mode == "rccl1":

@@ -21,6 +21,8 @@ void hd_dcsrch(double f, double g, double *stp, double ftol, double gtol, double
                double stpmax, char *task, int32_t *isave, double *dsave) {
   lbh::dcsrch(f, g, *stp, ftol, gtol, xtol, stpmin, stpmax, task, isave, dsave);
 }
+void hd_hpsolb32(int64_t n, double *t, uint32_t *iorder, int iheap) { lbh::hpsolb(n, t, iorder, iheap); }
+void hd_hpsolb64(int64_t n, double *t, int64_t *iorder, int iheap) { lbh::hpsolb(n, t, iorder, iheap); }
 void hd_fmt(double v, int w, int d, int letter, char *out, int cap) {
   std::string s = lbr::fexp(v, w, d, (char)letter);
   std::snprintf(out, cap, "%s", s.c_str());

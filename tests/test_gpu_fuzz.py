@@ -1,10 +1,12 @@
 """Randomised differential test: random box-constrained problems (random n, m, bound types incl.
 fixed and unbounded variables, separable + coupled + non-convex objectives, random factr/pgtol)
-solved call by call through the reference-shaped host entry and by the oracle.  Every setulb
-return must match (task, iteration, nfg, nseg, nfree; f to 1e-8) -- except that a run may part
-ways late (second half), where with factr = 0 the stop test acts on rounding noise, provided
-the final f agrees to 1e-7.  Exercises the production iteration (speculative update pass, pending
-pair, functional Cauchy point, skipped updates, restarts) on shapes no hand-written case covers."""
+solved call by call through the device-pointer entry and by the oracle.  Every setulb return
+must match (task, iteration, nfg, nseg, nfree; f to 1e-8); where a run leaves the oracle's
+trajectory, the split must be reproduced by ONE oracle call from the GPU's own previous state
+(one-step parity: integers exactly, floats to 1e-10), and the final f agrees to 1e-7.  There is no
+allowance for unexplained splits.  Exercises the production iteration (speculative update pass,
+pending pair, functional Cauchy point, skipped updates, restarts) on shapes no hand-written case
+covers."""
 import numpy as np
 import pytest
 
@@ -48,65 +50,123 @@ def make(po, seed, nmax, mlo, mhi):
     return po.Problem("fuzz%d" % seed, n, m, x0, l, u, nbd, factr, pgtol, fg, np.float64)
 
 
+def _state(po, p, sol, x, g):
+    """the caller arrays of a DEFAULT (production-path) context after a setulb return; export_state is
+    read-only: it writes z and d out where the lean subspace pass left them implicit, nothing else"""
+    import torch
+    torch.cuda.synchronize()
+    wa, iwa = sol.export_state()
+    return po.State(p.n, p.m, x.cpu().numpy(), g.cpu().numpy(), sol.f.copy(), wa, iwa, sol.task.copy(),
+                    sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(), sol.dsave.copy())
+
+
+def _explain_divergence(po, p, prev, got):
+    """The trajectories parted ways at this call.  One ORACLE call from the GPU's own previous
+    state (every caller array as the production context exported it, f and g as the test evaluated
+    them at the GPU's x) must reproduce the GPU's call: task, every counter, iwhere exactly, floats to
+    1e-10 -- then the GPU took a correct reference step from a state that differed from the oracle's
+    trajectory by rounding, and the split is drift, not a defect."""
+    from test_gpu_parity import compare_states
+    s = prev.copy()
+    po.call(po.Engine("oracle"), p, s)
+    # by design (DESIGN.md section 7): at a NEW_X return a production context already holds the iwhere
+    # pattern of the NEXT cauchy scan; xp / the enter-leave half of Indx2 are not materialised
+    compare_states(got, s, p.n, p.m, po, skip=("xp",), check_lists=False,
+                   check_iwhere=got.task_s.startswith("FG_LN"))
+
+
+def drive_with_replay(po, p, max_iter, **ctx):
+    """Run p on the GPU (default context + ctx), call by call beside the oracle's trajectory.
+    -> (split, n_calls): split = index of the first call that differs from the oracle's trajectory
+    (None: equal to the end).  A split that one oracle call from the GPU's previous state does not
+    reproduce raises."""
+    import torch
+    import lbfgsb_amd as la
+
+    def row(t, isave, f):
+        return (t[:12], int(isave[29]), int(isave[33]), int(isave[32]), int(isave[37]), float(f))
+    ro = []
+    so = po.run(po.Engine("oracle"), p, max_iter=max_iter,
+                snapshot=lambda k, s: ro.append(row(s.task_s, s.isave, s.f[0])))
+    sol = la.DeviceSolver(p.n, p.m, **ctx)
+    try:
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        rg, prev, split = [], None, None
+        for _ in range(100000):
+            t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            rg.append(row(t, sol.isave, sol.f[0]))
+            k = len(rg) - 1
+            cur = None
+            if split is None:
+                cur = _state(po, p, sol, x, g)
+                same = (k < len(ro) and ro[k][:5] == rg[k][:5]
+                        and abs(ro[k][5] - rg[k][5]) <= 1e-8 * max(1.0, abs(ro[k][5])))
+                if not same:
+                    split = k
+                    assert prev is not None, (p.name, "diverged at the very first call", ro[:1], rg[:1])
+                    try:
+                        _explain_divergence(po, p, prev, cur)
+                    except AssertionError as e:
+                        raise AssertionError(
+                            "%s (n=%d m=%d): call %d differs from the oracle's trajectory (%s vs %s) and is "
+                            "NOT reproduced by one oracle call from the GPU's previous state: %s"
+                            % (p.name, p.n, p.m, k, ro[k:k + 1], rg[k:k + 1], e))
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+                if cur is not None:
+                    cur.f[0], cur.g = sol.f[0], gh.copy()
+            elif t.startswith("NEW_X"):
+                if sol.isave[29] >= max_iter:
+                    break
+            else:
+                break
+            prev = cur
+        fgp, fo = float(sol.f[0]), float(so.f[0])
+    finally:
+        sol.close()
+    if split is None:
+        assert len(rg) == len(ro), (p.name, len(rg), len(ro))
+    else:
+        assert abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), (p.name, p.n, p.m, split, len(ro), len(rg), fo, fgp)
+    return split, len(ro)
+
+
 @pytest.mark.parametrize("first,count,nmax,mlo,mhi,switch", [
     (0, 120, 400, 1, 13, None), (5000, 40, 3000, 11, 33, None),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
-    (7000, 40, 1500, 1, 25, "LBFGSB_SPEC_CAPTURE=1"), (7100, 40, 1500, 1, 25, "LBFGSB_TWO_PASS=0"),
-    (7200, 40, 1500, 1, 25, "LBFGSB_LEAN=0")])
-def test_random_problems_against_oracle(oracle_built, monkeypatch, first, count, nmax, mlo, mhi, switch):
+    (7000, 40, 1500, 1, 25, "spec_capture=1"), (7100, 40, 1500, 1, 25, "two_pass=0"),
+    (7200, 40, 1500, 1, 25, "lean=0")])
+def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi, switch):
     po = oracle_built
-    import lbfgsb_amd as la
-    if switch:
-        monkeypatch.setenv(*switch.split("="))
-
-    def row(s):
-        return (s.task_s[:12], int(s.isave[29]), int(s.isave[33]), int(s.isave[32]), int(s.isave[37]),
-                float(s.f[0]))
-    late = 0
+    opts = {switch.split("=")[0]: float(switch.split("=")[1])} if switch else {}
+    splits = []
     for seed in range(first, first + count):
-        p = make(po, seed, nmax, mlo, mhi)
-        ro = []
-        so = po.run(po.Engine("oracle"), p, max_iter=80, snapshot=lambda k, s: ro.append(row(s)))
-        s = po.State.fresh(p)
-        nbd = p.nbd.astype(np.int32)
-        rg = []
-        for _ in range(100000):
-            la.setulb(p.n, p.m, s.x, p.l, p.u, nbd, s.f, s.g, p.factr, p.pgtol, s.wa, s.iwa, s.task,
-                      -1, s.csave, s.lsave, s.isave, s.dsave)
-            rg.append(row(s))
-            t = s.task_s
-            if t.startswith("FG"):
-                s.f[0] = p.fg(s.x, s.g)
-            elif t.startswith("NEW_X"):
-                if s.isave[29] >= 80:
-                    break
-            else:
-                break
-        k = 0
-        while (k < min(len(ro), len(rg)) and ro[k][:5] == rg[k][:5]
-               and abs(ro[k][5] - rg[k][5]) <= 1e-8 * max(1.0, abs(ro[k][5]))):
-            k += 1
-        if k == len(ro) == len(rg):
-            continue
-        late += 1
-        fo, fgp = float(so.f[0]), float(s.f[0])
-        assert k >= 0.4 * len(ro) and abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), \
-            (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
-    assert late <= 0.2 * count      # the vast majority match through the last call
+        split, ncalls = drive_with_replay(po, make(po, seed, nmax, mlo, mhi), 80, options=opts)
+        if split is not None:
+            splits.append((seed, split, ncalls))
+    print("%d of %d runs left the oracle's trajectory, each reproduced by a one-step oracle replay "
+          "(seed, first differing call, calls): %s" % (len(splits), count, splits))
 
 
-def test_random_problems_parallel_gcp_search(oracle_built, monkeypatch):
-    """The opt-in parallel GCP search on random problems: LBFGSB_PG_MIN=0 sends EVERY walk that
+def test_random_problems_parallel_gcp_search(oracle_built):
+    """The opt-in parallel GCP search on random problems: option pg_min = 0 sends EVERY walk that
     passes its first breakpoint through it -- the closed form when no pair is stored, the sort +
     scans (with the f2 clamp) when pairs are stored -- on all bound types, fixed and unbounded
     variables, m = 1..12.  Against the oracle's sequential walk: same iteration / nfg columns,
     nseg and nfree within 2, f to 1e-8, call by call over the first 12
-    iterations; a run may part ways late only at rounding level (final f to 1e-7)."""
+    iterations; a run may part ways late only at rounding level (final f to 1e-7).  (The flag is a
+    declared deviation from the reference's arithmetic: a one-step replay against the sequential
+    oracle is not the bar here.)"""
     po = oracle_built
     import torch
     import lbfgsb_amd as la
-    monkeypatch.setenv("LBFGSB_PG_MIN", "0")
     searched, late, count = 0, 0, 60
     for seed in range(9000, 9000 + count):
         p = make(po, seed, 2500, 1, 13)
@@ -117,7 +177,7 @@ def test_random_problems_parallel_gcp_search(oracle_built, monkeypatch):
                     snapshot=lambda k, s: ro.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
                                                      int(s.isave[37]), float(s.f[0])))
                     if s.task_s.startswith("NEW_X") else None)
-        sol = la.DeviceSolver(p.n, p.m, parallel_gcp=True)
+        sol = la.DeviceSolver(p.n, p.m, parallel_gcp=True, options={"pg_min": 0})
         x = torch.from_numpy(p.x0.copy()).cuda()
         g = torch.zeros_like(x)
         l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
@@ -154,54 +214,17 @@ def test_random_problems_parallel_gcp_search(oracle_built, monkeypatch):
     assert late <= 0.2 * count
 
 
-def test_random_problems_exact_tie_order(oracle_built, monkeypatch):
-    """LBFGSB_F_EXACT_TIES with LBFGSB_EXACT_ALWAYS=1: EVERY walk of 40 random problems is replayed
-    in the order of the reference's heap (all breakpoint times on the host, hpsolb, records
-    gathered in pop order) instead of the device's (t, index) order.  Same bar as the main
-    differential test: every NEW_X row (iteration, nfg, nseg, nfree; f to 1e-8) equals the
-    oracle's; a run may part ways late only at rounding level."""
+def test_random_problems_exact_tie_order(oracle_built):
+    """Option exact_always = 1: EVERY walk of 40 random problems is replayed in the order of the
+    reference's heap (all breakpoint times on the host, hpsolb, records gathered in pop order)
+    instead of the device's (t, index) order -- the route a walk that ends inside a group of equal
+    breakpoints takes by default.  Same bar as the main differential test: every return equals the
+    oracle's; a split must be reproduced by a one-step oracle replay."""
     po = oracle_built
-    import torch
-    import lbfgsb_amd as la
-    monkeypatch.setenv("LBFGSB_EXACT_ALWAYS", "1")
-    late, count = 0, 40
-    for seed in range(9500, 9500 + count):
-        p = make(po, seed, 1500, 1, 13)
-        ro = []
-        so = po.run(po.Engine("oracle"), p, max_iter=30,
-                    snapshot=lambda k, s: ro.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
-                                                     int(s.isave[37]), float(s.f[0])))
-                    if s.task_s.startswith("NEW_X") else None)
-        sol = la.DeviceSolver(p.n, p.m, exact_ties=True)
-        x = torch.from_numpy(p.x0.copy()).cuda()
-        g = torch.zeros_like(x)
-        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
-        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
-        rg = []
-        for _ in range(100000):
-            t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
-            if t.startswith("FG"):
-                xh = x.cpu().numpy()
-                gh = np.empty_like(xh)
-                sol.f[0] = p.fg(xh, gh)
-                g.copy_(torch.from_numpy(gh))
-            elif t.startswith("NEW_X"):
-                rg.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
-                           float(sol.f[0])))
-                if sol.isave[29] >= 30:
-                    break
-            else:
-                break
-        fgp = float(sol.f[0])
-        sol.close()
-        k = 0
-        while (k < min(len(ro), len(rg)) and ro[k][:4] == rg[k][:4]
-               and abs(ro[k][4] - rg[k][4]) <= 1e-8 * max(1.0, abs(ro[k][4]))):
-            k += 1
-        if k == len(ro) == len(rg):
-            continue
-        late += 1
-        fo = float(so.f[0])
-        assert k >= 0.4 * len(ro) and abs(fo - fgp) <= 1e-7 * max(1.0, abs(fo)), \
-            (seed, p.n, p.m, k, len(ro), len(rg), ro[max(0, k - 1):k + 1], rg[max(0, k - 1):k + 1])
-    assert late <= 0.2 * count
+    splits = []
+    for seed in range(9500, 9540):
+        split, ncalls = drive_with_replay(po, make(po, seed, 1500, 1, 13), 30, options={"exact_always": 1})
+        if split is not None:
+            splits.append((seed, split, ncalls))
+    print("exact order: %d of 40 runs left the oracle's trajectory, each reproduced one-step: %s"
+          % (len(splits), splits))

@@ -135,7 +135,7 @@ def test_sharded_parallel_gcp_with_pairs_stored(oracle_built, tmp_path, monkeypa
 
 @pytest.mark.parametrize("world,mode", [(3, "gloo"), (2, "fakerccl")])
 def test_sharded_exact_tie_order(oracle_built, tmp_path, monkeypatch, world, mode):
-    """LBFGSB_F_EXACT_TIES over several ranks: every rank holds all breakpoint times, pops the
+    """The reference's tie order over several ranks: every rank holds all breakpoint times, pops the
     same replicated heap (hpsolb, src/lbfgsb.f90:2079-2157) and gathers the records of the rows it
     owns.  On a problem made of 8 exact copies of 257 variables -- groups of equal breakpoints
     whose members sit on different ranks, alive over 40 iterations -- the iterate x itself must
@@ -155,25 +155,25 @@ def test_sharded_exact_tie_order(oracle_built, tmp_path, monkeypatch, world, mod
                 snapshot=lambda k, s: rows.append([int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
                                                    int(s.isave[37]), float(s.f[0])])
                 if s.task_s.startswith("NEW_X") else None)
-    # (on this trajectory no walk happens to END inside a group, so the replay would never be
-    #  triggered by itself: LBFGSB_EXACT_ALWAYS sends every walk through the multi-rank heap order)
-    monkeypatch.setenv("LBFGSB_EXACT_ALWAYS", "1")
+    # (on this trajectory few walks happen to END inside a group, so the replay would hardly be
+    #  triggered by itself: variant "symx" sets the option exact_always, which sends every walk
+    #  through the multi-rank heap order)
     res = launch(world, mode, n, m, iters, "symx", str(tmp_path / "out.json"))
-    monkeypatch.delenv("LBFGSB_EXACT_ALWAYS")
     assert res["stats"]["syncs"] > 0
     assert len(res["rows"]) == len(rows) == iters
     for a, b in zip(res["rows"], rows):
         assert a[:4] == b[:4], (a, b)
         assert a[4] == pytest.approx(b[4], rel=1e-10)
     assert np.max(np.abs(np.array(res["x"]) - so.x)) <= 1e-9
-    # the default order on the same ranks: same scalars, x equal up to a permutation inside the groups
+    # variable order (LBFGSB_F_INDEX_TIES) on the same ranks: same scalars, x equal up to a
+    # permutation inside the groups
     res_d = launch(world, mode, n, m, iters, "sym", str(tmp_path / "out2.json"))
     for a, b in zip(res_d["rows"], rows):
         assert a[:4] == b[:4], (a, b)
     xa = np.sort(np.array(res_d["x"]).reshape(8, 257), axis=0)
     xb = np.sort(so.x.reshape(8, 257), axis=0)
     assert np.max(np.abs(xa - xb)) <= 1e-9
-    print("tie splits: %d (default order), %d (exact)" % (res_d["tie_splits"], res["tie_splits"]))
+    print("tie splits: %d (variable order), %d (heap order)" % (res_d["tie_splits"], res["tie_splits"]))
 
 
 @pytest.mark.parametrize("world,mode", [(3, "gloo"), (2, "fakerccl")])

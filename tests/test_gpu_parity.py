@@ -1009,25 +1009,21 @@ def test_parallel_gcp_opt_in(env, kind):
 @pytest.mark.parametrize("handover", [False, True], ids=["", "handover"])
 @pytest.mark.parametrize("n,m,mixed,min_agree", [(1000, 10, False, 72), (4096, 10, True, 80),
                                                  (100003, 5, False, 60)])
-def test_device_path_to_convergence_against_oracle(env, monkeypatch, n, m, mixed, min_agree, handover):
+def test_device_path_to_convergence_against_oracle(env, n, m, mixed, min_agree, handover):
     """The production path (device pointers, speculative update pass, pending pair, functional
     Cauchy point, on-device objective) run to CONVERGENCE with factr = pgtol = 0: the integer
     columns (iteration, nfg, nseg, nfree) equal the oracle's for at least `min_agree` iterations
     (all 72 of the n = 1000 fixture; beyond that the stop test acts on rounding noise), f agrees
-    to 1e-11 throughout, same final message.  `handover`: with LBFGSB_SPEC_CAPTURE=1 the update
+    to 1e-11 throughout, same final message.  `handover`: with the option spec_capture = 1 the update
     pass also hands the next walk's first breakpoints over (off by default: DESIGN.md section 4)."""
     po, torch, la = env["po"], env["torch"], env["la"]
-    if handover:
-        monkeypatch.setenv("LBFGSB_SPEC_CAPTURE", "1")
-    else:
-        monkeypatch.delenv("LBFGSB_SPEC_CAPTURE", raising=False)
     p = po.problem_quadratic(n, m, mixed_nbd=mixed)
     rows_o = []
     so = po.run(po.Engine("oracle"), p,
                 snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
                                                      int(s.isave[37]), float(s.f[0])))
                 if s.task_s.startswith("NEW_X") else None)
-    sol = la.DeviceSolver(n, m)
+    sol = la.DeviceSolver(n, m, options={"spec_capture": 1} if handover else None)
     x = torch.from_numpy(p.x0.copy()).cuda()
     g = torch.zeros_like(x)
     l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
@@ -1175,10 +1171,10 @@ def _craft_tie_split(po, want_non_prefix=True):
     raise AssertionError("no tie-split construction found")
 
 
-def _one_call(env, p, s_in, **ctx_flags):
+def _one_call(env, p, s_in, mirror=True, **ctx_flags):
     po, torch, la = env["po"], env["torch"], env["la"]
     s = s_in.copy()
-    sol = la.DeviceSolver(p.n, p.m, mirror_index=True, **ctx_flags)
+    sol = la.DeviceSolver(p.n, p.m, mirror_index=mirror, **ctx_flags)
     try:
         x, g = _dev(torch, s.x), _dev(torch, s.g)
         l, u, nbd = _dev(torch, p.l), _dev(torch, p.u), _dev(torch, p.nbd.astype(np.int32))
@@ -1197,25 +1193,31 @@ def _one_call(env, p, s_in, **ctx_flags):
 
 
 def test_walk_ending_inside_a_tie_group(env):
-    """The case VERDICT r1 asked for: a walk that ends INSIDE a group of equal breakpoints, where
-    the reference's heap order (hpsolb :2079) -- not the variable order -- decides which members
-    are fixed (here a non-prefix subset of the group).
-      * default context: the call is detected (tie_splits == 1); the generalized Cauchy POINT is
-        the reference's (every member of the group reaches its bound at t* whether it is labelled
-        fixed or not: xp to 1e-12), iwhere differs from the reference's only inside the group;
-      * LBFGSB_F_EXACT_TIES: the walk is replayed in the reference's own order and the whole state
-        equals the oracle's as in every other one-step test (iwhere, Index, counters exactly)."""
+    """The case VERDICT r1 / r2 asked for: a walk that ends INSIDE a group of equal breakpoints,
+    where the reference's heap order (hpsolb :2079) -- not the variable order -- decides which
+    members are fixed (here a non-prefix subset of the group).
+      * DEFAULT context: the call is detected (tie_splits == 1), the walk is replayed in the
+        reference's own order and the whole state equals the oracle's as in every other one-step
+        test (iwhere, Index, counters exactly);
+      * LBFGSB_F_INDEX_TIES (opt-out): the generalized Cauchy POINT is still the reference's (every
+        member of the group reaches its bound at t* whether it is labelled fixed or not: xp to
+        1e-12), iwhere differs from the reference's only inside the group (a prefix of it)."""
     po = env["po"]
     q, s, group, want = _craft_tie_split(po)
     n, m = q.n, q.m
     fixed_ref = want.iwa[n:2 * n][group] > 0
     assert 0 < fixed_ref.sum() < len(group) and not np.all(fixed_ref[:fixed_ref.sum()])
-    # exact order: full one-step parity
-    got, splits = _one_call(env, q, s, exact_ties=True)
+    # default flags: the reference's order, full one-step parity
+    got, splits = _one_call(env, q, s)
     assert splits == 1
     compare_states(got, want, n, m, po)
-    # default order
-    got, splits = _one_call(env, q, s)
+    assert np.array_equal(got.iwa[n:2 * n], want.iwa[n:2 * n])
+    # the same through a production (non-mirror) context
+    got_p, splits_p = _one_call(env, q, s, mirror=False)
+    assert splits_p == 1
+    assert np.array_equal(got_p.iwa[n:2 * n], want.iwa[n:2 * n])
+    # opt-out: variable order
+    got, splits = _one_call(env, q, s, index_ties=True)
     assert splits == 1
     off = po.wa_offsets(n, m)
     o, ln = off["xp"]
@@ -1229,9 +1231,10 @@ def test_walk_ending_inside_a_tie_group(env):
 def test_tie_groups_of_identical_variables_trajectory(env):
     """Problems with EXACT symmetries (copies of the same variable) keep whole groups of equal
     breakpoints alive over many iterations.  A walk that ends inside such a group fixes the same
-    NUMBER of copies in either order (identical jumps), so the default path and the reference
-    stay equal in every scalar -- iteration, nfg, nseg, nfree, f -- and in x up to a permutation
-    inside the groups; with LBFGSB_F_EXACT_TIES also x itself is equal."""
+    NUMBER of copies in either order (identical jumps), so with LBFGSB_F_INDEX_TIES (variable
+    order) the run and the reference stay equal in every scalar -- iteration, nfg, nseg, nfree, f --
+    and in x up to a permutation inside the groups; the DEFAULT context replays such walks in the
+    reference's order and x itself is equal."""
     po, torch, la = env["po"], env["torch"], env["la"]
     base, copies, m, iters = 257, 8, 5, 40
     n = base * copies
@@ -1278,7 +1281,7 @@ def test_tie_groups_of_identical_variables_trajectory(env):
         splits = sol.tie_splits()
         sol.close()
         return rows, xs, splits
-    rows_g, xs_g, splits = run_gpu()
+    rows_g, xs_g, splits = run_gpu(index_ties=True)
     assert len(rows_g) == len(rows_o)
     for ra, rb in zip(rows_g, rows_o):
         assert ra[:4] == rb[:4], (ra, rb)
@@ -1287,11 +1290,11 @@ def test_tie_groups_of_identical_variables_trajectory(env):
         ga = np.sort(xa.reshape(copies, base), axis=0)
         gb = np.sort(xb.reshape(copies, base), axis=0)
         assert np.max(np.abs(ga - gb)) <= 1e-9
-    rows_e, xs_e, splits_e = run_gpu(exact_ties=True)
+    rows_e, xs_e, splits_e = run_gpu()
     assert [r[:4] for r in rows_e] == [r[:4] for r in rows_o]
     for xa, xb in zip(xs_e, xs_o):
         assert np.max(np.abs(xa - xb)) <= 1e-9
-    print("tie splits on this trajectory: %d (default), %d (exact ties)" % (splits, splits_e))
+    print("tie splits on this trajectory: %d (index order), %d (default: replayed)" % (splits, splits_e))
 
 
 def test_zz_factor_errors_are_explained_by_conditioning(env):

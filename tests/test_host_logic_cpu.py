@@ -1,6 +1,6 @@
 """CPU tests of the PRODUCT's host logic (no GPU): the 2m x 2m algebra that stays on the host
-(lbfgsb_amd/csrc/host_dense.hpp: dpofa, dtrsl, bmv, formt, dcsrch -- reference
-src/lbfgsb_linpack_module.f90:30,87 and src/lbfgsb.f90:1057,1926,2942) against the oracle,
+(lbfgsb_amd/csrc/host_dense.hpp: dpofa, dtrsl, bmv, formt, dcsrch, hpsolb -- reference
+src/lbfgsb_linpack_module.f90:30,87 and src/lbfgsb.f90:1057,1926,2942,2079) against the oracle,
 bit for bit, and the Fortran edit-descriptor emulation of report.hpp."""
 import ctypes as C
 import os
@@ -129,6 +129,29 @@ def test_dcsrch_bit_identical_sequences(libs):
                 st.append(trace)
             assert st[0] == st[1]
             assert st[0][-1][0].startswith((b"CONV", b"WARN"))
+
+
+def test_hpsolb_bit_identical_pop_order(libs):
+    """hpsolb (src/lbfgsb.f90:2079-2157) as the product replays it for walks that end inside a group
+    of equal breakpoints: heap build + pops over keys with MANY ties must leave t and iorder exactly
+    as the oracle's restatement does after every pop -- with 32-bit and with 64-bit row numbers."""
+    hd, orc = libs
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 17, 64, 257, 1000):
+        vals = rng.integers(0, max(2, n // 6), n).astype(np.float64) * 0.125   # groups of equal keys
+        for width in (32, 64):
+            t1, t2 = vals.copy(), vals.copy()
+            io_o = np.arange(1, n + 1, dtype=np.int32)
+            io_p = (np.arange(1, n + 1, dtype=np.uint32) if width == 32
+                    else np.arange(1, n + 1, dtype=np.int64) + (1 << 33))
+            fn = hd.hd_hpsolb32 if width == 32 else hd.hd_hpsolb64
+            for k, nleft in enumerate(range(n, 0, -1)):
+                orc.lbo_hpsolb(nleft, _p(t1), _p(io_o), 0 if k == 0 else 1)
+                fn(C.c_int64(nleft), _p(t2), _p(io_p), 0 if k == 0 else 1)
+                assert t1.tobytes() == t2.tobytes()
+                got = io_p.astype(np.int64) - (0 if width == 32 else (1 << 33))
+                assert np.array_equal(got, io_o.astype(np.int64)), (n, width, k)
+            assert np.all(np.diff(t1[::-1]) >= 0)      # popped in ascending order of t
 
 
 def test_fortran_edit_descriptors(libs):
