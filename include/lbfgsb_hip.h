@@ -300,6 +300,10 @@ int lbfgsb_hip_set_option(lbfgsb_hip_ctx *ctx, const char *name, double value);
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
                      int64_t *cauchy_fullsorts, double *wait_seconds);
 
+/* several ranks: collectives issued so far (all-gathers of partial sums, of breakpoint records, of
+ * halo values) and the bytes THIS rank contributed to them */
+int lbfgsb_hip_comm_stats(lbfgsb_hip_ctx *ctx, int64_t *collectives, int64_t *bytes_contributed);
+
 /* how many subspace minimisations so far took the two-pass route (W'Z r in closed form, no
  * cmprlb pass over W: col <= 20, walk of <= 2^20 segments, no stored s_i with its free part a
  * tiny remainder of the column) and

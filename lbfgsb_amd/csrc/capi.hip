@@ -206,6 +206,13 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
   return 0;
 }
 
+int lbfgsb_hip_comm_stats(lbfgsb_hip_ctx *ctx, int64_t *collectives, int64_t *bytes_contributed) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (collectives) *collectives = ctx->ncoll;
+  if (bytes_contributed) *bytes_contributed = ctx->coll_bytes;
+  return 0;
+}
+
 int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *three_pass,
                            int64_t *handed_windows) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");

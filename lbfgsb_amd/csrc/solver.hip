@@ -252,6 +252,7 @@ class Solver final : public lbfgsb_hip_ctx {
                                       hipGetErrorString(e));
     }
     if ((size_t)k > res_len) return fail(LBFGSB_E_STATE, "fetch: more partials than the buffer holds");
+    if (comm || nranks > 1) ncoll++, coll_bytes += (int64_t)k * 8;
     if (comm) {
       if (g_rccl.AllGather(q.d_res, d_res_all, (size_t)k, ncclDouble, comm, stream) != ncclSuccess)
         return fail(LBFGSB_E_COMM, "ncclAllGather of the partial sums failed");
@@ -328,6 +329,7 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // every rank contributes d_msg[0..count) (device); all of it lands in h_msg_all (rank-major)
   int exchange(size_t count) {
+    if (comm || nranks > 1) ncoll++, coll_bytes += (int64_t)count * 8;
     if (nranks == 1 && !comm) {
       HIPCHK(hipMemcpyAsync(h_msg_all, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
                             stream));
@@ -949,6 +951,7 @@ class Solver final : public lbfgsb_hip_ctx {
   size_t pg_tmp_bytes = 0;
   // all-gather of a large device buffer (count doubles per rank), rank-major into d_recv
   int allgather_big(const double *d_send, double *d_recv, size_t count) {
+    ncoll++, coll_bytes += (int64_t)count * 8;
     if (comm) {
       if (g_rccl.AllGather(d_send, d_recv, count, ncclDouble, comm, stream) != ncclSuccess)
         return fail(LBFGSB_E_COMM, "ncclAllGather failed");

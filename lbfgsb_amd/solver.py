@@ -317,4 +317,7 @@ class DeviceSolver:
     def stats(self):
         a, b, c, w = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
         check(self.lib.lbfgsb_hip_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(w)))
-        return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value, wait_seconds=w.value)
+        nc, nb = C.c_int64(), C.c_int64()
+        check(self.lib.lbfgsb_hip_comm_stats(self.h, C.byref(nc), C.byref(nb)))
+        return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value, wait_seconds=w.value,
+                    collectives=nc.value, collective_bytes=nb.value)

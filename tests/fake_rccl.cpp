@@ -1,7 +1,7 @@
 // Stand-in for the few RCCL entry points the solver binds (ncclGetUniqueId, ncclCommInitRank,
-// ncclCommDestroy, ncclAllReduce, ncclAllGather, ncclGroupStart/End), for TESTS ONLY: the ranks
-// are processes that share ONE GPU -- which real RCCL refuses -- and exchange through a POSIX
-// shared-memory segment.  Collectives are executed synchronously on the host (stream sync, D2H,
+// ncclCommDestroy, ncclAllGather; ncclAllReduce / ncclGroupStart/End are kept for older builds), for
+// TESTS ONLY: the ranks are processes -- or threads of one process -- that share ONE GPU, which
+// real RCCL refuses, and exchange through a POSIX shared-memory segment.  Collectives are executed synchronously on the host (stream sync, D2H,
 // barrier, reduce in rank order, H2D): slow, but the solver's communicator code path (grouped
 // sum/min/max all-reduces on adjacent segments, all-gathers of record chunks, counts, offsets)
 // runs exactly as with the real library.  Selected with LBFGSB_RCCL_LIBRARY.
@@ -19,7 +19,7 @@
 #include <vector>
 
 namespace {
-constexpr size_t SLOT = (size_t)64 << 20;  // bytes per rank
+constexpr size_t SLOT = (size_t)128 << 20;  // bytes per rank (only touched pages are ever backed)
 struct Shared {
   std::atomic<int> arrived;
   std::atomic<int> generation;

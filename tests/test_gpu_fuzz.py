@@ -72,7 +72,7 @@ def _explain_divergence(po, p, prev, got):
     # by design: at a NEW_X return a production context already holds the iwhere
     # pattern of the NEXT cauchy scan; xp / the enter-leave half of Indx2 are not materialised
     compare_states(got, s, p.n, p.m, po, skip=("xp",), check_lists=False,
-                   check_iwhere=got.task_s.startswith("FG_LN"))
+                   check_iwhere=got.task_s.startswith("FG_LN"), stpmx_cond=True)
 
 
 def drive_with_replay(po, p, max_iter, **ctx):
