@@ -147,6 +147,27 @@ int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const voi
                           char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave,
                           double *dsave);
 
+/* -------------------------------------------------------------------------
+ * setulb, device-pointer form with PING-PONG iterate buffers.  The reference's line search starts
+ * every iteration with two n-vector copies, t = x and r = g (lnsrlb, src/lbfgsb.f90:2235-2236), so
+ * that the previous iterate survives the trial points written into x and g.  On a bandwidth-bound
+ * device those copies are 16 of the 40 bytes per row the one storing pass of an iteration writes.
+ * Here the caller hands over TWO buffers for x and TWO for g; nothing is copied: the pair that holds
+ * the iterate BECOMES (t, r), the trial point is written to the other pair.
+ *   *cur (out) = which pair (0 or 1) this return refers to:
+ *     task 'FG...'        evaluate f at x[*cur], write the gradient into g[*cur], pass f as usual;
+ *     task 'NEW_X', terminal tasks   x[*cur], g[*cur] are the iterate and its gradient.
+ *   task 'START': x0 holds the starting point (the call returns 'FG_START' with *cur = 0).
+ * The four buffers must stay the same for the whole run; a run uses either this entry or
+ * lbfgsb_hip_setulb_dev, not both (LBFGSB_E_STATE).  Everything else -- task protocol, isave / dsave /
+ * lsave, results bit for bit -- as lbfgsb_hip_setulb_dev; lbfgsb_hip_export_state writes the
+ * reference's t and r slots from wherever they live.
+ * ------------------------------------------------------------------------- */
+int lbfgsb_hip_setulb_dev_pp(lbfgsb_hip_ctx *ctx, void *x0, void *x1, const void *l, const void *u,
+                             const int32_t *nbd, double *f, void *g0, void *g1, double factr,
+                             double pgtol, char *task, int iprint, char *csave, int32_t *lsave,
+                             int32_t *isave, double *dsave, int32_t *cur);
+
 /* Stream ordering.  Every kernel of a context runs on ITS stream (the one given to
  * lbfgsb_hip_create, or a private non-blocking stream).  On an 'FG...' re-entry the library
  * reads g (and x, if the caller touched it) on that stream: whatever produced them must be

@@ -23,6 +23,8 @@ PROTOTYPES = {
     "lbfgsb_hip_comm_init_host": (C.c_int, [_vp, ALLREDUCE_FN, ALLGATHER_FN, _vp, C.c_int, C.c_int]),
     "lbfgsb_hip_setulb_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
                                         _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_setulb_dev_pp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double,
+                                           C.c_double, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_setulb_host": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
                                          C.c_double, C.c_double, _vp, _vp, _vp, C.c_int32, _vp,
                                          _vp, _vp, _vp, _cp, C.c_int32, C.c_int32]),

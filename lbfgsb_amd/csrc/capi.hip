@@ -77,6 +77,17 @@ int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const voi
   return rc;
 }
 
+int lbfgsb_hip_setulb_dev_pp(lbfgsb_hip_ctx *ctx, void *x0, void *x1, const void *l, const void *u,
+                             const int32_t *nbd, double *f, void *g0, void *g1, double factr,
+                             double pgtol, char *task, int iprint, char *csave, int32_t *lsave,
+                             int32_t *isave, double *dsave, int32_t *cur) {
+  if (!ctx || !cur) return fail(LBFGSB_E_ARG, "setulb_dev_pp: NULL argument");
+  const int rc = ctx->setulb_dev_pp(x0, x1, l, u, nbd, f, g0, g1, factr, pgtol, task, iprint, csave,
+                                    lsave, isave, dsave, cur);
+  if (iprint >= 0) std::fflush(stdout);
+  return rc;
+}
+
 int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
                         const int32_t *nbd, void *g, double factr, double pgtol, int max_iter,
                         int max_fg, int iprint, lbfgsb_fg_fn fg, void *user, int builtin_kind,

@@ -457,8 +457,9 @@ __global__ __launch_bounds__(BLOCK) void lnsrlb_begin_kernel(
       }
     }
     st<W>(d + i, dv);
-    st<W>(t + i, xv);
-    st<W>(r + i, gv);
+    // t, r == nullptr (ping-pong iterate buffers): x and g stay where they are and BECOME t and r
+    if (t) st<W>(t + i, xv);
+    if (r) st<W>(r + i, gv);
   });
   block_reduce_store<3>(acc, 2, 1, 0, part, MAX_BLOCKS);
 }

@@ -28,6 +28,8 @@ __device__ __forceinline__ double subsm_dir(double xk, double zk, double gk, con
 // dtd = d'd, the stpmx ratios; g'd is dd_p itself.  The Cauchy point is evaluated per row
 // (xcp_row), the subspace minimiser written to `zout`; neither xp (:2787) nor the direction is
 // stored (the backtracking branch regenerates both: cauchy_finish_kernel, subsm_dir_kernel).
+// pr / pd: where a pending pair's y and s are read from (r, and d or t); rout / tvec: where r = g
+// and t = x are stored (nullptr: not stored, see below).
 // res: sum [0] = #bound hits (iword), [1] = dd_p (= g'd), [2] = dtd ; min [3] = stpmx
 template <typename T>
 struct SubsmCtx {
@@ -69,7 +71,7 @@ struct SubsmTrip {
 };
 template <typename T, int MC, bool NT, bool PSPEC, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
-    int64_t n, double tsum, T *__restrict__ zout, T *r,
+    int64_t n, double tsum, T *__restrict__ zout, const T *pr, T *rout,
     const T *__restrict__ l, const T *__restrict__ u, const nb_t *__restrict__ nbd,
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
@@ -78,9 +80,10 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
-  // stores every trip issues: z, d, t, r (+ the committed pair in the steady-state shape)
-  constexpr int NS = PSPEC ? 6 : 4;
-  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, r, pd, nbd, iwhere, ldw, m, head, col, pe};
+  // stores every trip issues (a lower bound: the counted wait of the pipelined loop may then wait
+  // for a few stores too): the trial point / z (+ the committed pair in the steady-state shape)
+  constexpr int NS = PSPEC ? 3 : 1;
+  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, pr, pd, nbd, iwhere, ldw, m, head, col, pe};
   for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -151,27 +154,31 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     // zout == dvec == nullptr ("lean"): the first trial step is 1, so x = z is stored below and
     // both z and d = x - t stay implicit until something needs them as vectors (solver.hip,
     // ensure_d) -- 5 store streams instead of 7.
+    // tvec == rout == nullptr (ping-pong iterate buffers, lbfgsb_hip_setulb_dev_pp): t = x and
+    // r = g are not copies but a change of roles -- the trial point goes to the OTHER x buffer
+    // (xout; it holds t of the previous line search, which pd reads above, row by row before this
+    // store), the caller's next gradient to the other g buffer: 3 store streams instead of 5.
     if (NT) {
       if (zout) stnt<W>(zout + i, zv);
       if (dvec) stnt<W>(dvec + i, dv);
-      stnt<W>(tvec + i, xv);
-      stnt<W>(r + i, gv);
+      if (tvec) stnt<W>(tvec + i, xv);
+      if (rout) stnt<W>(rout + i, gv);
       if (xout) stnt<W>(xout + i, zv);
     } else {
       if (zout) st<W>(zout + i, zv);
       if (dvec) st<W>(dvec + i, dv);
-      st<W>(tvec + i, xv);  // t = x (:2235)
-      st<W>(r + i, gv);     // r = g (:2236)
+      if (tvec) st<W>(tvec + i, xv);  // t = x (:2235)
+      if (rout) st<W>(rout + i, gv);  // r = g (:2236)
       // first trial point of the line search when its step is known to be 1: x = z (:2265);
-      // xout aliases xx (each row is read above before it is written here)
+      // xout may alias xx (each row is read above before it is written here)
       if (xout) st<W>(xout + i, zv);
     }
   });
   block_reduce_store<4>(acc, 3, 1, 0, part, MAX_BLOCKS);
 }
 template <typename T>
-void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
-                         const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
+void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr, T *rout, const T *l,
+                         const T *u, const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
                          const T *pd) {
@@ -182,9 +189,9 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const 
   DISPATCH_MAXC_NT(col, q.nt,                                                                       \
                    DISPATCH_PIPE(MC, hipLaunchKernelGGL(                                            \
                                          (subsm_update_kernel<T, MC, NTV, PSPECV, PIPEV>), dim3(gr),\
-                                         dim3(BLOCK), 0, q.stream, n, tsum, zout, r, l, u, nbd,     \
-                                         iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head, col,  \
-                                         theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,         \
+                                         dim3(BLOCK), 0, q.stream, n, tsum, zout, pr, rout, l, u,   \
+                                         nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head,  \
+                                         col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,    \
                                          w.wy + slot, w.ws + slot, q.d_part)))
   if (spec)
     LB_SUBSM(true);
@@ -243,7 +250,7 @@ void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, con
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
-  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, T *, const T *, const T *, const nb_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *); \
+  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, const T *, T *, const T *, const T *, const nb_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *); \
   template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *);
 INSTANTIATE(double)
 INSTANTIATE(float)

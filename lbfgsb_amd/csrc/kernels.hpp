@@ -260,10 +260,12 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
 // exactly -g); wv = K^-1 W'r.
 // res sum-slots: [0] = #bound hits (iword), [1] = dd_p (= g'(z-x)), [2] = dtd ; min-slot [3] =
 // stpmx candidate.  xout (= the caller's x, or nullptr): also store the first trial point of the
-// line search, x = z, when its step length is known to be 1 (:2265).
+// line search, x = z, when its step length is known to be 1 (:2265).  pr: the vector a pending
+// pair's y is formed from (r of the previous line search); rout / tvec: where r = g and t = x are
+// stored -- nullptr with ping-pong iterate buffers, where they are a change of roles, not copies.
 template <typename T>
-void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, T *r, const T *l, const T *u,
-                         const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
+void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr, T *rout, const T *l,
+                         const T *u, const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
                          const T *pd);

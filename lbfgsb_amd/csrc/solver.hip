@@ -34,7 +34,17 @@ class Solver final : public lbfgsb_hip_ctx {
   // ---- device state ----
   T *ws = nullptr, *wy = nullptr, *zero_buf = nullptr;
   int64_t ld = 0;
-  T *z = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *xp = nullptr, *tbrk = nullptr;
+  T *z = nullptr, *d = nullptr, *xp = nullptr, *tbrk = nullptr;
+  // t (the iterate at the start of the current line search, lnsrlb :2235) and r (its gradient,
+  // :2236) are ROLES: the kernels read them through these two pointers.  With the classic entry
+  // they always point at the context's own buffers (t_own, r_own), which the line-search set-up
+  // fills with copies of x and g.  With ping-pong iterate buffers (setulb_dev_pp) the set-up copies
+  // nothing: x and g stay where they are and BECOME t and r, the trial point goes to the other pair.
+  T *t = nullptr, *r = nullptr, *t_own = nullptr, *r_own = nullptr;
+  bool pp = false;        // this run uses the ping-pong entry
+  T *xb[2] = {nullptr, nullptr}, *gb[2] = {nullptr, nullptr};
+  int pp_cur = 0;         // the pair the last return referred to
+  const T *x_lean = nullptr;  // where the first trial point of a lean subspace pass lives (d = x_lean - t)
   lbk::iw_t *iwhere = nullptr;  // one byte per row (the reference's int32 only in export/import)
   int32_t *index = nullptr, *indx2 = nullptr, *scan_tmp = nullptr;
   int8_t *wasfree = nullptr, *prevfree = nullptr;
@@ -88,7 +98,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (p) (void)hipFree(p);
       p = nullptr;
     };
-    F(ws), F(wy), F(zero_buf), F(z), F(r), F(d), F(t), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
+    F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all);
@@ -140,10 +150,11 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&zero_buf, 256));  // read by the unroll slots beyond the stored pairs
     HIPCHK(hipMemsetAsync(zero_buf, 0, 256, stream));
     const size_t vb = (size_t)(n + 32) * sizeof(T);
-    for (T **p : {&z, &r, &d, &t, &xp, &tbrk}) {
+    for (T **p : {&z, &r_own, &d, &t_own, &xp, &tbrk}) {
       HIPCHK(hipMalloc(p, vb));
       HIPCHK(hipMemsetAsync(*p, 0, vb, stream));
     }
+    t = t_own, r = r_own;
     HIPCHK(hipMalloc(&iwhere, (size_t)(n + 32) * sizeof(lbk::iw_t)));
     HIPCHK(hipMalloc(&nbd8, (size_t)(n + 32) * sizeof(lbk::nb_t)));
     HIPCHK(hipMemsetAsync(iwhere, 0, (size_t)(n + 32) * sizeof(lbk::iw_t), stream));
@@ -1832,13 +1843,18 @@ class Solver final : public lbfgsb_hip_ctx {
     // is written (5 store streams instead of 7); they stay implicit until ensure_d()
     const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass) && !(flags & LBFGSB_F_MIRROR_INDEX);
     clk_begin(2);
-    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, l, u, nbd8, iwhere, x, g, W(),
-                                head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d, t,
-                                ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0, pend, d_src());
+    // (ping-pong buffers: no t = x, r = g copies -- the roles change below -- and the trial point
+    //  goes to the other x buffer, which is where the pending pair's t is read from, row by row)
+    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, l, u, nbd8,
+                                iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
+                                pp ? (T *)nullptr : t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
+                                pend, d_src());
     clk_end(2);
     pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
     d_impl = z_in_x = lean;
     z_valid = !lean;
+    if (lean) x_lean = xmut;
+    if (pp) t = const_cast<T *>(x), r = const_cast<T *>(g);  // t = x, r = g (:2235-2236) as a change of roles
     CHK(fetch(3, 1, 0));
     iword = h_res[0] > 0.0 ? 1 : 0;
     const double dd_p = h_res[1];
@@ -1854,7 +1870,8 @@ class Solver final : public lbfgsb_hip_ctx {
     ls.ready = false;  // z changes below: lnsrlb_begin redoes d, t, r
     d_impl = z_in_x = false;  // (and the backtracking kernel writes all of z)
     if (ls.x_is_z) {   // ... from the iterate itself, which the pass above saved in t
-      HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      // (ping-pong buffers: the trial point went to the other buffer, x still is the iterate)
+      if (!pp) HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
       ls.x_is_z = false;
     }
     if (rep.out && !quiet && print_level >= 0) {
@@ -2035,6 +2052,19 @@ class Solver final : public lbfgsb_hip_ctx {
     pend.on = 0, pend.impl = 0;  // the memory is dropped, an uncommitted pair with it
   }
 
+  // x = t, g = r (:568-569, :736-737).  Ping-pong buffers: the previous iterate still sits in its
+  // own pair, which simply becomes the pair the caller is pointed at again.
+  int restore_iterate(Mainlb &L) {
+    if (pp && (t == xb[0] || t == xb[1])) {
+      pp_cur = t == xb[0] ? 0 : 1;
+      L.x = xb[pp_cur], L.g = gb[pp_cur];
+      return 0;
+    }
+    if (L.x != t) HIPCHK(hipMemcpyAsync(L.x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    if (L.g != r) HIPCHK(hipMemcpyAsync(L.g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    return 0;
+  }
+
   // task = 'START' (:430-507): errclb, active, the first f,g request
   int phase_start(Mainlb &L, Flow &flow) {
     MAINLB_VIEW(L);
@@ -2184,8 +2214,7 @@ class Solver final : public lbfgsb_hip_ctx {
     } else if (!lbh::str60_pre(task, "FG_ST")) {
       if (lbh::str60_pre(task, "STOP")) {
         if (std::strncmp(task + 6, "CPU", 3) == 0) {  // :566-571
-          HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-          HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+          CHK(restore_iterate(L));
           HIPCHK(hipStreamSynchronize(stream));
           *f = fold;
         }
@@ -2227,7 +2256,7 @@ class Solver final : public lbfgsb_hip_ctx {
     ls.x_is_z = false;
     ls_do_stpmx = cnstnd && iter != 0;
     ls_unit_step = !(iter == 0 && !boxed);  // lnsrlb :2228-2232
-    xmut = x;
+    xmut = pp ? xb[1 - pp_cur] : x;  // where this iteration's trial points go
     if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
       gcp = Gcp{};
       gcp.copy_x = true;
@@ -2397,13 +2426,16 @@ class Solver final : public lbfgsb_hip_ctx {
     MAINLB_VIEW(L);
     const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
     bool ls_abort = false;
-    if (!lbh::str60_pre(task, "FG_LN")) {
+    const bool setup_call = !lbh::str60_pre(task, "FG_LN");  // first call of this iteration's line search
+    if (setup_call) {
       const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
       double stpmx_cand;
       if (ls.ready) {  // d, t, r, dtd, g'd came out of the subsm pass
         dtd = ls.dtd, gd = ls.gd, stpmx_cand = ls.stpmx;
       } else {
-        lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, t, r, do_stpmx);
+        lbk::launch_lnsrlb_begin<T>(q, n, z, x, g, l, u, nbd, d, pp ? (T *)nullptr : t, pp ? (T *)nullptr : r,
+                                    do_stpmx);
+        if (pp) t = x, r = g;  // (roles instead of copies)
         CHK(fetch(2, 1, 0));
         dtd = h_res[0], gd = h_res[1], stpmx_cand = h_res[2];
       }
@@ -2436,8 +2468,10 @@ class Solver final : public lbfgsb_hip_ctx {
         nfgv++;
         iback = ifun - 1;
         if (!(ls.x_is_z && ifun == 1 && stp == 1.0)) {  // else x = z is already in place
-          CHK(ensure_d(x));  // (x still is the rejected first trial point z)
-          lbk::launch_lnsrlb_step<T>(q, n, x, z, d, t, stp);
+          CHK(ensure_d(setup_call ? xmut : x));  // (it still holds the rejected first trial point z)
+          // (the set-up call writes this iteration's first trial point: xmut -- the caller's x, or the
+          //  other buffer of a ping-pong pair; later calls are entered with x = the trial buffer)
+          lbk::launch_lnsrlb_step<T>(q, n, setup_call ? xmut : x, z, d, t, stp);
         }
         ls.x_is_z = false;
         spec.valid = false;  // the trial point was not accepted
@@ -2451,9 +2485,8 @@ class Solver final : public lbfgsb_hip_ctx {
     }
 
     if (info != 0 || iback >= 20) {  // :734-769
-      CHK(ensure_d(x));
-      HIPCHK(hipMemcpyAsync(x, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-      HIPCHK(hipMemcpyAsync(g, r, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      CHK(ensure_d(setup_call ? xmut : x));  // (d, z as vectors before the trial point goes)
+      CHK(restore_iterate(L));
       *f = fold;
       if (col == 0) {
         if (info == 0) {
@@ -2477,6 +2510,8 @@ class Solver final : public lbfgsb_hip_ctx {
       prelims = linesearch = true;
       return again(flow);
     } else if (lbh::str60_pre(task, "FG_LN")) {
+      // ping-pong buffers: the caller evaluates f, g at the OTHER pair from here on
+      if (pp && setup_call) pp_cur ^= 1, L.x = xb[pp_cur], L.g = gb[pp_cur];
       save_locals(L);
       if (!(flags & LBFGSB_F_NO_RETURN_SYNC)) {
         const double t0 = now_s();
@@ -2645,11 +2680,49 @@ class Solver final : public lbfgsb_hip_ctx {
   int setulb_dev(void *x_, const void *l_, const void *u_, const int32_t *nbd, double *f,
                  void *g_, double factr, double pgtol, char *task, int iprint, char *csave,
                  int32_t *lsave, int32_t *isave_user, double *dsave) override {
+    if (lbh::str60_eq(task, "START")) {
+      pp = false;
+      t = t_own, r = r_own;
+    } else if (pp) {
+      return fail(LBFGSB_E_STATE, "this run was started with lbfgsb_hip_setulb_dev_pp");
+    }
+    Mainlb L;
+    L.x = (T *)x_, L.g = (T *)g_;
+    return drive(L, l_, u_, nbd, f, factr, pgtol, task, iprint, csave, lsave, isave_user, dsave);
+  }
+
+  // the same with ping-pong iterate buffers (include/lbfgsb_hip.h): x0/x1 and g0/g1 are two pairs of
+  // caller buffers; *cur tells which pair this return refers to
+  int setulb_dev_pp(void *x0, void *x1, const void *l_, const void *u_, const int32_t *nbd, double *f,
+                    void *g0, void *g1, double factr, double pgtol, char *task, int iprint, char *csave,
+                    int32_t *lsave, int32_t *isave_user, double *dsave, int32_t *cur) override {
+    if (!x0 || !x1 || !g0 || !g1 || x0 == x1 || g0 == g1)
+      return fail(LBFGSB_E_ARG, "setulb_dev_pp needs two distinct x and two distinct g buffers");
+    for (const void *p : {(const void *)x1, (const void *)g1})
+      if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
+    if (lbh::str60_eq(task, "START")) {
+      pp = true, pp_cur = 0;
+      xb[0] = (T *)x0, xb[1] = (T *)x1, gb[0] = (T *)g0, gb[1] = (T *)g1;
+      t = t_own, r = r_own;
+    } else if (!pp) {
+      return fail(LBFGSB_E_STATE, "this run was started with lbfgsb_hip_setulb_dev");
+    } else if (xb[0] != (T *)x0 || xb[1] != (T *)x1 || gb[0] != (T *)g0 || gb[1] != (T *)g1) {
+      return fail(LBFGSB_E_ARG, "setulb_dev_pp: the four buffers must not change during a run");
+    }
+    Mainlb L;
+    L.x = xb[pp_cur], L.g = gb[pp_cur];
+    const int rc = drive(L, l_, u_, nbd, f, factr, pgtol, task, iprint, csave, lsave, isave_user, dsave);
+    if (cur) *cur = pp_cur;
+    return rc;
+  }
+
+  int drive(Mainlb &L, const void *l_, const void *u_, const int32_t *nbd, double *f, double factr,
+            double pgtol, char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave_user,
+            double *dsave) {
     HIPCHK(hipSetDevice(device));
     print_level = iprint;
     quiet = rank != 0;
-    Mainlb L;
-    L.x = (T *)x_, L.g = (T *)g_, L.l = (const T *)l_, L.u = (const T *)u_, L.nbd = nbd, L.f = f;
+    L.l = (const T *)l_, L.u = (const T *)u_, L.nbd = nbd, L.f = f;
     L.factr = factr, L.pgtol = pgtol, L.task = task, L.csave = csave, L.lsave = lsave;
     L.isave = isave_user + 21, L.dsave = dsave, L.ipr = quiet ? -1 : iprint;
     for (const void *p : {(const void *)L.x, (const void *)L.l, (const void *)L.u, (const void *)L.g})
@@ -2713,8 +2786,8 @@ class Solver final : public lbfgsb_hip_ctx {
     (void)mm;
     // (z and d left implicit by a lean subspace pass: written out for the export only -- the
     //  state of the run does not change, both buffers are dead storage while d_impl stands)
-    if (d_impl && cx)
-      lbk::launch_dz_materialise<T>(q, n, (const T *)cx, t, d, z_in_x ? z : (T *)nullptr);
+    if (d_impl && x_lean)
+      lbk::launch_dz_materialise<T>(q, n, x_lean, t, d, z_in_x ? z : (T *)nullptr);
     for (T *src : {z, r, d, t, xp}) {
       HIPCHK(hipMemcpyAsync(ps, src, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
       ps += n;
@@ -2771,6 +2844,7 @@ class Solver final : public lbfgsb_hip_ctx {
       for (double &e : v) e = (double)*ps++;
     };
     get(sy), get(ss), get(wt), get(wn), get(snd);
+    t = t_own, r = r_own;  // (the imported t and r live in the context's own buffers, whichever entry is used)
     for (T *dst : {z, r, d, t, xp}) {
       HIPCHK(hipMemcpyAsync(dst, ps, (size_t)n * sizeof(T), hipMemcpyHostToDevice, stream));
       ps += n;
@@ -2846,7 +2920,7 @@ class Solver final : public lbfgsb_hip_ctx {
     std::memset(&cf, 0, sizeof cf);
     if (which == 0 || which == 2)
       lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
-                                cf, which == 2 ? 1 : 0, r, d, lbk::Pend{1, 0.5, 0});
+                                cf, which == 2 ? 1 : 0, r_own, d, lbk::Pend{1, 0.5, 0});
     else if (which == 1)
       lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     else if (which == 3 || which == 4) {
@@ -2856,12 +2930,12 @@ class Solver final : public lbfgsb_hip_ctx {
       //  the z buffer here instead of the caller's x -- the same five store streams)
       const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
       if (which == 3)  // with a pending pair: the variant every iteration after an update runs
-        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r, l, u, nbd8, iwhere,
-                                    (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
-                                    lean ? (T *)nullptr : d, t, lean ? z : (T *)nullptr, 1,
-                                    lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t : d);
+        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r_own, pp ? (T *)nullptr : r_own, l, u,
+                                    nbd8, iwhere, (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
+                                    lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own, lean ? z : (T *)nullptr, 1,
+                                    lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t_own : d);
       else             // as the evaluation of a trial point: reduces only
-        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, nbd8, (const T *)g, r, lean ? t : d,
+        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, nbd8, (const T *)g, r_own, lean ? t_own : d,
                                    lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
                                    (head + col - 2) % m + 1, 0, 0, nr_flag(col));
     } else

@@ -105,6 +105,10 @@ struct lbfgsb_hip_ctx {
   virtual int setulb_dev(void *x, const void *l, const void *u, const int32_t *nbd, double *f,
                          void *g, double factr, double pgtol, char *task, int iprint, char *csave,
                          int32_t *lsave, int32_t *isave, double *dsave) = 0;
+  virtual int setulb_dev_pp(void *x0, void *x1, const void *l, const void *u, const int32_t *nbd,
+                            double *f, void *g0, void *g1, double factr, double pgtol, char *task,
+                            int iprint, char *csave, int32_t *lsave, int32_t *isave, double *dsave,
+                            int32_t *cur) = 0;
   virtual int export_state(void *wa, int32_t *iwa) = 0;
   virtual int import_state(const void *wa, const int32_t *iwa, const int32_t *isave) = 0;
   virtual int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd,

@@ -185,6 +185,25 @@ class DeviceSolver:
                                              _p(self.isave), _p(self.dsave)))
         return self.task_s
 
+    def setulb_pp(self, xs, l, u, nbd, gs, factr: float, pgtol: float, iprint: int = -1):
+        """Ping-pong form (lbfgsb_hip_setulb_dev_pp): xs = (x0, x1), gs = (g0, g1) -- two pairs of
+        device buffers, x0 holding the starting point.  -> (task, cur): evaluate f, g at xs[cur] into
+        gs[cur] on 'FG...'; xs[cur], gs[cur] are the iterate and its gradient on 'NEW_X' and at the end."""
+        if not isinstance(xs[0], np.ndarray):
+            t = self.task_s
+            if t == "START":
+                import torch
+                torch.cuda.synchronize()
+            elif t.startswith("FG") and not self.same_stream_objective:
+                self.wait_stream()
+        cur = C.c_int32(0)
+        check(self.lib.lbfgsb_hip_setulb_dev_pp(self.h, _p(xs[0]), _p(xs[1]), _p(l), _p(u), _p(nbd),
+                                                _p(self.f), _p(gs[0]), _p(gs[1]), float(factr),
+                                                float(pgtol), _p(self.task), int(iprint), _p(self.csave),
+                                                _p(self.lsave), _p(self.isave), _p(self.dsave),
+                                                C.byref(cur)))
+        return self.task_s, int(cur.value)
+
     def minimize(self, x, l, u, nbd, g, fg=None, builtin: int = 0, factr: float = 1e7,
                  pgtol: float = 1e-5, max_iter: int = 0, max_fg: int = 0, iprint: int = -1) -> str:
         """The reference's @todo wrapper (src/lbfgsb.f90:36-37): run the reverse-communication

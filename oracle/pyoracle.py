@@ -36,11 +36,11 @@ def _ptr(a: np.ndarray):
 
 class Engine:
     """A setulb-compatible CPU engine: the oracle ('oracle') or the real
-    reference ('ref', 'ref_i8', 'ref_r32')."""
+    reference ('ref', 'ref_i8', 'ref_r32', 'ref_r32_i8')."""
 
     def __init__(self, kind: str = "oracle"):
         self.kind = kind
-        self.real = np.float32 if kind.endswith("r32") else np.float64
+        self.real = np.float32 if "r32" in kind else np.float64
         self.int = np.int64 if kind.endswith("i8") else np.int32
         creal = C.c_float if self.real == np.float32 else C.c_double
         cint = C.c_int64 if self.int == np.int64 else C.c_int

@@ -152,3 +152,71 @@ def test_minimize_callback_exception_is_raised(env):
     assert sol.task_s.startswith("STOP: THE OBJECTIVE CALLBACK RETURNED NaN")
     assert len(calls) == 3
     sol.close()
+
+
+def test_ping_pong_entry_is_bit_identical_to_the_classic_one():
+    """lbfgsb_hip_setulb_dev_pp against lbfgsb_hip_setulb_dev on the same problems: the two entries
+    differ only in WHERE t, r and the trial point live (roles of two caller buffer pairs instead of
+    copies), so every return must be identical bit for bit -- task, every isave / dsave slot, f -- and so
+    must the reference-layout state (export_state: z, r, d, t, Ws, Wy, the m x m matrices, iwhere) and
+    the iterate itself.  Problems: the bounded quadratic with all four bound types, box-bounded
+    Rosenbrock (rejected trials, non-unit steps), an unconstrained and an all-but-fixed problem, and
+    random problems that take restarts and the backtracking branch of subsm."""
+    import numpy as np
+    import torch
+    import lbfgsb_amd as la
+    from oracle import pyoracle as po
+    from test_gpu_fuzz import make
+    TIME_D = [5, 6, 7, 8, 9]
+    problems = [po.problem_quadratic(4099, 7, mixed_nbd=True), po.problem_rosenbrock(1000, 10, 0.0, 0.0),
+                po.problem_rosenbrock(25, 5, 1e7, 1e-5)]
+    q = po.problem_quadratic(777, 5)
+    q.nbd[:] = 0
+    problems.append(q)
+    problems += [make(po, seed, 600, 1, 25) for seed in range(11000, 11040)]
+    swaps = 0
+    for p in problems:
+        def run(pp):
+            sol = la.DeviceSolver(p.n, p.m)
+            xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.full((p.n,), 5.0, dtype=torch.float64, device="cuda")]
+            gs = [torch.zeros_like(xs[0]), torch.full_like(xs[0], 9.0)]
+            l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+            nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+            x, g, cur, trace, curs = xs[0], gs[0], 0, [], []
+            for _ in range(400):
+                if pp:
+                    t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                    x, g = xs[cur], gs[cur]
+                else:
+                    t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+                torch.cuda.synchronize()
+                wa, iwa = sol.export_state()
+                ds = sol.dsave.copy()
+                ds[TIME_D] = 0
+                trace.append((t, sol.isave[21:44].copy(), ds, float(sol.f[0]), wa, iwa, x.cpu().numpy(),
+                              g.cpu().numpy()))
+                curs.append(cur)
+                if t.startswith("FG"):
+                    xh = x.cpu().numpy()
+                    gh = np.empty_like(xh)
+                    sol.f[0] = p.fg(xh, gh)
+                    g.copy_(torch.from_numpy(gh))
+                elif t.startswith("NEW_X"):
+                    if sol.isave[29] >= 40:
+                        break
+                else:
+                    break
+            sol.close()
+            return trace, curs
+        a, _ = run(False)
+        b, curs = run(True)
+        swaps += sum(1 for c0, c1 in zip(curs, curs[1:]) if c0 != c1)
+        assert len(a) == len(b), (p.name, len(a), len(b))
+        for k, (ra, rb) in enumerate(zip(a, b)):
+            assert ra[0] == rb[0], (p.name, k, ra[0], rb[0])
+            assert np.array_equal(ra[1], rb[1]), (p.name, k, ra[1], rb[1])
+            assert ra[2].tobytes() == rb[2].tobytes() and ra[3] == rb[3], (p.name, k)
+            assert ra[4].tobytes() == rb[4].tobytes(), (p.name, k, "wa differs", ra[0])
+            assert np.array_equal(ra[5], rb[5]), (p.name, k, "iwa differs")
+            assert ra[6].tobytes() == rb[6].tobytes() and ra[7].tobytes() == rb[7].tobytes(), (p.name, k, "x / g")
+    assert swaps > 500      # the pairs really did change roles

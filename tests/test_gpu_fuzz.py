@@ -75,11 +75,11 @@ def _explain_divergence(po, p, prev, got):
                    check_iwhere=got.task_s.startswith("FG_LN"), stpmx_cond=True)
 
 
-def drive_with_replay(po, p, max_iter, **ctx):
+def drive_with_replay(po, p, max_iter, pp=False, **ctx):
     """Run p on the GPU (default context + ctx), call by call beside the oracle's trajectory.
     -> (split, n_calls): split = index of the first call that differs from the oracle's trajectory
     (None: equal to the end).  A split that one oracle call from the GPU's previous state does not
-    reproduce raises."""
+    reproduce raises.  pp: through the ping-pong entry (lbfgsb_hip_setulb_dev_pp)."""
     import torch
     import lbfgsb_amd as la
 
@@ -90,13 +90,18 @@ def drive_with_replay(po, p, max_iter, **ctx):
                 snapshot=lambda k, s: ro.append(row(s.task_s, s.isave, s.f[0])))
     sol = la.DeviceSolver(p.n, p.m, **ctx)
     try:
-        x = torch.from_numpy(p.x0.copy()).cuda()
-        g = torch.zeros_like(x)
+        xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.full((p.n,), 7.0, dtype=torch.float64, device="cuda")]
+        gs = [torch.zeros_like(xs[0]), torch.full_like(xs[0], -3.0)]
+        x, g = xs[0], gs[0]
         l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
         nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
         rg, prev, split = [], None, None
         for _ in range(100000):
-            t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            if pp:
+                t, cur_i = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                x, g = xs[cur_i], gs[cur_i]
+            else:
+                t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
             rg.append(row(t, sol.isave, sol.f[0]))
             k = len(rg) - 1
             cur = None
@@ -139,16 +144,19 @@ def drive_with_replay(po, p, max_iter, **ctx):
 
 @pytest.mark.parametrize("first,count,nmax,mlo,mhi,switch", [
     (0, 120, 400, 1, 13, None), (5000, 40, 3000, 11, 33, None),
+    # the ping-pong entry (t = x, r = g as a change of roles between two caller buffer pairs)
+    (0, 120, 400, 1, 13, "pp"), (5000, 40, 3000, 11, 33, "pp"), (7300, 40, 1500, 1, 25, "pp,lean=0"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
     (7000, 40, 1500, 1, 25, "spec_capture=1"), (7100, 40, 1500, 1, 25, "two_pass=0"),
     (7200, 40, 1500, 1, 25, "lean=0")])
 def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi, switch):
     po = oracle_built
-    opts = {switch.split("=")[0]: float(switch.split("=")[1])} if switch else {}
+    words = switch.split(",") if switch else []
+    opts = {w.split("=")[0]: float(w.split("=")[1]) for w in words if "=" in w}
     splits = []
     for seed in range(first, first + count):
-        split, ncalls = drive_with_replay(po, make(po, seed, nmax, mlo, mhi), 80, options=opts)
+        split, ncalls = drive_with_replay(po, make(po, seed, nmax, mlo, mhi), 80, pp="pp" in words, options=opts)
         if split is not None:
             splits.append((seed, split, ncalls))
     print("%d of %d runs left the oracle's trajectory, each reproduced by a one-step oracle replay "

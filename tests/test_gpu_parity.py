@@ -689,7 +689,12 @@ def test_headline_config_n1e8_fp64_anchors(env):
     for got, want in zip(rows, ref["rows"]):
         assert got[:4] == (want["iter"], want["nfg"], want["nseg"], want["nfree"]), (got, want)
         assert got[4] == pytest.approx(want["f"], rel=1e-9), (got, want)
-        assert got[5] == pytest.approx(want["sbgnrm"], rel=1e-7), (got, want)
+        # (once a line search has interpolated -- nfg > iter + 1, iteration 14 here -- its step comes
+        #  from DIFFERENCES of f: f ~ 4.2e8 falls by ~1.6e3 per iteration, so the 1e-11 relative
+        #  difference between the caller's two ways of summing 1e8 terms of f is amplified by
+        #  f / delta f ~ 2.6e5 into the step, hence into x and |proj g|)
+        assert got[5] == pytest.approx(want["sbgnrm"], rel=1e-7 if want["nfg"] == want["iter"] + 1 else 1e-5), \
+            (got, want)
     assert closed_steps >= 8, (closed_steps, three_steps)
     rows2, _ = run()
     assert rows2 == rows       # bit for bit, f and |proj g| included
