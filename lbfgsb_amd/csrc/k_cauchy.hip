@@ -676,7 +676,44 @@ size_t sort_pairs_temp_bytes(size_t count) {
   (void)rocprim::radix_sort_pairs(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint64_t *)nullptr, (uint64_t *)nullptr, count, 0, 32,
                                   (hipStream_t)0);
-  return b1 > b2 ? b1 : b2;
+  size_t b3 = 0;
+  (void)rocprim::radix_sort_keys(nullptr, b3, (const uint32_t *)nullptr, (uint32_t *)nullptr, count, 0, 32,
+                                 (hipStream_t)0);
+  b1 = b1 > b2 ? b1 : b2;
+  return b1 > b3 ? b1 : b3;
+}
+// ---- ascending order for a list of <= 2^18 row numbers (freev's changed rows): the list is
+//      appended with an atomic counter, i.e. in an order that may change from run to run, and
+//      formk's patch sums run over it -- sorted, the sums are reproducible bit for bit ----
+constexpr int SMALL_SORT = 2048;
+__global__ __launch_bounds__(BLOCK) void sort_u32_small_kernel(uint32_t *keys, uint32_t cnt) {
+  __shared__ uint32_t sm[SMALL_SORT];
+  for (int k = threadIdx.x; k < SMALL_SORT; k += BLOCK) sm[k] = (uint32_t)k < cnt ? keys[k] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int size = 2; size <= SMALL_SORT; size <<= 1)      // bitonic network, one workgroup
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int k = threadIdx.x; k < SMALL_SORT / 2; k += BLOCK) {
+        const int lo = 2 * k - (k & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint32_t a = sm[lo], b = sm[hi];
+        if ((a > b) == up) sm[lo] = b, sm[hi] = a;
+      }
+      __syncthreads();
+    }
+  for (int k = threadIdx.x; k < SMALL_SORT; k += BLOCK)
+    if ((uint32_t)k < cnt) keys[k] = sm[k];
+}
+uint32_t *launch_sort_u32(Queue &q, void *d_temp, size_t temp_bytes, uint32_t *keys, uint32_t *scratch,
+                          uint32_t count) {
+  if (count <= 1) return keys;
+  if (count <= (uint32_t)SMALL_SORT) {
+    hipLaunchKernelGGL(sort_u32_small_kernel, dim3(1), dim3(BLOCK), 0, q.stream, keys, count);
+    LB_LAUNCHED(q);
+    return keys;
+  }
+  (void)rocprim::radix_sort_keys(d_temp, temp_bytes, keys, scratch, (size_t)count, 0, 32, q.stream);
+  LB_LAUNCHED(q);
+  return scratch;
 }
 void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_t *idx_in,
                         uint32_t *idx_out, const uint64_t *keys_in, uint64_t *keys_out,

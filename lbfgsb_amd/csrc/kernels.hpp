@@ -137,6 +137,10 @@ size_t sort_pairs_temp_bytes(size_t count);
 void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t *keys_in,
                        uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out,
                        size_t count);
+// ascending order for a list of row numbers (freev's changed rows, <= 2^18): in place for short lists
+// (one-workgroup bitonic network), through `scratch` otherwise; returns where the sorted list is
+uint32_t *launch_sort_u32(Queue &q, void *d_temp, size_t temp_bytes, uint32_t *keys, uint32_t *scratch,
+                          uint32_t count);
 // stable sort of the same pairs by idx (first pass of a (t, idx) lexicographic order)
 void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_t *idx_in,
                         uint32_t *idx_out, const uint64_t *keys_in, uint64_t *keys_out,

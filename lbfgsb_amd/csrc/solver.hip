@@ -1577,7 +1577,12 @@ class Solver final : public lbfgsb_hip_ctx {
     std::vector<double> P;
     if (nchg > 0 && upcl > 0) {
       if (nchg > (int64_t)CHG_CAP) return formk_scratch(col, head);  // whole Gram is cheaper
-      lbk::launch_formk_patch<T>(q, d_chg, std::min<uint32_t>(chg_local, CHG_CAP), W(), head, upcl);
+      // (the list was appended with an atomic counter: put it in ascending order first, so that the
+      //  patch sums -- and with them WN1, the subspace step, the whole trajectory -- are
+      //  reproducible bit for bit; idx[1] is free here: the walk is over)
+      const uint32_t nl = std::min<uint32_t>(chg_local, CHG_CAP);
+      const uint32_t *lst = lbk::launch_sort_u32(q, sort_tmp, sort_tmp_bytes, d_chg, idx[1], nl);
+      lbk::launch_formk_patch<T>(q, lst, nl, W(), head, upcl);
       const int E = 2 * upcl * upcl + upcl;
       CHK(fetch(E, 0, 0));
       P.assign(h_res, h_res + E);
@@ -2257,6 +2262,9 @@ class Solver final : public lbfgsb_hip_ctx {
     ls_do_stpmx = cnstnd && iter != 0;
     ls_unit_step = !(iter == 0 && !boxed);  // lnsrlb :2228-2232
     xmut = pp ? xb[1 - pp_cur] : x;  // where this iteration's trial points go
+    // this trip's operands (an unconstrained problem never calls cauchy(), and with ping-pong buffers
+    // the iterate changes place from one iteration to the next)
+    cx = x, cl = l, cu = u, cg = g, cnbd = nbd;
     if (!cnstnd && col > 0) {  // :607-611  (z = x, kept in functional form)
       gcp = Gcp{};
       gcp.copy_x = true;

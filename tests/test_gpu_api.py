@@ -218,5 +218,7 @@ def test_ping_pong_entry_is_bit_identical_to_the_classic_one():
             assert ra[2].tobytes() == rb[2].tobytes() and ra[3] == rb[3], (p.name, k)
             assert ra[4].tobytes() == rb[4].tobytes(), (p.name, k, "wa differs", ra[0])
             assert np.array_equal(ra[5], rb[5]), (p.name, k, "iwa differs")
-            assert ra[6].tobytes() == rb[6].tobytes() and ra[7].tobytes() == rb[7].tobytes(), (p.name, k, "x / g")
+            assert ra[6].tobytes() == rb[6].tobytes(), (p.name, k, "x")
+            # (at an 'FG' return g[cur] is the buffer the caller is about to write the gradient into)
+            assert ra[0].startswith("FG") or ra[7].tobytes() == rb[7].tobytes(), (p.name, k, "g")
     assert swaps > 500      # the pairs really did change roles

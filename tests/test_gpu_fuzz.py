@@ -60,7 +60,7 @@ def _state(po, p, sol, x, g):
                     sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(), sol.dsave.copy())
 
 
-def _explain_divergence(po, p, prev, got):
+def _explain_divergence(po, p, prev, got, pp=False):
     """The trajectories parted ways at this call.  One ORACLE call from the GPU's own previous
     state (every caller array as the production context exported it, f and g as the test evaluated
     them at the GPU's x) must reproduce the GPU's call: task, every counter, iwhere exactly, floats to
@@ -69,6 +69,11 @@ def _explain_divergence(po, p, prev, got):
     from test_gpu_parity import compare_states
     s = prev.copy()
     po.call(po.Engine("oracle"), p, s)
+    if pp and got.task_s.startswith("FG"):
+        # ping-pong entry: at an 'FG' return g[cur] is the buffer the caller is about to write into,
+        # not the old gradient (that one lives on as r, which the comparison below covers)
+        got = got.copy()
+        got.g = s.g.copy()
     # by design: at a NEW_X return a production context already holds the iwhere
     # pattern of the NEXT cauchy scan; xp / the enter-leave half of Indx2 are not materialised
     compare_states(got, s, p.n, p.m, po, skip=("xp",), check_lists=False,
@@ -113,7 +118,7 @@ def drive_with_replay(po, p, max_iter, pp=False, **ctx):
                     split = k
                     assert prev is not None, (p.name, "diverged at the very first call", ro[:1], rg[:1])
                     try:
-                        _explain_divergence(po, p, prev, cur)
+                        _explain_divergence(po, p, prev, cur, pp)
                     except AssertionError as e:
                         raise AssertionError(
                             "%s (n=%d m=%d): call %d differs from the oracle's trajectory (%s vs %s) and is "
