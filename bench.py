@@ -5,16 +5,19 @@ Workload (BASELINE.json metric): separable bounded quadratic, n = 1e8, m = 10, f
 l = -1, u = +1, x0 = 0, factr = pgtol = 0, on-device objective.  A "step"
 is one L-BFGS-B iteration (one NEW_X return): every kernel of the hot path runs, plus the
 f/g evaluations the line search asks for.  With --gpus N the n rows are sharded over N
-ranks (STRONG scaling: n stays 1e8) and every reduction is completed with RCCL all-reduces
-on the <= 4m+5 partials.
+ranks (STRONG scaling: n stays 1e8) and every reduction is completed with ONE RCCL collective
+per host sync (all-gather of the <= 8m+15 partials, reduced in rank order on every rank).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n ROWS] [--m M]
 
 Prints ONE JSON line (rank 0).  `value` = K / wall time of the K timed iterations
 (objective evaluations included; `iters_per_sec_setulb_only` excludes them).
-`roofline` is measured live on the WS/WY matvec kernel (wtv_kernel) with HIP events on the
-stream it runs on.  `cpu_baseline` times the real reference (oracle/_ref) on host cores,
-rank 0 at N=1 only, on a bounded sample.
+`roofline` is the DOMINANT kernel of the iteration (the one storing pass, subsm_update_kernel),
+timed live with HIP events on the solver's stream inside the timed region; the read-only pass
+that carries the WS/WY matvecs (update_scan_kernel) and the bare W'v kernel are reported beside
+it.  `cpu_baseline` times the real reference (oracle/_ref) on one host core, rank 0 at N=1 only,
+on a bounded sample, and quotes the one full-size run on file.  `other_configs` (N=1 only): short
+legs for BASELINE.json configs[1], [2], [4] and the per-rank shape of configs[3].
 """
 import argparse
 import json
@@ -44,15 +47,22 @@ def parse():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--real32", action="store_true", help="REAL32 context (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs for the other BASELINE.json configs (N=1 only anyway)")
     ap.add_argument("--cpu-n", type=int, default=20_000_000,
                     help="rows of the CPU reference sample (same problem, same m)")
     ap.add_argument("--rccl-self", action="store_true",
                     help="single GPU: attach a 1-rank RCCL communicator, so that every reduction pays a "
-                         "real ncclAllReduce + D2H + sync (latency floor of the sharded path; use with "
+                         "real RCCL collective + D2H + sync (latency floor of the sharded path; use with "
                          "--rows 12500000 = the per-rank shape of n=1e8 over 8 GPUs)")
     ap.add_argument("--allow-gloo-fallback", action="store_true",
                     help="multi-GPU: if the RCCL communicator cannot be created, complete the reductions "
                          "through a gloo host group instead of exiting non-zero")
+    ap.add_argument("--classic", action="store_true",
+                    help="drive lbfgsb_hip_setulb_dev (t = x, r = g as copies: 5 store streams in the storing "
+                         "pass) instead of the ping-pong entry lbfgsb_hip_setulb_dev_pp (3 store streams)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="lbfgsb_hip_set_option on every context of the run (A/B measurements)")
     ap.add_argument("--roofline-reps", type=int, default=20)
     return ap.parse_args()
 
@@ -96,8 +106,9 @@ def cpu_baseline(m, n_full, n_sample):
     the one that can run n = 1e8 at all) on ONE host core -- it is single
     threaded by construction -- on the same problem at n_sample rows.  Iterations with col = m
     are timed inside setulb only (the objective is excluded); the value is scaled linearly in n
-    to n_full rows (every loop of the reference is O(n) at fixed m; SURVEY.md section 6 measured
-    0.19 / 1.95 / 21.8 s per iteration at n = 1e6 / 1e7 / 1e8)."""
+    to n_full rows.  The one FULL-SIZE run on file (profiles/r3a_cpu_ref_full_n1e8_m10.json, the same
+    build on a GPU box's host) is quoted beside it: at n = 1e8 the reference is slower than the linear
+    scaling of the sample says (caches, TLB), `extrapolated_over_measured_full_size` says by how much."""
     from oracle import pyoracle as po
     kind, eng = "reference", None
     for name in ("ref_i8", "ref"):
@@ -138,7 +149,7 @@ def cpu_baseline(m, n_full, n_sample):
     k = max(1, k1 - k0)
     per_iter = (marks[k1] - marks[k0]) / k
     cpu = host_cpu()
-    return {
+    out = {
         "value": 1.0 / per_iter * n_sample / n_full,
         "unit": "iters/sec",
         "cores": 1,
@@ -157,6 +168,202 @@ def cpu_baseline(m, n_full, n_sample):
                   % (n_sample, n_full / n_sample, m, k, len(marks), per_iter, n_full, marks[0],
                      cpu["model"], cpu["cores_total"]),
     }
+    full_file = os.path.join(ROOT, "profiles", "r3a_cpu_ref_full_n1e8_m10.json")
+    if os.path.exists(full_file) and n_full == 100_000_000 and m == 10:
+        try:
+            d = json.load(open(full_file))
+            out["full_size_run_on_file"] = {
+                "source": "profiles/r3a_cpu_ref_full_n1e8_m10.json (profiles/scripts/cpu_ref_full.py: the same "
+                          "reference build, n = 1e8, m = 10, 16 iterations, one core; not re-run here)",
+                "iters_per_sec": d["iters_per_sec_col_eq_m"], "s_per_iter": d["s_per_iter_col_eq_m"],
+                "iters_timed": d["iters_timed_col_eq_m"], "first_iteration_s": d["first_iteration_s"],
+                "peak_rss_gb": d["peak_rss_gb"], "host_cpu_model": d["host"]["model"],
+            }
+            out["extrapolated_over_measured_full_size"] = out["value"] / d["iters_per_sec_col_eq_m"]
+        except Exception:   # noqa: BLE001
+            pass
+    return out
+
+
+def problem_tensors(torch, dev, kind, n_loc, row0, real32):
+    """x0, l, u, nbd of this rank's rows: kind 0 = separable bounded quadratic,
+    kind 1 = extended Rosenbrock with the drivers' box (test/driver1.f90:233-251)."""
+    rdt = torch.float32 if real32 else torch.float64
+    if kind == 0:
+        x = torch.zeros(n_loc, dtype=rdt, device=dev)
+        l = torch.full_like(x, -1.0)
+        u = torch.full_like(x, 1.0)
+    else:
+        x = torch.full((n_loc,), 3.0, dtype=rdt, device=dev)
+        u = torch.full_like(x, 100.0)
+        l = torch.full_like(x, -100.0)
+        l[(row0 % 2)::2] = 1.0          # odd 1-based global index
+    nbd = torch.full((n_loc,), 2, dtype=torch.int32, device=dev)
+    return x, l, u, nbd
+
+
+class Run:
+    """one solver context + its problem, advanced iteration by iteration"""
+
+    def __init__(self, torch, dist, la, a, *, n, m, real32, kind, world, rank, local_rank, rccl_self, opts,
+                 parallel_gcp=False):
+        self.torch, self.dist, self.world = torch, dist, world
+        self.kind, self.n, self.m = kind, n, m
+        dev = torch.device("cuda", local_rank)
+        self.dev = dev
+        row0, n_loc = la.block_partition(n, world, rank)
+        self.n_loc = n_loc
+        mk = lambda: la.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,   # noqa: E731
+                                     same_stream_objective=True, real32=real32, options=opts,
+                                     parallel_gcp=parallel_gcp)
+        self.sol = mk()
+        self.collective = "none"
+        if world > 1:
+            # RCCL on the solver's stream.  A scaling curve must never silently be a gloo curve: if
+            # the communicator cannot be created on some rank the run exits non-zero, unless
+            # --allow-gloo-fallback asks for the (tiny) reductions to go through a gloo host group.
+            ok = 1
+            with stdout_to_stderr():
+                try:
+                    la.attach_rccl(self.sol, rank, world, dev)
+                except Exception as e:   # noqa: BLE001
+                    ok = 0
+                    sys.stderr.write("rank %d: RCCL communicator failed (%r)\n" % (rank, e))
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.collective = ("one RCCL all-gather of the <=8m+15 fp64 partials per host sync, reduced in "
+                                   "rank order on every rank")
+            elif not a.allow_gloo_fallback:
+                self.sol.close()
+                dist.destroy_process_group()
+                raise SystemExit("RCCL communicator unavailable on some rank (pass --allow-gloo-fallback "
+                                 "to measure with a gloo host group instead)")
+            else:
+                self.sol.close()
+                self.sol = mk()
+                la.attach_host_group(self.sol, rank, world, group=dist.new_group(backend="gloo"))
+                self.collective = "gloo host all-reduce (RCCL communicator unavailable; --allow-gloo-fallback)"
+        elif rccl_self:
+            with stdout_to_stderr():
+                la.attach_rccl(self.sol, 0, 1, dev)
+            self.collective = "RCCL all-gather on a 1-rank communicator (--rccl-self: latency floor)"
+        x, self.l, self.u, self.nbd = problem_tensors(torch, dev, kind, n_loc, row0, real32)
+        self.pp = not a.classic
+        # ping-pong entry: two pairs of iterate / gradient buffers, the library tells which one is live
+        self.xs = [x, torch.empty_like(x)] if self.pp else [x]
+        self.gs = [torch.zeros_like(x), torch.empty_like(x)] if self.pp else [torch.zeros_like(x)]
+        self.cur = 0
+        self.t_setulb = 0.0
+
+    @property
+    def x(self):
+        return self.xs[self.cur]
+
+    @property
+    def g(self):
+        return self.gs[self.cur]
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def advance(self, iters):
+        sol = self.sol
+        done = 0
+        while done < iters:
+            t0 = time.perf_counter()
+            if self.pp:
+                task, self.cur = sol.setulb_pp(self.xs, self.l, self.u, self.nbd, self.gs, 0.0, 0.0)
+            else:
+                task = sol.setulb(self.xs[0], self.l, self.u, self.nbd, self.gs[0], 0.0, 0.0)
+            self.t_setulb += time.perf_counter() - t0
+            if task.startswith("FG"):
+                sol.objective(self.kind, self.x, self.g, deferred=True)   # f rides back with the next call's sums
+            elif task.startswith("NEW_X"):
+                done += 1
+            else:
+                raise SystemExit("solver stopped: " + task)
+
+    def close(self):
+        self.sol.close()
+        self.xs = self.gs = self.l = self.u = self.nbd = None
+        self.torch.cuda.empty_cache()
+
+
+def timed_leg(run, steps, warm_min, need_full_memory=True):
+    """first iteration apart, then untimed until the memory is full (col == m) and at least
+    warm_min iterations have run, then `steps` timed iterations bracketed by barriers."""
+    sol, m = run.sol, run.m
+    run.barrier()
+    tw0 = time.perf_counter()
+    run.advance(1)
+    run.barrier()
+    first_iter_s = time.perf_counter() - tw0
+    nseg_first = int(sol.isave[32])
+    warm_done = 1
+    while warm_done < warm_min or (need_full_memory and int(sol.isave[27]) < m):
+        run.advance(1)
+        warm_done += 1
+        if warm_done > warm_min + 4 * m + 20:
+            raise SystemExit("col never reached m = %d (skipped updates?)" % m)
+    run.barrier()
+    ts0, st0 = run.t_setulb, sol.stats()
+    sol.pass_clock(1)            # hipEvents around every launch of the three W passes
+    cols_timed = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run.advance(1)
+        cols_timed.append(int(sol.isave[27]))
+    run.barrier()
+    dt = time.perf_counter() - t0
+    clocks = sol.pass_clock(0)   # {pass: (ms_total, launches)} over the timed region
+    dt_setulb = run.t_setulb - ts0
+    if run.world > 1:
+        tt = run.torch.tensor([dt, dt_setulb], dtype=run.torch.float64, device=run.dev)
+        run.dist.all_reduce(tt, op=run.dist.ReduceOp.MAX)
+        dt, dt_setulb = float(tt[0]), float(tt[1])
+    st1 = sol.stats()
+    return dict(first_iter_s=first_iter_s, nseg_first=nseg_first, warm_done=warm_done, cols_timed=cols_timed,
+                dt=dt, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1)
+
+
+def pass_bytes(col, rbytes, pp, lean=True):
+    """algorithmic bytes per row of the two passes over W of an iteration"""
+    upd = (2 * (col - 1) + 6) * rbytes + 2          # 2(col-1) W columns + x, l, u, g, r, t + nbd, iwhere (1 B each)
+    n_st = (3 if pp else 5) if lean else (5 if pp else 7)
+    sub = (2 * col + 4 + n_st) * rbytes + 2         # 2 col W (the pending pair from r, t) + l, u, x, g + stores
+    return upd, sub, n_st
+
+
+def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, steps, warm_min, local_rank, opts):
+    """a short leg for one of the other BASELINE.json configs: it/s and the two pass fractions"""
+    run = Run(torch, dist, la, a, n=n, m=m, real32=real32, kind=kind, world=1, rank=0, local_rank=local_rank,
+              rccl_self=rccl_self, opts=opts)
+    try:
+        r = timed_leg(run, steps, warm_min, need_full_memory=(kind == 0))
+        col = int(run.sol.isave[27])
+        rb = 4 if real32 else 8
+        upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0)
+        passes = {}
+        for key, bpr in (("update_scan", upd_b), ("subsm_update", sub_b)):
+            ms, cnt = r["clocks"][key]
+            if cnt:
+                ach = bpr * run.n_loc / (ms / cnt * 1e-3) / 1e9
+                passes[key] = {"avg_launch_ms": ms / cnt, "launches_timed": cnt, "achieved_GBs": ach,
+                               "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_row": bpr}
+        closed, three, _ = run.sol.path_counts()
+        return {"config": name, "n": n, "m": m, "dtype": "f32" if real32 else "f64", "value": steps / r["dt"],
+                "unit": "iters/sec", "ms_per_step": r["dt"] / steps * 1e3, "steps": steps,
+                "warmup_run": r["warm_done"], "col_timed": [min(r["cols_timed"]), max(r["cols_timed"])],
+                "first_iteration_s": r["first_iter_s"], "first_iteration_nseg": r["nseg_first"],
+                "host_syncs_per_iter": (r["st1"]["syncs"] - r["st0"]["syncs"]) / steps,
+                "passes": passes, "subspace_steps_closed_form": closed, "subspace_steps_three_pass": three,
+                "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0])}
+    finally:
+        run.close()
 
 
 def main():
@@ -185,138 +392,50 @@ def main():
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=dev)
+    opts = {}
+    for kv in a.opt:
+        k, v = kv.split("=", 1)
+        opts[k] = float(v)
 
     n, m = a.n, a.m
-    # contiguous block sharding of the rows
-    row0, n_loc = lbfgsb_amd.block_partition(n, world, rank)
-    # the objective below is the library's own kernel on the solver's stream, so the FG return
-    # needs no host sync
-    sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,
-                                  same_stream_objective=True, real32=a.real32)
-    rdt = torch.float32 if a.real32 else torch.float64
     rbytes = 4 if a.real32 else 8
-    collective = "none"
-    if world > 1:
-        # RCCL on the solver's stream.  A scaling curve must never silently be a gloo curve: if
-        # the communicator cannot be created on some rank the run exits non-zero, unless
-        # --allow-gloo-fallback asks for the (tiny) reductions to go through a gloo host group.
-        ok = 1
-        with stdout_to_stderr():
-            try:
-                lbfgsb_amd.attach_rccl(sol, rank, world, dev)
-            except Exception as e:   # noqa: BLE001
-                ok = 0
-                sys.stderr.write("rank %d: RCCL communicator failed (%r)\n" % (rank, e))
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            collective = "RCCL all-reduce of <=4m+11 fp64 partials per phase"
-        elif not a.allow_gloo_fallback:
-            sol.close()
-            dist.destroy_process_group()
-            raise SystemExit("RCCL communicator unavailable on some rank (pass --allow-gloo-fallback "
-                             "to measure with a gloo host group instead)")
-        else:
-            sol.close()
-            sol = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,
-                                          same_stream_objective=True, real32=a.real32)
-            lbfgsb_amd.attach_host_group(sol, rank, world, group=dist.new_group(backend="gloo"))
-            collective = "gloo host all-reduce (RCCL communicator unavailable; --allow-gloo-fallback)"
-    elif a.rccl_self:
-        with stdout_to_stderr():
-            lbfgsb_amd.attach_rccl(sol, 0, 1, dev)
-        collective = "RCCL all-reduce on a 1-rank communicator (--rccl-self: latency floor)"
-
-    x = torch.zeros(n_loc, dtype=rdt, device=dev)
-    g = torch.zeros_like(x)
-    l = torch.full_like(x, -1.0)
-    u = torch.full_like(x, 1.0)
-    nbd = torch.full((n_loc,), 2, dtype=torch.int32, device=dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    t_setulb = 0.0
-    iter_marks = []          # (wall, t_setulb) at each NEW_X
-
-    def advance(iters):
-        nonlocal t_setulb
-        done = 0
-        while done < iters:
-            t0 = time.perf_counter()
-            task = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
-            t_setulb += time.perf_counter() - t0
-            if task.startswith("FG"):
-                sol.objective(0, x, g, deferred=True)   # f rides back with the next call's sums
-            elif task.startswith("NEW_X"):
-                done += 1
-                iter_marks.append((time.perf_counter(), t_setulb))
-            else:
-                raise SystemExit("solver stopped: " + task)
-
-    barrier()
-    tw0 = time.perf_counter()
-    advance(1)
-    barrier()
-    first_iter_s = time.perf_counter() - tw0
-    nseg_first = int(sol.isave[32])
+    # the objective is the library's own kernel on the solver's stream, so the FG return needs no
+    # host sync; contiguous block sharding of the rows
+    run = Run(torch, dist, lbfgsb_amd, a, n=n, m=m, real32=a.real32, kind=0, world=world, rank=rank,
+              local_rank=local_rank, rccl_self=a.rccl_self, opts=opts)
+    sol, n_loc = run.sol, run.n_loc
     # Untimed until the memory is full (col == m): whatever --warmup says, at least m + 1
     # iterations run first, so that every timed launch streams all 2m columns of W and the
     # roofline bytes below (computed for col = m) are the bytes each timed launch really moved.
-    warm_done = 1
-    warm_min = max(a.warmup, m + 1)
-    while warm_done < warm_min or int(sol.isave[27]) < m:
-        advance(1)
-        warm_done += 1
-        if warm_done > warm_min + 4 * m + 20:
-            raise SystemExit("col never reached m = %d (skipped updates?)" % m)
-    barrier()
-    ts0 = t_setulb
-    st0 = sol.stats()
-    sol.pass_clock(1)            # hipEvents around every launch of the three W passes
-    cols_timed = []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        advance(1)
-        cols_timed.append(int(sol.isave[27]))
-    barrier()
-    dt = time.perf_counter() - t0
-    clocks = sol.pass_clock(0)   # {pass: (ms_total, launches)} over the timed region
+    r = timed_leg(run, a.steps, max(a.warmup, m + 1))
+    cols_timed, clocks, dt, dt_setulb = r["cols_timed"], r["clocks"], r["dt"], r["dt_setulb"]
     assert min(cols_timed) == max(cols_timed) == m, cols_timed
-    dt_setulb = t_setulb - ts0
-    if world > 1:
-        tt = torch.tensor([dt, dt_setulb], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, dt_setulb = float(tt[0]), float(tt[1])
-    stats = sol.stats()
+    stats, st0 = r["st1"], r["st0"]
     f_final = float(sol.f[0])
     col = int(sol.isave[27])
     nfree = int(sol.isave[37])
 
-    # ---- roofline, live, hipEvents on the solver's stream ----
-    # (1) the kernel that carries the WS/WY matvec INSIDE the iteration: cmprlb_wtv_kernel
-    #     (r of cmprlb + W'r of subsm + formk's new row sums in one pass); algorithmic bytes per
-    #     row = 2col reads of W + x, g reads (fp64) + iwhere (1 byte); xcp and r stay in registers
-    #     (subsm_update_kernel recomputes it), so the pass writes nothing but its partials
-    # (2) the bare W'v kernel (wtv_kernel), (2col+1) n s bytes -- BASELINE.md's definition
+    # ---- rooflines, live, hipEvents on the solver's stream ----
     head = int(sol.isave[26])
     mc = 5 if col <= 5 else 10 if col <= 10 else 20 if col <= 20 else 32
     # load policy the library picked (solver.hip init): nontemporal when W >> Infinity Cache
     ld_rows = (n_loc + 31) // 32 * 32
     nt = 2 * ld_rows * m * rbytes > (192 << 20)
-    if os.environ.get("LBFGSB_NT") in ("0", "1"):
-        nt = os.environ["LBFGSB_NT"] == "1"
+    if "nt" in opts:
+        nt = opts["nt"] != 0
     nts = "true" if nt else "false"
+    tname = "float" if a.real32 else "double"
+    lean = opts.get("lean", 1) != 0
+    upd_bpr, sub_bpr, n_st = pass_bytes(col, rbytes, run.pp, lean)
 
-    def traffic_of(name, rows):
-        tf = os.path.join(ROOT, "profiles", name)
+    def static_traffic(fname, key, rows):
+        tf = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(tf) and not a.real32 and col == 10:   # measured for fp64, col = 10
             try:
-                return json.load(open(tf)).get("hbm_bytes_per_row") * rows
-            except Exception:
+                d = json.load(open(tf))
+                d = d[key] if key else d
+                return d.get("hbm_bytes_per_row") * rows
+            except Exception:   # noqa: BLE001
                 return None
         return None
 
@@ -328,62 +447,57 @@ def main():
     # back to back after the run is kept beside it as a cross-check.  Passes over W of one
     # iteration: update_scan_kernel (read-only: the WS/WY matvecs W'd of cauchy and S'y, S's of
     # matupd, + formk's new row), subsm_update_kernel (W wv; the one pass that stores) and -- only
-    # where the closed form for W'Z r does not apply (m > 10, few free variables, long walks) --
-    # cmprlb_wtv_kernel (r of cmprlb + W'r of subsm).
-    tname = "float" if a.real32 else "double"
-
-    def pass_traffic(key, rows):
-        tf = os.path.join(ROOT, "profiles", "w_pass_traffic.json")
-        if os.path.exists(tf) and not a.real32 and col == 10:
-            try:
-                return json.load(open(tf))[key]["hbm_bytes_per_row"] * rows
-            except Exception:
-                return None
-        return None
-
-    def pass_record(key, which, label, alg_bytes, stores, traffic_key):
-        ms_iso = sol.kernel_time(which, x, g, col, head, a.roofline_reps)
+    # where the closed form for W'Z r does not apply (m > 20, long walks) -- cmprlb_wtv_kernel.
+    def pass_record(key, which, label, bpr, stores, traffic_key):
+        alg_bytes = bpr * n_loc
+        ms_iso = sol.kernel_time(which, run.x, run.g, col, head, a.roofline_reps)
         ms_run, cnt = in_run(key)
         ms = ms_run if ms_run is not None else ms_iso
         ach = alg_bytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pass_traffic(traffic_key, n_loc),
-                "traffic_source": "profiles/w_pass_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                  "passes over this bench at n=1e8, in-iteration launches of this kernel "
-                                  "[profiles/r03d_*]: bytes per row x rows; not re-measured in this run)",
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
-                "launches_timed": cnt,
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": static_traffic("w_pass_traffic.json", traffic_key, n_loc),
+                "traffic_source": "profiles/w_pass_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                  "over this bench at n=1e8, in-iteration launches of this kernel: bytes per "
+                                  "row x rows; not re-measured in this run)",
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_row": bpr,
+                "avg_launch_ms": ms, "launches_timed": cnt,
                 "timing": ("hipEvents around each launch inside the timed region" if cnt else
                            "not launched inside the timed region: back-to-back launches after it"),
                 "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col,
                 "stores": stores}
-    n_sub = in_run("subsm_update")[1]
     rec_us = pass_record("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
-                         "first trial point)" % (tname, mc, nts),
-                         ((2 * (col - 1) + 6) * rbytes + 2) * n_loc, "none", "update_scan")
-    # the subspace pass stores t, r, the first trial point x and the pending Ws/Wy column; z and
-    # d = x - t stay implicit while the unit first trial step stands (LBFGSB_LEAN=0: stored too)
-    lean = os.environ.get("LBFGSB_LEAN", "1") != "0"
-    n_st = 5 if lean else 6 + (1 if n_sub else 0)
-    rec_su = pass_record("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (pending pair committed)"
-                         % (tname, mc, nts), ((2 * col + 4 + n_st) * rbytes + 2) * n_loc,
-                         ("t, r, trial x + Ws/Wy column (5 of %d streams)" % (2 * col + 9)) if lean else
-                         ("z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11)),
-                         "subsm_update")
+                         "first trial point: W'd of cauchy, S'y / S's of matupd, formk's new row)"
+                         % (tname, mc, nts), upd_bpr, "none", "update_scan")
+    entry = "ping-pong entry" if run.pp else "classic entry"
+    if run.pp:
+        st_txt = "trial x + Ws/Wy column (3 of %d streams; t = x, r = g are a change of roles)" % (2 * col + 7)
+    elif lean:
+        st_txt = "t, r, trial x + Ws/Wy column (5 of %d streams)" % (2 * col + 9)
+    else:
+        st_txt = "z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11)
+    rec_su = pass_record("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (%s, pending pair committed)"
+                         % (tname, mc, nts, entry), sub_bpr, st_txt,
+                         "subsm_update_pp" if run.pp else "subsm_update")
     rec_cw = pass_record("cmprlb_wtv", 2, "cmprlb_wtv_kernel<%s, %d, true, %s>" % (tname, mc, nts),
-                         ((2 * col + 2) * rbytes + 1) * n_loc, "none", "cmprlb_wtv")
+                         (2 * col + 2) * rbytes + 1, "none", "cmprlb_wtv")
     closed_steps, three_steps, handed_windows = sol.path_counts()
-    if rec_cw["launches_timed"]:      # three-pass iteration: cmprlb_wtv carries W'r inside it
-        roofline, others = rec_cw, [rec_us, rec_su]
-    else:                             # two-pass iteration: the update pass carries the matvecs
+    if not rec_cw["launches_timed"]:
         rec_cw["note"] = "not part of this run's iteration (W'Z r in closed form); timed back to back"
-        roofline, others = rec_us, [rec_su, rec_cw]
-    ms_kernel = sol.wtv_time(g, col, head, a.roofline_reps)
+    # the headline roofline is the DOMINANT kernel of the iteration: the one with the largest total
+    # time inside the timed region -- the storing pass
+    recs = [rec_su, rec_us] + ([rec_cw] if rec_cw["launches_timed"] else [])
+    recs.sort(key=lambda d: -(d["avg_launch_ms"] * max(d["launches_timed"], 1)))
+    roofline = recs[0]
+    roofline["dominant"] = "largest share of the iteration: %.2f of %.2f ms per step" % (
+        roofline["avg_launch_ms"] * roofline["launches_timed"] / a.steps, dt / a.steps * 1e3)
+    others = recs[1:] + ([] if rec_cw["launches_timed"] else [rec_cw])
+    ms_kernel = sol.wtv_time(run.g, col, head, a.roofline_reps)
     alg_bytes = (2 * col + 1) * n_loc * rbytes
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
-    roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s, %d, %s>" % ("float" if a.real32 else "double", mc, nts),
+    roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s, %d, %s> (the bare WS/WY matvec W'v)" % (tname, mc, nts),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of("wtv_traffic.json", n_loc),
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": static_traffic("wtv_traffic.json", None, n_loc),
                     "traffic_source": "profiles/wtv_traffic.json (static PMC measurement, see roofline)",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms_kernel,
                     "rows_per_launch": n_loc, "col": col}
@@ -395,7 +509,7 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "warmup_run": warm_done,
+        "warmup_run": r["warm_done"],
         "col_min_timed": min(cols_timed),
         "col_max_timed": max(cols_timed),
         "ms_per_step": dt / a.steps * 1e3,
@@ -408,17 +522,22 @@ def main():
                                "l=-1,u=1,x0=0, on-device objective"
                                % (n, m, "fp32 storage/fp64 accumulate" if a.real32 else "fp64"),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "parallelism": "rows/%d" % world,
-                   "collective": collective},
+                   "collective": run.collective,
+                   "entry": ("lbfgsb_hip_setulb_dev_pp (ping-pong iterate buffers)" if run.pp
+                             else "lbfgsb_hip_setulb_dev"),
+                   "options": opts},
         "iters_per_sec_setulb_only": a.steps / dt_setulb,
-        "first_iteration_s": first_iter_s,
-        "first_iteration_nseg": nseg_first,
+        "first_iteration_s": r["first_iter_s"],
+        "first_iteration_nseg": r["nseg_first"],
         "f_final": f_final,
         "col": col,
         "nfree": nfree,
         "host_syncs_per_iter": (stats["syncs"] - st0["syncs"]) / a.steps,
+        "collectives_per_iter": (stats["collectives"] - st0["collectives"]) / a.steps,
         "kernel_launches_per_iter": (stats["launches"] - st0["launches"]) / a.steps,
         "host_blocked_ms_per_iter": (stats["wait_seconds"] - st0["wait_seconds"]) / a.steps * 1e3,
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
+        "tie_splits": sol.tie_splits(),
         "subspace_steps_closed_form": closed_steps,
         "subspace_steps_three_pass": three_steps,
         "cauchy_walks_served_by_update_pass": handed_windows,
@@ -426,31 +545,43 @@ def main():
         "roofline_wtv": roofline_wtv,
         "roofline_other_w_passes": others,
     }
-    sol.close()
+    run.close()
     # the opt-in closed-form GCP (LBFGSB_F_PARALLEL_GCP): only the first iteration differs
     # (col = 0, nseg ~ 0.977 n); timed on a fresh context, outside the timed region above
     try:
         if world > 1:      # single-GPU leg only: no second communicator inside the scaling runs
             raise RuntimeError("skipped for n_gpus > 1")
-        sol2 = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,
-                                       same_stream_objective=True, real32=a.real32,
-                                       parallel_gcp=True)
-        x.zero_()
-        barrier()
+        run2 = Run(torch, dist, lbfgsb_amd, a, n=n, m=m, real32=a.real32, kind=0, world=1, rank=0,
+                   local_rank=local_rank, rccl_self=False, opts=opts, parallel_gcp=True)
+        run2.barrier()
         tp0 = time.perf_counter()
-        while True:
-            task = sol2.setulb(x, l, u, nbd, g, 0.0, 0.0)
-            if task.startswith("FG"):
-                sol2.f[0] = sol2.objective(0, x, g)
-            else:
-                break
-        barrier()
+        run2.advance(1)
+        run2.barrier()
         out["first_iteration_parallel_gcp_s"] = time.perf_counter() - tp0
-        out["first_iteration_parallel_gcp_nseg"] = int(sol2.isave[32])
-        sol2.close()
-    except Exception as e:
+        out["first_iteration_parallel_gcp_nseg"] = int(run2.sol.isave[32])
+        run2.close()
+    except Exception as e:   # noqa: BLE001
         out["first_iteration_parallel_gcp_s"] = None
         out["first_iteration_parallel_gcp_error"] = repr(e)
+    # ---- the other BASELINE.json configs, short legs (N = 1 only; each a fresh context) ----
+    if world == 1 and not a.no_other_configs and not a.real32 and n == 100_000_000 and m == 10:
+        legs = [
+            ("configs[1]: separable bounded quadratic n=1e6, m=10, fp64", dict(n=1_000_000, m=10, real32=False,
+             kind=0, rccl_self=False, steps=40, warm_min=12)),
+            ("configs[2]: extended Rosenbrock with box bounds n=1e7, m=10, fp64", dict(n=10_000_000, m=10,
+             real32=False, kind=1, rccl_self=False, steps=16, warm_min=12)),
+            ("configs[4]: n=1e8, m=20, REAL32 (fp32 storage/kernels, fp64 accumulators)", dict(n=100_000_000,
+             m=20, real32=True, kind=0, rccl_self=False, steps=16, warm_min=21)),
+            ("configs[3] per-rank shape: 1.25e7 rows (n=1e8 over 8 GPUs), 1-rank RCCL communicator behind "
+             "every sync", dict(n=12_500_000, m=10, real32=False, kind=0, rccl_self=True, steps=60, warm_min=12)),
+        ]
+        out["other_configs"] = []
+        for name, kw in legs:
+            try:
+                out["other_configs"].append(other_config(torch, dist, lbfgsb_amd, a, name, local_rank=local_rank,
+                                                         opts=opts, **kw))
+            except BaseException as e:   # noqa: BLE001  (a leg must never take the headline line down)
+                out["other_configs"].append({"config": name, "error": repr(e)})
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(m, n, min(a.cpu_n, n))

@@ -16,9 +16,15 @@ import json
 import statistics
 import sys
 
+import os
+
+# PP=1 in the environment: the bench was driven through the ping-pong entry (3 store streams in the
+# storing pass: 218 B/row instead of 234)
+PP = os.environ.get("PP", "1") == "1"
 KERNELS = {
-    "update_scan": ("update_scan_kernel<double, 10, true, true, true>", lambda n: 194 * n),
-    "subsm_update": ("subsm_update_kernel<double, 10, true, true, false>", lambda n: 234 * n),
+    "update_scan": ("update_scan_kernel<double, 10, true, true, true", lambda n: 194 * n),
+    ("subsm_update_pp" if PP else "subsm_update"): ("subsm_update_kernel<double, 10, true, true, false>",
+                                                    lambda n: (218 if PP else 234) * n),
     "cmprlb_wtv": ("cmprlb_wtv_kernel<double, 10, true, true, true, false>", lambda n: 177 * n),
     "wtv": ("wtv_kernel<double, 10, true>", lambda n: 168 * n),
 }

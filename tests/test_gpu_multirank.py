@@ -282,6 +282,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
-    assert out["config"]["rows_per_gpu"] == 1000000 and out["config"]["collective"].startswith("RCCL")
+    assert out["config"]["rows_per_gpu"] == 1000000 and "RCCL" in out["config"]["collective"]
+    assert out["collectives_per_iter"] == out["host_syncs_per_iter"] > 0     # one collective per host sync
     assert out["first_iteration_nseg"] > 1900000     # ~0.977 n segments, walked across both ranks
     assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
