@@ -198,6 +198,21 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
                            void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
                            int32_t *lsave, int32_t *isave, void *dsave,
                            const char *iteration_file, int32_t real_bytes, int32_t mirror);
+/* The same for a caller whose default INTEGER / LOGICAL kind is int_bytes wide (4 or 8): nbd, iwa,
+ * lsave, isave are arrays of that width, n / m / iprint travel as int64.  This is the entry the
+ * Fortran module binds (int_bytes = storage_size(1)/8), so that ONE source serves an ordinary build
+ * and a -fdefault-integer-8 build -- the build BASELINE.md section 3 calls mandatory for n = 1e8,
+ * because the reference's own wa offsets (src/lbfgsb.f90:246-265) overflow a 32-bit integer there.
+ * With 8-byte integers isave(1:16) receive those offsets in full; n < 2^32 - 16 on one device.
+ * m > LBFGSB_MAX_M is answered the way the reference answers its own argument errors: task =
+ * 'ERROR: M > 32 (LIMIT OF LBFGSB_HIP)', return value 0, no iteration done (the reference itself puts
+ * no upper limit on m, :93-97). */
+int lbfgsb_hip_setulb_host_ik(int64_t n, int64_t m, void *x, const void *l, const void *u, const void *nbd,
+                              void *f, void *g, double factr, double pgtol, void *wa, void *iwa,
+                              char *task, int64_t iprint, char *csave, void *lsave, void *isave,
+                              void *dsave, const char *iteration_file, int32_t real_bytes,
+                              int32_t mirror, int32_t int_bytes);
+int lbfgsb_hip_release_host_ik(void *isave, int32_t int_bytes);
 /* A caller that leaves its loop without a terminal task FROM the library -- the reference's own
  * driver2/driver3 set task = 'STOP...' and exit (test/driver2.f90:174-195) -- releases the
  * context of the host-pointer form with this call (the Fortran module exports it as

@@ -28,6 +28,10 @@ PROTOTYPES = {
     "lbfgsb_hip_setulb_host": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
                                          C.c_double, C.c_double, _vp, _vp, _vp, C.c_int32, _vp,
                                          _vp, _vp, _vp, _cp, C.c_int32, C.c_int32]),
+    "lbfgsb_hip_setulb_host_ik": (C.c_int, [C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            C.c_double, C.c_double, _vp, _vp, _vp, C.c_int64, _vp,
+                                            _vp, _vp, _vp, _cp, C.c_int32, C.c_int32, C.c_int32]),
+    "lbfgsb_hip_release_host_ik": (C.c_int, [_vp, C.c_int32]),
     "lbfgsb_hip_pass_clock": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "lbfgsb_hip_get_stream": (C.c_void_p, [_vp]),
     "lbfgsb_hip_wait_stream": (C.c_int, [_vp, _vp]),

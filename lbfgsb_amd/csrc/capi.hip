@@ -315,14 +315,45 @@ int lbfgsb_hip_release_host(int32_t *isave) {
   return 0;
 }
 
-int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
-                           const int32_t *nbd, void *f, void *g, double factr, double pgtol,
-                           void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
-                           int32_t *lsave, int32_t *isave, void *dsave, const char *iteration_file,
-                           int32_t real_bytes, int32_t mirror) {
+// One implementation for both integer widths of the caller (int_bytes = 4: default integers of an
+// ordinary Fortran build; 8: -fdefault-integer-8, the build BASELINE.md section 3 calls mandatory for
+// n = 1e8 because the reference's own wa offsets overflow int32 there, src/lbfgsb.f90:246-265).  nbd,
+// iwa, lsave, isave are arrays of that width; inside, the library works with int32 copies (nbd is
+// narrowed once, on START; isave / lsave are 44 + 4 words per call; iwa only travels when mirror != 0).
+static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const void *u, const void *nbd_,
+                            void *f, void *g, double factr, double pgtol, void *wa, void *iwa_, char *task,
+                            int32_t iprint, char *csave, void *lsave_, void *isave_, void *dsave,
+                            const char *iteration_file, int32_t real_bytes, int32_t mirror, int int_bytes) {
   const bool r32 = real_bytes == 4;
   if (real_bytes != 4 && real_bytes != 8) return fail(LBFGSB_E_ARG, "real_bytes must be 4 or 8");
+  if (int_bytes != 4 && int_bytes != 8) return fail(LBFGSB_E_ARG, "int_bytes must be 4 or 8");
+  const bool i8 = int_bytes == 8;
   const size_t rb = (size_t)real_bytes;
+  // int32 views of the caller's small integer arrays
+  int32_t isave[44], lsave[4];
+  auto geti = [&](const void *p, int k) -> int64_t {
+    return i8 ? ((const int64_t *)p)[k] : (int64_t)((const int32_t *)p)[k];
+  };
+  auto puti = [&](void *p, int k, int64_t v) {
+    if (i8)
+      ((int64_t *)p)[k] = v;
+    else
+      ((int32_t *)p)[k] = (int32_t)std::min<int64_t>(std::max<int64_t>(v, INT32_MIN), INT32_MAX);
+  };
+  for (int k = 0; k < 44; ++k) {
+    const int64_t v = geti(isave_, k);
+    isave[k] = (int32_t)std::min<int64_t>(std::max<int64_t>(v, INT32_MIN), INT32_MAX);
+  }
+  for (int k = 0; k < 4; ++k) lsave[k] = geti(lsave_, k) != 0;
+  int64_t off64[16] = {0};
+  bool have_off = false;
+  auto finish_ints = [&]() {
+    for (int k = 0; k < 44; ++k) puti(isave_, k, isave[k]);
+    // the wa offsets of isave(1:16) in full width for a 64-bit caller (saturated for a 32-bit one)
+    if (have_off)
+      for (int k = 0; k < 16; ++k) puti(isave_, k, off64[k]);
+    for (int k = 0; k < 4; ++k) puti(lsave_, k, lsave[k]);
+  };
   lbfgsb_hip_ctx *ctx = nullptr;
   const bool start = lbh::str60_eq(task, "START");
   if (start) {
@@ -331,10 +362,24 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
     if (n <= 0 || m <= 0) {
       if (n <= 0) lbh::str60_set(task, "ERROR: N <= 0");
       if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
+      finish_ints();
+      return 0;
+    }
+    // The reference puts no upper limit on m (:93-97); this library's kernels are unrolled for at most
+    // LBFGSB_MAX_M pairs.  A caller written against the reference sees it the way it sees every other
+    // argument error: a task that starts with 'ERROR', no iteration done.
+    if (m > LBFGSB_MAX_M) {
+      lbh::str60_set(task, "ERROR: M > 32 (LIMIT OF LBFGSB_HIP)");
+      finish_ints();
+      return 0;
+    }
+    if (n > 0xFFFFFFF0ll) {
+      lbh::str60_set(task, "ERROR: N >= 2**32 ON ONE DEVICE (LIMIT OF LBFGSB_HIP)");
+      finish_ints();
       return 0;
     }
     int fl = (r32 ? LBFGSB_F_REAL32 : 0) | (mirror ? LBFGSB_F_MIRROR_INDEX : 0);
-    int rc = lbfgsb_hip_create(n, n, 0, m, fl, 0, nullptr, &ctx);
+    int rc = lbfgsb_hip_create(n, n, 0, (int)m, fl, 0, nullptr, &ctx);
     if (rc) return rc;
     if (iteration_file && iteration_file[0]) ctx->itfile_name = iteration_file;
     const size_t vb = ((size_t)n + 32) * rb;
@@ -348,7 +393,15 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
       HIPCHK(hipMemcpy(ctx->hx, x, (size_t)n * rb, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(ctx->hl, l, (size_t)n * rb, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(ctx->hu, u, (size_t)n * rb, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(ctx->hnbd, nbd, (size_t)n * 4, hipMemcpyHostToDevice));
+      if (i8) {  // (values outside int32 are invalid bound types anyway: errclb reports them)
+        std::vector<int32_t> nb((size_t)n);
+        const int64_t *src = (const int64_t *)nbd_;
+        for (int64_t k = 0; k < n; ++k)
+          nb[(size_t)k] = (src[k] < 0 || src[k] > 3) ? -1 : (int32_t)src[k];
+        HIPCHK(hipMemcpy(ctx->hnbd, nb.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      } else {
+        HIPCHK(hipMemcpy(ctx->hnbd, nbd_, (size_t)n * 4, hipMemcpyHostToDevice));
+      }
       return 0;
     };
     rc = stage();
@@ -356,18 +409,7 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
       lbfgsb_hip_destroy(ctx);
       return rc;
     }
-    std::memset(isave, 0, 44 * sizeof(int32_t));
-    // the wa offsets the reference persists in isave(4:16) (:250-265: lws, lwy, lsy, lss, lwt, lwn,
-    // lsnd, lz, lr, ld, lt, lxp, lwa; isave(1:3) = m*n, m^2, 4m^2), 1-based, computed in 64 bits
-    // and saturated (the reference's default-integer arithmetic wraps at n = 1e8, m = 10)
-    {
-      const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
-      const int64_t lws = 1, lwy = lws + mn, lsy = lwy + mn, lss = lsy + mm, lwt = lss + mm,
-                    lwn = lwt + mm, lsnd = lwn + 4 * mm, lz = lsnd + 4 * mm, lr = lz + n, ld_ = lr + n,
-                    lt = ld_ + n, lxp = lt + n, lwa = lxp + n;
-      const int64_t v[16] = {mn, mm, 4 * mm, lws, lwy, lsy, lss, lwt, lwn, lsnd, lz, lr, ld_, lt, lxp, lwa};
-      for (int k = 0; k < 16; ++k) isave[k] = (int32_t)std::min<int64_t>(v[k], INT32_MAX);
-    }
+    std::memset(isave, 0, sizeof isave);
     isave[16] = g_host.add(ctx);
     isave[17] = HOST_TAG;
   } else {
@@ -377,15 +419,24 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
     if (lbh::str60_pre(task, "FG"))
       HIPCHK(hipMemcpy(ctx->hg, g, (size_t)n * rb, hipMemcpyHostToDevice));
   }
+  // the wa offsets the reference persists in isave(4:16) (:250-265: lws, lwy, lsy, lss, lwt, lwn,
+  // lsnd, lz, lr, ld, lt, lxp, lwa; isave(1:3) = m*n, m^2, 4m^2), 1-based, computed in 64 bits
+  // (the reference's default-integer arithmetic wraps at n = 1e8, m = 10 in a 32-bit build)
+  {
+    const int64_t mn = m * n, mm = m * m;
+    const int64_t lws = 1, lwy = lws + mn, lsy = lwy + mn, lss = lsy + mm, lwt = lss + mm,
+                  lwn = lwt + mm, lsnd = lwn + 4 * mm, lz = lsnd + 4 * mm, lr = lz + n, ld_ = lr + n,
+                  lt = ld_ + n, lxp = lt + n, lwa = lxp + n;
+    const int64_t v[16] = {mn, mm, 4 * mm, lws, lwy, lsy, lss, lwt, lwn, lsnd, lz, lr, ld_, lt, lxp, lwa};
+    std::memcpy(off64, v, sizeof off64);
+    have_off = true;
+  }
   const int32_t keep_id = isave[16], keep_tag = isave[17];
-  int32_t keep16[16];
-  std::memcpy(keep16, isave, sizeof keep16);
   double fd = r32 ? (double)*(float *)f : *(double *)f;
   double ds[29];
   for (int i = 0; i < 29; ++i) ds[i] = r32 ? (double)((float *)dsave)[i] : ((double *)dsave)[i];
   int rc = ctx->setulb_dev(ctx->hx, ctx->hl, ctx->hu, ctx->hnbd, &fd, ctx->hg, factr, pgtol, task,
                            iprint, csave, lsave, isave, ds);
-  std::memcpy(isave, keep16, sizeof keep16);
   isave[16] = keep_id, isave[17] = keep_tag;
   if (iprint >= 0) std::fflush(stdout);
   if (rc) return rc;
@@ -402,8 +453,16 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
   HIPCHK(hipMemcpy(x, ctx->hx, (size_t)n * rb, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(g, ctx->hg, (size_t)n * rb, hipMemcpyDeviceToHost));
   if (mirror) {
-    rc = ctx->export_state(wa, iwa);
-    if (rc) return rc;
+    if (i8) {  // the library's int32 iwa, widened into the caller's
+      std::vector<int32_t> iw((size_t)3 * (size_t)n);
+      rc = ctx->export_state(wa, iw.data());
+      if (rc) return rc;
+      int64_t *dst = (int64_t *)iwa_;
+      for (size_t k = 0; k < iw.size(); ++k) dst[k] = iw[k];
+    } else {
+      rc = ctx->export_state(wa, (int32_t *)iwa_);
+      if (rc) return rc;
+    }
   } else if (wa) {
     // previous iterate: wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175
     const int64_t off_t = 2ll * m * n + 11ll * m * m + 3ll * n;
@@ -412,6 +471,41 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
   }
   if (!lbh::str60_pre(task, "FG") && !lbh::str60_pre(task, "NEW_X"))
     g_host.drop(isave);  // terminal task: CONVERGENCE / ABNORMAL / ERROR / STOP
+  finish_ints();
+  return 0;
+}
+
+int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
+                           const int32_t *nbd, void *f, void *g, double factr, double pgtol,
+                           void *wa, int32_t *iwa, char *task, int32_t iprint, char *csave,
+                           int32_t *lsave, int32_t *isave, void *dsave, const char *iteration_file,
+                           int32_t real_bytes, int32_t mirror) {
+  return setulb_host_impl(n, m, x, l, u, nbd, f, g, factr, pgtol, wa, iwa, task, iprint, csave, lsave, isave,
+                          dsave, iteration_file, real_bytes, mirror, 4);
+}
+
+int lbfgsb_hip_setulb_host_ik(int64_t n, int64_t m, void *x, const void *l, const void *u, const void *nbd,
+                              void *f, void *g, double factr, double pgtol, void *wa, void *iwa,
+                              char *task, int64_t iprint, char *csave, void *lsave, void *isave,
+                              void *dsave, const char *iteration_file, int32_t real_bytes,
+                              int32_t mirror, int32_t int_bytes) {
+  const int32_t ipr = (int32_t)std::min<int64_t>(std::max<int64_t>(iprint, -1), 1000);
+  return setulb_host_impl(n, m, x, l, u, nbd, f, g, factr, pgtol, wa, iwa, task, ipr, csave, lsave, isave,
+                          dsave, iteration_file, real_bytes, mirror, int_bytes);
+}
+
+int lbfgsb_hip_release_host_ik(void *isave, int32_t int_bytes) {
+  if (!isave || (int_bytes != 4 && int_bytes != 8)) return fail(LBFGSB_E_ARG, "release_host: bad argument");
+  int32_t tmp[44] = {0};
+  for (int k = 16; k < 18; ++k)
+    tmp[k] = int_bytes == 8 ? (int32_t)((int64_t *)isave)[k] : ((int32_t *)isave)[k];
+  g_host.drop(tmp);
+  for (int k = 16; k < 18; ++k) {
+    if (int_bytes == 8)
+      ((int64_t *)isave)[k] = 0;
+    else
+      ((int32_t *)isave)[k] = 0;
+  }
   return 0;
 }
 

@@ -222,3 +222,72 @@ def test_ping_pong_entry_is_bit_identical_to_the_classic_one():
             # (at an 'FG' return g[cur] is the buffer the caller is about to write the gradient into)
             assert ra[0].startswith("FG") or ra[7].tobytes() == rb[7].tobytes(), (p.name, k, "g")
     assert swaps > 500      # the pairs really did change roles
+
+
+def test_m_beyond_the_limit_is_answered_like_an_argument_error():
+    """The reference puts no upper limit on m (src/lbfgsb.f90:93-97); the kernels are unrolled for at
+    most LBFGSB_MAX_M = 32 pairs.  Through the reference-shaped host entry a larger m is answered the
+    way the reference answers its own argument errors -- task = 'ERROR: ...', no iteration, return
+    code 0 -- in both integer widths; the context entry refuses it with LBFGSB_E_ARG."""
+    import ctypes as C
+    import numpy as np
+    import lbfgsb_amd as la
+    from lbfgsb_amd import capi
+    from oracle import pyoracle as po
+    n, m = 50, 33
+    p = po.problem_quadratic(n, m)
+    s = po.State.fresh(p)
+    la.setulb(n, m, s.x, p.l, p.u, p.nbd.astype(np.int32), s.f, s.g, 0.0, 0.0, s.wa, s.iwa, s.task, -1,
+              s.csave, s.lsave, s.isave, s.dsave)
+    assert s.task_s == "ERROR: M > 32 (LIMIT OF LBFGSB_HIP)"
+    lib = la.load_library()
+    s8 = po.State.fresh(p, np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    rc = lib.lbfgsb_hip_setulb_host_ik(n, m, vp(s8.x), vp(p.l), vp(p.u), vp(p.nbd.astype(np.int64)), vp(s8.f),
+                                       vp(s8.g), 0.0, 0.0, vp(s8.wa), vp(s8.iwa), vp(s8.task), -1, vp(s8.csave),
+                                       vp(s8.lsave), vp(s8.isave), vp(s8.dsave), None, 8, 0, 8)
+    assert rc == 0 and s8.task_s == "ERROR: M > 32 (LIMIT OF LBFGSB_HIP)"
+    h = C.c_void_p()
+    assert lib.lbfgsb_hip_create(n, n, 0, m, 0, 0, None, C.byref(h)) == -101   # LBFGSB_E_ARG
+
+
+def test_host_entry_with_eight_byte_integers_matches_the_four_byte_one():
+    """lbfgsb_hip_setulb_host_ik with int_bytes = 8 (what a -fdefault-integer-8 Fortran build binds)
+    against the int32 entry on the same problem: same task sequence, same counters in isave(22:44), same
+    x, f to the last bit; isave(1:16) carry the wa offsets in full width."""
+    import ctypes as C
+    import numpy as np
+    import lbfgsb_amd as la
+    from oracle import pyoracle as po
+    lib = la.load_library()
+    p = po.problem_quadratic(3001, 6, mixed_nbd=True)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+
+    def run(ib):
+        it = np.int64 if ib == 8 else np.int32
+        s = po.State.fresh(p, it)
+        nbd = p.nbd.astype(it)
+        rows = []
+        for _ in range(500):
+            rc = lib.lbfgsb_hip_setulb_host_ik(p.n, p.m, vp(s.x), vp(p.l), vp(p.u), vp(nbd), vp(s.f), vp(s.g),
+                                               0.0, 0.0, vp(s.wa), vp(s.iwa), vp(s.task), -1, vp(s.csave),
+                                               vp(s.lsave), vp(s.isave), vp(s.dsave), None, 8, 0, ib)
+            assert rc == 0
+            t = s.task_s
+            rows.append((t, [int(v) for v in s.isave[21:44]], [int(v) for v in s.lsave], float(s.f[0]), s.x.copy()))
+            if t.startswith("FG"):
+                s.f[0] = p.fg(s.x, s.g)
+            elif t.startswith("NEW_X"):
+                if s.isave[29] >= 12:
+                    s.task[:] = po.pad60("STOP: done")
+            else:
+                break
+        return rows, s
+    r4, s4 = run(4)
+    r8, s8 = run(8)
+    assert len(r4) == len(r8) and r4[-1][0].startswith("STOP")
+    for a, b in zip(r4, r8):
+        assert a[:4] == b[:4] and a[4].tobytes() == b[4].tobytes()
+    mn, mm = p.m * p.n, p.m * p.m
+    assert list(s8.isave[:4]) == [mn, mm, 4 * mm, 1] and s8.isave[15] == 1 + 2 * mn + 11 * mm + 5 * p.n
+    assert list(s4.isave[:16]) == list(s8.isave[:16])      # (no saturation at this size)
