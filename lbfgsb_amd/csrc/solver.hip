@@ -23,7 +23,16 @@
 // cauchy_finish, formk_gram, update_pairs, lnsrlb_begin/step, pair_commit, xcp_fill,
 // subsm_dir/backtrack.
 //
-// There is no CPU fallback anywhere in this file.
+// Source layout: this file holds the context (allocation, the reductions across ranks) and the
+// mainlb state machine itself -- nine phase functions over one Mainlb struct, driven by drive(); the
+// member functions of the three big phases live in files of their own, included inside the class:
+//   solver_cauchy.inl    the Cauchy point: breakpoint provider, exact host walk, parallel search
+//   solver_subspace.inl  formk, cmprlb, subsm (the closed form, the storing pass, backtracking)
+//   solver_state.inl     export / import in the reference's wa / iwa layout, per-kernel doors
+// Two device-pointer entries share the state machine: setulb_dev (the caller's x and g in place,
+// t = x / r = g as copies) and setulb_dev_pp (two caller buffer pairs that swap roles, no copies).
+//
+// There is no CPU fallback anywhere in these files.
 #include "solver_base.hpp"
 
 namespace {
@@ -299,1673 +308,8 @@ class Solver final : public lbfgsb_hip_ctx {
 
   lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m, zero_buf}; }
 
-  // =================================================================== cauchy
-  // Breakpoint provider: hands the replicated host walk the breakpoints of ALL ranks in
-  // ascending (t, global index) order (SURVEY.md 7.3-1 option (a)).  Each rank keeps its own
-  // candidates sorted on the device; chunks of records are all-gathered and merged on the
-  // host.  A merged record is "safe" to consume once no rank can still hold an earlier one.
-  struct MRec {
-    double t;
-    int64_t gidx;
-    int rank;
-    const double *rec;
-  };
-  struct Provider {
-    bool have = false;   // candidate lists exist on the devices
-    bool full = false;   // lists = ALL remaining breakpoints (full sort)
-    double win_hi = -1;  // lists cover every breakpoint after the fetch cursor with t <= win_hi
-    uint32_t Cl = 0;     // local list length
-    uint32_t pl = 0;     // local list position of the first record not yet consumed
-    int cur = 0;         // which keys/idx buffer holds the sorted local list
-    std::vector<MRec> M; // merged chunk, all ranks
-    const double *raw = nullptr;  // single rank, col = 0: the chunk itself is in order (records of
-                                  // 4 doubles); M is then only sized, not filled
-    size_t mpos = 0, safe_end = 0;
-    bool more_anywhere = false;
-    std::vector<uint32_t> taken;
-    uint32_t next_chunk = 64;
-    int grow = 0;
-    // the reference's own pop order (bkmin first, then hpsolb's heap), replayed on the host over
-    // ALL breakpoints; records are gathered in that order
-    bool exact = false;
-    std::vector<double> ht;       // heap keys   (t of hpsolb, 0-based)
-    std::vector<uint32_t> hio;    // heap values (iorder: GLOBAL rows), n_global < 2^32 ...
-    std::vector<int64_t> hio64;   // ... and beyond (h64)
-    bool h64 = false;
-    std::vector<int64_t> hrow0;   // first global row of every rank (+ nglob at the end)
-    int64_t hleft = 0;            // nleft of the reference's walk for the NEXT pop
-    bool hbuilt = false;
-    int64_t hibkmin = -1;
-  };
-
-  // every rank contributes d_msg[0..count) (device); all of it lands in h_msg_all (rank-major)
-  int exchange(size_t count) {
-    if (comm || nranks > 1) ncoll++, coll_bytes += (int64_t)count * 8;
-    if (nranks == 1 && !comm) {
-      HIPCHK(hipMemcpyAsync(h_msg_all, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
-                            stream));
-      {
-        const double t0 = now_s();
-        HIPCHK(hipStreamSynchronize(stream));
-        t_wait += now_s() - t0;
-      }
-    } else if (comm) {
-      if (g_rccl.AllGather(d_msg, d_msg_all, count, ncclDouble, comm, stream) != ncclSuccess)
-        return fail(LBFGSB_E_COMM, "ncclAllGather failed");
-      HIPCHK(hipMemcpyAsync(h_msg_all, d_msg_all, (size_t)nranks * count * sizeof(double),
-                            hipMemcpyDeviceToHost, stream));
-      {
-        const double t0 = now_s();
-        HIPCHK(hipStreamSynchronize(stream));
-        t_wait += now_s() - t0;
-      }
-    } else {
-      if (!cb_ag) return fail(LBFGSB_E_COMM, "multi-rank context without an all-gather");
-      HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg, count * sizeof(double), hipMemcpyDeviceToHost,
-                            stream));
-      {
-        const double t0 = now_s();
-        HIPCHK(hipStreamSynchronize(stream));
-        t_wait += now_s() - t0;
-      }
-      if (cb_ag(cb_user, h_msg_loc, h_msg_all, (int64_t)(count * sizeof(double))) != 0)
-        return fail(LBFGSB_E_COMM, "host all-gather callback failed");
-    }
-    nsync++;
-    return 0;
-  }
-  int put_header(double a, double b) {
-    h_hdr[0] = a, h_hdr[1] = b;
-    HIPCHK(hipMemcpyAsync(d_msg, h_hdr, 2 * sizeof(double), hipMemcpyHostToDevice, stream));
-    return 0;
-  }
-  // breakpoint times as a vector: written by cauchy_scan_kernel; the fused update pass does
-  // not store them (the usual short walk recomputes the few it needs), so the rare consumers
-  // of the vector (full sort, cursor-based cauchy_finish) fill it in first
-  bool tbrk_valid = false;
-  const int32_t *cnbd = nullptr;
-  // nbd as one byte per row for the passes over W (lbk::nb_t): packed when a run starts, when a
-  // state is imported, and whenever the caller's pointer changes.  Like l and u, nbd must not
-  // change between START and the end of a run (the reference reads it afresh on every call,
-  // but a run whose bound types change under it has no meaning there either).
-  lbk::nb_t *nbd8 = nullptr;
-  const int32_t *nbd8_src = nullptr;
-  int ensure_nbd8(const int32_t *nbd) {
-    if (nbd8_src == nbd) return 0;
-    lbk::launch_nbd_pack(q, n, nbd, nbd8);
-    nbd8_src = nbd;
-    return 0;
-  }
-  // the pair accepted by matupd in this call, not yet stored in W (see lbk::Pend)
-  lbk::Pend pend{0, 1.0, 0};
-  // ---- lean subspace pass: z and d stay implicit (z = x, d = x - t) while the unit first trial
-  //      step stands; ensure_d() writes them out for everything but the hot path ----
-  bool d_impl = false;
-  bool z_in_x = false;  // ... and z too: until the next cauchy gives z a new meaning
-  bool lean_on = true;  // (option "lean")
-  const T *d_src() const { return d_impl ? t : d; }  // what the kernels read the direction from
-  int ensure_d(const T *x) {
-    if (!d_impl) return 0;
-    lbk::launch_dz_materialise<T>(q, n, x, t, d, z_in_x ? z : (T *)nullptr);
-    if (z_in_x) z_valid = true;
-    d_impl = false, z_in_x = false;
-    if (pend.on) pend.impl = 0;
-    return 0;
-  }
-  // sums of an update_scan pass that ran as the evaluation of an accepted trial point (kept
-  // from the FG_LNSRCH entry that returned NEW_X to the NEW_X entry that performs the update)
-  struct Spec {
-    bool valid = false;
-    const void *x = nullptr, *g = nullptr;
-    double stp = 0.0;
-    int head = 0, col = 0, itail = 0;
-    double res[lbk::RES_MAX];
-  } spec;
-  int commit_pending(const T *g, int col, int head) {
-    if (pend.on) {
-      CHK(ensure_d((const T *)cx));
-      lbk::launch_pair_commit<T>(q, n, g, r, d, pend, W(), head, col);
-    }
-    pend.on = 0;
-    return 0;
-  }
-  int ensure_tbrk() {
-    if (!tbrk_valid)
-      lbk::launch_tbrk_fill<T>(q, n, (const T *)cx, (const T *)cl, (const T *)cu, cnbd, (const T *)cg,
-                               iwhere, tbrk);
-    tbrk_valid = true;
-    return 0;
-  }
-  int local_count(double lo_t, int64_t lo_i, double hi, uint32_t cap, uint32_t &cnt) {
-    CHK(ensure_tbrk());
-    lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], cap, d_count);
-    HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    nsync++;
-    cnt = *h_count;
-    return 0;
-  }
-
-  static constexpr uint32_t FAST_CAP = 256;  // candidates delivered by the one-sync fast path
-  // ---- candidates handed over by the update pass itself (update_scan_kernel, cand_hi) ----
-  static constexpr uint32_t SPEC_CAP = 128;
-  uint64_t *sp_keys = nullptr;
-  uint32_t *sp_idx = nullptr, *sp_count = nullptr;
-  double *sp_msg = nullptr, *sp_msg_all = nullptr, *h_sp_all = nullptr, *h_sp_loc = nullptr;
-  struct SpecCand {
-    bool valid = false, fresh = false;
-    double hi = -1.0;
-    int col = 0;
-  } spcand;
-  double last_tsum = 0.0, last_dtm0 = 0.0;  // where the previous walk ended / first aimed
-  size_t sp_len() const { return 2 + (size_t)SPEC_CAP * (2 * m + 4); }
-  double spec_factor = 2.0;
-  // Off unless option "spec_capture" = 1: measured at n = 1e8 / 1.25e7 (profiles/README.md, r02q) a walk
-  // either crosses no breakpoint at all or hundreds to thousands -- SPEC_CAP records serve 0-3 of 31.
-  bool spec_on = false;
-  double spec_hi(bool cnstnd) const {  // the guess: a little beyond where the previous walk ended
-    if (!spec_on || !cnstnd || iter_seen < 3) return -1.0;  // (the first walks cross most breakpoints)
-    return last_tsum > 0.0 && std::isfinite(last_tsum) ? spec_factor * last_tsum : -1.0;
-  }
-  int iter_seen = 0;
-  // queue the gather of the candidates' records and their way to the host (all ranks') behind the
-  // update pass; spec_land() completes it after the phase's one host sync
-  int spec_queue(const T *x, const T *l, const T *u, const T *g, int head, int col, double stp) {
-    lbk::launch_cauchy_gather_dyn<T>(q, sp_idx, sp_keys, sp_count, SPEC_CAP, row0, x, l, u, g, W(), head,
-                                     col, r, d_src(), lbk::Pend{1, stp, d_impl ? 1 : 0}, sp_msg);
-    const size_t cnt = 2 + (size_t)SPEC_CAP * (2 * col + 4);
-    if (nranks == 1 && !comm) {
-      HIPCHK(hipMemcpyAsync(h_sp_all, sp_msg, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
-    } else if (comm) {
-      if (g_rccl.AllGather(sp_msg, sp_msg_all, cnt, ncclDouble, comm, stream) != ncclSuccess)
-        return fail(LBFGSB_E_COMM, "ncclAllGather failed");
-      HIPCHK(hipMemcpyAsync(h_sp_all, sp_msg_all, (size_t)nranks * cnt * sizeof(double),
-                            hipMemcpyDeviceToHost, stream));
-    } else {
-      HIPCHK(hipMemcpyAsync(h_sp_loc, sp_msg, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
-    }
-    return 0;
-  }
-  size_t sp_stride = 0;  // doubles per rank in h_sp_all
-  int spec_land(int col, double hi) {
-    const int recl = 2 * col + 4;
-    sp_stride = 2 + (size_t)SPEC_CAP * recl;
-    if (nranks > 1 && !comm) {
-      // host all-gather: first the counts, then only as many records as the fullest rank has
-      if (!cb_ag) return fail(LBFGSB_E_COMM, "multi-rank context without an all-gather");
-      double *cnts = h_sp_all + (size_t)nranks * sp_len() - nranks;  // (tail of the buffer)
-      if (cb_ag(cb_user, h_sp_loc, cnts, (int64_t)sizeof(double)) != 0)
-        return fail(LBFGSB_E_COMM, "host all-gather callback failed");
-      double mx = 0.0;
-      for (int rk = 0; rk < nranks; ++rk) mx = std::max(mx, cnts[rk]);
-      const size_t keep = (size_t)std::min<double>(mx, (double)SPEC_CAP);
-      sp_stride = 2 + keep * recl;
-      if (cb_ag(cb_user, h_sp_loc, h_sp_all, (int64_t)(sp_stride * sizeof(double))) != 0)
-        return fail(LBFGSB_E_COMM, "host all-gather callback failed");
-    }
-    spcand.valid = true, spcand.fresh = true, spcand.hi = hi, spcand.col = col;
-    return 0;
-  }
-
-  // *big != nullptr: if more than PG_MIN candidates lie in the window, only report their number
-  // (the caller switches to the parallel search) instead of ordering them
-  // (option "pg_min" lowers it so that tests can send small problems through the search)
-  double PG_MIN = 32768.0;
-  int window_fetch(Provider &pv, double lo_t, int64_t lo_i, double hi, const T *x, const T *l,
-                   const T *u, const T *g, int head, int col, double *big = nullptr) {
-    // window compaction + record gather + ONE all-gather/sync: enough for the usual short walk
-    const int recl = 2 * col + 4;
-    pf_valid = false;  // (new candidate lists: a prefetched chunk of the old ones is void)
-    if (debug_walk && lo_t < 0.0) {
-      double c0 = spcand.valid ? h_sp_all[0] : -1.0;
-      std::fprintf(stderr, "[spec] valid=%d fresh=%d hi_asked=%g spec_hi=%g factor=%g count0=%g\n",
-                   (int)spcand.valid, (int)spcand.fresh, hi, spcand.hi, spec_factor, c0);
-    }
-    if (spcand.valid && spcand.fresh && lo_t < 0.0 && hi > spcand.hi)
-      spec_factor = std::min(4.0, spec_factor * 1.5);  // the guess was short: aim further next time
-    if (spcand.valid && spcand.fresh && lo_t < 0.0 && hi <= spcand.hi && spcand.col == col) {
-      // the update pass already delivered every breakpoint up to spcand.hi with its record
-      spcand.fresh = false;
-      const size_t scount = sp_stride;
-      double gsum = 0.0;
-      bool all_in = true;
-      for (int rk = 0; rk < nranks; ++rk) {
-        const double c = h_sp_all[(size_t)rk * scount];
-        gsum += c;
-        if (c > (double)SPEC_CAP) all_in = false;
-      }
-      // adapt the guess: too many candidates -> aim closer next time, few -> a little wider
-      if (!all_in)
-        spec_factor = std::max(1.05, 0.5 * (spec_factor + 1.0));
-      else if (gsum < 0.25 * SPEC_CAP)
-        spec_factor = std::min(4.0, spec_factor * 1.25);
-      if (all_in) {
-        if (big) *big = gsum;
-        pv.have = true, pv.full = false;
-        pv.win_hi = spcand.hi;
-        pv.Cl = (uint32_t)h_sp_all[(size_t)rank * scount];
-        pv.pl = pv.Cl;  // everything is already on the host
-        pv.cur = 0;
-        pv.M.clear();
-        pv.raw = nullptr;
-        for (int rk = 0; rk < nranks; ++rk) {
-          const double *base = h_sp_all + (size_t)rk * scount;
-          const uint32_t lr = (uint32_t)base[0];
-          for (uint32_t k = 0; k < lr; ++k) {
-            const double *rec = base + 2 + (size_t)k * recl;
-            pv.M.push_back(MRec{rec[0], (int64_t)rec[1], rk, rec});
-          }
-        }
-        std::sort(pv.M.begin(), pv.M.end(), [](const MRec &a, const MRec &b) {
-          return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
-        });
-        pv.mpos = 0;
-        pv.safe_end = pv.M.size();
-        pv.more_anywhere = false;
-        pv.taken.assign(nranks, 0);
-        pv.next_chunk = 64;
-        nspecwin++;
-        return 0;
-      }
-    }
-    if (tbrk_valid)
-      lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
-                                   d_count);
-    else
-      lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, nbd8, g, iwhere, lo_t, lo_i, hi, keys[0],
-                                       idx[0], SEL_CAP, d_count);
-    lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
-                                     head, col, r, d_src(), pend, d_msg);
-    const size_t fcount = 2 + (size_t)FAST_CAP * recl;
-    CHK(exchange(fcount));
-    double gsum = 0.0;
-    bool all_small = true;
-    for (int rk = 0; rk < nranks; ++rk) {
-      const double c = h_msg_all[(size_t)rk * fcount];
-      gsum += c;
-      if (c > (double)FAST_CAP) all_small = false;
-    }
-    uint32_t cnt = (uint32_t)h_msg_all[(size_t)rank * fcount];
-    if (big) {
-      *big = gsum;
-      if (gsum > PG_MIN) return 0;
-    }
-    if (all_small) {
-      pv.have = true;
-      pv.full = false;
-      pv.win_hi = hi;
-      pv.Cl = cnt;
-      pv.pl = cnt;  // everything is already on the host
-      pv.cur = 0;
-      pv.M.clear();
-      pv.raw = nullptr;
-      for (int rk = 0; rk < nranks; ++rk) {
-        const double *base = h_msg_all + (size_t)rk * fcount;
-        const uint32_t lr = (uint32_t)base[0];
-        for (uint32_t k = 0; k < lr; ++k) {
-          const double *rec = base + 2 + (size_t)k * recl;
-          pv.M.push_back(MRec{rec[0], (int64_t)rec[1], rk, rec});
-        }
-      }
-      std::sort(pv.M.begin(), pv.M.end(), [](const MRec &a, const MRec &b) {
-        return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
-      });
-      pv.mpos = 0;
-      pv.safe_end = pv.M.size();
-      pv.more_anywhere = false;
-      pv.taken.assign(nranks, 0);
-      pv.next_chunk = 64;
-      return 0;
-    }
-    pv.have = true;
-    pv.pl = 0;
-    pv.taken.clear();
-    pv.M.clear();
-    pv.mpos = pv.safe_end = 0;
-    pv.more_anywhere = true;  // forces a refill
-    pv.next_chunk = 64;
-    if (gsum <= (double)SEL_CAP) {
-      pv.full = false;
-      pv.win_hi = hi;
-      pv.Cl = cnt;
-      pv.cur = 0;
-      if (cnt > 1) {
-        // (t, idx) lexicographic order: stable sort by idx, then stable sort by t
-        lbk::launch_sort_by_idx(q, sort_tmp, sort_tmp_bytes, idx[0], idx[1], keys[0], keys[1], cnt);
-        lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[1], keys[0], idx[1], idx[0], cnt);
-      }
-    } else {
-      // too many candidates in the window: order ALL remaining breakpoints once
-      nfullsort++;
-      CHK(ensure_sel((size_t)n));
-      CHK(local_count(lo_t, lo_i, std::numeric_limits<double>::max(), 0, cnt));  // (fills tbrk)
-      lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, lo_t, lo_i, keys[0], idx[0]);
-      lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1],
-                             (size_t)n);
-      pv.full = true;
-      pv.win_hi = std::numeric_limits<double>::infinity();
-      pv.Cl = cnt;  // the rest of the sorted array are non-candidates (key = ~0)
-      pv.cur = 1;
-    }
-    return 0;
-  }
-
-  // ---- breakpoints in the reference's own order ----
-  // cauchy takes the smallest breakpoint from the scan (first minimum in variable order, :1384-
-  // 1389), then moves the last list entry into its slot, builds hpsolb's heap over the rest and
-  // pops one breakpoint per segment (:1391-1403).  Among EQUAL breakpoints that order is a
-  // property of the heap, not of the variables; it matters only when the walk ends inside a
-  // group of equal breakpoints (then it decides which of them are fixed).  Replaying it needs the
-  // whole list on the host: O(n) transfer + heap build, so it runs only for a call whose walk did
-  // end inside such a group (or from the start under iprint >= 99); LBFGSB_F_INDEX_TIES opts out.
-  int exact_init(Provider &pv) {
-    CHK(ensure_tbrk());
-    std::vector<T> tb((size_t)n);
-    HIPCHK(hipMemcpyAsync(tb.data(), tbrk, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    nsync++;
-    pv = Provider{};
-    pv.exact = true;
-    pv.h64 = nglob >= 0xffffffffll;
-    pv.ht.clear(), pv.hio.clear(), pv.hio64.clear();
-    const double inf = std::numeric_limits<double>::infinity();
-    // every rank's breakpoint times, in global variable order (ranks own ascending row blocks)
-    std::vector<double> tall;
-    std::vector<int64_t> cnt(nranks, n);
-    pv.hrow0.assign((size_t)nranks + 1, 0);
-    int64_t nmax = n;
-    if (nranks > 1) {
-      CHK(put_header((double)n, (double)row0));
-      CHK(exchange(2));
-      nmax = 0;
-      for (int rk = 0; rk < nranks; ++rk) {
-        cnt[rk] = (int64_t)h_msg_all[2 * (size_t)rk];
-        pv.hrow0[rk] = (int64_t)h_msg_all[2 * (size_t)rk + 1];
-        nmax = std::max(nmax, cnt[rk]);
-      }
-      std::vector<double> mine((size_t)nmax, -1.0);
-      for (int64_t i = 0; i < n; ++i) mine[(size_t)i] = (double)tb[(size_t)i];
-      double *dsend = nullptr, *drecv = nullptr;
-      HIPCHK(hipMalloc(&dsend, (size_t)nmax * sizeof(double)));
-      if (hipMalloc(&drecv, (size_t)nmax * nranks * sizeof(double)) != hipSuccess) {
-        (void)hipFree(dsend);
-        return fail(LBFGSB_E_NOGPU, "exact tie order: no memory for the gathered breakpoint times");
-      }
-      tall.resize((size_t)nmax * nranks);
-      int rc = 0;
-      if (hipMemcpy(dsend, mine.data(), (size_t)nmax * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(LBFGSB_E_NOGPU, "exact tie order: upload failed");
-      if (!rc) rc = allgather_big(dsend, drecv, (size_t)nmax);
-      if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = fail(LBFGSB_E_NOGPU, "exact tie order: sync");
-      if (!rc && hipMemcpy(tall.data(), drecv, tall.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(LBFGSB_E_NOGPU, "exact tie order: download failed");
-      (void)hipFree(dsend), (void)hipFree(drecv);
-      if (rc) return rc;
-    } else {
-      pv.hrow0[0] = row0;
-      tall.resize((size_t)n);
-      for (int64_t i = 0; i < n; ++i) tall[(size_t)i] = (double)tb[(size_t)i];
-    }
-    pv.hrow0[nranks] = nglob;
-    double bk = 0.0;
-    for (int rk = 0; rk < nranks; ++rk)
-      for (int64_t i = 0; i < cnt[rk]; ++i) {  // the list of :1306-1322: variables with a finite breakpoint
-        const double t = tall[(size_t)rk * (size_t)nmax + (size_t)i];
-        if (!(t >= 0.0) || t == inf) continue;
-        pv.ht.push_back(t);
-        if (pv.h64)
-          pv.hio64.push_back(pv.hrow0[rk] + i);
-        else
-          pv.hio.push_back((uint32_t)(pv.hrow0[rk] + i));
-        if (pv.ht.size() == 1 || t < bk) bk = t, pv.hibkmin = (int64_t)pv.ht.size() - 1;
-      }
-    pv.hleft = (int64_t)pv.ht.size();
-    pv.hbuilt = false;
-    pv.have = true, pv.full = true;
-    pv.win_hi = inf;
-    pv.M.clear();
-    pv.mpos = pv.safe_end = 0;
-    pv.more_anywhere = pv.hleft > 0;
-    pv.taken.assign(nranks, 0);
-    pv.next_chunk = 1;  // the first record is the scan's minimum itself
-    return 0;
-  }
-  int refill_exact(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
-    const int recl = 2 * col + 4;
-    const uint32_t chunk_cap = (uint32_t)std::min<size_t>((msg_len - 2) / (size_t)recl, CHUNK_MAX);
-    const uint32_t want = std::min<uint32_t>(pv.next_chunk, chunk_cap);
-    pv.next_chunk = std::min<uint32_t>(std::max<uint32_t>(pv.next_chunk, 16) * 4, chunk_cap);
-    // the next `want` pops of the reference's walk (every rank pops the same replicated heap);
-    // each rank gathers the records of the rows it owns, in that order
-    std::vector<uint64_t> hk;
-    std::vector<uint32_t> hi;
-    std::vector<int> owner;
-    const int64_t nbreak = (int64_t)pv.ht.size();
-    const auto io_at = [&](size_t k) -> int64_t { return pv.h64 ? pv.hio64[k] : (int64_t)pv.hio[k]; };
-    while (owner.size() < want && pv.hleft > 0) {
-      double tj;
-      int64_t grow;
-      if (pv.hleft == nbreak) {  // iter == 1 (:1384-1389)
-        tj = pv.ht[(size_t)pv.hibkmin], grow = io_at((size_t)pv.hibkmin);
-      } else {
-        if (!pv.hbuilt) {  // iter == 2: the last entry replaces the used one (:1391-1398)
-          if (pv.hibkmin != nbreak - 1) {
-            pv.ht[(size_t)pv.hibkmin] = pv.ht[(size_t)nbreak - 1];
-            if (pv.h64)
-              pv.hio64[(size_t)pv.hibkmin] = pv.hio64[(size_t)nbreak - 1];
-            else
-              pv.hio[(size_t)pv.hibkmin] = pv.hio[(size_t)nbreak - 1];
-          }
-        }
-        if (pv.h64)
-          lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio64.data(), pv.hbuilt ? 1 : 0);
-        else
-          lbh::hpsolb(pv.hleft, pv.ht.data(), pv.hio.data(), pv.hbuilt ? 1 : 0);
-        pv.hbuilt = true;
-        tj = pv.ht[(size_t)pv.hleft - 1], grow = io_at((size_t)pv.hleft - 1);
-      }
-      pv.hleft--;
-      const int rk = (int)(std::upper_bound(pv.hrow0.begin(), pv.hrow0.end(), grow) -
-                           pv.hrow0.begin()) - 1;
-      owner.push_back(rk);
-      if (rk == rank) {
-        uint64_t bits;
-        std::memcpy(&bits, &tj, 8);
-        hk.push_back(bits);
-        hi.push_back((uint32_t)(grow - row0));
-      }
-    }
-    const uint32_t len = (uint32_t)owner.size(), own = (uint32_t)hk.size();
-    pv.M.clear();
-    pv.mpos = pv.safe_end = 0;
-    pv.more_anywhere = pv.hleft > 0;
-    pv.taken.assign(nranks, 0);
-    pv.raw = nullptr;
-    if (len == 0) return 0;
-    if (own) {
-      HIPCHK(hipMemcpyAsync(keys[0], hk.data(), (size_t)own * 8, hipMemcpyHostToDevice, stream));
-      HIPCHK(hipMemcpyAsync(idx[0], hi.data(), (size_t)own * 4, hipMemcpyHostToDevice, stream));
-      lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], own, row0, x, l, u, g, W(), head, col, r, d_src(), pend,
-                                   d_msg + 2);
-    }
-    CHK(put_header((double)own, (double)pv.hleft));
-    const size_t count = 2 + (size_t)len * recl;
-    CHK(exchange(count));  // (also orders the pageable uploads above)
-    pv.M.resize(len);
-    std::vector<uint32_t> cur(nranks, 0);
-    for (uint32_t k = 0; k < len; ++k) {
-      const int rk = owner[k];
-      const double *rec = h_msg_all + (size_t)rk * count + 2 + (size_t)cur[rk]++ * recl;
-      pv.M[k] = MRec{rec[0], (int64_t)rec[1], rk, rec};
-    }
-    pv.safe_end = len;
-    return 0;
-  }
-
-  // all-gather the next chunk of every rank's local list and merge
-  int refill(Provider &pv, const T *x, const T *l, const T *u, const T *g, int head, int col) {
-    if (pv.exact) return refill_exact(pv, x, l, u, g, head, col);
-    const int recl = 2 * col + 4;
-    const uint32_t chunk = pv.next_chunk;
-    // the message buffer holds CHUNK_MAX records of the widest kind (col = m); narrower records
-    // (col = 0 on the first iteration: 4 doubles) travel in proportionally longer chunks
-    const uint32_t chunk_cap = (uint32_t)((msg_len - 2) / (size_t)recl);
-    pv.next_chunk = std::min<uint32_t>(pv.next_chunk * 4, chunk_cap);
-    const uint32_t len = std::min<uint32_t>(chunk, pv.Cl - pv.pl);
-    const size_t count = 2 + (size_t)chunk * recl;
-    const bool single = nranks == 1 && !comm;
-    if (single && pf_valid && pf_pl == pv.pl && pf_len == len && pf_cur == pv.cur) {
-      // this chunk was gathered and copied while the host walked the previous one
-      const double t0 = now_s();
-      HIPCHK(hipEventSynchronize(pf_ev));
-      t_wait += now_s() - t0;
-      nsync++;
-      std::swap(h_msg_all, h_msg_loc);
-      std::swap(d_msg, d_msg2);
-      h_msg_all[0] = (double)pf_len, h_msg_all[1] = (double)pf_rem;
-    } else {
-      lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
-                                   W(), head, col, r, d_src(), pend, d_msg + 2);
-      CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
-      CHK(exchange(count));
-    }
-    pf_valid = false;
-    const bool rawmode = single && col == 0 && print_level < 100 && !debug_walk;
-    pv.raw = nullptr;
-    if (single && pv.Cl - pv.pl > len) {  // prefetch the chunk after this one
-      const uint32_t npl = pv.pl + len;
-      const uint32_t nlen = std::min<uint32_t>(pv.next_chunk, pv.Cl - npl);
-      lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + npl, keys[pv.cur] + npl, nlen, row0, x, l, u, g, W(),
-                                   head, col, r, d_src(), pend, d_msg2 + 2);
-      HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg2, (2 + (size_t)nlen * recl) * sizeof(double),
-                            hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipEventRecord(pf_ev, stream));
-      pf_valid = true, pf_pl = npl, pf_len = nlen, pf_rem = pv.Cl - npl - nlen, pf_cur = pv.cur;
-    }
-    pv.M.clear();
-    pv.more_anywhere = false;
-    double bt = std::numeric_limits<double>::infinity();
-    int64_t bi = std::numeric_limits<int64_t>::max();
-    for (int rk = 0; rk < nranks; ++rk) {
-      const double *base = h_msg_all + (size_t)rk * count;
-      const uint32_t lr = (uint32_t)base[0];
-      const size_t at = pv.M.size();
-      pv.M.resize(at + lr);
-      if (rawmode) {
-        pv.raw = base + 2;
-      } else {
-        MRec *out = pv.M.data() + at;
-        for (uint32_t k = 0; k < lr; ++k) {
-          const double *rec = base + 2 + (size_t)k * recl;
-          out[k] = MRec{rec[0], (int64_t)rec[1], rk, rec};
-        }
-      }
-      if (base[1] > 0.0) {  // this rank holds later records: nothing beyond its last one is safe
-        pv.more_anywhere = true;
-        const double *last = base + 2 + (size_t)(lr - 1) * recl;
-        if (last[0] < bt || (last[0] == bt && (int64_t)last[1] < bi)) bt = last[0], bi = (int64_t)last[1];
-      }
-    }
-    auto less = [](const MRec &a, const MRec &b) {
-      return a.t < b.t || (a.t == b.t && a.gidx < b.gidx);
-    };
-    if (nranks > 1) {
-      // every rank's run is already sorted: merge the runs pairwise (O(N log ranks))
-      std::vector<size_t> cut;
-      cut.push_back(0);
-      for (size_t k = 1; k < pv.M.size(); ++k)
-        if (pv.M[k].rank != pv.M[k - 1].rank) cut.push_back(k);
-      cut.push_back(pv.M.size());
-      while (cut.size() > 2) {
-        std::vector<size_t> nxt;
-        for (size_t k = 0; k + 2 < cut.size(); k += 2) {
-          std::inplace_merge(pv.M.begin() + cut[k], pv.M.begin() + cut[k + 1],
-                             pv.M.begin() + cut[k + 2], less);
-          nxt.push_back(cut[k]);
-        }
-        if (cut.size() % 2 == 0) nxt.push_back(cut[cut.size() - 2]);
-        nxt.push_back(pv.M.size());
-        cut.swap(nxt);
-      }
-    }
-    pv.safe_end = pv.M.size();
-    if (pv.more_anywhere && nranks > 1) {  // (a single rank's own run is safe to its end)
-      size_t k = 0;
-      while (k < pv.M.size() && (pv.M[k].t < bt || (pv.M[k].t == bt && pv.M[k].gidx <= bi))) ++k;
-      pv.safe_end = k;
-    }
-    pv.mpos = 0;
-    pv.taken.assign(nranks, 0);
-    if (debug_walk) {
-      std::fprintf(stderr, "[refill] chunk=%u len=%u Cl=%u pl=%u cur=%d M=%zu safe=%zu more=%d\n", chunk,
-                   len, pv.Cl, pv.pl, pv.cur, pv.M.size(), pv.safe_end, (int)pv.more_anywhere);
-      for (size_t k = 0; k < pv.M.size() && k < 30; ++k)
-        std::fprintf(stderr, "   rec %zu: t=%.17g gidx=%lld d=%g z=%g\n", k, pv.M[k].t,
-                     (long long)pv.M[k].gidx, pv.M[k].rec[2], pv.M[k].rec[3]);
-    }
-    return 0;
-  }
-
-  // The Cauchy point is kept in functional form (tsum + iwhere, see xcp_row in kernels_common.hpp)
-  // and only written out as a vector where one is needed: subsm skipped, the backtracking
-  // branch of subsm, state export.
-  struct Gcp {
-    double tsum = 0.0, last_t = -1.0;
-    int64_t last_i = -1;
-    bool copy_x = false;  // xcp = x without a cauchy scan behind it (tbrk is stale)
-  } gcp;
-  bool z_valid = false;
-  static constexpr size_t FIX_CAP = 65536;
-  std::vector<int64_t> fixlist;
-  bool fix_overflow = false;
-  int64_t *d_fix = nullptr, *h_fix = nullptr;
-
-  int write_xcp(T *dst, const T *x, const T *l, const T *u, const T *g) {
-    if (gcp.copy_x) {
-      HIPCHK(hipMemcpyAsync(dst, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-    } else {
-      lbk::launch_xcp_fill<T>(q, n, x, g, l, u, iwhere, gcp.tsum, dst);
-    }
-    return 0;
-  }
-  int ensure_z(const T *x, const T *l, const T *u, const T *g) {
-    if (!z_valid) CHK(write_xcp(z, x, l, u, g));
-    z_valid = true;
-    return 0;
-  }
-  // end of cauchy: make iwhere final (rows fixed by the walk) without writing xcp
-  int close_gcp(double tsum, double last_t, int64_t last_i) {
-    gcp.tsum = tsum, gcp.last_t = last_t, gcp.last_i = last_i, gcp.copy_x = false;
-    z_valid = false;
-    if (fix_overflow) {  // long walk: the cursor-based kernel (it writes z on the way)
-      CHK(ensure_tbrk());
-      lbk::launch_cauchy_finish<T>(q, n, row0, (const T *)cx, (const T *)cl, (const T *)cu,
-                                   (const T *)cg, tbrk, iwhere, z, tsum, last_t, last_i);
-      z_valid = true;
-    } else {
-      for (size_t at = 0; at < fixlist.size(); at += FIX_CAP) {  // (one piece unless exact order)
-        const size_t cnt = std::min(FIX_CAP, fixlist.size() - at);
-        if (at) HIPCHK(hipStreamSynchronize(stream));  // h_fix is reused
-        std::memcpy(h_fix, fixlist.data() + at, cnt * sizeof(int64_t));
-        HIPCHK(hipMemcpyAsync(d_fix, h_fix, cnt * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-        lbk::launch_cauchy_fix(q, d_fix, (int)cnt, row0, n, iwhere);
-      }
-    }
-    return 0;
-  }
-  const void *cx = nullptr, *cl = nullptr, *cu = nullptr, *cg = nullptr;  // this call's operands
-
-  // ---- parallel GCP search for col > 0 (LBFGSB_F_PARALLEL_GCP; k_cauchy.hip "parallel GCP") ----
-  double *pg_buf = nullptr;
-  size_t pg_bytes = 0;
-  void *pg_tmp = nullptr;
-  size_t pg_tmp_bytes = 0;
-  // all-gather of a large device buffer (count doubles per rank), rank-major into d_recv
-  int allgather_big(const double *d_send, double *d_recv, size_t count) {
-    ncoll++, coll_bytes += (int64_t)count * 8;
-    if (comm) {
-      if (g_rccl.AllGather(d_send, d_recv, count, ncclDouble, comm, stream) != ncclSuccess)
-        return fail(LBFGSB_E_COMM, "ncclAllGather failed");
-      return 0;
-    }
-    if (!cb_ag) return fail(LBFGSB_E_COMM, "multi-rank context without an all-gather");
-    std::vector<double> hs(count), hr(count * (size_t)nranks);
-    HIPCHK(hipMemcpyAsync(hs.data(), d_send, count * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    if (cb_ag(cb_user, hs.data(), hr.data(), (int64_t)(count * sizeof(double))) != 0)
-      return fail(LBFGSB_E_COMM, "host all-gather callback failed");
-    HIPCHK(hipMemcpyAsync(d_recv, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));  // (hr is a temporary)
-    return 0;
-  }
-  int parallel_gcp(const T *x, const T *l, const T *u, const T *g, double theta, int col, int head,
-                   const double *p0, double *c, double f1_0, double f2_0, double f2_org, bool bnded,
-                   int64_t nbreak, int &nseg, int &info, bool &done) {
-    done = false;
-    const int col2 = 2 * col;
-    const bool multi = nranks > 1;
-    // this rank's breakpoints in (t, index) order
-    CHK(ensure_sel((size_t)n));
-    uint32_t cnt = 0;
-    CHK(local_count(-1.0, -1, std::numeric_limits<double>::max(), 0, cnt));  // (fills tbrk)
-    // every rank's count (the ranks take the same decisions below)
-    std::vector<double> counts(nranks, (double)cnt);
-    if (multi) {
-      CHK(put_header((double)cnt, 0.0));
-      CHK(exchange(2));
-      for (int rk = 0; rk < nranks; ++rk) counts[rk] = h_msg_all[2 * (size_t)rk];
-    }
-    int64_t nb = 0, nbmax = 0;
-    for (double cv : counts) nb += (int64_t)cv, nbmax = std::max<int64_t>(nbmax, (int64_t)cv);
-    const int64_t nbp = (nb + 31) / 32 * 32;          // stride of the arrays the scans run on
-    const int64_t lbp = (nbmax + 31) / 32 * 32;       // stride of one rank's gathered arrays
-    if (nb != nbreak || nb == 0) return 0;
-    if (multi && (uint64_t)nranks * (uint64_t)lbp >= 0xffffffffull) return 0;
-    const int narr_l = 4 + 2 * col2;                   // tt, dd, a0, gi, wb[col2], uu[col2]
-    const size_t narr = 7 + 3 * (size_t)col2;          // + df2, a1, df1, sq[col2]
-    const size_t small = (size_t)col2 * col2 + 4 * (size_t)col2 + 16 + 2 * (size_t)nranks + 96;
-    const size_t gath = multi ? (size_t)narr_l * lbp * ((size_t)nranks + 1) : 0;
-    const size_t bytes = (narr * (size_t)nbp + gath + small) * sizeof(double);
-    bool fits = true;
-    if (bytes > pg_bytes) {
-      if (pg_buf) (void)hipFree(pg_buf);
-      pg_buf = nullptr, pg_bytes = 0;
-      size_t mfree = 0, mtotal = 0;
-      (void)hipMemGetInfo(&mfree, &mtotal);
-      if (bytes > mfree / 10 * 9 || hipMalloc(&pg_buf, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        fits = false;
-      } else {
-        pg_bytes = bytes;
-      }
-    }
-    // (every allocation of this search happens BEFORE the ranks vote: a rank that cannot allocate
-    //  votes "does not fit" and all of them replay the walk exactly -- none is left waiting in a
-    //  collective)
-    const size_t tb = std::max(lbk::scan_temp_bytes((size_t)nb), lbk::f2scan_temp_bytes((size_t)nb)) + 256;
-    if (fits && tb > pg_tmp_bytes) {
-      if (pg_tmp) (void)hipFree(pg_tmp);
-      pg_tmp = nullptr, pg_tmp_bytes = 0;
-      if (hipMalloc(&pg_tmp, tb) != hipSuccess) {
-        (void)hipGetLastError();
-        pg_tmp = nullptr;
-        fits = false;
-      } else {
-        pg_tmp_bytes = tb;
-      }
-    }
-    if (fits && ensure_sel(std::max((size_t)n, (size_t)nranks * (size_t)lbp)) != 0) {
-      (void)hipGetLastError();
-      fits = false;
-      // (the window buffers of the exact replay must exist again)
-      if (sel_alloc == 0) CHK(ensure_sel(SEL_CAP));
-    }
-    if (multi) {  // one rank short of memory sends every rank back to the exact replay
-      CHK(put_header(fits ? 1.0 : 0.0, 0.0));
-      CHK(exchange(2));
-      for (int rk = 0; rk < nranks; ++rk) fits = fits && h_msg_all[2 * (size_t)rk] > 0.0;
-    }
-    if (!fits) return 0;
-    nfullsort++;
-    lbk::launch_cauchy_allkeys<T>(q, n, row0, tbrk, -1.0, -1, keys[0], idx[0]);
-    lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1], (size_t)n);
-    // arrays the scans run on (stride nbp); dd and a0 are dead after pgcp_terms and then hold the
-    // 2 nb doubles of the f2 maps
-    double *tt = pg_buf, *dd = tt + nbp, *a0 = dd + nbp, *df2 = a0 + nbp, *a1 = df2 + nbp,
-           *df1 = a1 + nbp, *gi = df1 + nbp, *wb = gi + nbp, *pp = wb + (size_t)col2 * nbp,
-           *sq = pp + (size_t)col2 * nbp, *dM = sq + (size_t)col2 * nbp, *dp0 = dM + (size_t)col2 * col2,
-           *ulast = dp0 + col2, *pick = ulast + col2, *dcnt = pick + 4 + 2 * col2,
-           *dmap = dcnt + nranks, *L = dmap + 80, *G = L + (size_t)narr_l * lbp;
-    // M as a dense matrix: column a = bmv(e_a)   (host, O(col^3))
-    std::vector<double> M((size_t)col2 * col2), e(col2), out(col2);
-    for (int a = 0; a < col2; ++a) {
-      std::fill(e.begin(), e.end(), 0.0);
-      e[a] = 1.0;
-      info = lbh::bmv(m, sy.data(), wt.data(), col, e.data(), out.data());
-      if (info != 0) return 0;
-      for (int b = 0; b < col2; ++b) M[(size_t)b + (size_t)a * col2] = out[b];
-    }
-    HIPCHK(hipMemcpyAsync(dM, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(dp0, p0, col2 * sizeof(double), hipMemcpyHostToDevice, stream));
-    std::vector<int> map(narr_l);
-    if (multi) {
-      // where array a of a rank's gathered block goes among the scan arrays (units of nbp)
-      map[0] = 0, map[1] = 1, map[2] = 2, map[3] = 6;
-      for (int cc = 0; cc < col2; ++cc) map[4 + cc] = 7 + cc, map[4 + col2 + cc] = 7 + col2 + cc;
-      HIPCHK(hipMemcpyAsync(dcnt, counts.data(), nranks * sizeof(double), hipMemcpyHostToDevice, stream));
-      HIPCHK(hipMemcpyAsync(dmap, map.data(), narr_l * sizeof(int), hipMemcpyHostToDevice, stream));
-    }
-    HIPCHK(hipStreamSynchronize(stream));  // (M, p0, counts, map are host temporaries)
-    if (!multi) {
-      lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], nb, nbp, x, l, u, g, W(), head, col, theta, r,
-                                 d_src(), pend, tt, dd, a0, wb, pp, (double *)nullptr, row0);
-    } else {
-      // own records in local order -> all ranks -> merged by (t, global index): the merge sort is
-      // stable and ranks own ascending row blocks, so equal t keep global index order
-      double *Lt = L, *Ld = L + lbp, *La = L + 2 * lbp, *Lg = L + 3 * lbp, *Lw = L + 4 * lbp,
-             *Lu = Lw + (size_t)col2 * lbp;
-      HIPCHK(hipMemsetAsync(L, 0, (size_t)narr_l * lbp * sizeof(double), stream));
-      if (cnt)
-        lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], (int64_t)cnt, lbp, x, l, u, g, W(), head, col, theta,
-                                   r, d_src(), pend, Lt, Ld, La, Lw, Lu, Lg, row0);
-      CHK(allgather_big(L, G, (size_t)narr_l * lbp));
-      const size_t slots = (size_t)nranks * lbp;
-      lbk::launch_pgcp_mergekeys(q, nranks, lbp, narr_l, dcnt, G, keys[0], idx[0]);
-      lbk::launch_sort_pairs(q, sort_tmp, sort_tmp_bytes, keys[0], keys[1], idx[0], idx[1], slots);
-      lbk::launch_pgcp_permute(q, nb, nbp, lbp, narr_l, idx[1], G, pg_buf, (const int *)dmap);
-    }
-    lbk::launch_pgcp_last(q, nb, nbp, col2, pp, ulast);
-    for (int cc = 0; cc < col2; ++cc)
-      lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, pp + (size_t)cc * nbp, pp + (size_t)cc * nbp, (size_t)nb, 1);
-    lbk::launch_pgcp_dtp(q, nb, nbp, col2, tt, pp, sq);
-    for (int cc = 0; cc < col2; ++cc)
-      lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, sq + (size_t)cc * nbp, sq + (size_t)cc * nbp, (size_t)nb, 0);
-    lbk::launch_pgcp_terms(q, nb, nbp, col2, theta, dM, dp0, tt, dd, a0, wb, pp, sq, df2, a1);
-    // f2 after every breakpoint, with the clamp f2 = max(epsmch f2_org, .) of :1483 (df2 -> F2 in place)
-    const double eps_clamp = (sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
-                                             : std::numeric_limits<double>::epsilon()) * f2_org;
-    lbk::launch_pgcp_f2(q, pg_tmp, pg_tmp_bytes, nb, f2_0, eps_clamp, df2, dd, df2);
-    lbk::launch_pgcp_f1(q, nb, f2_0, tt, df2, a1, df1);
-    lbk::launch_scan(q, pg_tmp, pg_tmp_bytes, df1, df1, (size_t)nb, 0);
-    lbk::launch_pgcp_find(q, nb, f1_0, f2_0, tt, df1, df2);
-    CHK(fetch(0, 1, 0));
-    const int64_t ks = h_res[0] < (double)nb ? (int64_t)h_res[0] : nb;  // breakpoints crossed
-    lbk::launch_pgcp_pick(q, ks, nb, nbp, col2, f1_0, f2_0, tt, df1, df2, pp, ulast, sq, idx[1],
-                          multi ? gi : (const double *)nullptr, pick);
-    std::vector<double> pk(4 + 2 * (size_t)col2);
-    if (multi) {  // every rank continues from rank 0's numbers, bit for bit
-      HIPCHK(hipMemcpyAsync(d_msg, pick, pk.size() * sizeof(double), hipMemcpyDeviceToDevice, stream));
-      CHK(exchange(pk.size()));
-      std::memcpy(pk.data(), h_msg_all, pk.size() * sizeof(double));
-    } else {
-      HIPCHK(hipMemcpyAsync(pk.data(), pick, pk.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
-      nsync++;
-    }
-    const double t_last = pk[0], f1p = pk[1], f2p = pk[2];
-    const int64_t i_last = ks > 0 ? (multi ? 0 : row0) + (int64_t)pk[3] : -1;
-    double dtm;
-    bool all_fixed = false;
-    if (ks < nb) {
-      dtm = -f1p / f2p;
-    } else if (nb == nglob) {  // every variable fixed (:1436-1442)
-      dtm = 0.0;
-      all_fixed = true;
-    } else if (bnded) {
-      dtm = 0.0;
-    } else {
-      dtm = -f1p / f2p;
-    }
-    if (debug_walk)
-      std::fprintf(stderr, "[pgcp r%d] nb=%lld ks=%lld t_last=%.17g i_last=%lld f1=%.17g f2=%.17g dtm=%.17g p0[0]=%.17g f1_0=%.17g f2_0=%.17g\n",
-                   rank, (long long)nb, (long long)ks, t_last, (long long)i_last, f1p, f2p, dtm, p0[0], f1_0, f2_0);
-    if (dtm <= 0.0) dtm = 0.0;
-    const double tsum = t_last + dtm;
-    for (int a = 0; a < col2; ++a)
-      c[a] = (t_last * p0[a] - pk[4 + col2 + a]) + dtm * (p0[a] - pk[4 + a]);
-    const int64_t ns = 1 + ks - (all_fixed ? 1 : 0);
-    nseg = (int)std::min<int64_t>(ns, std::numeric_limits<int>::max());
-    // iwhere and z by the cursor: everything up to the last crossed breakpoint is fixed
-    gcp = Gcp{};
-    gcp.tsum = tsum, gcp.last_t = ks > 0 ? t_last : -1.0, gcp.last_i = i_last;
-    lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tsum, gcp.last_t, gcp.last_i);
-    z_valid = true;
-    done = true;
-    return 0;
-  }
-
-  // an n-vector on the host, for the iprint >= 100 dumps (debugging sizes, this rank's rows)
-  std::vector<double> host_vec(const T *dptr) {
-    std::vector<T> tmp((size_t)n);
-    (void)hipMemcpyAsync(tmp.data(), dptr, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
-    return std::vector<double>(tmp.begin(), tmp.end());
-  }
-  void dump_cauchy_x(const T *x, const T *l, const T *u, const T *g) {  // :1345, :1527
-    (void)write_xcp(xp, x, l, u, g);
-    const std::vector<double> v = host_vec(xp);
-    rep.vec_rows("Cauchy X =  ", v.data(), n);
-  }
-
-  // Generalized Cauchy point, reference :1157-1532.  p,c,wbp,v = wa8m slots.
-  // results of the n-loop of cauchy when it was fused into the matupd pass
-  struct ScanOut {
-    bool ready = false;
-    double p[2 * lbk::MAXM];
-    double f1 = 0, nbreak = 0, nunb = 0, nunbnz = 0, bkmin = 0;
-  } scan;
-
-  int cauchy(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
-             int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
-    double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
-    cx = x, cl = l, cu = u, cg = g, cnbd = nbd;
-    pf_valid = false;
-    fixlist.clear();
-    fix_overflow = false;
-    closed_ok = false;
-    z_in_x = false;  // z means this call's Cauchy point from here on
-    std::memset(nrc, 0, sizeof nrc);
-    const int ipr = quiet ? -1 : print_level;
-    if (sbgnrm <= 0.0) {  // :1245-1249
-      scan.ready = false;
-      gcp = Gcp{};
-      gcp.copy_x = true;
-      z_valid = false;
-      return 0;
-    }
-    const int col2 = 2 * col;
-    const int MC = col ? lbk::maxc_for(col) : 0;
-    if (ipr >= 99) std::fprintf(rep.out, "\n---------------- CAUCHY entered-------------------\n");
-    auto leave = [&](double tsum_, double lt, int64_t li) -> int {  // update() :1519-1530
-      CHK(close_gcp(tsum_, lt, li));
-      if (ipr > 100) dump_cauchy_x(x, l, u, g);
-      if (ipr >= 99) std::fprintf(rep.out, "\n---------------- exit CAUCHY----------------------\n\n");
-      return 0;
-    };
-    if (!scan.ready) {
-      lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
-      tbrk_valid = true;
-      CHK(fetch(2 * MC + 4, 1, 0));
-      for (int j = 0; j < col; ++j) {
-        scan.p[j] = h_res[j];
-        scan.p[col + j] = h_res[MC + j];
-      }
-      scan.f1 = h_res[2 * MC], scan.nbreak = h_res[2 * MC + 1], scan.nunb = h_res[2 * MC + 2];
-      scan.nunbnz = h_res[2 * MC + 3], scan.bkmin = h_res[2 * MC + 4];
-    }
-    scan.ready = false;
-    for (int j = 0; j < col2; ++j) p[j] = scan.p[j];
-    double f1 = scan.f1;
-    const int64_t nbreak = (int64_t)scan.nbreak;
-    const int64_t nunb = (int64_t)scan.nunb;
-    const bool bnded = scan.nunbnz == 0.0;
-    const double bkmin = scan.bkmin;
-    if (theta != 1.0)
-      for (int j = 0; j < col; ++j) p[col + j] = theta * p[col + j];  // :1337
-    p_ini_max = 0.0;
-    for (int j = 0; j < 2 * col; ++j) p_ini_max = std::max(p_ini_max, std::fabs(p[j]));
-
-    double last_t = -1.0;
-    int64_t last_i = -1;
-    if (nbreak == 0 && nunb == 0) {  // d = 0: xcp = x (:1343-1347)
-      CHK(close_gcp(0.0, last_t, last_i));
-      if (ipr > 100) dump_cauchy_x(x, l, u, g);
-      return 0;
-    }
-    for (int j = 0; j < col2; ++j) c[j] = 0.0;
-    double f2 = -theta * f1;  // :1357-1363
-    const double f2_org = f2;
-    if (col > 0) {
-      info = lbh::bmv(m, sy.data(), wt.data(), col, p, v);
-      if (info != 0) return 0;
-      f2 = f2 - lbh::dot_seq(col2, v, p);
-    }
-    double dtm = -f1 / f2;
-    double tsum = 0.0;
-    nseg = 1;
-    last_dtm0 = dtm;
-    if (ipr >= 99) std::fprintf(rep.out, " There are %11lld   breakpoints \n", (long long)nbreak);  // :1367
-
-    if (col == 0 && nbreak != 0 && (flags & LBFGSB_F_PARALLEL_GCP) && dtm >= bkmin) {
-      // B = theta*I: phi'(t) = -(1 - theta t) * (remaining d'd), so the walk stops at t = 1/theta
-      // having fixed exactly the breakpoints t_j <= 1/theta (see include/lbfgsb_hip.h).
-      const double tstar = 1.0 / theta;
-      // ... as long as the reference's clamp f2 = max(epsmch f2_org, f2) (:1483) cannot act before
-      // t*: f2 = theta * (d'd over the rows still moving), which only shrinks along the walk, so
-      // it is enough to look at what is left beyond t* (with a margin for the rounding noise the
-      // sequential recurrence carries); otherwise: the exact replay below
-      CHK(ensure_tbrk());
-      lbk::launch_gcp_rest_mass<T>(q, n, g, tbrk, tstar);
-      CHK(fetch(1, 0, 0));
-      if (h_res[0] >= 1.0e4 * epsmch * (-f1)) {
-      lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tstar, tstar,
-                                   std::numeric_limits<int64_t>::max(), 1);
-      gcp = Gcp{};
-      gcp.tsum = tstar, gcp.last_t = tstar, gcp.last_i = std::numeric_limits<int64_t>::max();
-      z_valid = true;
-      CHK(fetch(1, 0, 0));
-      const int64_t done = (int64_t)h_res[0];
-      // the walk counts a segment per fixed variable except a last one that fixes all n (:1436)
-      const int64_t ns = 1 + done - ((done == nbreak && nbreak == nglob) ? 1 : 0);
-      nseg = (int)std::min<int64_t>(ns, std::numeric_limits<int>::max());
-      if (ipr >= 99) std::fprintf(rep.out, "\n---------------- exit CAUCHY----------------------\n\n");
-      return 0;
-      }
-      ngcp_clamped++;
-    }
-
-    // Equal breakpoints are delivered in index order, the reference pops them in heap order
-    // (hpsolb :2079); the two differ in effect only if the walk ends INSIDE such a group.  That
-    // is detected (tie_split), counted, and the walk is then replayed from its start in the
-    // reference's own order (exact_init / refill_exact) -- unless LBFGSB_F_INDEX_TIES opts out.
-    const bool can_exact = !(flags & LBFGSB_F_INDEX_TIES);
-    // (a replay would print the walk twice: under iprint >= 99 the walk runs in that order from the
-    //  start; option "exact_always": every walk in that order, for tests)
-    bool exact_run = can_exact && (print_level >= 99 || exact_always);
-    std::vector<double> p_start(p, p + col2);
-    const double f1_start = f1, f2_start = f2, dtm_start = dtm;
-    for (;;) {  // at most two trips: the second one in exact order
-    bool tie_split = false;
-    if (nbreak != 0) {
-      int64_t nleft = nbreak;
-      int64_t iter = 1;
-      double tj = 0.0;
-      Provider pv;
-      if (exact_run) CHK(exact_init(pv));
-      const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
-      for (;;) {
-        const double tj0 = tj;
-        // (control flow follows print_level, which every rank shares -- ipr is -1 on the quiet ranks)
-        if (iter == 1 && print_level < 100) {  // smallest breakpoint known from the scan: usual exit (:1384-1389)
-          if (dtm < bkmin - tj0) break;
-        }
-        // ---- no pair stored and records on the host: the same steps as below in a tight loop
-        //      (the first iteration walks ~n of them; per record only :1416-1434, :1452-1453,
-        //       :1483-1497 remain, in the reference's operation order) ----
-        if (col == 0 && print_level < 100 && pv.have && pv.mpos < pv.safe_end) {
-          const MRec *M = pv.M.data();
-          size_t pos = pv.mpos;
-          const size_t end = pv.safe_end;
-          const double inf = std::numeric_limits<double>::infinity();
-          bool stop = false;
-          while (pos < end) {
-            // (single rank: the records themselves, 4 doubles each, in order; else the merged list)
-            const double *rec = pv.raw ? pv.raw + pos * 4 : M[pos].rec;
-            const double mt = rec[0];
-            if (!(mt <= (tj + dtm) * INFL && mt < inf)) {  // beyond reach: dtm < dt
-              tie_split = last_t >= 0.0 && mt == last_t;
-              stop = true;
-              break;
-            }
-            const double dt = mt - tj;
-            if (dtm < dt) {  // :1416
-              tie_split = last_t >= 0.0 && mt == last_t;
-              stop = true;
-              break;
-            }
-            pv.taken[pv.raw ? 0 : M[pos].rank]++;
-            ++pos;
-            tsum = tsum + dt;
-            nleft = nleft - 1;
-            iter = iter + 1;
-            const double dibp = rec[2];
-            const double zibp = rec[3];
-            tj = mt;
-            last_t = mt;
-            last_i = (int64_t)rec[1];
-            if (!fix_overflow) {
-              if (pv.exact || fixlist.size() < FIX_CAP)  // (exact order: no cursor describes the set)
-                fixlist.push_back(last_i * 2 + (dibp > 0.0 ? 1 : 0));
-              else
-                fix_overflow = true;
-            }
-            if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
-              dtm = dt;
-              pv.mpos = pos;
-              return leave(tsum, last_t, last_i);
-            }
-            nseg = nseg + 1;
-            const double dibp2 = dibp * dibp;
-            f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;  // :1452-1453
-            f2 = f2 - theta * dibp2;
-            f2 = std::max(epsmch * f2_org, f2);  // :1483
-            if (nleft > 0) {
-              dtm = -f1 / f2;
-            } else if (bnded) {
-              f1 = 0.0;
-              f2 = 0.0;
-              dtm = 0.0;
-              stop = true;
-              break;
-            } else {
-              dtm = -f1 / f2;
-              stop = true;
-              break;
-            }
-          }
-          pv.mpos = pos;
-          if (stop) break;
-          continue;  // records used up: refill below on the next trip
-        }
-        // ---- next breakpoint after (last_t, last_i), if it can matter: t <= tj0 + dtm ----
-        // (iprint >= 100 reports the distance to the next breakpoint of every segment, :1408-1412:
-        //  then the next one is always fetched)
-        const double hi_need =
-            print_level >= 100 ? std::numeric_limits<double>::infinity() : (tj0 + dtm) * INFL;
-        const double *rec = nullptr;
-        int64_t rec_gi = -1;
-        bool to_tight_loop = false;
-        for (;;) {
-          if (pv.raw && pv.have && pv.mpos < pv.safe_end) {  // (M is not filled in this mode)
-            to_tight_loop = true;
-            break;
-          }
-          if (pv.have && pv.mpos < pv.safe_end) {
-            const MRec &mr = pv.M[pv.mpos];
-            if (mr.t <= hi_need && mr.t < std::numeric_limits<double>::infinity()) {
-              rec = mr.rec;
-              rec_gi = mr.gidx;
-            }
-            break;
-          }
-          if (pv.have && (pv.mpos < pv.M.size() || pv.more_anywhere)) {
-            pv.pl += pv.taken.empty() ? 0 : pv.taken[rank];
-            CHK(refill(pv, x, l, u, g, head, col));
-            continue;
-          }
-          if (pv.have && (pv.full || pv.win_hi >= hi_need)) break;  // nothing left in reach
-          // (re)fetch: ask further ahead each time so long walks need few round trips
-          double hi = hi_need;
-          if (pv.grow > 0 && std::isfinite(hi_need)) {
-            const double base = last_t > 0 ? last_t : 0.0;
-            hi = base + (hi_need - base) * std::ldexp(1.0, std::min(pv.grow, 40));
-          }
-          pv.grow++;
-          double in_window = 0.0;
-          const bool may_pg = col > 0 && (flags & LBFGSB_F_PARALLEL_GCP) && iter == 1 && !pv.have &&
-                              print_level < 99;
-          CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col, may_pg ? &in_window : nullptr));
-          if (may_pg && in_window > PG_MIN) {
-            // many breakpoints within reach and pairs stored: sort + scans on the device (opt-in)
-            bool done = false;
-            CHK(parallel_gcp(x, l, u, g, theta, col, head, p, c, f1, f2, f2_org, bnded, nbreak, nseg, info,
-                             done));
-            if (info != 0) return 0;
-            if (done) return 0;
-            pv.grow = 0;  // (did not fit in memory: replay the walk as usual)
-            pv.have = false;
-            CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col));
-          }
-        }
-        if (to_tight_loop) continue;
-        if (!rec) {  // next breakpoint is beyond tj0 + dtm  =>  dtm < dt
-          tie_split = last_t >= 0.0 && pv.have && pv.mpos < pv.safe_end && pv.M[pv.mpos].t == last_t;
-          break;
-        }
-        tj = rec[0];
-        const double dt = tj - tj0;
-        if (dt != 0.0 && ipr >= 100) {  // :1408-1412
-          std::fprintf(rep.out, "\n");
-          rep.piece(nseg, f1, f2);
-          std::fprintf(rep.out, "Distance to the next break point =  %s\n", lbr::fD(dt, 11, 4).c_str());
-          std::fprintf(rep.out, "Distance to the stationary point =  %s\n", lbr::fD(dtm, 11, 4).c_str());
-        }
-        if (dtm < dt) {  // :1416
-          tie_split = last_t >= 0.0 && tj == last_t;
-          break;
-        }
-
-        // fix this variable (:1421-1434)
-        pv.taken[pv.M[pv.mpos].rank]++;
-        pv.mpos++;
-        tsum = tsum + dt;
-        nleft = nleft - 1;
-        iter = iter + 1;
-        const double dibp = rec[2];
-        const double zibp = rec[3];
-        last_t = tj;
-        last_i = rec_gi;
-        if (pv.exact || fixlist.size() < FIX_CAP)
-          fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
-        else
-          fix_overflow = true;
-        if (col > 0 && col <= two_pass_maxcol) {
-          // this row leaves the free set: its share of formk's new row/column moves from the
-          // free sums to the active ones (the update pass summed with the pre-walk split)
-          const double yk = rec[4 + col - 1], sk = rec[4 + 2 * col - 1];
-          for (int j = 0; j < col; ++j) {
-            nrc[0][j] += yk * rec[4 + j];        // - sum_free y_new Wy_j
-            nrc[1][j] += sk * rec[4 + col + j];  // + sum_act  s_new Ws_j
-            nrc[2][j] += sk * rec[4 + j];        // + sum_act  s_new Wy_j
-            nrc[3][j] += rec[4 + col + j] * yk;  // - sum_free Ws_j y_new
-          }
-        }
-        if (ipr >= 100)  // :1435
-          std::fprintf(rep.out, " Variable  %11lld   is fixed.\n", (long long)rec_gi + 1);
-        if (nleft == 0 && nbreak == nglob) {  // all n variables fixed (:1436-1442)
-          dtm = dt;
-          if (col > 0)
-            for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];
-          return leave(tsum, last_t, last_i);  // no row is left to move: tsum is moot
-        }
-        nseg = nseg + 1;
-        const double dibp2 = dibp * dibp;
-        f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;  // :1452-1453
-        f2 = f2 - theta * dibp2;
-        if (col > 0) {
-          if (dt != 0.0)
-            for (int j = 0; j < col2; ++j) c[j] = c[j] + dt * p[j];
-          for (int j = 0; j < col; ++j) {
-            wbp[j] = rec[4 + j];
-            wbp[col + j] = theta * rec[4 + col + j];
-          }
-          info = lbh::bmv(m, sy.data(), wt.data(), col, wbp, v);
-          if (info != 0) return 0;
-          const double wmc = lbh::dot_seq(col2, c, v);
-          const double wmp = lbh::dot_seq(col2, p, v);
-          const double wmw = lbh::dot_seq(col2, wbp, v);
-          if (-dibp != 0.0)
-            for (int j = 0; j < col2; ++j) p[j] = p[j] + (-dibp) * wbp[j];
-          f1 = f1 + dibp * wmc;
-          f2 = f2 + 2.0 * dibp * wmp - dibp2 * wmw;
-        }
-        f2 = std::max(epsmch * f2_org, f2);  // :1483
-        if (nleft > 0) {
-          dtm = -f1 / f2;
-        } else if (bnded) {
-          f1 = 0.0;
-          f2 = 0.0;
-          dtm = 0.0;
-          break;
-        } else {
-          dtm = -f1 / f2;
-          break;
-        }
-      }
-    }
-    if (tie_split && !exact_run) {
-      ntiesplit++;
-      if (can_exact) {  // replay from the start of the walk, in the reference's order
-        exact_run = true;
-        std::copy(p_start.begin(), p_start.end(), p);
-        for (int j = 0; j < col2; ++j) c[j] = 0.0;
-        f1 = f1_start, f2 = f2_start, dtm = dtm_start, tsum = 0.0, nseg = 1;
-        last_t = -1.0, last_i = -1;
-        fixlist.clear();
-        fix_overflow = false;
-        std::memset(nrc, 0, sizeof nrc);
-        continue;
-      }
-    }
-    break;
-    }
-    if (debug_walk)
-      std::fprintf(stderr, "[cauchy] nseg=%d tsum=%g dtm=%g last=(%.17g,%lld)\n", nseg, tsum, dtm,
-                   last_t, (long long)last_i);
-    if (ipr >= 99) {  // :1502-1508
-      std::fprintf(rep.out, "\n GCP found in this segment\n");
-      rep.piece(nseg, f1, f2);
-      std::fprintf(rep.out, "Distance to the stationary point =  %s\n", lbr::fD(dtm, 11, 4).c_str());
-    }
-    if (dtm <= 0.0) dtm = 0.0;  // :1509
-    tsum = tsum + dtm;
-    if (col > 0 && dtm != 0.0)
-      for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
-    last_tsum = tsum;
-    iter_seen++;
-    if (col > 0) {
-      // p = W'd over the variables that still move = the free variables: with it W'Z r needs no
-      // pass over W (subspace_closed_form).  Not when p is what little is left of a much larger p
-      // (nor after a walk of more than 2^20 segments: the host corrections of formk's new row
-      // are then no longer small change).
-      double pm = 0.0;
-      for (int j = 0; j < col2; ++j) p_fin[j] = p[j], pm = std::max(pm, std::fabs(p[j]));
-      closed_ok = nseg <= (1 << 20) && pm >= 1e-3 * p_ini_max && p_ini_max > 0.0;
-    }
-    return leave(tsum, last_t, last_i);
-  }
-
-  // ==================================================================== formk
-  // WN1 from scratch: one masked Gram pass over W (any col; also the fallback when too many
-  // variables changed status for the sparse patches)
-  int formk_scratch(int col, int head) {
-    CHK(commit_pending((const T *)cg, col, head));
-    lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
-    const int E = 2 * col * col + col;
-    CHK(fetch(E, 0, 0));
-    lbh::Mat WN1{snd.data(), 2 * m};
-    const int tri = col * (col + 1) / 2;
-    for (int i = 0; i < col; ++i)
-      for (int j = 0; j <= i; ++j) {
-        WN1(i, j) = h_res[i * (i + 1) / 2 + j];                  // Y'ZZ'Y
-        WN1(m + i, m + j) = h_res[tri + i * (i + 1) / 2 + j];    // S'AA'S
-      }
-    for (int i = 0; i < col; ++i)
-      for (int j = 0; j < col; ++j) WN1(m + i, j) = h_res[2 * tri + i * col + j];  // L_a + R_z
-    return 0;
-  }
-
-  // WN1 kept incrementally exactly as the reference does (:1735-1851): shift, new row and
-  // column from `nr` (the four sum vectors that rode along in the cmprlb_wtv pass), and
-  // patches for the variables that entered / left the free set (sparse signed Gram).
-  int formk_incremental(int col, int head, bool updatd, int iupdat, const double *nr, int MCnr) {
-    const int m2 = 2 * m;
-    lbh::Mat WN1{snd.data(), m2};
-    const int upcl = updatd ? col - 1 : col;
-    const int64_t nchg = nenter_g + (nglob + 1 - ileave_g);
-    bool patched = false;
-    std::vector<double> P;
-    if (nchg > 0 && upcl > 0) {
-      if (nchg > (int64_t)CHG_CAP) return formk_scratch(col, head);  // whole Gram is cheaper
-      // (the list was appended with an atomic counter: put it in ascending order first, so that the
-      //  patch sums -- and with them WN1, the subspace step, the whole trajectory -- are
-      //  reproducible bit for bit; idx[1] is free here: the walk is over)
-      const uint32_t nl = std::min<uint32_t>(chg_local, CHG_CAP);
-      const uint32_t *lst = lbk::launch_sort_u32(q, sort_tmp, sort_tmp_bytes, d_chg, idx[1], nl);
-      lbk::launch_formk_patch<T>(q, lst, nl, W(), head, upcl);
-      const int E = 2 * upcl * upcl + upcl;
-      CHK(fetch(E, 0, 0));
-      P.assign(h_res, h_res + E);
-      patched = true;
-    }
-    if (updatd) {
-      if (iupdat > m) {  // shift old part of WN1 (:1736-1744)
-        for (int jy = 0; jy < m - 1; ++jy) {
-          const int js = m + jy;
-          for (int i = 0; i < m - 1 - jy; ++i) {
-            WN1(jy + i, jy) = WN1(jy + 1 + i, jy + 1);
-            WN1(js + i, js) = WN1(js + 1 + i, js + 1);
-          }
-          for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
-        }
-      }
-      const int nw = col - 1;  // new pair = logical column col-1 (:1746-1793)
-      for (int jy = 0; jy < col; ++jy) {
-        WN1(nw, jy) = nr[0 * MCnr + jy];          // Y'ZZ'Y row
-        WN1(m + nw, m + jy) = nr[1 * MCnr + jy];  // S'AA'S row
-        WN1(m + nw, jy) = nr[2 * MCnr + jy];      // L_a row
-      }
-      for (int i = 0; i < col; ++i) WN1(m + i, nw) = nr[3 * MCnr + i];  // R_z column
-    }
-    if (patched) {  // :1801-1851 (P = sums over entering rows - sums over leaving rows)
-      const int tri = upcl * (upcl + 1) / 2;
-      for (int iy = 0; iy < upcl; ++iy)
-        for (int jy = 0; jy <= iy; ++jy) {
-          WN1(iy, jy) = WN1(iy, jy) + P[iy * (iy + 1) / 2 + jy];
-          WN1(m + iy, m + jy) = WN1(m + iy, m + jy) - P[tri + iy * (iy + 1) / 2 + jy];
-        }
-      for (int is = 0; is < upcl; ++is)
-        for (int jy = 0; jy < upcl; ++jy) {
-          const double psy = P[2 * tri + is * upcl + jy];
-          if (is <= jy)
-            WN1(m + is, jy) = WN1(m + is, jy) + psy;
-          else
-            WN1(m + is, jy) = WN1(m + is, jy) - psy;
-        }
-    }
-    return 0;
-  }
-
-  // upper triangle of WN from WN1 and the two Cholesky factorisations (:1856-1906)
-  void formk_factor(int col, double theta, int &info) {
-    const int m2 = 2 * m;
-    lbh::Mat WN{wn.data(), m2}, WN1{snd.data(), m2}, SY{sy.data(), m};
-    for (int iy = 0; iy < col; ++iy) {
-      const int is = col + iy, is1 = m + iy;
-      for (int jy = 0; jy <= iy; ++jy) {
-        const int js = col + jy, js1 = m + jy;
-        WN(jy, iy) = WN1(iy, jy) / theta;
-        WN(js, is) = WN1(is1, js1) * theta;
-      }
-      for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
-      for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
-      WN(iy, iy) = WN(iy, iy) + SY(iy, iy);
-    }
-    if (lbh::dpofa(WN, col) != 0) {  // :1880-1884
-      info = -1;
-      return;
-    }
-    const int col2 = 2 * col;
-    for (int js = col; js < col2; ++js) (void)lbh::dtrsl(WN, col, &WN(0, js), 11);
-    for (int is = col; is < col2; ++is)
-      for (int js = is; js < col2; ++js)
-        WN(is, js) = WN(is, js) + lbh::dot_seq(col, &WN(0, is), &WN(0, js));
-    lbh::Mat WN22{&WN(col, col), m2};
-    if (lbh::dpofa(WN22, col) != 0) {  // :1902-1906
-      info = -2;
-      return;
-    }
-    info = 0;
-  }
-
-  int formk(int col, int head, double theta, int &info) {
-    CHK(formk_scratch(col, head));
-    formk_factor(col, theta, info);
-    return 0;
-  }
-
-  // ========================================================== cmprlb + subsm
-  // coefficients of cmprlb: wa(1:2m) = M c (bmv, :1569) -> a1_j, a2_j = theta * (.) (:1576-1577)
-  // (kept in cm_cf / cm_plain: subsm_update_kernel recomputes r from them)
-  lbk::Coef cm_cf;
-  bool cm_plain = false;
-  bool cmprlb_coef(int col, double theta, bool cnstnd, lbk::Coef &cf, bool &plain) {
-    std::memset(&cf, 0, sizeof cf);
-    plain = !cnstnd && col > 0;
-    if (!plain) {
-      if (lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]) != 0) return false;
-      for (int j = 0; j < col; ++j) {
-        cf.a[j] = wa8m[j];
-        cf.a[lbk::MAXM + j] = theta * wa8m[col + j];
-      }
-    }
-    cm_cf = cf, cm_plain = plain;
-    return true;
-  }
-
-  // W'Z r without a pass over W (cmprlb :1565-1583 folded into subsm :2742-2754).  On the free
-  // rows the Cauchy point is x + tsum d with d = -g, so
-  //     r = (1 - theta tsum) d + W (M c)   on the free rows Z,   and
-  //     W'Z r = (1 - theta tsum) W'Z d + (W'ZZ'W) (M c).
-  // W'Z d is the p the walk ends with (it carries W'd over the variables that still move,
-  // :1300-1304, :1463-1470); W'ZZ'W is in WN1 and in matupd's matrices:  Y'ZZ'Y = WN1(1:col,1:col),
-  // S'ZZ'S = S'S - S'AA'S = Ss - WN1(m+1:,m+1:),  S'ZZ'Y = R_z above the diagonal (WN1), Sy - L_a
-  // below it (:1756-1793).  Equal to the sums over the rows up to reassociation -- and to the
-  // rounding of z - x, which the row form carries at 1 ulp of x per row: the caller uses this
-  // form only when neither the free set nor p is a small remainder of something much larger.
-  // ... which is the case while every stored s_i keeps at least 1e-5 of its squared norm on the free
-  // rows (variables that sit at a bound do not move: their part of s is zero unless they have
-  // just arrived, so a small free SET alone does not make the free PART small)
-  // The same kind of difference gives sum_free s_i y_j below the diagonal: Sy(i,j) - L_a(i,j)
-  // (total minus active).  Entry by entry that difference may be small against its operands without
-  // harm -- what must not drown is its contribution to W'Z r, which is measured against the free
-  // norms |Z's_i| |Z'y_j| (Cauchy-Schwarz bounds the exact value by them): the rounding error of the
-  // difference, ~eps (|Sy| + |L_a|), has to stay below 1e-5 of that scale.
-  bool closed_form_safe(int col) const {
-    const double *WN1 = snd.data(), *SS = ss.data(), *SY = sy.data();
-    const int m2 = 2 * m;
-    const double eps = std::numeric_limits<double>::epsilon();
-    for (int i = 0; i < col; ++i) {
-      const double tot = SS[(size_t)i + (size_t)i * m];
-      const double act = WN1[(size_t)(m + i) + (size_t)(m + i) * m2];
-      if (!(tot - act >= 1.0e-5 * tot)) return false;
-    }
-    for (int i = 1; i < col; ++i) {
-      const double ssf = SS[(size_t)i + (size_t)i * m] - WN1[(size_t)(m + i) + (size_t)(m + i) * m2];
-      for (int j = 0; j < i; ++j) {
-        const double yyf = WN1[(size_t)j + (size_t)j * m2];
-        const double tot = SY[(size_t)i + (size_t)j * m], act = WN1[(size_t)(m + i) + (size_t)j * m2];
-        const double scale = std::sqrt(std::fabs(ssf) * std::fabs(yyf));
-        if (!(eps * (std::fabs(tot) + std::fabs(act)) <= 1.0e-5 * scale)) return false;
-      }
-    }
-    return true;
-  }
-  void subspace_closed_form(int col, double theta, double *wv) {
-    const int m2 = 2 * m;
-    lbh::Mat WN1{snd.data(), m2}, SY{sy.data(), m}, SS{ss.data(), m};
-    const double k1 = 1.0 - theta * gcp.tsum;
-    auto YYf = [&](int i, int j) { return i >= j ? WN1(i, j) : WN1(j, i); };
-    auto SSf = [&](int i, int j) {
-      const double tot = i <= j ? SS(i, j) : SS(j, i);
-      const double act = i >= j ? WN1(m + i, m + j) : WN1(m + j, m + i);
-      return tot - act;
-    };
-    auto SYf = [&](int is, int jy) {  // sum_free s_is y_jy
-      return is <= jy ? WN1(m + is, jy) : SY(is, jy) - WN1(m + is, jy);
-    };
-    const double *a1 = cm_cf.a, *a2 = cm_cf.a + lbk::MAXM;  // (M c)_j, theta (M c)_{col+j}
-    for (int i = 0; i < col; ++i) {
-      double ay = k1 * p_fin[i], as = k1 * (p_fin[col + i] / theta);
-      for (int j = 0; j < col; ++j) {
-        ay = ay + YYf(i, j) * a1[j] + SYf(j, i) * a2[j];
-        as = as + SYf(i, j) * a1[j] + SSf(i, j) * a2[j];
-      }
-      wv[i] = ay;
-      wv[col + i] = theta * as;
-    }
-  }
-
-  // do_formk: formk is pending for this iteration and col <= 10: its new row/column sums ride
-  // along in the cmprlb_wtv pass and the status changes are patched sparsely.
-  // closed: no cmprlb pass at all -- new row from the update pass (nrpre, corrected by the
-  // walk), W'Z r in closed form.
-  int subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
-               int col, int head, bool cnstnd, int &iword, int &info, bool do_formk, bool updatd,
-               int iupdat, const double *pre, bool closed = false) {
-    // cmprlb :1548-1586 (+ W'r of subsm).  `pre` != nullptr: the pass was already launched
-    // together with freev's counts (one fetch for both) and its sums are in pre[].
-    const int MC = lbk::maxc_for(col);
-    const bool newrow = do_formk && updatd;
-    const double *res = pre;
-    const int ipr = quiet ? -1 : print_level;
-    if (closed) {
-      lbk::Coef cf;
-      bool plain;
-      if (!cmprlb_coef(col, theta, cnstnd, cf, plain)) {
-        info = -8;
-        return 0;
-      }
-      nclosed++;
-    } else if (!pre) {
-      lbk::Coef cf;
-      bool plain;
-      if (!cmprlb_coef(col, theta, cnstnd, cf, plain)) {
-        // (the reference would run formk first, :663; either failure refreshes the memory,
-        //  after which WN1 is rebuilt from new rows only)
-        info = -8;
-        return 0;
-      }
-      CHK(ensure_d(x));
-      clk_begin(0);
-      lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
-                                newrow ? 1 : 0, r, d, pend);
-      clk_end(0);
-      CHK(fetch((newrow ? 6 : 2) * MC, 0, 0));
-      res = h_res;
-    }
-    double *wv = &wa8m[0];
-    if (!closed) {
-      nthreepass++;
-      for (int i = 0; i < col; ++i) {
-        wv[i] = res[i];
-        wv[col + i] = theta * res[MC + i];
-      }
-    }
-    if (do_formk) {
-      double nr[4 * lbk::MAXM];
-      if (closed) {
-        if (newrow) {
-          for (int j = 0; j < col; ++j) {
-            nr[0 * MC + j] = nrpre.t[0][j] - nrc[0][j];
-            nr[1 * MC + j] = nrpre.t[1][j] + nrc[1][j];
-            nr[2 * MC + j] = nrpre.t[2][j] + nrc[2][j];
-            nr[3 * MC + j] = nrpre.t[3][j] - nrc[3][j];
-          }
-        }
-      } else if (newrow) {
-        std::memcpy(nr, res + 2 * MC, sizeof(double) * 4 * MC);
-      }
-      CHK(formk_incremental(col, head, updatd, iupdat, nr, MC));
-      formk_factor(col, theta, info);
-      if (info != 0) return 0;
-    }
-    if (closed && !closed_form_safe(col)) {
-      // the free part of some s_i is a tiny remainder of the whole column: S'ZZ'S = S'S - S'AA'S
-      // would lose it to cancellation.  W'Z r from a pass over W after all (WN1 is complete: no
-      // new-row sums)
-      CHK(ensure_d(x));
-      clk_begin(0);
-      lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cm_cf, 0, r, d, pend);
-      clk_end(0);
-      CHK(fetch(2 * MC, 0, 0));
-      for (int i = 0; i < col; ++i) {
-        wv[i] = h_res[i];
-        wv[col + i] = theta * h_res[MC + i];
-      }
-      closed = false;
-      nclosed--, nthreepass++;
-    }
-    if (closed) subspace_closed_form(col, theta, wv);
-    if (ipr >= 99) std::fprintf(rep.out, "\n----------------SUBSM entered-----------------\n\n");  // :2738
-    lbh::Mat WN{wn.data(), 2 * m};
-    const int col2 = 2 * col;
-    info = lbh::dtrsl(WN, col2, wv, 11);
-    if (info != 0) return 0;
-    for (int i = 0; i < col; ++i) wv[i] = -wv[i];
-    info = lbh::dtrsl(WN, col2, wv, 1);
-    if (info != 0) return 0;
-    lbk::Coef cw;
-    std::memset(&cw, 0, sizeof cw);
-    for (int j = 0; j < col; ++j) {
-      cw.a[j] = wv[j];
-      cw.a[lbk::MAXM + j] = wv[col + j];
-    }
-    // d, t, r get their line-search values in the same pass (see subsm_update_kernel); xp = xcp
-    // (:2787) is written out only for state export -- and below if the backtracking branch runs
-    if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));
-    // lean: the first trial step is 1 and x = z is stored by the pass, so neither z nor d = x - t
-    // is written (5 store streams instead of 7); they stay implicit until ensure_d()
-    const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass) && !(flags & LBFGSB_F_MIRROR_INDEX);
-    clk_begin(2);
-    // (ping-pong buffers: no t = x, r = g copies -- the roles change below -- and the trial point
-    //  goes to the other x buffer, which is where the pending pair's t is read from, row by row)
-    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, l, u, nbd8,
-                                iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
-                                pp ? (T *)nullptr : t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
-                                pend, d_src());
-    clk_end(2);
-    pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
-    d_impl = z_in_x = lean;
-    z_valid = !lean;
-    if (lean) x_lean = xmut;
-    if (pp) t = const_cast<T *>(x), r = const_cast<T *>(g);  // t = x, r = g (:2235-2236) as a change of roles
-    CHK(fetch(3, 1, 0));
-    iword = h_res[0] > 0.0 ? 1 : 0;
-    const double dd_p = h_res[1];
-    ls.ready = true;
-    ls.x_is_z = ls_unit_step;
-    ls.gd = dd_p;
-    ls.dtd = h_res[2];
-    ls.stpmx = h_res[3];
-    if (iword == 0 || dd_p <= 0.0) {  // :2820, :2828
-      if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");  // :2883
-      return 0;
-    }
-    ls.ready = false;  // z changes below: lnsrlb_begin redoes d, t, r
-    d_impl = z_in_x = false;  // (and the backtracking kernel writes all of z)
-    if (ls.x_is_z) {   // ... from the iterate itself, which the pass above saved in t
-      // (ping-pong buffers: the trial point went to the other buffer, x still is the iterate)
-      if (!pp) HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-      ls.x_is_z = false;
-    }
-    if (rep.out && !quiet && print_level >= 0) {
-      std::fprintf(rep.out, " Positive dir derivative in projection \n");
-      std::fprintf(rep.out, " Using the backtracking step \n");
-    }
-    // xp = xcp and the Newton direction as vectors (the direction goes to tbrk, which the
-    // cursor-based cauchy_finish_kernel has read by then)
-    if (!(flags & LBFGSB_F_MIRROR_INDEX)) CHK(write_xcp(xp, x, l, u, g));
-    lbk::launch_subsm_dir<T>(q, n, xp, iwhere, x, g, W(), head, col, theta, cm_cf, cw, tbrk);
-    tbrk_valid = false;
-    lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
-    CHK(fetch(0, 1, 0));
-    const double alpha = std::min(1.0, h_res[0]);
-    int64_t ibd = -1;
-    if (alpha < 1.0) {
-      lbk::launch_subsm_argalpha<T>(q, n, row0, xp, tbrk, l, u, nbd, iwhere, alpha);
-      CHK(fetch(0, 1, 0));
-      ibd = (int64_t)h_res[0];
-    }
-    lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, tbrk, l, u, iwhere, alpha, ibd);
-    if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");
-    return 0;
-  }
-
-  // line-search set-up values when they were produced by the subsm pass
-  struct LsOut {
-    bool ready = false;
-    bool x_is_z = false;  // the pass already stored the first trial point x = z
-    double gd = 0, dtd = 0, stpmx = 0;
-  } ls;
-  bool ls_do_stpmx = false;
-  bool ls_unit_step = false;  // the first trial step of this iteration's line search is 1
-  T *xmut = nullptr;          // the caller's x of this call
-  // sums of a cmprlb_wtv pass that was launched together with freev's counts
-  double pre_res[6 * lbk::MAXM];
-  bool pre_valid = false;
-  // ---- two-pass iteration (col <= 10): formk's new row rides in the update pass with the
-  //      pre-walk free set, the walk corrects it for the rows it fixes, and W'Z r follows in
-  //      closed form from the walk's p and WN1 (subspace_closed_form) -- no cmprlb pass ----
-  bool two_pass = true;  // (option "two_pass")
-  // (col <= 20: beyond that the update pass has no registers for the 4 col + 4 extra sums;
-  //  option "two_pass_maxcol" lowers the limit, for measurements)
-  int two_pass_maxcol = 20;
-  bool exact_always = false;  // (option "exact_always": every walk in the reference's heap order)
-
-  // lbfgsb_hip_set_option: measurement / test switches of THIS context (include/lbfgsb_hip.h)
-  int set_option(const char *name, double v) override {
-    const std::string k = name ? name : "";
-    const auto flag = [&](bool &dst) -> int {
-      if (v != 0.0 && v != 1.0) return fail(LBFGSB_E_ARG, "set_option: " + k + " takes 0 or 1");
-      dst = v != 0.0;
-      return 0;
-    };
-    const auto in_range = [&](int lo, int hi, int &dst) -> int {
-      if (!(v >= lo && v <= hi) || v != std::floor(v))
-        return fail(LBFGSB_E_ARG, "set_option: " + k + " out of range");
-      dst = (int)v;
-      return 0;
-    };
-    if (k == "two_pass") return flag(two_pass);
-    if (k == "two_pass_maxcol") return in_range(0, 20, two_pass_maxcol);
-    if (k == "lean") return flag(lean_on);
-    if (k == "spec_capture") return flag(spec_on);
-    if (k == "exact_always") return flag(exact_always);
-    if (k == "nt") return flag(q.nt);
-    if (k == "pg_min") {
-      if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
-      PG_MIN = v;
-      return 0;
-    }
-    if (k == "wgrid") return in_range(1, lbk::MAX_BLOCKS - 1, q.tune.wgrid);
-    if (k == "pipe") return in_range(-1, 1, q.tune.pipe);
-    if (k == "pair") return in_range(0, 2, q.tune.pair);
-    if (k == "gram_rows") return in_range(0, 1, q.tune.gram_rows);
-    return fail(LBFGSB_E_ARG, "set_option: unknown option '" + k + "'");
-  }
-  // update_scan_kernel's NEWROW flag for the pass that forms pair number `colnew`
-  int nr_flag(int colnew) const { return two_pass && colnew <= two_pass_maxcol ? 1 : 0; }
-  struct NewRow {
-    bool valid = false;
-    int col = 0;
-    double t[4][lbk::MAXM];  // logical columns 0..col-1: Y'ZZ'Y row, S'AA'S row, L_a row, R_z column
-  } nrpre;
-  double nrc[4][lbk::MAXM];  // what the walk's fixed rows take from / add to them
-  double p_fin[2 * lbk::MAXM], p_ini_max = 0.0;
-  bool closed_ok = false;    // this call's cauchy left everything the closed form needs
-  int64_t nclosed = 0, nthreepass = 0;
-
+#include "solver_cauchy.inl"    // the Cauchy point: breakpoint provider, walk, parallel search
+#include "solver_subspace.inl"  // formk, cmprlb, subsm
   int print_level = -1;
 
   // =================================================================== mainlb
@@ -2772,255 +1116,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
   bool index_valid = false;  // a freev has run: wasfree is the membership of Index(1:nfree)
 
-  // ============================================================ state exchange
-  int export_state(void *wa_, int32_t *iwa) override {
-    // several ranks: every rank exports ITS rows in the same layout (n = n_local); the host matrices
-    // are replicated, Index is the local list and -- the global counters of isave not telling how
-    // many of THIS rank's rows are free -- Indx2(1) carries the local free count
-    if (nranks != 1 && index)
-      return fail(LBFGSB_E_STATE, "export_state: contexts that mirror Index are single-rank");
-    HIPCHK(hipSetDevice(device));
-    T *wa = (T *)wa_;
-    const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
-    HIPCHK(hipMemcpy2DAsync(wa, (size_t)n * sizeof(T), ws, (size_t)ld * sizeof(T),
-                            (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpy2DAsync(wa + mn, (size_t)n * sizeof(T), wy, (size_t)ld * sizeof(T),
-                            (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, stream));
-    T *ps = wa + 2 * mn;
-    auto put = [&](const std::vector<double> &v) {
-      for (double e : v) *ps++ = (T)e;
-    };
-    put(sy), put(ss), put(wt), put(wn), put(snd);
-    (void)mm;
-    // (z and d left implicit by a lean subspace pass: written out for the export only -- the
-    //  state of the run does not change, both buffers are dead storage while d_impl stands)
-    if (d_impl && x_lean)
-      lbk::launch_dz_materialise<T>(q, n, x_lean, t, d, z_in_x ? z : (T *)nullptr);
-    for (T *src : {z, r, d, t, xp}) {
-      HIPCHK(hipMemcpyAsync(ps, src, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
-      ps += n;
-    }
-    put(wa8m);
-    if (iwa) {
-      if (index) {
-        HIPCHK(hipMemcpyAsync(iwa, index, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(iwa + 2 * n, indx2, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-      }
-    }
-    HIPCHK(hipStreamSynchronize(stream));
-    if (iwa) {  // iwhere: one byte per row on the device, int32 in the reference's layout
-      std::vector<lbk::iw_t> h((size_t)n);
-      HIPCHK(hipMemcpy(h.data(), iwhere, (size_t)n * sizeof(lbk::iw_t), hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < n; ++i) iwa[n + i] = h[(size_t)i];
-      if (!index) {
-        // Contexts that do not mirror the reference's lists keep only the MEMBERSHIP of the free
-        // set as of the last freev (wasfree): Index is rebuilt from it in freev's order (:2044-
-        // 2054: free variables ascending from the front, active ones from the back).  The
-        // enter/leave segments of Indx2 are dead outside the call that made them (formk reads
-        // them in the same call, the next freev overwrites them): exported as zeros.
-        std::memset(iwa, 0, (size_t)n * 4);
-        std::memset(iwa + 2 * n, 0, (size_t)n * 4);
-        if (index_valid) {
-          std::vector<int8_t> wf((size_t)n);
-          HIPCHK(hipMemcpy(wf.data(), wasfree, (size_t)n, hipMemcpyDeviceToHost));
-          int64_t nf = 0, ia = n;
-          for (int64_t i = 0; i < n; ++i) {
-            if (wf[(size_t)i])
-              iwa[nf++] = (int32_t)(i + 1);
-            else
-              iwa[--ia] = (int32_t)(i + 1);
-          }
-          if (nranks != 1) iwa[2 * n] = (int32_t)nf;
-        }
-      }
-    }
-    return 0;
-  }
-
-  int import_state(const void *wa_, const int32_t *iwa, const int32_t *isave_user) override {
-    if (nranks != 1 && index)
-      return fail(LBFGSB_E_STATE, "import_state: contexts that mirror Index are single-rank");
-    HIPCHK(hipSetDevice(device));
-    const T *wa = (const T *)wa_;
-    const int64_t mn = (int64_t)m * n;
-    HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
-                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), wa + mn, (size_t)n * sizeof(T),
-                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
-    const T *ps = wa + 2 * mn;
-    auto get = [&](std::vector<double> &v) {
-      for (double &e : v) e = (double)*ps++;
-    };
-    get(sy), get(ss), get(wt), get(wn), get(snd);
-    t = t_own, r = r_own;  // (the imported t and r live in the context's own buffers, whichever entry is used)
-    for (T *dst : {z, r, d, t, xp}) {
-      HIPCHK(hipMemcpyAsync(dst, ps, (size_t)n * sizeof(T), hipMemcpyHostToDevice, stream));
-      ps += n;
-    }
-    get(wa8m);
-    z_valid = true;  // z as imported
-    spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, tbrk_valid = false, scan.ready = false;
-    nbd8_src = nullptr;
-    spcand.valid = false;
-    {
-      std::vector<lbk::iw_t> h((size_t)n);
-      for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)iwa[n + i];
-      HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
-    }
-    // free-set membership as of the last freev: Index(1:nfree)
-    std::vector<int8_t> wf((size_t)n, 0);
-    const int64_t nfree_glob = isave_user[37];
-    const int64_t nfree = nranks != 1 ? (int64_t)iwa[2 * n] : nfree_glob;  // (see export_state)
-    bool have_index = false;
-    for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
-    if (!have_index) {  // state from before the first freev (START / FG_START)
-      std::fill(wf.begin(), wf.end(), (int8_t)1);
-    } else {
-      if (nfree < 0 || nfree > n) return fail(LBFGSB_E_STATE, "import_state: isave(38) (nfree) out of range");
-      for (int64_t i = 0; i < nfree; ++i) {
-        const int64_t k = iwa[i];
-        if (k < 1 || k > n) return fail(LBFGSB_E_STATE, "import_state: Index entry out of range");
-        wf[(size_t)(k - 1)] = 1;
-      }
-    }
-    index_valid = have_index;
-    HIPCHK(hipMemcpyAsync(wasfree, wf.data(), (size_t)n, hipMemcpyHostToDevice, stream));
-    if (index) {
-      HIPCHK(hipMemcpyAsync(index, iwa, (size_t)n * 4, hipMemcpyHostToDevice, stream));
-      HIPCHK(hipMemcpyAsync(indx2, iwa + 2 * n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
-    }
-    HIPCHK(hipStreamSynchronize(stream));
-    nfree_g = nfree_glob;
-    nenter_g = isave_user[40];
-    ileave_g = isave_user[39];
-    return 0;
-  }
-
-  // ======================================================= per-kernel entries
-  int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd, const void *g,
-               double *out) override {
-    HIPCHK(hipSetDevice(device));
-    lbk::launch_projgr<T>(q, n, (const T *)x, (const T *)l, (const T *)u, nbd, (const T *)g);
-    CHK(fetch(0, 0, 1));
-    *out = h_res[0];
-    return 0;
-  }
-  int k_wtv(const void *v, int col, int head, double *out, bool launch_only) override {
-    HIPCHK(hipSetDevice(device));
-    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "wtv: bad col/head");
-    if (launch_only) {
-      lbk::launch_wtv_nofinalize<T>(q, n, W(), head, col, (const T *)v);
-      return 0;
-    }
-    lbk::launch_wtv<T>(q, n, W(), head, col, (const T *)v);
-    const int MC = lbk::maxc_for(col);
-    CHK(fetch(2 * MC, 0, 0));
-    for (int j = 0; j < col; ++j) {
-      out[j] = h_res[j];
-      out[col + j] = h_res[MC + j];
-    }
-    return 0;
-  }
-  int k_launch(int which, const void *x, const void *g, int col, int head) override {
-    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "bad col/head");
-    HIPCHK(hipSetDevice(device));
-    lbk::Coef cf;
-    std::memset(&cf, 0, sizeof cf);
-    if (which == 0 || which == 2)
-      lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
-                                cf, which == 2 ? 1 : 0, r_own, d, lbk::Pend{1, 0.5, 0});
-    else if (which == 1)
-      lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
-    else if (which == 3 || which == 4) {
-      if (!cl || !cu || !cnbd) return fail(LBFGSB_E_STATE, "kernel_time: run an iteration first");
-      const T *l = (const T *)cl, *u = (const T *)cu;
-      // (the variants the iteration launches; the lean subspace pass stores its trial point into
-      //  the z buffer here instead of the caller's x -- the same five store streams)
-      const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
-      if (which == 3)  // with a pending pair: the variant every iteration after an update runs
-        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r_own, pp ? (T *)nullptr : r_own, l, u,
-                                    nbd8, iwhere, (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
-                                    lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own, lean ? z : (T *)nullptr, 1,
-                                    lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t_own : d);
-      else             // as the evaluation of a trial point: reduces only
-        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, nbd8, (const T *)g, r_own, lean ? t_own : d,
-                                   lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
-                                   (head + col - 2) % m + 1, 0, 0, nr_flag(col));
-    } else
-      return fail(LBFGSB_E_ARG, "unknown kernel");
-    return 0;
-  }
-  int k_set_w(const void *hws, const void *hwy) override {
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), hws, (size_t)n * sizeof(T),
-                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), hwy, (size_t)n * sizeof(T),
-                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    return 0;
-  }
-  int k_set_iwhere(const int32_t *h_iw) override {
-    HIPCHK(hipSetDevice(device));
-    std::vector<lbk::iw_t> h((size_t)n);
-    for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)h_iw[i];
-    HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
-    return 0;
-  }
-  int k_formk_gram(int col, int head, double *out) override {
-    HIPCHK(hipSetDevice(device));
-    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "formk_gram: bad col/head");
-    lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
-    const int E = 2 * col * col + col;
-    CHK(fetch(E, 0, 0));
-    std::memcpy(out, h_res, sizeof(double) * E);
-    return 0;
-  }
-  int k_objective(int kind, const void *x, void *g, double *f) override {
-    HIPCHK(hipSetDevice(device));
-    if (kind == 0) {
-      lbk::launch_obj_quadratic<T>(q, n, row0, (const T *)x, (T *)g);
-    } else if (kind == 1) {
-      if (nglob < 2) return fail(LBFGSB_E_ARG, "rosenbrock objective needs n >= 2");
-      double xl = 0.0, xr = 0.0;
-      if (nranks > 1) {  // 1-element halo: every rank's first and last x, all-gathered
-        lbk::launch_halo_pack<T>(q, n, (const T *)x, d_msg);
-        CHK(exchange(2));
-        if (rank > 0) xl = h_msg_all[2 * (rank - 1) + 1];
-        if (rank < nranks - 1) xr = h_msg_all[2 * (rank + 1)];
-      }
-      lbk::launch_obj_rosenbrock<T>(q, n, row0, nglob, (const T *)x, (T *)g, xl, xr);
-    } else {
-      return fail(LBFGSB_E_ARG, "unknown objective kind");
-    }
-    f_scale = kind == 0 ? 0.5 : 4.0;
-    if (!f) {  // deferred: no host sync here
-      f_pending = true;
-      return 0;
-    }
-    CHK(fetch(1, 0, 0));
-    *f = f_scale * h_res[0];
-    return 0;
-  }
-  int sync() override {
-    HIPCHK(hipStreamSynchronize(stream));
-    return 0;
-  }
-  int attach_rccl(ncclComm_t c, int rank_, int nranks_) override {
-    if (comm) g_rccl.CommDestroy(comm);  // (a second init replaces the communicator)
-    comm = nullptr;
-    CHK(set_ranks(rank_, nranks_));
-    comm = c;
-    return 0;
-  }
-  int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank_,
-                  int nranks_) override {
-    cb_ar = ar, cb_ag = ag, cb_user = user;
-    return set_ranks(rank_, nranks_);
-  }
-  void path_counts(int64_t &closed_form, int64_t &three_pass) const override {
-    closed_form = nclosed, three_pass = nthreepass;
-  }
-  const void *prev_iterate() const override { return t; }
+#include "solver_state.inl"     // state exchange, per-kernel doors, communicators
 };
 
 }  // namespace

@@ -1,0 +1,252 @@
+// solver_state.inl -- member functions of Solver<T> (included inside the class body in solver.hip):
+// export / import of the state in the reference's wa / iwa layout (:246-284), the per-kernel doors of
+// the C ABI, communicator attachment.
+  // ============================================================ state exchange
+  int export_state(void *wa_, int32_t *iwa) override {
+    // several ranks: every rank exports ITS rows in the same layout (n = n_local); the host matrices
+    // are replicated, Index is the local list and -- the global counters of isave not telling how
+    // many of THIS rank's rows are free -- Indx2(1) carries the local free count
+    if (nranks != 1 && index)
+      return fail(LBFGSB_E_STATE, "export_state: contexts that mirror Index are single-rank");
+    HIPCHK(hipSetDevice(device));
+    T *wa = (T *)wa_;
+    const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
+    HIPCHK(hipMemcpy2DAsync(wa, (size_t)n * sizeof(T), ws, (size_t)ld * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpy2DAsync(wa + mn, (size_t)n * sizeof(T), wy, (size_t)ld * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, stream));
+    T *ps = wa + 2 * mn;
+    auto put = [&](const std::vector<double> &v) {
+      for (double e : v) *ps++ = (T)e;
+    };
+    put(sy), put(ss), put(wt), put(wn), put(snd);
+    (void)mm;
+    // (z and d left implicit by a lean subspace pass: written out for the export only -- the
+    //  state of the run does not change, both buffers are dead storage while d_impl stands)
+    if (d_impl && x_lean)
+      lbk::launch_dz_materialise<T>(q, n, x_lean, t, d, z_in_x ? z : (T *)nullptr);
+    for (T *src : {z, r, d, t, xp}) {
+      HIPCHK(hipMemcpyAsync(ps, src, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, stream));
+      ps += n;
+    }
+    put(wa8m);
+    if (iwa) {
+      if (index) {
+        HIPCHK(hipMemcpyAsync(iwa, index, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(iwa + 2 * n, indx2, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+      }
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    if (iwa) {  // iwhere: one byte per row on the device, int32 in the reference's layout
+      std::vector<lbk::iw_t> h((size_t)n);
+      HIPCHK(hipMemcpy(h.data(), iwhere, (size_t)n * sizeof(lbk::iw_t), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < n; ++i) iwa[n + i] = h[(size_t)i];
+      if (!index) {
+        // Contexts that do not mirror the reference's lists keep only the MEMBERSHIP of the free
+        // set as of the last freev (wasfree): Index is rebuilt from it in freev's order (:2044-
+        // 2054: free variables ascending from the front, active ones from the back).  The
+        // enter/leave segments of Indx2 are dead outside the call that made them (formk reads
+        // them in the same call, the next freev overwrites them): exported as zeros.
+        std::memset(iwa, 0, (size_t)n * 4);
+        std::memset(iwa + 2 * n, 0, (size_t)n * 4);
+        if (index_valid) {
+          std::vector<int8_t> wf((size_t)n);
+          HIPCHK(hipMemcpy(wf.data(), wasfree, (size_t)n, hipMemcpyDeviceToHost));
+          int64_t nf = 0, ia = n;
+          for (int64_t i = 0; i < n; ++i) {
+            if (wf[(size_t)i])
+              iwa[nf++] = (int32_t)(i + 1);
+            else
+              iwa[--ia] = (int32_t)(i + 1);
+          }
+          if (nranks != 1) iwa[2 * n] = (int32_t)nf;
+        }
+      }
+    }
+    return 0;
+  }
+
+  int import_state(const void *wa_, const int32_t *iwa, const int32_t *isave_user) override {
+    if (nranks != 1 && index)
+      return fail(LBFGSB_E_STATE, "import_state: contexts that mirror Index are single-rank");
+    HIPCHK(hipSetDevice(device));
+    const T *wa = (const T *)wa_;
+    const int64_t mn = (int64_t)m * n;
+    HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), wa + mn, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    const T *ps = wa + 2 * mn;
+    auto get = [&](std::vector<double> &v) {
+      for (double &e : v) e = (double)*ps++;
+    };
+    get(sy), get(ss), get(wt), get(wn), get(snd);
+    t = t_own, r = r_own;  // (the imported t and r live in the context's own buffers, whichever entry is used)
+    for (T *dst : {z, r, d, t, xp}) {
+      HIPCHK(hipMemcpyAsync(dst, ps, (size_t)n * sizeof(T), hipMemcpyHostToDevice, stream));
+      ps += n;
+    }
+    get(wa8m);
+    z_valid = true;  // z as imported
+    spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, tbrk_valid = false, scan.ready = false;
+    nbd8_src = nullptr;
+    spcand.valid = false;
+    {
+      std::vector<lbk::iw_t> h((size_t)n);
+      for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)iwa[n + i];
+      HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
+    }
+    // free-set membership as of the last freev: Index(1:nfree)
+    std::vector<int8_t> wf((size_t)n, 0);
+    const int64_t nfree_glob = isave_user[37];
+    const int64_t nfree = nranks != 1 ? (int64_t)iwa[2 * n] : nfree_glob;  // (see export_state)
+    bool have_index = false;
+    for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
+    if (!have_index) {  // state from before the first freev (START / FG_START)
+      std::fill(wf.begin(), wf.end(), (int8_t)1);
+    } else {
+      if (nfree < 0 || nfree > n) return fail(LBFGSB_E_STATE, "import_state: isave(38) (nfree) out of range");
+      for (int64_t i = 0; i < nfree; ++i) {
+        const int64_t k = iwa[i];
+        if (k < 1 || k > n) return fail(LBFGSB_E_STATE, "import_state: Index entry out of range");
+        wf[(size_t)(k - 1)] = 1;
+      }
+    }
+    index_valid = have_index;
+    HIPCHK(hipMemcpyAsync(wasfree, wf.data(), (size_t)n, hipMemcpyHostToDevice, stream));
+    if (index) {
+      HIPCHK(hipMemcpyAsync(index, iwa, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(indx2, iwa + 2 * n, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    nfree_g = nfree_glob;
+    nenter_g = isave_user[40];
+    ileave_g = isave_user[39];
+    return 0;
+  }
+
+  // ======================================================= per-kernel entries
+  int k_projgr(const void *x, const void *l, const void *u, const int32_t *nbd, const void *g,
+               double *out) override {
+    HIPCHK(hipSetDevice(device));
+    lbk::launch_projgr<T>(q, n, (const T *)x, (const T *)l, (const T *)u, nbd, (const T *)g);
+    CHK(fetch(0, 0, 1));
+    *out = h_res[0];
+    return 0;
+  }
+  int k_wtv(const void *v, int col, int head, double *out, bool launch_only) override {
+    HIPCHK(hipSetDevice(device));
+    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "wtv: bad col/head");
+    if (launch_only) {
+      lbk::launch_wtv_nofinalize<T>(q, n, W(), head, col, (const T *)v);
+      return 0;
+    }
+    lbk::launch_wtv<T>(q, n, W(), head, col, (const T *)v);
+    const int MC = lbk::maxc_for(col);
+    CHK(fetch(2 * MC, 0, 0));
+    for (int j = 0; j < col; ++j) {
+      out[j] = h_res[j];
+      out[col + j] = h_res[MC + j];
+    }
+    return 0;
+  }
+  int k_launch(int which, const void *x, const void *g, int col, int head) override {
+    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "bad col/head");
+    HIPCHK(hipSetDevice(device));
+    lbk::Coef cf;
+    std::memset(&cf, 0, sizeof cf);
+    if (which == 0 || which == 2)
+      lbk::launch_cmprlb_wtv<T>(q, n, (const T *)x, (const T *)g, 0.5, iwhere, W(), head, col, 1.0,
+                                cf, which == 2 ? 1 : 0, r_own, d, lbk::Pend{1, 0.5, 0});
+    else if (which == 1)
+      lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
+    else if (which == 3 || which == 4) {
+      if (!cl || !cu || !cnbd) return fail(LBFGSB_E_STATE, "kernel_time: run an iteration first");
+      const T *l = (const T *)cl, *u = (const T *)cu;
+      // (the variants the iteration launches; the lean subspace pass stores its trial point into
+      //  the z buffer here instead of the caller's x -- the same five store streams)
+      const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
+      if (which == 3)  // with a pending pair: the variant every iteration after an update runs
+        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r_own, pp ? (T *)nullptr : r_own, l, u,
+                                    nbd8, iwhere, (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
+                                    lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own, lean ? z : (T *)nullptr, 1,
+                                    lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t_own : d);
+      else             // as the evaluation of a trial point: reduces only
+        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, nbd8, (const T *)g, r_own, lean ? t_own : d,
+                                   lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
+                                   (head + col - 2) % m + 1, 0, 0, nr_flag(col));
+    } else
+      return fail(LBFGSB_E_ARG, "unknown kernel");
+    return 0;
+  }
+  int k_set_w(const void *hws, const void *hwy) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), hws, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), hwy, (size_t)n * sizeof(T),
+                            (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int k_set_iwhere(const int32_t *h_iw) override {
+    HIPCHK(hipSetDevice(device));
+    std::vector<lbk::iw_t> h((size_t)n);
+    for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)h_iw[i];
+    HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int k_formk_gram(int col, int head, double *out) override {
+    HIPCHK(hipSetDevice(device));
+    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "formk_gram: bad col/head");
+    lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
+    const int E = 2 * col * col + col;
+    CHK(fetch(E, 0, 0));
+    std::memcpy(out, h_res, sizeof(double) * E);
+    return 0;
+  }
+  int k_objective(int kind, const void *x, void *g, double *f) override {
+    HIPCHK(hipSetDevice(device));
+    if (kind == 0) {
+      lbk::launch_obj_quadratic<T>(q, n, row0, (const T *)x, (T *)g);
+    } else if (kind == 1) {
+      if (nglob < 2) return fail(LBFGSB_E_ARG, "rosenbrock objective needs n >= 2");
+      double xl = 0.0, xr = 0.0;
+      if (nranks > 1) {  // 1-element halo: every rank's first and last x, all-gathered
+        lbk::launch_halo_pack<T>(q, n, (const T *)x, d_msg);
+        CHK(exchange(2));
+        if (rank > 0) xl = h_msg_all[2 * (rank - 1) + 1];
+        if (rank < nranks - 1) xr = h_msg_all[2 * (rank + 1)];
+      }
+      lbk::launch_obj_rosenbrock<T>(q, n, row0, nglob, (const T *)x, (T *)g, xl, xr);
+    } else {
+      return fail(LBFGSB_E_ARG, "unknown objective kind");
+    }
+    f_scale = kind == 0 ? 0.5 : 4.0;
+    if (!f) {  // deferred: no host sync here
+      f_pending = true;
+      return 0;
+    }
+    CHK(fetch(1, 0, 0));
+    *f = f_scale * h_res[0];
+    return 0;
+  }
+  int sync() override {
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int attach_rccl(ncclComm_t c, int rank_, int nranks_) override {
+    if (comm) g_rccl.CommDestroy(comm);  // (a second init replaces the communicator)
+    comm = nullptr;
+    CHK(set_ranks(rank_, nranks_));
+    comm = c;
+    return 0;
+  }
+  int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank_,
+                  int nranks_) override {
+    cb_ar = ar, cb_ag = ag, cb_user = user;
+    return set_ranks(rank_, nranks_);
+  }
+  void path_counts(int64_t &closed_form, int64_t &three_pass) const override {
+    closed_form = nclosed, three_pass = nthreepass;
+  }
+  const void *prev_iterate() const override { return t; }
