@@ -330,11 +330,13 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
                 dt=dt, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1)
 
 
-def pass_bytes(col, rbytes, pp, lean=True):
-    """algorithmic bytes per row of the two passes over W of an iteration"""
-    upd = (2 * (col - 1) + 6) * rbytes + 2          # 2(col-1) W columns + x, l, u, g, r, t + nbd, iwhere (1 B each)
+def pass_bytes(col, rbytes, pp, lean=True, ub=0):
+    """algorithmic bytes per row of the two passes over W of an iteration (DESIGN.md section 4a);
+    ub = lbfgsb_hip_uniform_bounds mask: bound arrays that hold one value are not streamed"""
+    bounds = (0 if ub & 1 else rbytes) + (0 if ub & 2 else rbytes) + (0 if ub & 4 else 1)   # l, u, nbd
+    upd = (2 * (col - 1) + 4) * rbytes + 1 + bounds   # 2(col-1) W columns + x, g, r, t + iwhere (1 B) + bounds
     n_st = (3 if pp else 5) if lean else (5 if pp else 7)
-    sub = (2 * col + 4 + n_st) * rbytes + 2         # 2 col W (the pending pair from r, t) + l, u, x, g + stores
+    sub = (2 * col + 2 + n_st) * rbytes + 1 + bounds  # 2 col W (the pending pair from r, t) + x, g + bounds + stores
     return upd, sub, n_st
 
 
@@ -346,7 +348,8 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
         r = timed_leg(run, steps, warm_min, need_full_memory=(kind == 0))
         col = int(run.sol.isave[27])
         rb = 4 if real32 else 8
-        upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0)
+        ub = run.sol.uniform_bounds()
+        upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0, ub)
         passes = {}
         for key, bpr in (("update_scan", upd_b), ("subsm_update", sub_b)):
             ms, cnt = r["clocks"][key]
@@ -361,7 +364,8 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "first_iteration_s": r["first_iter_s"], "first_iteration_nseg": r["nseg_first"],
                 "host_syncs_per_iter": (r["st1"]["syncs"] - r["st0"]["syncs"]) / steps,
                 "passes": passes, "subspace_steps_closed_form": closed, "subspace_steps_three_pass": three,
-                "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0])}
+                "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0]),
+                "uniform_bounds_mask": ub, "options": opts}
     finally:
         run.close()
 
@@ -426,7 +430,9 @@ def main():
     nts = "true" if nt else "false"
     tname = "float" if a.real32 else "double"
     lean = opts.get("lean", 1) != 0
-    upd_bpr, sub_bpr, n_st = pass_bytes(col, rbytes, run.pp, lean)
+    ub = sol.uniform_bounds()
+    upd_bpr, sub_bpr, n_st = pass_bytes(col, rbytes, run.pp, lean, ub)
+    ubs = "_ub%d" % ub if ub else ""
 
     def static_traffic(fname, key, rows):
         tf = os.path.join(ROOT, "profiles", fname)
@@ -468,7 +474,7 @@ def main():
                 "stores": stores}
     rec_us = pass_record("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
                          "first trial point: W'd of cauchy, S'y / S's of matupd, formk's new row)"
-                         % (tname, mc, nts), upd_bpr, "none", "update_scan")
+                         % (tname, mc, nts), upd_bpr, "none", "update_scan" + ubs)
     entry = "ping-pong entry" if run.pp else "classic entry"
     if run.pp:
         st_txt = "trial x + Ws/Wy column (3 of %d streams; t = x, r = g are a change of roles)" % (2 * col + 7)
@@ -478,7 +484,7 @@ def main():
         st_txt = "z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11)
     rec_su = pass_record("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (%s, pending pair committed)"
                          % (tname, mc, nts, entry), sub_bpr, st_txt,
-                         "subsm_update_pp" if run.pp else "subsm_update")
+                         ("subsm_update_pp" if run.pp else "subsm_update") + ubs)
     rec_cw = pass_record("cmprlb_wtv", 2, "cmprlb_wtv_kernel<%s, %d, true, %s>" % (tname, mc, nts),
                          (2 * col + 2) * rbytes + 1, "none", "cmprlb_wtv")
     closed_steps, three_steps, handed_windows = sol.path_counts()
@@ -525,7 +531,12 @@ def main():
                    "collective": run.collective,
                    "entry": ("lbfgsb_hip_setulb_dev_pp (ping-pong iterate buffers)" if run.pp
                              else "lbfgsb_hip_setulb_dev"),
-                   "options": opts},
+                   "options": opts,
+                   "uniform_bounds_mask": ub,
+                   "uniform_bounds": "l, u, nbd of this workload hold one value each (detected at START, bit 0/1/2 = "
+                                     "l/u/nbd): the passes over W read them as constants, not as 8+8+1 B/row "
+                                     "streams; other_configs has the same workload with the detection off"
+                                     if ub else "not detected / off: l, u, nbd are streamed"},
         "iters_per_sec_setulb_only": a.steps / dt_setulb,
         "first_iteration_s": r["first_iter_s"],
         "first_iteration_nseg": r["nseg_first"],
@@ -566,6 +577,9 @@ def main():
     # ---- the other BASELINE.json configs, short legs (N = 1 only; each a fresh context) ----
     if world == 1 and not a.no_other_configs and not a.real32 and n == 100_000_000 and m == 10:
         legs = [
+            ("headline workload with the uniform-bounds detection OFF (l, u, nbd streamed per row)",
+             dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12,
+                  opts=dict(opts, uniform_bounds=0))),
             ("configs[1]: separable bounded quadratic n=1e6, m=10, fp64", dict(n=1_000_000, m=10, real32=False,
              kind=0, rccl_self=False, steps=40, warm_min=12)),
             ("configs[2]: extended Rosenbrock with box bounds n=1e7, m=10, fp64", dict(n=10_000_000, m=10,
@@ -578,8 +592,9 @@ def main():
         out["other_configs"] = []
         for name, kw in legs:
             try:
+                kw.setdefault("opts", opts)
                 out["other_configs"].append(other_config(torch, dist, lbfgsb_amd, a, name, local_rank=local_rank,
-                                                         opts=opts, **kw))
+                                                         **kw))
             except BaseException as e:   # noqa: BLE001  (a leg must never take the headline line down)
                 out["other_configs"].append({"config": name, "error": repr(e)})
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -324,6 +324,7 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           go to the sort + scans
  *   "exact_always" (0/1)    every Cauchy walk in the reference's heap order from its start (tests)
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
+ *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "wgrid" (1..2047)       workgroups of the passes over W (default 768)
  *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule / off / on
  *   "pair" (0/1/2)          MC = 20 update pass: lane pairs share accumulators (off / 1 trip / 2 trips)
@@ -335,6 +336,18 @@ int lbfgsb_hip_set_option(lbfgsb_hip_ctx *ctx, const char *name, double value);
  * and the seconds the host spent blocked waiting for the stream */
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
                      int64_t *cauchy_fullsorts, double *wait_seconds);
+
+/* Uniform bounds.  Bound arrays that hold ONE value each -- the box [a, b]^n, x >= 0 -- are the common
+ * case, and on a bandwidth-bound device streaming 2 x 8 + 1 constant bytes per row through each of the
+ * two passes over W of an iteration is 8 % of its traffic.  At task 'START' the pass that validates
+ * the bounds (errclb, src/lbfgsb.f90:1601-1643) also checks, bit for bit, whether every l_i equals l_1,
+ * every u_i equals u_1, every nbd_i equals nbd_1 (among this rank's rows); the passes over W then read
+ * the value from a 64-byte buffer instead of the array -- same arithmetic, same results bit for bit.
+ * *mask: bit 0 = l, bit 1 = u, bit 2 = nbd is treated as uniform in the current run.  The arrays must
+ * not change during a run (as for nbd above); passing OTHER array pointers than at 'START' switches the
+ * corresponding bit off.  Option "uniform_bounds" = 0 (lbfgsb_hip_set_option, before START) disables
+ * the detection. */
+int lbfgsb_hip_uniform_bounds(lbfgsb_hip_ctx *ctx, int32_t *mask);
 
 /* several ranks: collectives issued so far (all-gathers of partial sums, of breakpoint records, of
  * halo values) and the bytes THIS rank contributed to them */

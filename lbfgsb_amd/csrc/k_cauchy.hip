@@ -193,17 +193,17 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
     int64_t n, int64_t row0, const T *__restrict__ x, const T *__restrict__ l,
     const T *__restrict__ u, const nb_t *__restrict__ nbd, const T *__restrict__ g,
     const iw_t *__restrict__ iwhere, double lo_t, int64_t lo_i, double hi_t, uint64_t *keys,
-    uint32_t *idx, uint32_t cap, uint32_t *count) {
+    uint32_t *idx, uint32_t cap, uint32_t *count, int ub) {
   const int lane = threadIdx.x & 63;
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], tv[W];
     int nb[W], iw[W];
     ldx<W, true>(x + i, xv);
-    ldx<W, true>(l + i, lv);
-    ldx<W, true>(u + i, uv);
+    ldx<W, true>((ub & 1) ? l : l + i, lv);  // (uniform bounds: constant buffers, see UpdScanCtx)
+    ldx<W, true>((ub & 2) ? u : u + i, uv);
     ldx<W, true>(g + i, gv);
-    ldi<W>(nbd + i, nb);
+    ldi<W>((ub & 4) ? nbd : nbd + i, nb);
     ldi<W>(iwhere + i, iw);
     unsigned bits = 0;
 #pragma unroll
@@ -237,11 +237,11 @@ template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
                               const nb_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
-                              uint32_t *d_count) {
+                              uint32_t *d_count, int ub) {
   (void)hipMemsetAsync(d_count, 0, sizeof(uint32_t), q.stream);
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(cauchy_window_fly_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, l,
-                     u, nbd, g, iwhere, lo_t, lo_i, hi_t, keys, idx, cap, d_count);
+                     u, nbd, g, iwhere, lo_t, lo_i, hi_t, keys, idx, cap, d_count, ub);
   LB_LAUNCHED(q);
 }
 // iwhere update of cauchy's n-loop alone (:1284-1291), for contexts whose speculative update pass
@@ -1153,7 +1153,7 @@ void launch_freev_lists(Queue &q, int64_t n, const iw_t *iwhere, const int8_t *p
   template void launch_cauchy_allkeys<T>(Queue &, int64_t, int64_t, const T *, double, int64_t, uint64_t *, uint32_t *); \
   template void launch_cauchy_gather<T>(Queue &, const uint32_t *, const uint64_t *, uint32_t, int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, const T *, const T *, Pend, double *); \
   template void launch_cauchy_gather_dyn<T>(Queue &, const uint32_t *, const uint64_t *, const uint32_t *, uint32_t, int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, const T *, const T *, Pend, double *); \
-  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *, const T *, const nb_t *, const T *, const iw_t *, double, int64_t, double, uint64_t *, uint32_t *, uint32_t, uint32_t *); \
+  template void launch_cauchy_window_fly<T>(Queue &, int64_t, int64_t, const T *, const T *, const T *, const nb_t *, const T *, const iw_t *, double, int64_t, double, uint64_t *, uint32_t *, uint32_t, uint32_t *, int); \
   template void launch_iwhere_update<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, iw_t *); \
   template void launch_pgcp_gather<T>(Queue &, const uint32_t *, const uint64_t *, int64_t, int64_t, const T *, const T *, const T *, const T *, WStore<T>, int, int, double, const T *, const T *, Pend, double *, double *, double *, double *, double *, double *, int64_t); \
   template void launch_gcp_rest_mass<T>(Queue &, int64_t, const T *, const T *, double); \

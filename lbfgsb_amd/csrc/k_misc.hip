@@ -135,7 +135,9 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void errclb_kernel(int64_t n, int64_t row0, const T *l,
                                                        const T *u, const int32_t *nbd,
                                                        double *part) {
-  double acc[2] = {0, 0};
+  double acc[5] = {0, 0, 0, 0, 0};
+  const double l0 = (double)l[0], u0 = (double)u[0];
+  const int nb0 = nbd[0];
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double lv[W], uv[W];
@@ -148,9 +150,13 @@ __global__ __launch_bounds__(BLOCK) void errclb_kernel(int64_t n, int64_t row0, 
       const double gi = (double)(row0 + i + k + 1);
       if (nb[k] < 0 || nb[k] > 3) acc[0] = fmax(acc[0], gi);
       if (nb[k] == 2 && lv[k] > uv[k]) acc[1] = fmax(acc[1], gi);
+      // uniform bounds: is every entry the first one, bit for bit?  (-0.0 vs 0.0 and NaN count as different)
+      if (__double_as_longlong(lv[k]) != __double_as_longlong(l0)) acc[2] = 1.0;
+      if (__double_as_longlong(uv[k]) != __double_as_longlong(u0)) acc[3] = 1.0;
+      if (nb[k] != nb0) acc[4] = 1.0;
     }
   });
-  block_reduce_store<2>(acc, 0, 0, 2, part, MAX_BLOCKS);
+  block_reduce_store<5>(acc, 0, 0, 5, part, MAX_BLOCKS);
 }
 template <typename T>
 void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
@@ -159,7 +165,7 @@ void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
   hipLaunchKernelGGL(errclb_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, row0, l, u, nbd,
                      q.d_part);
   LB_LAUNCHED(q);
-  launch_finalize(q, g, 0, 0, 2);
+  launch_finalize(q, g, 0, 0, 5);
 }
 
 

@@ -39,6 +39,7 @@ struct SubsmCtx {
   int64_t ldw;
   int m, head, col;
   Pend pe;
+  int ub;  // uniform bounds: bit 0 l, bit 1 u, bit 2 nbd are 64-byte constant buffers (see UpdScanCtx)
 };
 template <typename T, int MC, int W, bool NT, bool PSPEC>
 struct SubsmTrip {
@@ -48,11 +49,11 @@ struct SubsmTrip {
   RawOf<iw_t, W> riw;
   __device__ __forceinline__ void issue(const SubsmCtx<T> &c, int64_t i) {
     constexpr int B = (int)sizeof(T) * W;
-    raw_issue<B, NT>(rl, c.l + i);
-    raw_issue<B, NT>(ru, c.u + i);
+    raw_issue<B, NT>(rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(ru, (c.ub & 2) ? c.u : c.u + i);
     raw_issue<B, NT>(rx, c.xx + i);
     raw_issue<B, NT>(rg, c.gg + i);
-    raw_issue<W, false>(rnb, c.nbd + i);
+    raw_issue<W, false>(rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
     raw_issue<W, false>(riw, c.iwhere + i);
     // a pending pair is read from (r, d) -- or (r, t) when d is implicit -- which this pass
     // overwrites further down
@@ -76,14 +77,14 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
     int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
-    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, double *part) {
+    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
   // stores every trip issues (a lower bound: the counted wait of the pipelined loop may then wait
   // for a few stores too): the trial point / z (+ the committed pair in the steady-state shape)
   constexpr int NS = PSPEC ? 3 : 1;
-  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, pr, pd, nbd, iwhere, ldw, m, head, col, pe};
+  const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, pr, pd, nbd, iwhere, ldw, m, head, col, pe, ub};
   for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -181,7 +182,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
                          const T *u, const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
-                         const T *pd) {
+                         const T *pd, int ub) {
   const int gr = grid_for_w(q, n, VecOf<T>::V);
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   const bool spec = pe.on && col == maxc_for(col);
@@ -192,7 +193,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
                                          dim3(BLOCK), 0, q.stream, n, tsum, zout, pr, rout, l, u,   \
                                          nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head,  \
                                          col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,    \
-                                         w.wy + slot, w.ws + slot, q.d_part)))
+                                         w.wy + slot, w.ws + slot, ub, q.d_part)))
   if (spec)
     LB_SUBSM(true);
   else
@@ -250,7 +251,7 @@ void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, con
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
-  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, const T *, T *, const T *, const T *, const nb_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *); \
+  template void launch_subsm_update<T>(Queue &, int64_t, double, T *, const T *, T *, const T *, const T *, const nb_t *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *, T *, T *, int, Pend, const T *, int); \
   template void launch_subsm_dir<T>(Queue &, int64_t, const T *, const iw_t *, const T *, const T *, WStore<T>, int, int, double, const Coef &, const Coef &, T *);
 INSTANTIATE(double)
 INSTANTIATE(float)

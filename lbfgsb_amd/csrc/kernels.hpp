@@ -94,7 +94,8 @@ template <typename T>
 void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd,
                    iw_t *iwhere, int8_t *wasfree);
 // errclb (ref :1601-1643): res max-slots: [0]=largest 1-based global index with invalid nbd
-// (0 if none), [1]=largest index with l>u and nbd==2.
+// (0 if none), [1]=largest index with l>u and nbd==2; [2], [3], [4] = 1 if some l_i / u_i / nbd_i
+// differs from the first one of this rank's rows (uniform-bounds detection, see `ub` below).
 template <typename T>
 void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
                    const int32_t *nbd);
@@ -163,7 +164,7 @@ template <typename T>
 void launch_cauchy_window_fly(Queue &q, int64_t n, int64_t row0, const T *x, const T *l, const T *u,
                               const nb_t *nbd, const T *g, const iw_t *iwhere, double lo_t,
                               int64_t lo_i, double hi_t, uint64_t *keys, uint32_t *idx, uint32_t cap,
-                              uint32_t *d_count);
+                              uint32_t *d_count, int ub = 0);
 // cauchy's iwhere update (:1284-1291) alone
 template <typename T>
 void launch_iwhere_update(Queue &q, int64_t n, const T *x, const T *l, const T *u,
@@ -272,7 +273,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
                          const T *u, const nb_t *nbd, const iw_t *iwhere, const T *xx, const T *gg,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
-                         const T *pd);
+                         const T *pd, int ub = 0);
 // the Newton direction of the free rows as a vector (0 elsewhere) -- backtracking branch only
 template <typename T>
 void launch_subsm_dir(Queue &q, int64_t n, const T *xcp, const iw_t *iwhere, const T *xx,
@@ -324,7 +325,11 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         double stp, iw_t *iwhere, T *tbrk, WStore<T> w, int head, int col, int itail,
                         int store_pair, int store_iw, int newrow = 0, double cand_hi = -1.0,
                         uint64_t *ckeys = nullptr, uint32_t *cidx = nullptr, uint32_t ccap = 0,
-                        uint32_t *ccount = nullptr);
+                        uint32_t *ccount = nullptr, int ub = 0);
+// ub (launch_update_scan, launch_subsm_update, launch_cauchy_window_fly): UNIFORM BOUNDS.  bit 0: every
+// l_i is one value, bit 1: every u_i, bit 2: every nbd_i -- the corresponding pointer then is a
+// 64-byte device buffer filled with that value, which every lane reads from its start (a cache hit
+// instead of an HBM stream of 8 / 8 / 1 bytes per row).  Detected at START (errclb's pass).
 // cand_hi >= 0: rows whose breakpoint t lies in [0, cand_hi] are appended (unordered) to
 // ckeys / cidx (capacity ccap), *ccount = how many there are (zeroed by the launch)
 // newrow (col - 1 <= 10): 4 MC + 4 more sum slots in front of the min / max slots -- the new

@@ -54,6 +54,18 @@ class Solver final : public lbfgsb_hip_ctx {
   T *xb[2] = {nullptr, nullptr}, *gb[2] = {nullptr, nullptr};
   int pp_cur = 0;         // the pair the last return referred to
   const T *x_lean = nullptr;  // where the first trial point of a lean subspace pass lives (d = x_lean - t)
+  // ---- uniform bounds: l, u, nbd that hold ONE value each (the box [a, b]^n, x >= 0, ...) are not
+  //      streamed by the passes over W: the kernels read a 64-byte constant buffer instead (8 + 8 + 1
+  //      bytes per row less in each of the two passes; kernels.hpp `ub`).  Detected at START by
+  //      errclb's pass, bit for bit; l, u, nbd must not change during a run anyway. ----
+  bool ub_on = true;          // (option "uniform_bounds")
+  int ub_mask = 0;            // bit 0 l, bit 1 u, bit 2 nbd
+  char *ub_buf = nullptr;     // 3 x 64 bytes on the device
+  const void *ub_l = nullptr, *ub_u = nullptr;  // the caller arrays the detection looked at
+  const int32_t *ub_nbd = nullptr;
+  const T *lk(const T *l) const { return (ub_mask & 1) ? (const T *)ub_buf : l; }
+  const T *uk(const T *u) const { return (ub_mask & 2) ? (const T *)(ub_buf + 64) : u; }
+  const lbk::nb_t *nbk() const { return (ub_mask & 4) ? (const lbk::nb_t *)(ub_buf + 128) : nbd8; }
   lbk::iw_t *iwhere = nullptr;  // one byte per row (the reference's int32 only in export/import)
   int32_t *index = nullptr, *indx2 = nullptr, *scan_tmp = nullptr;
   int8_t *wasfree = nullptr, *prevfree = nullptr;
@@ -110,7 +122,8 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all);
+        F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all),
+        F(ub_buf);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
@@ -156,6 +169,7 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&wy, wbytes));
     HIPCHK(hipMemsetAsync(ws, 0, wbytes, stream));
     HIPCHK(hipMemsetAsync(wy, 0, wbytes, stream));
+    HIPCHK(hipMalloc(&ub_buf, 192));
     HIPCHK(hipMalloc(&zero_buf, 256));  // read by the unroll slots beyond the stored pairs
     HIPCHK(hipMemsetAsync(zero_buf, 0, 256, stream));
     const size_t vb = (size_t)(n + 32) * sizeof(T);
@@ -438,7 +452,32 @@ class Solver final : public lbfgsb_hip_ctx {
     if (m <= 0) lbh::str60_set(task, "ERROR: M <= 0");
     if (factr < 0.0) lbh::str60_set(task, "ERROR: FACTR < 0");
     lbk::launch_errclb<T>(q, n, row0, l, u, nbd);
-    CHK(fetch(0, 0, 2));
+    CHK(fetch(0, 0, 5));
+    {
+      // uniform bounds (this rank's rows; every rank decides for itself: only loads are affected)
+      ub_mask = 0;
+      if (ub_on) {
+        T lu0[2];
+        int32_t nb0 = 0;
+        HIPCHK(hipMemcpy(&lu0[0], l, sizeof(T), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&lu0[1], u, sizeof(T), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&nb0, nbd, sizeof(int32_t), hipMemcpyDeviceToHost));
+        // (h_res[2..4] are maxima over ALL ranks: a rank whose own rows are uniform but another's
+        //  are not simply keeps streaming -- harmless)
+        char host[192];
+        std::memset(host, 0, sizeof host);
+        for (int k = 0; k < (int)(64 / sizeof(T)); ++k) {
+          std::memcpy(host + k * sizeof(T), &lu0[0], sizeof(T));
+          std::memcpy(host + 64 + k * sizeof(T), &lu0[1], sizeof(T));
+        }
+        std::memset(host + 128, (int)(lbk::nb_t)nb0, 64);
+        HIPCHK(hipMemcpy(ub_buf, host, sizeof host, hipMemcpyHostToDevice));
+        if (h_res[2] == 0.0) ub_mask |= 1;
+        if (h_res[3] == 0.0) ub_mask |= 2;
+        if (h_res[4] == 0.0 && nb0 >= 0 && nb0 <= 3) ub_mask |= 4;
+        ub_l = l, ub_u = u, ub_nbd = nbd;
+      }
+    }
     {
       const int64_t k6 = (int64_t)h_res[0], k7 = (int64_t)h_res[1];
       if (k6 > 0 || k7 > 0) {
@@ -530,9 +569,9 @@ class Solver final : public lbfgsb_hip_ctx {
         q.res_off = fo;
         // (the MC = 20 instantiation with the new-row sums has no registers for the hand-over)
         const double chi = (nr_flag(c2) && lbk::maxc_for(c2 - 1) > 10) ? -1.0 : spec_hi(cnstnd);
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd8, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+        lbk::launch_update_scan<T>(q, n, x, lk(l), uk(u), nbk(), g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
                                    (T *)nullptr, W(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
-                                   sp_keys, sp_idx, SPEC_CAP, sp_count);
+                                   sp_keys, sp_idx, SPEC_CAP, sp_count, ub_mask);
         q.res_off = 0;
         clk_end(1);
         spcand.valid = false;
@@ -963,9 +1002,9 @@ class Solver final : public lbfgsb_hip_ctx {
       } else {
         clk_begin(1);
         const double chi = (nr_flag(col) && lbk::maxc_for(col - 1) > 10) ? -1.0 : spec_hi(cnstnd);
-        lbk::launch_update_scan<T>(q, n, x, l, u, nbd8, g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+        lbk::launch_update_scan<T>(q, n, x, lk(l), uk(u), nbk(), g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
                                    (T *)nullptr, W(), head, col, itail, 0, 1, nr_flag(col), chi,
-                                   sp_keys, sp_idx, SPEC_CAP, sp_count);
+                                   sp_keys, sp_idx, SPEC_CAP, sp_count, ub_mask);
         clk_end(1);
         spcand.valid = false;
         if (chi >= 0.0) CHK(spec_queue(x, l, u, g, head, col, stp));
@@ -1081,6 +1120,11 @@ class Solver final : public lbfgsb_hip_ctx {
       if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
     if (lbh::str60_eq(task, "START")) nbd8_src = nullptr;  // (a new run may reuse the buffer)
     CHK(ensure_nbd8(nbd));
+    if (ub_mask && !lbh::str60_eq(task, "START")) {  // other arrays than the ones START looked at
+      if (L.l != ub_l) ub_mask &= ~1;
+      if (L.u != ub_u) ub_mask &= ~2;
+      if (nbd != ub_nbd) ub_mask &= ~4;
+    }
     Flow flow = NEXT;
 #define PHASE(call)               \
   {                               \

@@ -277,8 +277,8 @@
       lbk::launch_cauchy_window<T>(q, n, row0, tbrk, lo_t, lo_i, hi, keys[0], idx[0], SEL_CAP,
                                    d_count);
     else
-      lbk::launch_cauchy_window_fly<T>(q, n, row0, x, l, u, nbd8, g, iwhere, lo_t, lo_i, hi, keys[0],
-                                       idx[0], SEL_CAP, d_count);
+      lbk::launch_cauchy_window_fly<T>(q, n, row0, x, lk(l), uk(u), nbk(), g, iwhere, lo_t, lo_i, hi, keys[0],
+                                       idx[0], SEL_CAP, d_count, ub_mask);
     lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
                                      head, col, r, d_src(), pend, d_msg);
     const size_t fcount = 2 + (size_t)FAST_CAP * recl;

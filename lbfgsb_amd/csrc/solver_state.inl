@@ -167,14 +167,16 @@
       //  the z buffer here instead of the caller's x -- the same five store streams)
       const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
       if (which == 3)  // with a pending pair: the variant every iteration after an update runs
-        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r_own, pp ? (T *)nullptr : r_own, l, u,
-                                    nbd8, iwhere, (const T *)x, (const T *)g, W(), head, col, 1.0, cf, cf,
-                                    lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own, lean ? z : (T *)nullptr, 1,
-                                    lbk::Pend{1, 0.5, lean ? 1 : 0}, lean ? t_own : d);
+        lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r_own, pp ? (T *)nullptr : r_own, lk(l),
+                                    uk(u), nbk(), iwhere, (const T *)x, (const T *)g, W(), head, col, 1.0, cf,
+                                    cf, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own,
+                                    lean ? z : (T *)nullptr, 1, lbk::Pend{1, 0.5, lean ? 1 : 0},
+                                    lean ? t_own : d, ub_mask);
       else             // as the evaluation of a trial point: reduces only
-        lbk::launch_update_scan<T>(q, n, (const T *)x, l, u, nbd8, (const T *)g, r_own, lean ? t_own : d,
-                                   lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
-                                   (head + col - 2) % m + 1, 0, 0, nr_flag(col));
+        lbk::launch_update_scan<T>(q, n, (const T *)x, lk(l), uk(u), nbk(), (const T *)g, r_own,
+                                   lean ? t_own : d, lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
+                                   (head + col - 2) % m + 1, 0, 0, nr_flag(col), -1.0, nullptr, nullptr, 0,
+                                   nullptr, ub_mask);
     } else
       return fail(LBFGSB_E_ARG, "unknown kernel");
     return 0;
@@ -250,3 +252,4 @@
     closed_form = nclosed, three_pass = nthreepass;
   }
   const void *prev_iterate() const override { return t; }
+  int uniform_mask() const override { return ub_mask; }

@@ -308,10 +308,10 @@
     clk_begin(2);
     // (ping-pong buffers: no t = x, r = g copies -- the roles change below -- and the trial point
     //  goes to the other x buffer, which is where the pending pair's t is read from, row by row)
-    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, l, u, nbd8,
-                                iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
+    lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, lk(l), uk(u),
+                                nbk(), iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
                                 pp ? (T *)nullptr : t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
-                                pend, d_src());
+                                pend, d_src(), ub_mask);
     clk_end(2);
     pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
     d_impl = z_in_x = lean;
@@ -405,6 +405,11 @@
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
       PG_MIN = v;
       return 0;
+    }
+    if (k == "uniform_bounds") {
+      const int rc = flag(ub_on);
+      if (!ub_on) ub_mask = 0;
+      return rc;
     }
     if (k == "wgrid") return in_range(1, lbk::MAX_BLOCKS - 1, q.tune.wgrid);
     if (k == "pipe") return in_range(-1, 1, q.tune.pipe);

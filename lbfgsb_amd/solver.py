@@ -327,6 +327,12 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_path_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def uniform_bounds(self) -> int:
+        """bit 0 / 1 / 2: l / u / nbd hold one value each and are read as constants by the passes over W"""
+        c = C.c_int32()
+        check(self.lib.lbfgsb_hip_uniform_bounds(self.h, C.byref(c)))
+        return int(c.value)
+
     def tie_splits(self) -> int:
         """setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints"""
         c = C.c_int64()

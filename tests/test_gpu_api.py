@@ -291,3 +291,64 @@ def test_host_entry_with_eight_byte_integers_matches_the_four_byte_one():
     mn, mm = p.m * p.n, p.m * p.m
     assert list(s8.isave[:4]) == [mn, mm, 4 * mm, 1] and s8.isave[15] == 1 + 2 * mn + 11 * mm + 5 * p.n
     assert list(s4.isave[:16]) == list(s8.isave[:16])      # (no saturation at this size)
+
+
+def test_uniform_bounds_are_detected_and_change_nothing():
+    """Bound arrays that hold one value each are read as constants by the passes over W
+    (lbfgsb_hip_uniform_bounds): detection per array (l, u, nbd independently), and the trajectory --
+    every isave / dsave slot, f, x, the exported state -- is bit for bit the one of a context with the
+    detection switched off."""
+    import numpy as np
+    import torch
+    import lbfgsb_amd as la
+    from oracle import pyoracle as po
+    TIME_D = [5, 6, 7, 8, 9]
+    cases = []
+    cases.append((po.problem_quadratic(5003, 7), 7))                      # l, u, nbd all uniform
+    cases.append((po.problem_quadratic(4099, 6, mixed_nbd=True), 3))      # nbd varies
+    cases.append((po.problem_rosenbrock(1000, 10, 0.0, 0.0), 6))          # l alternates, u and nbd uniform
+    q = po.problem_quadratic(3001, 12)
+    q.u[17] = np.nextafter(1.0, 2.0)                                      # one entry differs in the last bit
+    cases.append((q, 5))
+    q = po.problem_quadratic(2000, 5)
+    q.l[:] = -0.0
+    q.l[3] = 0.0                                                          # -0.0 vs 0.0 count as different
+    q.u[:] = 2.0
+    cases.append((q, 6))
+    for p, want_mask in cases:
+        def run(on):
+            sol = la.DeviceSolver(p.n, p.m, options={"uniform_bounds": 1 if on else 0})
+            xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.zeros(p.n, dtype=torch.float64, device="cuda")]
+            gs = [torch.zeros_like(xs[0]), torch.zeros_like(xs[0])]
+            l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+            nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+            trace, mask = [], None
+            for _ in range(300):
+                t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                if mask is None:
+                    mask = sol.uniform_bounds()
+                torch.cuda.synchronize()
+                wa, iwa = sol.export_state()
+                ds = sol.dsave.copy()
+                ds[TIME_D] = 0
+                trace.append((t, sol.isave[21:44].copy(), ds, float(sol.f[0]), wa, iwa, xs[cur].cpu().numpy()))
+                if t.startswith("FG"):
+                    xh = xs[cur].cpu().numpy()
+                    gh = np.empty_like(xh)
+                    sol.f[0] = p.fg(xh, gh)
+                    gs[cur].copy_(torch.from_numpy(gh))
+                elif t.startswith("NEW_X"):
+                    if sol.isave[29] >= 30:
+                        break
+                else:
+                    break
+            sol.close()
+            return trace, mask
+        a, mask_on = run(True)
+        b, mask_off = run(False)
+        assert mask_on == want_mask and mask_off == 0, (p.name, mask_on, mask_off, want_mask)
+        assert len(a) == len(b)
+        for k, (ra, rb) in enumerate(zip(a, b)):
+            assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[3] == rb[3], (p.name, k)
+            assert ra[2].tobytes() == rb[2].tobytes() and ra[4].tobytes() == rb[4].tobytes(), (p.name, k)
+            assert np.array_equal(ra[5], rb[5]) and ra[6].tobytes() == rb[6].tobytes(), (p.name, k)
