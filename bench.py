@@ -312,11 +312,15 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
     run.barrier()
     ts0, st0 = run.t_setulb, sol.stats()
     sol.pass_clock(1)            # hipEvents around every launch of the three W passes
-    cols_timed = []
+    cols_timed, step_ms = [], []
     t0 = time.perf_counter()
+    tp = t0
     for _ in range(steps):
         run.advance(1)
         cols_timed.append(int(sol.isave[27]))
+        tn = time.perf_counter()      # (host clock at the NEW_X return: no extra sync, the value is K / dt)
+        step_ms.append((tn - tp) * 1e3)
+        tp = tn
     run.barrier()
     dt = time.perf_counter() - t0
     clocks = sol.pass_clock(0)   # {pass: (ms_total, launches)} over the timed region
@@ -327,7 +331,8 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
         dt, dt_setulb = float(tt[0]), float(tt[1])
     st1 = sol.stats()
     return dict(first_iter_s=first_iter_s, nseg_first=nseg_first, warm_done=warm_done, cols_timed=cols_timed,
-                dt=dt, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1)
+                dt=dt, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1,
+                step_ms_median=float(np.median(step_ms)), step_ms_max=float(np.max(step_ms)))
 
 
 def pass_bytes(col, rbytes, pp, lean=True, ub=0):
@@ -360,6 +365,7 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
         closed, three, _ = run.sol.path_counts()
         return {"config": name, "n": n, "m": m, "dtype": "f32" if real32 else "f64", "value": steps / r["dt"],
                 "unit": "iters/sec", "ms_per_step": r["dt"] / steps * 1e3, "steps": steps,
+                "ms_per_step_median": r["step_ms_median"], "ms_per_step_max": r["step_ms_max"],
                 "warmup_run": r["warm_done"], "col_timed": [min(r["cols_timed"]), max(r["cols_timed"])],
                 "first_iteration_s": r["first_iter_s"], "first_iteration_nseg": r["nseg_first"],
                 "host_syncs_per_iter": (r["st1"]["syncs"] - r["st0"]["syncs"]) / steps,
@@ -519,6 +525,8 @@ def main():
         "col_min_timed": min(cols_timed),
         "col_max_timed": max(cols_timed),
         "ms_per_step": dt / a.steps * 1e3,
+        "ms_per_step_median": r["step_ms_median"],
+        "ms_per_step_max": r["step_ms_max"],
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
