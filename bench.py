@@ -369,6 +369,7 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "warmup_run": r["warm_done"], "col_timed": [min(r["cols_timed"]), max(r["cols_timed"])],
                 "first_iteration_s": r["first_iter_s"], "first_iteration_nseg": r["nseg_first"],
                 "host_syncs_per_iter": (r["st1"]["syncs"] - r["st0"]["syncs"]) / steps,
+                "freev_passes_skipped_per_iter": (r["st1"]["freev_skipped"] - r["st0"]["freev_skipped"]) / steps,
                 "passes": passes, "subspace_steps_closed_form": closed, "subspace_steps_three_pass": three,
                 "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0]),
                 "uniform_bounds_mask": ub, "options": opts}
@@ -556,6 +557,7 @@ def main():
         "kernel_launches_per_iter": (stats["launches"] - st0["launches"]) / a.steps,
         "host_blocked_ms_per_iter": (stats["wait_seconds"] - st0["wait_seconds"]) / a.steps * 1e3,
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
+        "freev_passes_skipped_per_iter": (stats["freev_skipped"] - st0["freev_skipped"]) / a.steps,
         "tie_splits": sol.tie_splits(),
         "subspace_steps_closed_form": closed_steps,
         "subspace_steps_three_pass": three_steps,

@@ -349,6 +349,11 @@ int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
  * the detection. */
 int lbfgsb_hip_uniform_bounds(lbfgsb_hip_ctx *ctx, int32_t *mask);
 
+/* iterations so far whose freev (src/lbfgsb.f90:1980-2059) needed neither its counting pass nor a host
+ * sync: no iwhere entry had changed since the previous freev (the update pass counts the entries it
+ * changes, the walk knows the rows it fixes), so nobody entered or left the free set */
+int lbfgsb_hip_freev_skipped(lbfgsb_hip_ctx *ctx, int64_t *count);
+
 /* several ranks: collectives issued so far (all-gathers of partial sums, of breakpoint records, of
  * halo values) and the bytes THIS rank contributed to them */
 int lbfgsb_hip_comm_stats(lbfgsb_hip_ctx *ctx, int64_t *collectives, int64_t *bytes_contributed);

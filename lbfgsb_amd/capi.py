@@ -56,6 +56,7 @@ PROTOTYPES = {
     "lbfgsb_hip_set_option": (C.c_int, [_vp, _cp, C.c_double]),
     "lbfgsb_hip_comm_stats": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_uniform_bounds": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_freev_skipped": (C.c_int, [_vp, _vp]),
 }
 
 F_REAL32 = 1

@@ -224,6 +224,12 @@ int lbfgsb_hip_comm_stats(lbfgsb_hip_ctx *ctx, int64_t *collectives, int64_t *by
   return 0;
 }
 
+int lbfgsb_hip_freev_skipped(lbfgsb_hip_ctx *ctx, int64_t *count) {
+  if (!ctx || !count) return fail(LBFGSB_E_ARG, "freev_skipped: NULL argument");
+  *count = ctx->freev_skipped();
+  return 0;
+}
+
 int lbfgsb_hip_uniform_bounds(lbfgsb_hip_ctx *ctx, int32_t *mask) {
   if (!ctx || !mask) return fail(LBFGSB_E_ARG, "uniform_bounds: NULL argument");
   *mask = ctx->uniform_mask();

@@ -503,6 +503,7 @@ class Solver final : public lbfgsb_hip_ctx {
       rep.vec_a4("U =", host_vec(u).data(), n);
     }
     lbk::launch_active<T>(q, n, x, l, u, nbd, iwhere, wasfree);  // :965-1040
+    iw_dirty = 1.0;
     CHK(fetch(4, 0, 0));
     prjctd = h_res[0] > 0.0;
     cnstnd = h_res[1] > 0.0;
@@ -580,6 +581,7 @@ class Solver final : public lbfgsb_hip_ctx {
         if (chi >= 0.0) CHK(spec_land(c2, chi));
         if (fo) *f = f_scale * h_res[0];
         const double *R = h_res + fo;
+        if (store_iw) iw_dirty += R[4 * MCo + 8];  // (the pass stored the entries that changed)
         gd = R[4 * MCo + 7];
         spec_sbgnrm = R[4 * MCo + 10 + NX];
         std::memcpy(spec.res, R, sizeof(double) * (4 * MCo + 11 + NX));
@@ -680,21 +682,38 @@ class Solver final : public lbfgsb_hip_ctx {
         return again(flow);
       }
       // freev :1980-2059 (counts; the lists only when mirroring Index)
-      if (prevfree)
-        HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
-      const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
-      lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
-      index_valid = true;
-      if (track)
-        HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
-      // sets of sums with ONE host sync (it is wasted only if no variable is free)
-      pre_valid = false;
-      int npre = 0;
       // (two-pass iteration: no cmprlb pass if the closed form applies -- decided for good
       //  once nfree is known, below)
       const bool closed_cand = two_pass && closed_ok && col > 0 && col <= two_pass_maxcol &&
                                (!updatd || (nrpre.valid && nrpre.col == col));
+      const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
+      pre_valid = false;
+      if (track && closed_cand && index_valid && !index && iw_dirty == 0.0) {
+        // no iwhere entry has changed since the last freev: nobody enters, nobody leaves, nfree stands
+        // -- neither the counting pass nor a host sync (iw_dirty is a sum over all ranks)
+        nfreev_skipped++;
+        chg_local = 0;
+        cachyt += now_s() - cpu1;
+        nintol += nseg;
+        nenter_g = 0;
+        ileave_g = nglob + 1;
+        wrk = updatd;
+        if (ipr >= 99) {  // :2023-2057
+          std::fprintf(rep.out, " %11lld  variables leave; %11lld  variables enter\n", 0ll, 0ll);
+          std::fprintf(rep.out, " %11lld  variables are free at GCP %11d\n", (long long)nfree_g, iter + 1);
+        }
+        return 0;
+      }
+      if (prevfree)
+        HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
+      lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
+      index_valid = true;
+      iw_dirty = 0.0;
+      if (track)
+        HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
+      // sets of sums with ONE host sync (it is wasted only if no variable is free)
+      int npre = 0;
       if (col > 0 && !closed_cand) {
         lbk::Coef cf;
         bool plain;
@@ -998,7 +1017,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (reuse) {
         std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
         if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
-          lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere);  // the pass held it back
+          lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere), iw_dirty += 1.0;  // the pass held it back
       } else {
         clk_begin(1);
         const double chi = (nr_flag(col) && lbk::maxc_for(col - 1) > 10) ? -1.0 : spec_hi(cnstnd);
@@ -1010,6 +1029,7 @@ class Solver final : public lbfgsb_hip_ctx {
         if (chi >= 0.0) CHK(spec_queue(x, l, u, g, head, col, stp));
         CHK(fetch(4 * MCo + 9 + NX, 1, 1));
         if (chi >= 0.0) CHK(spec_land(col, chi));
+        iw_dirty += h_res[4 * MCo + 8];
       }
       nrpre.valid = false;
       if (NX) {  // formk's new row/column with the pre-walk free set (update_scan_kernel NEWROW)
@@ -1159,6 +1179,13 @@ class Solver final : public lbfgsb_hip_ctx {
 
   int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
   bool index_valid = false;  // a freev has run: wasfree is the membership of Index(1:nfree)
+  // How many iwhere entries have changed since the last freev pass (a count where the kernels report
+  // one, >= 1 where they do not).  Zero at the point where freev is due means: the free set is what
+  // the last freev left -- no variable entered or left (:2012-2035 would find nothing), nfree is
+  // unchanged -- and the counting pass and its host sync are skipped (in the steady state of a
+  // bounded problem most iterations cross no breakpoint and change no status).
+  double iw_dirty = 1.0;
+  int64_t nfreev_skipped = 0;
 
 #include "solver_state.inl"     // state exchange, per-kernel doors, communicators
 };

@@ -642,6 +642,7 @@
   int close_gcp(double tsum, double last_t, int64_t last_i) {
     gcp.tsum = tsum, gcp.last_t = last_t, gcp.last_i = last_i, gcp.copy_x = false;
     z_valid = false;
+    iw_dirty += fix_overflow ? 1.0 : (double)fixlist.size();  // rows whose iwhere the walk sets
     if (fix_overflow) {  // long walk: the cursor-based kernel (it writes z on the way)
       CHK(ensure_tbrk());
       lbk::launch_cauchy_finish<T>(q, n, row0, (const T *)cx, (const T *)cl, (const T *)cu,
@@ -854,6 +855,7 @@
     gcp = Gcp{};
     gcp.tsum = tsum, gcp.last_t = ks > 0 ? t_last : -1.0, gcp.last_i = i_last;
     lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tsum, gcp.last_t, gcp.last_i);
+    iw_dirty += 1.0;
     z_valid = true;
     done = true;
     return 0;
@@ -909,6 +911,7 @@
     };
     if (!scan.ready) {
       lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
+      iw_dirty += 1.0;  // (this scan does not count the entries it changes)
       tbrk_valid = true;
       CHK(fetch(2 * MC + 4, 1, 0));
       for (int j = 0; j < col; ++j) {
@@ -965,6 +968,7 @@
       if (h_res[0] >= 1.0e4 * epsmch * (-f1)) {
       lbk::launch_cauchy_finish<T>(q, n, row0, x, l, u, g, tbrk, iwhere, z, tstar, tstar,
                                    std::numeric_limits<int64_t>::max(), 1);
+      iw_dirty += 1.0;
       gcp = Gcp{};
       gcp.tsum = tstar, gcp.last_t = tstar, gcp.last_i = std::numeric_limits<int64_t>::max();
       z_valid = true;

@@ -82,6 +82,8 @@
     };
     get(sy), get(ss), get(wt), get(wn), get(snd);
     t = t_own, r = r_own;  // (the imported t and r live in the context's own buffers, whichever entry is used)
+    ub_mask = 0;           // (uniform bounds are detected by a START only)
+    iw_dirty = 1.0;        // (the imported iwhere has not been through a freev of this context)
     for (T *dst : {z, r, d, t, xp}) {
       HIPCHK(hipMemcpyAsync(dst, ps, (size_t)n * sizeof(T), hipMemcpyHostToDevice, stream));
       ps += n;
@@ -195,6 +197,7 @@
     std::vector<lbk::iw_t> h((size_t)n);
     for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)h_iw[i];
     HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
+    iw_dirty = 1.0;
     return 0;
   }
   int k_formk_gram(int col, int head, double *out) override {
@@ -251,5 +254,6 @@
   void path_counts(int64_t &closed_form, int64_t &three_pass) const override {
     closed_form = nclosed, three_pass = nthreepass;
   }
+  int64_t freev_skipped() const override { return nfreev_skipped; }
   const void *prev_iterate() const override { return t; }
   int uniform_mask() const override { return ub_mask; }

@@ -344,5 +344,7 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(w)))
         nc, nb = C.c_int64(), C.c_int64()
         check(self.lib.lbfgsb_hip_comm_stats(self.h, C.byref(nc), C.byref(nb)))
+        fs = C.c_int64()
+        check(self.lib.lbfgsb_hip_freev_skipped(self.h, C.byref(fs)))
         return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value, wait_seconds=w.value,
-                    collectives=nc.value, collective_bytes=nb.value)
+                    collectives=nc.value, collective_bytes=nb.value, freev_skipped=fs.value)
