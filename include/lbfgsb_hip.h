@@ -159,7 +159,8 @@ int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const voi
  *     task 'NEW_X', terminal tasks   x[*cur], g[*cur] are the iterate and its gradient.
  *   task 'START': x0 holds the starting point (the call returns 'FG_START' with *cur = 0).
  * The four buffers must stay the same for the whole run; a run uses either this entry or
- * lbfgsb_hip_setulb_dev, not both (LBFGSB_E_STATE).  Everything else -- task protocol, isave / dsave /
+ * lbfgsb_hip_setulb_dev, not both (LBFGSB_E_STATE).  A run resumed from lbfgsb_hip_import_state may
+ * continue through either entry (here: iterate and gradient in x0 / g0, *cur = 0 until the next step).  Everything else -- task protocol, isave / dsave /
  * lsave, results bit for bit -- as lbfgsb_hip_setulb_dev; lbfgsb_hip_export_state writes the
  * reference's t and r slots from wherever they live.
  * ------------------------------------------------------------------------- */

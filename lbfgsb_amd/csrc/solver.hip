@@ -51,6 +51,8 @@ class Solver final : public lbfgsb_hip_ctx {
   // nothing: x and g stay where they are and BECOME t and r, the trial point goes to the other pair.
   T *t = nullptr, *r = nullptr, *t_own = nullptr, *r_own = nullptr;
   bool pp = false;        // this run uses the ping-pong entry
+  int entry_mode = 0;     // which entry this run belongs to: 0 not decided (fresh context, or a state was
+                          // imported: the next call decides), 1 setulb_dev, 2 setulb_dev_pp
   T *xb[2] = {nullptr, nullptr}, *gb[2] = {nullptr, nullptr};
   int pp_cur = 0;         // the pair the last return referred to
   const T *x_lean = nullptr;  // where the first trial point of a lean subspace pass lives (d = x_lean - t)
@@ -1091,10 +1093,10 @@ class Solver final : public lbfgsb_hip_ctx {
   int setulb_dev(void *x_, const void *l_, const void *u_, const int32_t *nbd, double *f,
                  void *g_, double factr, double pgtol, char *task, int iprint, char *csave,
                  int32_t *lsave, int32_t *isave_user, double *dsave) override {
-    if (lbh::str60_eq(task, "START")) {
-      pp = false;
-      t = t_own, r = r_own;
-    } else if (pp) {
+    if (lbh::str60_eq(task, "START") || entry_mode == 0) {
+      if (lbh::str60_eq(task, "START")) t = t_own, r = r_own;
+      pp = false, entry_mode = 1;
+    } else if (entry_mode != 1) {
       return fail(LBFGSB_E_STATE, "this run was started with lbfgsb_hip_setulb_dev_pp");
     }
     Mainlb L;
@@ -1111,11 +1113,13 @@ class Solver final : public lbfgsb_hip_ctx {
       return fail(LBFGSB_E_ARG, "setulb_dev_pp needs two distinct x and two distinct g buffers");
     for (const void *p : {(const void *)x1, (const void *)g1})
       if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
-    if (lbh::str60_eq(task, "START")) {
-      pp = true, pp_cur = 0;
+    if (lbh::str60_eq(task, "START") || entry_mode == 0) {
+      // (entry_mode == 0 without START: a run resumed from lbfgsb_hip_import_state -- the iterate and
+      //  its gradient are in x0 / g0, the imported t and r in the context's own buffers)
+      if (lbh::str60_eq(task, "START")) t = t_own, r = r_own;
+      pp = true, pp_cur = 0, entry_mode = 2;
       xb[0] = (T *)x0, xb[1] = (T *)x1, gb[0] = (T *)g0, gb[1] = (T *)g1;
-      t = t_own, r = r_own;
-    } else if (!pp) {
+    } else if (entry_mode != 2) {
       return fail(LBFGSB_E_STATE, "this run was started with lbfgsb_hip_setulb_dev");
     } else if (xb[0] != (T *)x0 || xb[1] != (T *)x1 || gb[0] != (T *)g0 || gb[1] != (T *)g1) {
       return fail(LBFGSB_E_ARG, "setulb_dev_pp: the four buffers must not change during a run");

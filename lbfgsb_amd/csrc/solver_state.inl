@@ -82,6 +82,7 @@
     };
     get(sy), get(ss), get(wt), get(wn), get(snd);
     t = t_own, r = r_own;  // (the imported t and r live in the context's own buffers, whichever entry is used)
+    entry_mode = 0;        // (either device-pointer entry may continue the imported run)
     ub_mask = 0;           // (uniform bounds are detected by a START only)
     iw_dirty = 1.0;        // (the imported iwhere has not been through a freev of this context)
     for (T *dst : {z, r, d, t, xp}) {

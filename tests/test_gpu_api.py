@@ -352,3 +352,78 @@ def test_uniform_bounds_are_detected_and_change_nothing():
             assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[3] == rb[3], (p.name, k)
             assert ra[2].tobytes() == rb[2].tobytes() and ra[4].tobytes() == rb[4].tobytes(), (p.name, k)
             assert np.array_equal(ra[5], rb[5]) and ra[6].tobytes() == rb[6].tobytes(), (p.name, k)
+
+
+def test_ping_pong_entry_with_mirrored_lists_and_across_a_checkpoint():
+    """Two corners of the ping-pong entry: (a) a context that mirrors the reference's arrays at every return
+    (LBFGSB_F_MIRROR_INDEX: z, d, xp stored, Index / Indx2 kept) driven through the ping-pong entry is bit for bit
+    the classic one, exported wa / iwa included; (b) checkpoint / resume: a run exported at a NEW_X return and
+    imported into a fresh context continues through the ping-pong entry (iterate in x0, gradient in g0) exactly
+    as the uninterrupted run."""
+    import numpy as np
+    import torch
+    import lbfgsb_amd as la
+    from oracle import pyoracle as po
+    TIME_D = [5, 6, 7, 8, 9]
+    for p in (po.problem_quadratic(4099, 7, mixed_nbd=True), po.problem_rosenbrock(1000, 10, 0.0, 0.0)):
+        def run(pp, mirror, stop_at=None, resume=None, iters=24):
+            sol = la.DeviceSolver(p.n, p.m, mirror_index=mirror)
+            x0 = p.x0.copy() if resume is None else resume["x"]
+            xs = [torch.from_numpy(x0).cuda(), torch.full((p.n,), 5.0, dtype=torch.float64, device="cuda")]
+            gs = [torch.zeros_like(xs[0]), torch.full_like(xs[0], 9.0)]
+            if resume is not None:
+                gs[0].copy_(torch.from_numpy(resume["g"]))
+                sol.import_state(resume["wa"], resume["iwa"], resume["isave"])
+                for nm in ("task", "csave", "lsave", "isave", "dsave", "f"):
+                    getattr(sol, nm)[:] = resume[nm]
+            l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+            nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+            x, g, trace, saved = xs[0], gs[0], [], None
+            for _ in range(400):
+                if pp:
+                    t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                    x, g = xs[cur], gs[cur]
+                else:
+                    t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+                torch.cuda.synchronize()
+                wa, iwa = sol.export_state()
+                ds = sol.dsave.copy()
+                ds[TIME_D] = 0
+                trace.append((t, sol.isave[21:44].copy(), ds, float(sol.f[0]), wa, iwa, x.cpu().numpy()))
+                if t.startswith("FG"):
+                    xh = x.cpu().numpy()
+                    gh = np.empty_like(xh)
+                    sol.f[0] = p.fg(xh, gh)
+                    g.copy_(torch.from_numpy(gh))
+                elif t.startswith("NEW_X"):
+                    if stop_at is not None and sol.isave[29] == stop_at:
+                        saved = dict(x=x.cpu().numpy(), g=g.cpu().numpy(), wa=wa, iwa=iwa, task=sol.task.copy(),
+                                     csave=sol.csave.copy(), lsave=sol.lsave.copy(), isave=sol.isave.copy(),
+                                     dsave=sol.dsave.copy(), f=sol.f.copy())
+                        break
+                    if sol.isave[29] >= iters:
+                        break
+                else:
+                    break
+            sol.close()
+            return trace, saved
+
+        def same(a, b, what, skip_first=False):
+            assert len(a) == len(b), (p.name, what, len(a), len(b))
+            for k, (ra, rb) in enumerate(zip(a, b)):
+                assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[3] == rb[3], (p.name, what, k)
+                assert ra[2].tobytes() == rb[2].tobytes() and ra[6].tobytes() == rb[6].tobytes(), (p.name, what, k)
+                if not skip_first:
+                    assert ra[4].tobytes() == rb[4].tobytes() and np.array_equal(ra[5], rb[5]), (p.name, what, k)
+        # (a) mirrored lists
+        a, _ = run(False, True)
+        b, _ = run(True, True)
+        same(a, b, "mirror")
+        # (b) checkpoint at iteration 9, resume through the ping-pong entry
+        full, _ = run(True, False)
+        head, saved = run(True, False, stop_at=9)
+        tail, _ = run(True, False, resume=saved)
+        assert saved is not None and len(head) + len(tail) == len(full)
+        # (the exported wa of a production context is a VIEW of the state -- z, xp slots are dead storage there --
+        #  so across the checkpoint the comparison is on what a caller sees: task, counters, scalars, f, x)
+        same(tail, full[len(head):], "resumed", skip_first=True)
