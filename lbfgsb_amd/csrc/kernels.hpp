@@ -142,6 +142,13 @@ void launch_sort_pairs(Queue &q, void *d_temp, size_t temp_bytes, const uint64_t
 // (one-workgroup bitonic network), through `scratch` otherwise; returns where the sorted list is
 uint32_t *launch_sort_u32(Queue &q, void *d_temp, size_t temp_bytes, uint32_t *keys, uint32_t *scratch,
                           uint32_t count);
+// several ranks: merge the all-gathered record chunks (nranks sorted runs, blocks of `stride` doubles:
+// count, more, records[chunk][recl]) into ONE (t, global index)-ordered run on the device.
+// out = { 4 doubles per rank: count, more, t and index of its last record | the merged records |
+// one byte per merged record: the rank it came from }
+void launch_merge_chunks(Queue &q, int nranks, uint32_t chunk, int recl, size_t stride, const double *all,
+                         uint64_t *keys0, uint64_t *keys1, uint32_t *vals0, uint32_t *vals1, void *d_temp,
+                         size_t temp_bytes, double *out);
 // stable sort of the same pairs by idx (first pass of a (t, idx) lexicographic order)
 void launch_sort_by_idx(Queue &q, void *d_temp, size_t temp_bytes, const uint32_t *idx_in,
                         uint32_t *idx_out, const uint64_t *keys_in, uint64_t *keys_out,

@@ -94,6 +94,15 @@ class Solver final : public lbfgsb_hip_ctx {
   int pf_cur = 0;
   double *h_hdr = nullptr;
   size_t msg_len = 0;  // doubles per rank message
+  // several ranks with a communicator: the all-gathered chunks are merged on the device (one sort of
+  // <= nranks * chunk keys) and arrive on the host as ONE ordered run (solver_cauchy.inl, refill)
+  uint64_t *mg_keys[2] = {nullptr, nullptr};
+  uint32_t *mg_vals[2] = {nullptr, nullptr};
+  void *mg_tmp = nullptr;
+  size_t mg_tmp_bytes = 0, mg_slots = 0;
+  double *d_merged = nullptr;
+  // doubles per rank of the merged message: records + 4 header doubles + one byte per record
+  size_t mg_stride() const { return msg_len + msg_len / 32 + 16; }
   // reductions (several ranks: every rank's partials, rank-major, see fetch)
   double *h_res = nullptr, *d_res_all = nullptr, *h_res_all = nullptr;
   size_t res_len = 0;
@@ -125,7 +134,7 @@ class Solver final : public lbfgsb_hip_ctx {
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all),
-        F(ub_buf);
+        F(ub_buf), F(mg_keys[0]), F(mg_keys[1]), F(mg_vals[0]), F(mg_vals[1]), F(mg_tmp), F(d_merged);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
     auto H = [](auto *&p) {
       if (p) (void)hipHostFree(p);
@@ -237,7 +246,13 @@ class Solver final : public lbfgsb_hip_ctx {
     if (h_msg_loc) (void)hipHostFree(h_msg_loc);
     d_msg_all = h_msg_all = h_msg_loc = nullptr;
     HIPCHK(hipMalloc(&d_msg_all, (size_t)nr * msg_len * sizeof(double)));
-    HIPCHK(hipHostMalloc(&h_msg_all, (size_t)nr * msg_len * sizeof(double)));
+    HIPCHK(hipHostMalloc(&h_msg_all, (size_t)nr * mg_stride() * sizeof(double)));
+    for (auto **p : {(void **)&mg_keys[0], (void **)&mg_keys[1], (void **)&mg_vals[0], (void **)&mg_vals[1],
+                     (void **)&mg_tmp, (void **)&d_merged}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    mg_slots = 0;
     HIPCHK(hipHostMalloc(&h_msg_loc, msg_len * sizeof(double)));
     if (sp_msg_all) (void)hipFree(sp_msg_all);
     if (h_sp_all) (void)hipHostFree(h_sp_all);
