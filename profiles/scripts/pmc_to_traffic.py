@@ -19,12 +19,16 @@ import sys
 import os
 
 # PP=1 in the environment: the bench was driven through the ping-pong entry (3 store streams in the
-# storing pass: 218 B/row instead of 234)
+# storing pass: 218 B/row instead of 234); UB=7: uniform bounds detected (l, u, nbd not streamed: 17 B/row
+# less in each of the two passes of the iteration)
 PP = os.environ.get("PP", "1") == "1"
+UB = int(os.environ.get("UB", "0"))
+_B = (0 if UB & 1 else 8) + (0 if UB & 2 else 8) + (0 if UB & 4 else 1)
+_S = "_ub%d" % UB if UB else ""
 KERNELS = {
-    "update_scan": ("update_scan_kernel<double, 10, true, true, true", lambda n: 194 * n),
-    ("subsm_update_pp" if PP else "subsm_update"): ("subsm_update_kernel<double, 10, true, true, false>",
-                                                    lambda n: (218 if PP else 234) * n),
+    "update_scan" + _S: ("update_scan_kernel<double, 10, true, true, true", lambda n: (177 + _B) * n),
+    ("subsm_update_pp" if PP else "subsm_update") + _S: ("subsm_update_kernel<double, 10, true, true, false>",
+                                                         lambda n: ((201 if PP else 217) + _B) * n),
     "cmprlb_wtv": ("cmprlb_wtv_kernel<double, 10, true, true, true, false>", lambda n: 177 * n),
     "wtv": ("wtv_kernel<double, 10, true>", lambda n: 168 * n),
 }
