@@ -76,8 +76,10 @@ def _explain_divergence(po, p, prev, got, pp=False):
         got.g = s.g.copy()
     # by design: at a NEW_X return a production context already holds the iwhere
     # pattern of the NEXT cauchy scan; xp / the enter-leave half of Indx2 are not materialised
+    # ... and after a REJECTED first trial (FG_LNSRCH in, FG_LNSRCH out) the pattern of the rejected point
     compare_states(got, s, p.n, p.m, po, skip=("xp",), check_lists=False,
-                   check_iwhere=got.task_s.startswith("FG_LN"), stpmx_cond=True)
+                   check_iwhere=got.task_s.startswith("FG_LN") and not prev.task_s.startswith("FG_LN"),
+                   stpmx_cond=True)
 
 
 def drive_with_replay(po, p, max_iter, pp=False, **ctx):
