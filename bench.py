@@ -288,8 +288,12 @@ class Run:
                 raise SystemExit("solver stopped: " + task)
 
     def close(self):
+        import gc
         self.sol.close()
         self.xs = self.gs = self.l = self.u = self.nbd = None
+        # (release the 10+ GB of this leg NOW: a cyclic-garbage pass that frees them in the middle of the next
+        #  leg's timed region costs that leg a 30-70 ms device-wide stall)
+        gc.collect()
         self.torch.cuda.empty_cache()
 
 
