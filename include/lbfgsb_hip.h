@@ -38,7 +38,12 @@ enum {
   LBFGSB_E_STATE = -104    /* call sequence violates the task protocol      */
 };
 
-#define LBFGSB_MAX_M 32
+/* m: the fused passes hold all 2 m operands of a row group in registers and are unrolled for at most
+ * LBFGSB_FUSED_M pairs (two passes over W per iteration for m <= 20, three for 21..32); beyond that a
+ * context composes the same steps from unfused tile kernels (k_wide.hip: correct, memory-bound, not
+ * fast).  LBFGSB_MAX_M only bounds the host's O(m^2) arrays. */
+#define LBFGSB_FUSED_M 32
+#define LBFGSB_MAX_M 1024
 
 /* flags for lbfgsb_hip_create */
 enum {
@@ -206,7 +211,7 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
  * because the reference's own wa offsets (src/lbfgsb.f90:246-265) overflow a 32-bit integer there.
  * With 8-byte integers isave(1:16) receive those offsets in full; n < 2^32 - 16 on one device.
  * m > LBFGSB_MAX_M is answered the way the reference answers its own argument errors: task =
- * 'ERROR: M > 32 (LIMIT OF LBFGSB_HIP)', return value 0, no iteration done (the reference itself puts
+ * 'ERROR: M > 1024 (LIMIT OF LBFGSB_HIP)', return value 0, no iteration done (the reference itself puts
  * no upper limit on m, :93-97). */
 int lbfgsb_hip_setulb_host_ik(int64_t n, int64_t m, void *x, const void *l, const void *u, const void *nbd,
                               void *f, void *g, double factr, double pgtol, void *wa, void *iwa,

@@ -377,11 +377,11 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
       finish_ints();
       return 0;
     }
-    // The reference puts no upper limit on m (:93-97); this library's kernels are unrolled for at most
-    // LBFGSB_MAX_M pairs.  A caller written against the reference sees it the way it sees every other
-    // argument error: a task that starts with 'ERROR', no iteration done.
+    // The reference puts no upper limit on m (:93-97); this library takes up to LBFGSB_MAX_M pairs (fused
+    // kernels up to LBFGSB_FUSED_M, unfused tiles beyond).  A caller written against the reference sees the
+    // limit the way it sees every other argument error: a task that starts with 'ERROR', no iteration done.
     if (m > LBFGSB_MAX_M) {
-      lbh::str60_set(task, "ERROR: M > 32 (LIMIT OF LBFGSB_HIP)");
+      lbh::str60_set(task, "ERROR: M > 1024 (LIMIT OF LBFGSB_HIP)");
       finish_ints();
       return 0;
     }

@@ -1,0 +1,158 @@
+// k_wide.hip -- m > 32: the same iteration out of UNFUSED pieces (part of the gfx950 kernel set).
+//
+// The fused passes of k_update / k_subsm / k_cmprlb keep all 2 col operands of a row group in
+// registers and are unrolled for at most MAXM = 32 pairs.  The reference puts no limit on m
+// (src/lbfgsb.f90:93-97); beyond 32 the solver composes the iteration from the two tile primitives
+// below plus the existing element-wise kernels, in tiles of <= 32 logical columns (circular
+// addressing makes a tile just another (head, col) pair):
+//   W' v            launch_wtv on a tile                      (cauchy's p, subsm's wv, matupd's dots,
+//                                                              formk's inner products with masked columns)
+//   out += W c      tile_axpy_kernel                          (cmprlb's r, subsm's Newton direction)
+// Memory-bound and simple on purpose: this is the completeness path, not the fast one (m <= 32 never
+// comes here).  Element-wise arithmetic follows the reference's operation order like everywhere else.
+#include "kernels_common.hpp"
+
+namespace lbk {
+
+// out_i (+)= sum_j (Wy(i,j) * a_j) / div + Ws(i,j) * b_j over the tc <= 32 logical columns of one tile,
+// j ascending as cmprlb :1576-1581 and subsm :2770-2778 run; rows with mask (iwhere > 0: not free) are
+// left alone when masked != 0.  div = theta for subsm's first term (the reference divides the PRODUCT).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void tile_axpy_kernel(int64_t n, const T *__restrict__ ws,
+                                                          const T *__restrict__ wy, int64_t ldw, int m,
+                                                          int head, int tc, Coef cf, double div,
+                                                          const iw_t *__restrict__ iwhere, int masked, T *out) {
+  for_rows<T, 1>(n, [&](int64_t i, auto) {
+    if (masked && iwhere[i] > 0) return;
+    double acc = (double)out[i];
+    for (int j = 0; j < tc; ++j) {
+      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
+      acc = acc + ((double)wy[off] * cf.a[j]) / div + (double)ws[off] * cf.a[MAXM + j];
+    }
+    out[i] = (T)acc;
+  });
+}
+template <typename T>
+void launch_tile_axpy(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, double div,
+                      const iw_t *iwhere, int masked, T *out) {
+  hipLaunchKernelGGL(tile_axpy_kernel<T>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy, w.ld,
+                     w.m, head, tc, cf, div, iwhere, masked, out);
+  LB_LAUNCHED(q);
+}
+
+// out_i = src_i on the rows selected (want_free: iwhere <= 0, else iwhere > 0), 0 elsewhere
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void masked_copy_kernel(int64_t n, const T *__restrict__ src,
+                                                            const iw_t *__restrict__ iwhere, int want_free,
+                                                            T *__restrict__ out) {
+  for_rows<T, 1>(n, [&](int64_t i, auto) {
+    const bool fr = iwhere[i] <= 0;
+    out[i] = (fr == (want_free != 0)) ? src[i] : (T)0;
+  });
+}
+template <typename T>
+void launch_masked_copy(Queue &q, int64_t n, const T *src, const iw_t *iwhere, int want_free, T *out) {
+  hipLaunchKernelGGL(masked_copy_kernel<T>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, src, iwhere,
+                     want_free, out);
+  LB_LAUNCHED(q);
+}
+
+// cauchy's direction as a vector (:1270-1330): d_i = -g_i for the variables that move (tbrk >= 0, incl.
+// +inf), 0 for the others (tbrk = -1), from the breakpoint times the scan has just written
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cauchy_dvec_kernel(int64_t n, const T *__restrict__ g,
+                                                            const T *__restrict__ tbrk, T *__restrict__ out) {
+  for_rows<T, 1>(n, [&](int64_t i, auto) { out[i] = (double)tbrk[i] >= 0.0 ? (T)(-(double)g[i]) : (T)0; });
+}
+template <typename T>
+void launch_cauchy_dvec(Queue &q, int64_t n, const T *g, const T *tbrk, T *out) {
+  hipLaunchKernelGGL(cauchy_dvec_kernel<T>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, g, tbrk, out);
+  LB_LAUNCHED(q);
+}
+
+// cmprlb's starting value (:1560-1567) on the free rows, 0 elsewhere: plain != 0 (unconstrained with pairs
+// stored): r = -g; else r = -theta (z - x) - g with z the Cauchy point
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cmprlb_init_kernel(int64_t n, const T *__restrict__ x,
+                                                            const T *__restrict__ g, const T *__restrict__ z,
+                                                            const iw_t *__restrict__ iwhere, double theta,
+                                                            int plain, T *__restrict__ out) {
+  for_rows<T, 1>(n, [&](int64_t i, auto) {
+    if (iwhere[i] > 0) {
+      out[i] = (T)0;
+    } else if (plain) {
+      out[i] = (T)(-(double)g[i]);
+    } else {
+      out[i] = (T)(-theta * ((double)z[i] - (double)x[i]) - (double)g[i]);
+    }
+  });
+}
+template <typename T>
+void launch_cmprlb_init(Queue &q, int64_t n, const T *x, const T *g, const T *z, const iw_t *iwhere,
+                        double theta, int plain, T *out) {
+  hipLaunchKernelGGL(cmprlb_init_kernel<T>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, x, g, z, iwhere,
+                     theta, plain, out);
+  LB_LAUNCHED(q);
+}
+
+// subsm's projected step (:2780-2827) from the Newton direction as a vector: dir_i *= 1/theta (dscal :2780,
+// written back: the backtracking branch needs it), z_i = P(z_i + dir_i) on the free rows with the bound
+// rules of :2789-2816.  res: sum [0] = #bound hits (iword), [1] = dd_p = sum (z_i - x_i) g_i over ALL rows
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void subsm_project_kernel(int64_t n, T *z, T *dir,
+                                                              const T *__restrict__ x, const T *__restrict__ g,
+                                                              const T *__restrict__ l, const T *__restrict__ u,
+                                                              const int32_t *__restrict__ nbd,
+                                                              const iw_t *__restrict__ iwhere, double rtheta,
+                                                              double *part) {
+  double acc[2] = {0.0, 0.0};
+  for_rows<T, 1>(n, [&](int64_t i, auto) {
+    double zk = (double)z[i];
+    if (iwhere[i] <= 0) {
+      const double dk = rtheta * (double)dir[i];
+      dir[i] = (T)dk;
+      const double xk = zk, lk = (double)l[i], uk = (double)u[i];
+      const int nb = nbd[i];
+      if (nb != 0) {
+        if (nb == 1) {
+          zk = fmax(lk, xk + dk);
+          if (zk == lk) acc[0] += 1.0;
+        } else if (nb == 2) {
+          const double t1 = fmax(lk, xk + dk);
+          zk = fmin(uk, t1);
+          if (zk == lk || zk == uk) acc[0] += 1.0;
+        } else if (nb == 3) {
+          zk = fmin(uk, xk + dk);
+          if (zk == uk) acc[0] += 1.0;
+        }
+      } else {
+        zk = xk + dk;
+      }
+      z[i] = (T)zk;
+      zk = (double)(T)zk;
+    }
+    acc[1] = acc[1] + (zk - (double)x[i]) * (double)g[i];
+  });
+  block_reduce_store<2>(acc, 2, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_subsm_project(Queue &q, int64_t n, T *z, T *dir, const T *x, const T *g, const T *l, const T *u,
+                          const int32_t *nbd, const iw_t *iwhere, double rtheta) {
+  const int gr = grid_for(n, 1);
+  hipLaunchKernelGGL(subsm_project_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, z, dir, x, g, l, u, nbd,
+                     iwhere, rtheta, q.d_part);
+  LB_LAUNCHED(q);
+  launch_finalize(q, gr, 2, 0, 0);
+}
+
+#define INSTANTIATE(T) \
+  template void launch_tile_axpy<T>(Queue &, int64_t, WStore<T>, int, int, const Coef &, double, const iw_t *, int, T *); \
+  template void launch_masked_copy<T>(Queue &, int64_t, const T *, const iw_t *, int, T *); \
+  template void launch_cauchy_dvec<T>(Queue &, int64_t, const T *, const T *, T *); \
+  template void launch_cmprlb_init<T>(Queue &, int64_t, const T *, const T *, const T *, const iw_t *, double, int, T *); \
+  template void launch_subsm_project<T>(Queue &, int64_t, T *, T *, const T *, const T *, const T *, const T *, const int32_t *, const iw_t *, double);
+INSTANTIATE(double)
+INSTANTIATE(float)
+#undef INSTANTIATE
+
+}  // namespace lbk

@@ -352,6 +352,27 @@ template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
                         WStore<T> w, int head, int col);
 
+// ---- m > 32: unfused tile primitives (k_wide.hip) -------------------------------------------------
+// out_i (+)= sum_j (Wy(i,j) a_j) / div + Ws(i,j) b_j over the tc <= 32 logical columns from `head`
+// (a = cf.a[0..), b = cf.a[MAXM..)); masked: only rows with iwhere <= 0
+template <typename T>
+void launch_tile_axpy(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, double div,
+                      const iw_t *iwhere, int masked, T *out);
+// out = src on the free (want_free) / active rows, 0 elsewhere
+template <typename T>
+void launch_masked_copy(Queue &q, int64_t n, const T *src, const iw_t *iwhere, int want_free, T *out);
+// cauchy's d as a vector from tbrk (moving rows: -g, others 0)
+template <typename T>
+void launch_cauchy_dvec(Queue &q, int64_t n, const T *g, const T *tbrk, T *out);
+// cmprlb's r before the W terms (0 on the rows that are not free)
+template <typename T>
+void launch_cmprlb_init(Queue &q, int64_t n, const T *x, const T *g, const T *z, const iw_t *iwhere,
+                        double theta, int plain, T *out);
+// subsm's projected step from the Newton direction vector; res sum [0] = iword count, [1] = dd_p
+template <typename T>
+void launch_subsm_project(Queue &q, int64_t n, T *z, T *dir, const T *x, const T *g, const T *l, const T *u,
+                          const int32_t *nbd, const iw_t *iwhere, double rtheta);
+
 // ---- built-in objectives -------------------------------------------------------
 // res sum [0] = f contribution of this rank
 template <typename T>

@@ -28,6 +28,7 @@
 // member functions of the three big phases live in files of their own, included inside the class:
 //   solver_cauchy.inl    the Cauchy point: breakpoint provider, exact host walk, parallel search
 //   solver_subspace.inl  formk, cmprlb, subsm (the closed form, the storing pass, backtracking)
+//   solver_wide.inl      m > 32: the same steps out of unfused tile primitives (k_wide.hip)
 //   solver_state.inl     export / import in the reference's wa / iwa layout, per-kernel doors
 // Two device-pointer entries share the state machine: setulb_dev (the caller's x and g in place,
 // t = x / r = g as copies) and setulb_dev_pp (two caller buffer pairs that swap roles, no copies).
@@ -234,6 +235,7 @@ class Solver final : public lbfgsb_hip_ctx {
     wn.assign((size_t)4 * m * m, 0.0);
     snd.assign((size_t)4 * m * m, 0.0);
     wa8m.assign((size_t)8 * m, 0.0);
+    scan.p.assign((size_t)2 * std::max(m, lbk::MAXM), 0.0);
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
@@ -341,6 +343,7 @@ class Solver final : public lbfgsb_hip_ctx {
 
 #include "solver_cauchy.inl"    // the Cauchy point: breakpoint provider, walk, parallel search
 #include "solver_subspace.inl"  // formk, cmprlb, subsm
+#include "solver_wide.inl"      // m > 32: the iteration out of unfused tile primitives
   int print_level = -1;
 
   // =================================================================== mainlb
@@ -573,7 +576,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // update is real (iwhere_update_kernel at the NEW_X entry).
       // Unconstrained problems (two_pass): the same pass -- every row is free, its p = W'd is
       // W'Z r itself (r = -g, c = 0), and the new pair needs no copy pass of its own.
-      if ((cnstnd || two_pass) && ifun == 1) {
+      if ((cnstnd || two_pass) && ifun == 1 && !wide()) {
         const int store_iw = (flags & LBFGSB_F_MIRROR_INDEX) ? 0 : 1;
         int c2, h2, it2;  // matupd's pointer update (:2303-2309), as if this trial is accepted
         if (iupdat + 1 <= m) {
@@ -731,7 +734,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
       // sets of sums with ONE host sync (it is wasted only if no variable is free)
       int npre = 0;
-      if (col > 0 && !closed_cand) {
+      if (col > 0 && !closed_cand && !wide()) {
         lbk::Coef cf;
         bool plain;
         if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
@@ -806,7 +809,7 @@ class Solver final : public lbfgsb_hip_ctx {
       CHK(ensure_z(x, l, u, g));
     } else {
       cpu1 = now_s();
-      const bool incr = wrk && col <= 20;  // incremental WN1, fused into the cmprlb pass
+      const bool incr = wrk && col <= 20 && !wide();  // incremental WN1, fused into the cmprlb pass
       if (wrk && !incr) CHK(formk(col, head, theta, info));
       if (info != 0) {  // :666-682
         if (ipr >= 1)
@@ -821,8 +824,11 @@ class Solver final : public lbfgsb_hip_ctx {
       // does not cancel)
       const bool closed = two_pass && closed_ok && col <= two_pass_maxcol && !pre_valid &&
                           (!updatd || (nrpre.valid && nrpre.col == col));
-      CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
-                   pre_valid ? pre_res : nullptr, closed));
+      if (wide())
+        CHK(wide_subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info));
+      else
+        CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
+                     pre_valid ? pre_res : nullptr, closed));
       pre_valid = false;
       if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
         if (ipr >= 1)
@@ -1025,7 +1031,12 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     const int MCo = lbk::maxc_for(col - 1);
     double rr;
-    if (cnstnd || two_pass) {
+    std::vector<double> wsy, wss;  // (m > 32: Sy's new row, Ss's new column from the tile passes)
+    if (wide()) {
+      CHK(ensure_d(x));
+      CHK(wide_matupd(g, stp, head, col, wsy, wss, rr));
+      spec.valid = false, pend.on = 0, scan.ready = false;
+    } else if (cnstnd || two_pass) {
       // the next loop trip starts with cauchy: do its n-loop in the same pass over W --
       // unless that pass already ran as the evaluation of the accepted trial point
       const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
@@ -1087,8 +1098,8 @@ class Solver final : public lbfgsb_hip_ctx {
       }
     }
     for (int j = 0; j < col - 1; ++j) {
-      SY(col - 1, j) = h_res[j];
-      SS(j, col - 1) = h_res[MCo + j];
+      SY(col - 1, j) = wide() ? wsy[j] : h_res[j];
+      SS(j, col - 1) = wide() ? wss[j] : h_res[MCo + j];
     }
     SS(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
     SY(col - 1, col - 1) = dr;

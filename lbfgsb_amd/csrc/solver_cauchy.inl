@@ -978,7 +978,7 @@
   // results of the n-loop of cauchy when it was fused into the matupd pass
   struct ScanOut {
     bool ready = false;
-    double p[2 * lbk::MAXM];
+    std::vector<double> p;  // 2 m
     double f1 = 0, nbreak = 0, nunb = 0, nunbnz = 0, bkmin = 0;
   } scan;
 
@@ -1009,7 +1009,9 @@
       if (ipr >= 99) std::fprintf(rep.out, "\n---------------- exit CAUCHY----------------------\n\n");
       return 0;
     };
-    if (!scan.ready) {
+    if (!scan.ready && wide()) {
+      CHK(wide_cauchy_scan(x, l, u, nbd, g, head, col));
+    } else if (!scan.ready) {
       lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
       iw_dirty += 1.0;  // (this scan does not count the entries it changes)
       tbrk_valid = true;
@@ -1287,7 +1289,7 @@
           pv.grow++;
           double in_window = 0.0;
           const bool may_pg = col > 0 && (flags & LBFGSB_F_PARALLEL_GCP) && iter == 1 && !pv.have &&
-                              print_level < 99;
+                              print_level < 99 && !wide();
           CHK(window_fetch(pv, last_t, last_i, hi, x, l, u, g, head, col, may_pg ? &in_window : nullptr));
           if (may_pg && in_window > PG_MIN) {
             // many breakpoints within reach and pairs stored: sort + scans on the device (opt-in)

@@ -140,6 +140,10 @@
   int k_wtv(const void *v, int col, int head, double *out, bool launch_only) override {
     HIPCHK(hipSetDevice(device));
     if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "wtv: bad col/head");
+    if (col > lbk::MAXM) {  // beyond the fused width: tile by tile
+      if (launch_only) return fail(LBFGSB_E_ARG, "wtv: launch-only timing is for col <= 32");
+      return wide_wtv((const T *)v, col, head, out, out + col);
+    }
     if (launch_only) {
       lbk::launch_wtv_nofinalize<T>(q, n, W(), head, col, (const T *)v);
       return 0;
@@ -154,7 +158,7 @@
     return 0;
   }
   int k_launch(int which, const void *x, const void *g, int col, int head) override {
-    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "bad col/head");
+    if (col < 1 || col > m || head < 1 || head > m || col > lbk::MAXM) return fail(LBFGSB_E_ARG, "bad col/head");
     HIPCHK(hipSetDevice(device));
     lbk::Coef cf;
     std::memset(&cf, 0, sizeof cf);
@@ -203,7 +207,8 @@
   }
   int k_formk_gram(int col, int head, double *out) override {
     HIPCHK(hipSetDevice(device));
-    if (col < 1 || col > m || head < 1 || head > m) return fail(LBFGSB_E_ARG, "formk_gram: bad col/head");
+    if (col < 1 || col > m || head < 1 || head > m || col > lbk::MAXM)
+      return fail(LBFGSB_E_ARG, "formk_gram: bad col/head");
     lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     const int E = 2 * col * col + col;
     CHK(fetch(E, 0, 0));

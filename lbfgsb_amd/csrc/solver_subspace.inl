@@ -8,6 +8,7 @@
   // variables changed status for the sparse patches)
   int formk_scratch(int col, int head) {
     CHK(commit_pending((const T *)cg, col, head));
+    if (wide()) return wide_formk(col, head);
     lbk::launch_formk_gram<T>(q, n, W(), head, col, iwhere);
     const int E = 2 * col * col + col;
     CHK(fetch(E, 0, 0));
@@ -425,7 +426,8 @@
     double t[4][lbk::MAXM];  // logical columns 0..col-1: Y'ZZ'Y row, S'AA'S row, L_a row, R_z column
   } nrpre;
   double nrc[4][lbk::MAXM];  // what the walk's fixed rows take from / add to them
-  double p_fin[2 * lbk::MAXM], p_ini_max = 0.0;
+  std::vector<double> p_fin = std::vector<double>(2 * (size_t)LBFGSB_MAX_M, 0.0);
+  double p_ini_max = 0.0;
   bool closed_ok = false;    // this call's cauchy left everything the closed form needs
   int64_t nclosed = 0, nthreepass = 0;
 

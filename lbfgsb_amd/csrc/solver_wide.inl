@@ -1,0 +1,147 @@
+// solver_wide.inl -- member functions of Solver<T> (included inside the class body in solver.hip):
+// the iteration for m > 32.  The reference puts no upper limit on m (src/lbfgsb.f90:93-97); the fused
+// passes are unrolled for at most MAXM = 32 pairs.  A context with more pairs composes every
+// n-dimensional step from the unfused pieces of k_wide.hip, in tiles of <= 32 logical columns (the
+// circular column addressing makes a tile just another (head, col) pair): matupd's dot products,
+// cauchy's p = W'd, formk's inner products (from scratch, one masked column at a time), cmprlb's r,
+// subsm's W'r and Newton direction, the projected step.  No pending pair, no speculative pass, no closed
+// form: the reference's own sequence of steps, each a memory-bound kernel -- the completeness path, not
+// the fast one.  Element-wise arithmetic in the reference's operation order, as everywhere.
+bool wide() const { return m > lbk::MAXM; }
+
+// outY[j] = Wy_j' v, outS[j] = Ws_j' v for the col logical columns, tile by tile (one fetch per tile)
+int wide_wtv(const T *v, int col, int head, double *outY, double *outS) {
+  for (int j0 = 0; j0 < col; j0 += lbk::MAXM) {
+    const int tc = std::min(lbk::MAXM, col - j0);
+    const int h = (head - 1 + j0) % m + 1;
+    lbk::launch_wtv<T>(q, n, W(), h, tc, v);
+    const int MC = lbk::maxc_for(tc);
+    CHK(fetch(2 * MC, 0, 0));
+    for (int j = 0; j < tc; ++j) outY[j0 + j] = h_res[j], outS[j0 + j] = h_res[MC + j];
+  }
+  return 0;
+}
+// out_i += sum_j (Wy(i,j) a_j) / div + Ws(i,j) b_j, j ascending over all col columns
+int wide_axpy(T *out, const double *a, const double *b, int col, int head, double div, int masked) {
+  for (int j0 = 0; j0 < col; j0 += lbk::MAXM) {
+    const int tc = std::min(lbk::MAXM, col - j0);
+    const int h = (head - 1 + j0) % m + 1;
+    lbk::Coef cf;
+    std::memset(&cf, 0, sizeof cf);
+    for (int j = 0; j < tc; ++j) cf.a[j] = a[j0 + j], cf.a[lbk::MAXM + j] = b[j0 + j];
+    lbk::launch_tile_axpy<T>(q, n, W(), h, tc, cf, div, iwhere, masked, out);
+  }
+  return 0;
+}
+T *wcol(T *base, int head, int j) const { return base + (int64_t)((head - 1 + j) % m) * ld; }
+
+// mainlb :812-824 + matupd :2291-2346: the new pair goes into its W slot at once; Sy's new row, Ss's new
+// column and rr = y'y from W' s and W' y
+int wide_matupd(const T *g, double stp, int head, int col, std::vector<double> &sy_row,
+                std::vector<double> &ss_col, double &rr) {
+  lbk::launch_pair_commit<T>(q, n, g, r, d, lbk::Pend{1, stp, 0}, W(), head, col);
+  std::vector<double> oy(col), os(col);
+  CHK(wide_wtv(wcol(ws, head, col - 1), col, head, oy.data(), os.data()));  // v = s
+  sy_row.assign(oy.begin(), oy.end());  // s'Wy_j  (:2335)
+  ss_col.assign(os.begin(), os.end());  // Ws_j's  (:2336)
+  CHK(wide_wtv(wcol(wy, head, col - 1), col, head, oy.data(), os.data()));  // v = y
+  rr = oy[col - 1];                     // y'y (:816)
+  return 0;
+}
+
+// cauchy's n-loop (:1270-1330) without the fused p: the col = 0 scan, then p = W'd with d as a vector
+int wide_cauchy_scan(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, int head, int col) {
+  lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, 0);
+  iw_dirty += 1.0;
+  tbrk_valid = true;
+  CHK(fetch(4, 1, 0));
+  scan.f1 = h_res[0], scan.nbreak = h_res[1], scan.nunb = h_res[2], scan.nunbnz = h_res[3];
+  scan.bkmin = h_res[4];
+  if (col > 0) {
+    lbk::launch_cauchy_dvec<T>(q, n, g, tbrk, xp);
+    CHK(wide_wtv(xp, col, head, &scan.p[0], &scan.p[col]));
+  }
+  return 0;
+}
+
+// formk's inner products from scratch (:1756-1851), one masked column at a time:
+//   Z Wy_j  -> Wy_i'(.) = Y'ZZ'Y(i,j),  Ws_i'(.) = R_z(i,j) (i <= j)
+//   A Ws_j  -> Ws_i'(.) = S'AA'S(i,j),  Wy_i'(.) = L_a(j,i) (j > i)
+int wide_formk(int col, int head) {
+  lbh::Mat WN1{snd.data(), 2 * m};
+  std::vector<double> a(col), b(col);
+  for (int j = 0; j < col; ++j) {
+    lbk::launch_masked_copy<T>(q, n, wcol(wy, head, j), iwhere, 1, xp);
+    CHK(wide_wtv(xp, col, head, a.data(), b.data()));
+    for (int i = j; i < col; ++i) WN1(i, j) = a[i];
+    for (int i = 0; i <= j; ++i) WN1(m + i, j) = b[i];
+    lbk::launch_masked_copy<T>(q, n, wcol(ws, head, j), iwhere, 0, xp);
+    CHK(wide_wtv(xp, col, head, a.data(), b.data()));
+    for (int i = j; i < col; ++i) WN1(m + i, m + j) = b[i];
+    for (int i = 0; i < j; ++i) WN1(m + j, i) = a[i];
+  }
+  return 0;
+}
+
+// cmprlb (:1548-1586) + subsm (:2676-2885) with r, W'r and the Newton direction as vectors (tbrk)
+int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta, int col,
+                  int head, bool cnstnd, int &iword, int &info) {
+  const int ipr = quiet ? -1 : print_level;
+  const bool plain = !cnstnd && col > 0;
+  std::vector<double> a1(col, 0.0), a2(col, 0.0);
+  if (!plain) {
+    if (lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]) != 0) {
+      info = -8;
+      return 0;
+    }
+    for (int j = 0; j < col; ++j) a1[j] = wa8m[j], a2[j] = theta * wa8m[col + j];  // :1576-1577
+  }
+  CHK(ensure_z(x, l, u, g));
+  lbk::launch_cmprlb_init<T>(q, n, x, g, z, iwhere, theta, plain ? 1 : 0, tbrk);
+  tbrk_valid = false;
+  if (!plain) CHK(wide_axpy(tbrk, a1.data(), a2.data(), col, head, 1.0, 1));
+  double *wv = &wa8m[0];
+  {
+    std::vector<double> oy(col), os(col);
+    CHK(wide_wtv(tbrk, col, head, oy.data(), os.data()));  // :2742-2754 (r is 0 off the free rows)
+    for (int i = 0; i < col; ++i) wv[i] = oy[i], wv[col + i] = theta * os[i];
+  }
+  nthreepass++;
+  if (ipr >= 99) std::fprintf(rep.out, "\n----------------SUBSM entered-----------------\n\n");  // :2738
+  lbh::Mat WN{wn.data(), 2 * m};
+  const int col2 = 2 * col;
+  info = lbh::dtrsl(WN, col2, wv, 11);
+  if (info != 0) return 0;
+  for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+  info = lbh::dtrsl(WN, col2, wv, 1);
+  if (info != 0) return 0;
+  CHK(wide_axpy(tbrk, wv, wv + col, col, head, theta, 1));  // :2770-2778
+  if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));  // :2787
+  lbk::launch_subsm_project<T>(q, n, z, tbrk, x, g, l, u, nbd, iwhere, 1.0 / theta);  // :2780-2827
+  z_valid = true;
+  CHK(fetch(2, 0, 0));
+  iword = h_res[0] > 0.0 ? 1 : 0;
+  const double dd_p = h_res[1];
+  ls.ready = false;
+  if (iword == 0 || dd_p <= 0.0) {  // :2820, :2828
+    if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");  // :2883
+    return 0;
+  }
+  if (rep.out && !quiet && print_level >= 0) {
+    std::fprintf(rep.out, " Positive dir derivative in projection \n");
+    std::fprintf(rep.out, " Using the backtracking step \n");
+  }
+  if (!(flags & LBFGSB_F_MIRROR_INDEX)) CHK(write_xcp(xp, x, l, u, g));
+  lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
+  CHK(fetch(0, 1, 0));
+  const double alpha = std::min(1.0, h_res[0]);
+  int64_t ibd = -1;
+  if (alpha < 1.0) {
+    lbk::launch_subsm_argalpha<T>(q, n, row0, xp, tbrk, l, u, nbd, iwhere, alpha);
+    CHK(fetch(0, 1, 0));
+    ibd = (int64_t)h_res[0];
+  }
+  lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, tbrk, l, u, iwhere, alpha, ibd);
+  if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");
+  return 0;
+}

@@ -225,28 +225,29 @@ def test_ping_pong_entry_is_bit_identical_to_the_classic_one():
 
 
 def test_m_beyond_the_limit_is_answered_like_an_argument_error():
-    """The reference puts no upper limit on m (src/lbfgsb.f90:93-97); the kernels are unrolled for at
-    most LBFGSB_MAX_M = 32 pairs.  Through the reference-shaped host entry a larger m is answered the
-    way the reference answers its own argument errors -- task = 'ERROR: ...', no iteration, return
-    code 0 -- in both integer widths; the context entry refuses it with LBFGSB_E_ARG."""
+    """The reference puts no upper limit on m (src/lbfgsb.f90:93-97); this library takes m <= LBFGSB_MAX_M
+    = 1024 (fused kernels up to 32 pairs, unfused tiles beyond: test_gpu_parity::test_wide_memory_*).
+    Through the reference-shaped host entry a larger m is answered the way the reference answers its own
+    argument errors -- task = 'ERROR: ...', no iteration, return code 0 -- in both integer widths; the
+    context entry refuses it with LBFGSB_E_ARG."""
     import ctypes as C
     import numpy as np
     import lbfgsb_amd as la
     from lbfgsb_amd import capi
     from oracle import pyoracle as po
-    n, m = 50, 33
+    n, m = 50, 1025
     p = po.problem_quadratic(n, m)
     s = po.State.fresh(p)
     la.setulb(n, m, s.x, p.l, p.u, p.nbd.astype(np.int32), s.f, s.g, 0.0, 0.0, s.wa, s.iwa, s.task, -1,
               s.csave, s.lsave, s.isave, s.dsave)
-    assert s.task_s == "ERROR: M > 32 (LIMIT OF LBFGSB_HIP)"
+    assert s.task_s == "ERROR: M > 1024 (LIMIT OF LBFGSB_HIP)"
     lib = la.load_library()
     s8 = po.State.fresh(p, np.int64)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
     rc = lib.lbfgsb_hip_setulb_host_ik(n, m, vp(s8.x), vp(p.l), vp(p.u), vp(p.nbd.astype(np.int64)), vp(s8.f),
                                        vp(s8.g), 0.0, 0.0, vp(s8.wa), vp(s8.iwa), vp(s8.task), -1, vp(s8.csave),
                                        vp(s8.lsave), vp(s8.isave), vp(s8.dsave), None, 8, 0, 8)
-    assert rc == 0 and s8.task_s == "ERROR: M > 32 (LIMIT OF LBFGSB_HIP)"
+    assert rc == 0 and s8.task_s == "ERROR: M > 1024 (LIMIT OF LBFGSB_HIP)"
     h = C.c_void_p()
     assert lib.lbfgsb_hip_create(n, n, 0, m, 0, 0, None, C.byref(h)) == -101   # LBFGSB_E_ARG
 

@@ -153,6 +153,8 @@ def drive_with_replay(po, p, max_iter, pp=False, **ctx):
     (0, 120, 400, 1, 13, None), (5000, 40, 3000, 11, 33, None),
     # the ping-pong entry (t = x, r = g as a change of roles between two caller buffer pairs)
     (0, 120, 400, 1, 13, "pp"), (5000, 40, 3000, 11, 33, "pp"), (7300, 40, 1500, 1, 25, "pp,lean=0"),
+    # m > 32: the iteration out of unfused tile primitives (solver_wide.inl)
+    (8000, 30, 1200, 33, 80, None), (8100, 20, 1200, 33, 80, "pp"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
     (7000, 40, 1500, 1, 25, "spec_capture=1"), (7100, 40, 1500, 1, 25, "two_pass=0"),

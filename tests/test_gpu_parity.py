@@ -695,6 +695,77 @@ def test_one_step_parity_at_size(env, kind, n, m, upto):
     assert tested >= 6, tested
 
 
+WIDE_CASES = [
+    ("quadmix2003_m40", dict(kind="quadmix", n=2003, m=40), 110, 3),
+    ("rosenbrock500_m33", dict(kind="ros", n=500, m=33, factr=0.0, pgtol=0.0), 90, 3),
+    ("quad3001_m70", dict(kind="quad", n=3001, m=70), 100, 4),
+]
+
+
+@pytest.mark.parametrize("name,spec,ncalls,stride", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_wide_memory_one_step_parity(env, name, spec, ncalls, stride):
+    """m > 32 (the reference puts no limit on m, src/lbfgsb.f90:93-97): beyond the width of the fused
+    kernels a context composes the iteration from unfused tile primitives (k_wide.hip, solver_wide.inl).
+    Same bar as every one-step test: each return of the oracle's trajectory -- through col = 33 ... m, the
+    shift of a full memory, rejected trials -- is the input of ONE GPU call (mirror context); output equal
+    to the oracle's next state: integers and lists exactly, floats at the one-step tolerances."""
+    po = env["po"]
+    p = make_problem(po, spec)
+    snaps = oracle_snapshots(po, p, ncalls)
+    assert max(int(s.isave[27]) for s in snaps) > 32          # the memory really grows beyond the fused width
+    tested = 0
+    for k in range(0, len(snaps) - 1, stride):
+        t = snaps[k].task_s
+        if not (t.startswith("FG") or t.startswith("NEW_X")):
+            continue
+        _, out = gpu_one_call(env, p, snaps[k])
+        compare_states(out, snaps[k + 1], p.n, p.m, po)
+        tested += 1
+    assert tested >= 20, tested
+
+
+@pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
+def test_wide_memory_trajectory_to_convergence(env, pp):
+    """m = 48 on the production path (default context, both device-pointer entries), bounded quadratic with all
+    four bound types, run to convergence with factr = pgtol = 0: integer columns equal the oracle's for at
+    least 60 iterations, f to 1e-10 throughout, same final message."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m = 5003, 48
+    p = po.problem_quadratic(n, m, mixed_nbd=True)
+    rows_o = []
+    so = po.run(po.Engine("oracle"), p,
+                snapshot=lambda k, s: rows_o.append((int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
+                                                     int(s.isave[37]), int(s.isave[27]), float(s.f[0])))
+                if s.task_s.startswith("NEW_X") else None)
+    sol = la.DeviceSolver(n, m)
+    xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.zeros(n, dtype=torch.float64, device="cuda")]
+    gs = [torch.zeros_like(xs[0]), torch.zeros_like(xs[0])]
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+    rows_g, cur = [], 0
+    for _ in range(100000):
+        if pp:
+            t, cur = sol.setulb_pp(xs, l, u, nbd, gs, 0.0, 0.0)
+        else:
+            t = sol.setulb(xs[0], l, u, nbd, gs[0], 0.0, 0.0)
+        if t.startswith("FG"):
+            sol.f[0] = sol.objective(0, xs[cur], gs[cur])
+        elif t.startswith("NEW_X"):
+            rows_g.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                           int(sol.isave[27]), float(sol.f[0])))
+        else:
+            break
+    sol.close()
+    assert t == so.task_s and t.startswith("CONVERGENCE")
+    assert max(r[4] for r in rows_o) == m
+    k = 0
+    while k < min(len(rows_o), len(rows_g)) and rows_o[k][:5] == rows_g[k][:5]:
+        k += 1
+    assert k >= 60, (k, rows_o[k - 1:k + 1], rows_g[k - 1:k + 1])
+    for a, b in zip(rows_g, rows_o):
+        assert a[5] == pytest.approx(b[5], rel=1e-10)
+
+
 def test_headline_config_n1e8_fp64_anchors(env):
     """The workload bench.py times (BASELINE.json metric: n = 1e8, m = 10, fp64, on-device
     objective) at full size, 14 iterations -- through the first full-sort walk, the filling of
