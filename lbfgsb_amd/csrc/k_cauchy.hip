@@ -686,13 +686,14 @@ size_t sort_pairs_temp_bytes(size_t count) {
 //      appended with an atomic counter, i.e. in an order that may change from run to run, and
 //      formk's patch sums run over it -- sorted, the sums are reproducible bit for bit ----
 constexpr int SMALL_SORT = 2048;
-__global__ __launch_bounds__(BLOCK) void sort_u32_small_kernel(uint32_t *keys, uint32_t cnt) {
+__global__ __launch_bounds__(BLOCK) void sort_u32_small_kernel(uint32_t *keys, uint32_t cnt, int npow2) {
   __shared__ uint32_t sm[SMALL_SORT];
-  for (int k = threadIdx.x; k < SMALL_SORT; k += BLOCK) sm[k] = (uint32_t)k < cnt ? keys[k] : 0xFFFFFFFFu;
+  // (the network is only as large as the list: npow2 = the power of two >= cnt, <= SMALL_SORT)
+  for (int k = threadIdx.x; k < npow2; k += BLOCK) sm[k] = (uint32_t)k < cnt ? keys[k] : 0xFFFFFFFFu;
   __syncthreads();
-  for (int size = 2; size <= SMALL_SORT; size <<= 1)      // bitonic network, one workgroup
+  for (int size = 2; size <= npow2; size <<= 1)      // bitonic network, one workgroup
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int k = threadIdx.x; k < SMALL_SORT / 2; k += BLOCK) {
+      for (int k = threadIdx.x; k < npow2 / 2; k += BLOCK) {
         const int lo = 2 * k - (k & (stride - 1)), hi = lo + stride;
         const bool up = (lo & size) == 0;
         const uint32_t a = sm[lo], b = sm[hi];
@@ -700,14 +701,16 @@ __global__ __launch_bounds__(BLOCK) void sort_u32_small_kernel(uint32_t *keys, u
       }
       __syncthreads();
     }
-  for (int k = threadIdx.x; k < SMALL_SORT; k += BLOCK)
+  for (int k = threadIdx.x; k < npow2; k += BLOCK)
     if ((uint32_t)k < cnt) keys[k] = sm[k];
 }
 uint32_t *launch_sort_u32(Queue &q, void *d_temp, size_t temp_bytes, uint32_t *keys, uint32_t *scratch,
                           uint32_t count) {
   if (count <= 1) return keys;
   if (count <= (uint32_t)SMALL_SORT) {
-    hipLaunchKernelGGL(sort_u32_small_kernel, dim3(1), dim3(BLOCK), 0, q.stream, keys, count);
+    int npow2 = 2;
+    while ((uint32_t)npow2 < count) npow2 <<= 1;
+    hipLaunchKernelGGL(sort_u32_small_kernel, dim3(1), dim3(BLOCK), 0, q.stream, keys, count, npow2);
     LB_LAUNCHED(q);
     return keys;
   }

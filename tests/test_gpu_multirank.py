@@ -54,6 +54,7 @@ def oracle_rows(po, n, m, iters, mixed):
     (2, "gloo", 30011, 20, 26, True),     # m = 20 until the memory is full: the pair-shared update pass,
                                           # its leftover rows, the closed form at col = 20, on 2 ranks
     (1, "rccl1", 50021, 5, 6, True),
+    (3, "gloo", 6007, 40, 46, True),      # m > 32: the unfused tile path (solver_wide.inl) over 3 ranks
 ])
 def test_sharded_trajectory_matches_oracle(oracle_built, tmp_path, world, mode, n, m, iters, mixed):
     po = oracle_built
