@@ -1,35 +1,40 @@
-"""One-off wider sweep of the randomised differential test (tests/test_gpu_fuzz.py) over seed
-ranges the committed suite does not use:  python profiles/scripts/fuzz_sweep.py [first] [count]"""
+"""One-off wider sweep of the randomised differential test (tests/test_gpu_fuzz.py: call by call beside the
+oracle; every split must be reproduced by a one-step oracle replay) over seed ranges the committed suite does
+not use, through both device-pointer entries, the fallback options and m > 32:
+
+    python profiles/scripts/fuzz_sweep.py [first] [count] > gpurun_out/fuzz_sweep.txt
+"""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import pytest  # noqa: E402
-
-
-class MP:
-    def setenv(self, k, v):
-        os.environ[k] = v
-
-
-import __graft_entry__ as ge  # noqa: E402
 import test_gpu_fuzz as tf  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
+po.build(ref=False)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-bad = 0
-for lo in range(first, first + count, 50):
-    for (nmax, mlo, mhi, sw) in ((600, 1, 13, None), (2500, 11, 33, None), (1200, 1, 25, "LBFGSB_TWO_PASS=0")):
-        for k in ("LBFGSB_TWO_PASS",):
-            os.environ.pop(k, None)
-        try:
-            tf.test_random_problems_against_oracle(po, MP(), lo, 50, nmax, mlo, mhi, sw)
-            print("ok", lo, nmax, mlo, mhi, sw, flush=True)
-        except AssertionError as e:
-            bad += 1
-            print("FAIL", lo, nmax, mlo, mhi, sw, str(e)[:400], flush=True)
-print("failures:", bad)
+MODES = [  # (nmax, mlo, mhi, pp, options)
+    (600, 1, 13, False, {}), (600, 1, 13, True, {}), (2500, 11, 33, True, {}), (2500, 11, 33, False, {}),
+    (1200, 1, 25, True, {"two_pass": 0}), (1200, 1, 25, False, {"lean": 0}), (1200, 1, 25, True, {"uniform_bounds": 0}),
+    (1200, 1, 25, True, {"spec_capture": 1}), (1000, 33, 90, True, {}), (1500, 1, 25, True, {"exact_always": 1}),
+]
+bad, total, splits, t0 = 0, 0, 0, time.time()
+for seed in range(first, first + count):
+    nmax, mlo, mhi, pp, opts = MODES[seed % len(MODES)]
+    p = tf.make(po, seed, nmax, mlo, mhi)
+    try:
+        split, _ = tf.drive_with_replay(po, p, 80, pp=pp, options=opts)
+        total += 1
+        splits += split is not None
+    except AssertionError as e:
+        bad += 1
+        print("FAIL seed %d mode %s: %s" % (seed, MODES[seed % len(MODES)], str(e)[:600]), flush=True)
+    if (seed - first) % 100 == 99:
+        print("... %d problems, %d splits (each reproduced one-step), %d failures, %.0f s"
+              % (total, splits, bad, time.time() - t0), flush=True)
+print("problems %d  splits reproduced %d  failures %d  (%.0f s)" % (total, splits, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
