@@ -13,7 +13,8 @@ per host sync (all-gather of the <= 8m+15 partials, reduced in rank order on eve
 Prints ONE JSON line (rank 0).  `value` = K / wall time of the K timed iterations
 (objective evaluations included; `iters_per_sec_setulb_only` excludes them).
 `roofline` is the DOMINANT kernel of the iteration (the one storing pass, subsm_update_kernel),
-timed live with HIP events on the solver's stream inside the timed region; the read-only pass
+timed live with HIP events on the solver's stream inside the timed region, its `traffic` counted in
+this run by two `rocprofv3 --pmc` child runs of this file after the timed legs (live_traffic()); the read-only pass
 that carries the WS/WY matvecs (update_scan_kernel) and the bare W'v kernel are reported beside
 it.  `cpu_baseline` times the real reference (oracle/_ref) on one host core, rank 0 at N=1 only,
 on a bounded sample, and quotes the one full-size run on file.  `other_configs` (N=1 only): short
@@ -64,6 +65,11 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="lbfgsb_hip_set_option on every context of the run (A/B measurements)")
     ap.add_argument("--roofline-reps", type=int, default=20)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that count the HBM bytes of the passes over W "
+                         "(N=1 only; skipped by itself when this process already runs under a profiler)")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="(internal) the run rocprofv3 counts: warm-up + timed iterations, then exit")
     return ap.parse_args()
 
 
@@ -99,6 +105,93 @@ def host_cpu():
     except (AttributeError, OSError):
         usable = os.cpu_count()
     return {"model": model, "cores_total": os.cpu_count(), "cores_usable": usable}
+
+
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def live_traffic(a, n_loc, timeout_s=240):
+    """HBM bytes per launch of the passes over W, COUNTED IN THIS RUN: two child runs of this file under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `rocprofv3 --pmc WRITE_SIZE --kernel-trace` (separate
+    passes, no other trace domain, the program itself after `--`: MI355X_MICROARCH.md, HBM / rocprofv3).
+    The child (--pmc-child) runs the same workload through the same entry: START, warm-up until the memory
+    is full, a few more iterations, exit.  Corrections for gfx950 as that guide prescribes: both counters
+    are in KiB, FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (x2), WRITE_SIZE is
+    exact.  Launches at col = m are the ones whose counter is within 1 % of the largest seen for that kernel
+    (earlier launches read fewer columns).  Returns {kernel family: bytes per launch} or raises."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import statistics
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    base = tempfile.mkdtemp(prefix="lbfgsb_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "4", "--warmup",
+             str(a.warmup), "--n", str(a.n), "--m", str(a.m), "--no-cpu-baseline", "--no-other-configs",
+             "--no-live-traffic"]
+    child += ["--real32"] if a.real32 else []
+    child += ["--classic"] if a.classic else []
+    for kv in a.opt:
+        child += ["--opt", kv]
+    counted = {}
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
+            left = timeout_s - (time.perf_counter() - t0)
+            if left < 20:
+                raise RuntimeError("no time left for the %s pass" % counter)
+            # own process group: on a timeout the profiler AND the program it started are ended (by the
+            # exact group id started here)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                  start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                raise RuntimeError("the %s pass did not finish in %.0f s" % (counter, left))
+            if pr.returncode != 0:
+                raise RuntimeError("rocprofv3 --pmc %s exited %d: %s" % (counter, pr.returncode,
+                                                                        err.decode(errors="replace")[-300:]))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("no counter_collection.csv from the %s pass" % counter)
+            per = {}
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == counter:
+                            per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            counted[counter] = per
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    out = {}
+    for fam in ("subsm_update_kernel", "update_scan_kernel"):
+        # the instantiation of this family that moved the most bytes = the one the timed iterations launch
+        fk = max((k for k in counted["FETCH_SIZE"] if fam in k), key=lambda k: sum(counted["FETCH_SIZE"][k]),
+                 default=None)
+        if fk is None or fk not in counted["WRITE_SIZE"]:
+            continue
+        f, w = counted["FETCH_SIZE"][fk], counted["WRITE_SIZE"][fk]
+        f_in = [v for v in f if v >= 0.99 * max(f)]
+        w_in = [v for v in w if v >= 0.99 * max(w)] if max(w) > 0.01 * max(f) else w
+        rd, wr = 2.0 * 1024.0 * statistics.median(f_in), 1024.0 * statistics.median(w_in)
+        out[fam] = {"kernel": fk[:120], "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                    "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_row": (rd + wr) / n_loc,
+                    "launches_counted": len(f_in), "FETCH_SIZE_KiB_raw_median": statistics.median(f_in),
+                    "WRITE_SIZE_KiB_raw_median": statistics.median(w_in)}
+    out["seconds"] = time.perf_counter() - t0
+    return out
 
 
 def cpu_baseline(m, n_full, n_sample):
@@ -425,6 +518,10 @@ def main():
     r = timed_leg(run, a.steps, max(a.warmup, m + 1))
     cols_timed, clocks, dt, dt_setulb = r["cols_timed"], r["clocks"], r["dt"], r["dt_setulb"]
     assert min(cols_timed) == max(cols_timed) == m, cols_timed
+    if a.pmc_child:   # (the run live_traffic() counts: nothing but the iterations themselves)
+        run.close()
+        print(json.dumps({"pmc_child": True, "steps": a.steps, "ms_per_step": dt / a.steps * 1e3}))
+        return
     stats, st0 = r["st1"], r["st0"]
     f_final = float(sol.f[0])
     col = int(sol.isave[27])
@@ -611,6 +708,31 @@ def main():
                                                          **kw))
             except BaseException as e:   # noqa: BLE001  (a leg must never take the headline line down)
                 out["other_configs"].append({"config": name, "error": repr(e)})
+    # ---- HBM traffic of the passes over W, counted in this run (contexts above are closed: the child
+    # has the card's memory to itself) ----
+    if rank == 0 and world == 1 and not a.no_live_traffic:
+        static_note = ("profiles/w_pass_traffic.json (rocprofv3 --pmc passes over this bench on file; the live "
+                       "count of this run was not taken: %s)")
+        try:
+            if under_profiler():
+                raise RuntimeError("this process itself runs under a profiler")
+            lt = live_traffic(a, n_loc)
+            for rec in [roofline] + others:
+                fam = rec["kernel"].split("<", 1)[0]
+                if fam in lt:
+                    rec["traffic_on_file"] = rec["traffic"]
+                    rec["traffic"] = lt[fam]["hbm_bytes_per_launch"]
+                    rec["traffic_over_algorithmic"] = rec["traffic"] / rec["algorithmic_bytes_per_launch"]
+                    rec["traffic_source"] = (
+                        "counted in this run: two child runs of this bench (same workload, same entry) under "
+                        "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE with --kernel-trace, launches at col = m; "
+                        "gfx950 corrections of MI355X_MICROARCH.md (KiB units, FETCH_SIZE x2)")
+                    rec["traffic_counters"] = lt[fam]
+            out["live_traffic_seconds"] = lt["seconds"]
+        except BaseException as e:   # noqa: BLE001  (the counters must never take the bench line down)
+            out["live_traffic_error"] = repr(e)[:400]
+            for rec in [roofline] + others:
+                rec["traffic_source"] = static_note % repr(e)[:120]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(m, n, min(a.cpu_n, n))
