@@ -290,6 +290,65 @@ int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy);
 int lbfgsb_hip_set_iwhere(lbfgsb_hip_ctx *ctx, const int32_t *h_iwhere);
 int lbfgsb_hip_formk_gram(lbfgsb_hip_ctx *ctx, int col, int head, double *h_out);
 
+/* -------------------------------------------------------------------------
+ * Routine doors: ONE routine of the reference each, on the STATE of the
+ * context -- Ws, Wy, Sy, Ss, Wt, WN, WN1 (snd), z, r, d, t, xp, the 8m work vectors, iwhere,
+ * Index, Indx2: what lbfgsb_hip_import_state loads and lbfgsb_hip_export_state reads back, in the
+ * reference's wa / iwa layout.  A parity test loads the inputs of a routine with import_state,
+ * calls the door, and compares export_state (and the door's scalar results) with the CPU twin
+ * run on the same arrays (tests/test_gpu_routines.py).  x, l, u, nbd, g and every *_out / *_in
+ * vector are DEVICE pointers of n values; everything else is host memory.  Single-rank
+ * contexts; every door ends with the stream synchronised.  The doors drive the library's own
+ * code (cauchy is the function the iteration calls; freev and matupd share their halves with
+ * the iteration; cmprlb, subsm and matupd's n-length sums run through the unfused tile functions
+ * that carry m > 32, valid for every m); the fused passes of the hot path are covered call by
+ * call by the one-step parity tests.  The reference's n-length level-1 BLAS call sites
+ * (dcopy / dscal / daxpy / ddot in mainlb, lnsrlb, matupd) have no kernels of their own in this
+ * library -- each is a term of one of these routines' passes -- and therefore no doors.
+ * ------------------------------------------------------------------------- */
+
+/* active, src/lbfgsb.f90:965-1040: x projected onto the box IN PLACE, iwhere initialised;
+ * h_flags[0..2] = prjctd, cnstnd, boxed */
+int lbfgsb_hip_active(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u, const int32_t *nbd,
+                      int32_t *h_flags);
+/* errclb, :1601-1643: task (60 chars) is left alone if the input is valid, else 'ERROR: ...',
+ * *h_info = -6 / -7 and *h_k = the 1-based index the reference would report */
+int lbfgsb_hip_errclb(lbfgsb_hip_ctx *ctx, const void *l, const void *u, const int32_t *nbd, double factr,
+                      char *task, int32_t *h_info, int64_t *h_k);
+/* cauchy, :1157-1532: reads W, Sy, Wt, iwhere; leaves the Cauchy point in z (and in xcp_out if not
+ * NULL), iwhere, p / c / wbp / v in the work vectors (wa8m(1:8m) of export_state), *h_nseg, *h_info */
+int lbfgsb_hip_cauchy(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u, const int32_t *nbd,
+                      const void *g, double theta, int col, int head, double sbgnrm, void *xcp_out,
+                      int32_t *h_nseg, int32_t *h_info);
+/* freev, :1980-2059: from iwhere and the previous free set (Index(1:nfree) of the imported state);
+ * Index / Indx2 are rebuilt in contexts created with LBFGSB_F_MIRROR_INDEX */
+int lbfgsb_hip_freev(lbfgsb_hip_ctx *ctx, int iter, int cnstnd, int updatd, int64_t *h_nfree,
+                     int64_t *h_nenter, int64_t *h_ileave, int32_t *h_wrk);
+/* formk, :1681-1908: WN1's inner products FROM SCRATCH over the free / active rows of iwhere (the
+ * reference keeps them incrementally: the same sums in another order), WN assembled and factorised
+ * on the host; *h_info = 0, -1 or -2 */
+int lbfgsb_hip_formk(lbfgsb_hip_ctx *ctx, int col, int head, double theta, int32_t *h_info);
+/* cmprlb, :1548-1586: r = -Z'(B(xcp - x) + g) from z (= xcp), W, Sy, Wt, c (work vector 2), iwhere;
+ * r_out: r scattered to its rows, 0 on the rows that are not free (the reference packs r by Index) */
+int lbfgsb_hip_cmprlb(lbfgsb_hip_ctx *ctx, const void *x, const void *g, double theta, int col, int head,
+                      int cnstnd, void *r_out, int32_t *h_info);
+/* subsm, :2676-2885: r_in as lbfgsb_hip_cmprlb writes it, WN of the state, z = xcp in;
+ * z = the subspace minimiser out (and xhat_out if not NULL), xp = xcp, *h_iword, *h_info */
+int lbfgsb_hip_subsm(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u, const int32_t *nbd,
+                     const void *g, const void *r_in, double theta, int col, int head, void *xhat_out,
+                     int32_t *h_iword, int32_t *h_info);
+/* lnsrlb, :2174-2275, with mainlb's d = z - x (:720-722) on the first call of an iteration's search.
+ * h_sc[8] = fold, gd, gdold, stp, dnorm, dtd, xstep, stpmx; h_ic[7] = iter, ifun, iback, nfgv, info,
+ * boxed, cnstnd; task, csave (60 chars), h_isave2[2], h_dsave13[13] as the reference's.  z, d, t, r are
+ * the state's; x receives the trial point. */
+int lbfgsb_hip_lnsrlb(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u, const int32_t *nbd,
+                      const void *g, double f, double *h_sc, int32_t *h_ic, char *task, char *csave,
+                      int32_t *h_isave2, double *h_dsave13);
+/* mainlb :812-824 + matupd, :2291-2346: y = g - r, s = stp d stored in W; Sy, Ss updated.
+ * h_ip[4] = iupdat (already counted up, :836), col, head, itail in / out; *h_theta = y'y / dr */
+int lbfgsb_hip_matupd(lbfgsb_hip_ctx *ctx, const void *g, double stp, double dr, double dtd, int32_t *h_ip,
+                      double *h_theta);
+
 /* bare streaming kernel launches, and the same bracketed by hipEvents on the
  * context's stream: *h_ms_per_launch = average duration of `reps` launches. */
 int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head);

@@ -57,6 +57,18 @@ PROTOTYPES = {
     "lbfgsb_hip_comm_stats": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_uniform_bounds": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_freev_skipped": (C.c_int, [_vp, _vp]),
+    # routine doors
+    "lbfgsb_hip_active": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_errclb": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
+    "lbfgsb_hip_cauchy": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, C.c_double,
+                                    _vp, _vp, _vp]),
+    "lbfgsb_hip_freev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_formk": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _vp]),
+    "lbfgsb_hip_cmprlb": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "lbfgsb_hip_subsm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp,
+                                   _vp]),
+    "lbfgsb_hip_lnsrlb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_matupd": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp]),
 }
 
 F_REAL32 = 1

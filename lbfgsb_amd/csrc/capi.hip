@@ -141,6 +141,58 @@ int lbfgsb_hip_projgr(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const v
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   return ctx->k_projgr(x, l, u, nbd, g, h_sbgnrm);
 }
+// ---- routine doors (solver_doors.inl) ----
+int lbfgsb_hip_active(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u, const int32_t *nbd,
+                      int32_t *h_flags) {
+  if (!ctx || !x || !l || !u || !nbd || !h_flags) return fail(LBFGSB_E_ARG, "active: NULL argument");
+  return ctx->r_active(x, l, u, nbd, h_flags);
+}
+int lbfgsb_hip_errclb(lbfgsb_hip_ctx *ctx, const void *l, const void *u, const int32_t *nbd, double factr,
+                      char *task, int32_t *h_info, int64_t *h_k) {
+  if (!ctx || !l || !u || !nbd || !task || !h_info || !h_k) return fail(LBFGSB_E_ARG, "errclb: NULL argument");
+  return ctx->r_errclb(l, u, nbd, factr, task, h_info, h_k);
+}
+int lbfgsb_hip_cauchy(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u, const int32_t *nbd,
+                      const void *g, double theta, int col, int head, double sbgnrm, void *xcp_out,
+                      int32_t *h_nseg, int32_t *h_info) {
+  if (!ctx || !x || !l || !u || !nbd || !g || !h_nseg || !h_info)
+    return fail(LBFGSB_E_ARG, "cauchy: NULL argument");
+  return ctx->r_cauchy(x, l, u, nbd, g, theta, col, head, sbgnrm, xcp_out, h_nseg, h_info);
+}
+int lbfgsb_hip_freev(lbfgsb_hip_ctx *ctx, int iter, int cnstnd, int updatd, int64_t *h_nfree,
+                     int64_t *h_nenter, int64_t *h_ileave, int32_t *h_wrk) {
+  if (!ctx || !h_nfree || !h_nenter || !h_ileave || !h_wrk) return fail(LBFGSB_E_ARG, "freev: NULL argument");
+  return ctx->r_freev(iter, cnstnd, updatd, h_nfree, h_nenter, h_ileave, h_wrk);
+}
+int lbfgsb_hip_formk(lbfgsb_hip_ctx *ctx, int col, int head, double theta, int32_t *h_info) {
+  if (!ctx || !h_info) return fail(LBFGSB_E_ARG, "formk: NULL argument");
+  return ctx->r_formk(col, head, theta, h_info);
+}
+int lbfgsb_hip_cmprlb(lbfgsb_hip_ctx *ctx, const void *x, const void *g, double theta, int col, int head,
+                      int cnstnd, void *r_out, int32_t *h_info) {
+  if (!ctx || !x || !g || !h_info) return fail(LBFGSB_E_ARG, "cmprlb: NULL argument");
+  return ctx->r_cmprlb(x, g, theta, col, head, cnstnd, r_out, h_info);
+}
+int lbfgsb_hip_subsm(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u, const int32_t *nbd,
+                     const void *g, const void *r_in, double theta, int col, int head, void *xhat_out,
+                     int32_t *h_iword, int32_t *h_info) {
+  if (!ctx || !x || !l || !u || !nbd || !g || !r_in || !h_iword || !h_info)
+    return fail(LBFGSB_E_ARG, "subsm: NULL argument");
+  return ctx->r_subsm(x, l, u, nbd, g, r_in, theta, col, head, xhat_out, h_iword, h_info);
+}
+int lbfgsb_hip_lnsrlb(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u, const int32_t *nbd,
+                      const void *g, double f, double *h_sc, int32_t *h_ic, char *task, char *csave,
+                      int32_t *h_isave2, double *h_dsave13) {
+  if (!ctx || !x || !l || !u || !nbd || !g || !h_sc || !h_ic || !task || !csave || !h_isave2 || !h_dsave13)
+    return fail(LBFGSB_E_ARG, "lnsrlb: NULL argument");
+  return ctx->r_lnsrlb(x, l, u, nbd, g, f, h_sc, h_ic, task, csave, h_isave2, h_dsave13);
+}
+int lbfgsb_hip_matupd(lbfgsb_hip_ctx *ctx, const void *g, double stp, double dr, double dtd, int32_t *h_ip,
+                      double *h_theta) {
+  if (!ctx || !g || !h_ip || !h_theta) return fail(LBFGSB_E_ARG, "matupd: NULL argument");
+  return ctx->r_matupd(g, stp, dr, dtd, h_ip, h_theta);
+}
+
 int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double *h_out) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   return ctx->k_wtv(v, col, head, h_out, false);

@@ -30,6 +30,7 @@
 //   solver_subspace.inl  formk, cmprlb, subsm (the closed form, the storing pass, backtracking)
 //   solver_wide.inl      m > 32: the same steps out of unfused tile primitives (k_wide.hip)
 //   solver_state.inl     export / import in the reference's wa / iwa layout, per-kernel doors
+//   solver_doors.inl     routine doors: one routine of the reference each, on the state of the context
 // Two device-pointer entries share the state machine: setulb_dev (the caller's x and g in place,
 // t = x / r = g as copies) and setulb_dev_pp (two caller buffer pairs that swap roles, no copies).
 //
@@ -658,6 +659,31 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   // generalized Cauchy point + freev (:599-646)
+  // freev's counting pass (:1980-2059), in two halves so that another pass can be queued between
+  // the launch and the one host sync that brings its three counts (h_res[0..2])
+  int freev_launch(bool track) {
+    if (prevfree)
+      HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
+    lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
+    index_valid = true;
+    iw_dirty = 0.0;
+    if (track)
+      HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return 0;
+  }
+  bool freev_land(bool track, bool updatd) {  // -> wrk (:2057)
+    chg_local = track ? *h_count : 0;
+    nfree_g = (int64_t)h_res[0];
+    if (track) {
+      nenter_g = (int64_t)h_res[1];
+      ileave_g = nglob + 1 - (int64_t)h_res[2];
+    } else {
+      nenter_g = 0;
+      ileave_g = nglob + 1;
+    }
+    return (ileave_g < nglob + 1) || (nenter_g > 0) || updatd;
+  }
+
   int phase_cauchy_freev(Mainlb &L, Flow &flow) {
     MAINLB_VIEW(L);
     if (ipr >= 99) std::fprintf(rep.out, "\n\nITERATION %5d\n", iter + 1);
@@ -724,13 +750,7 @@ class Solver final : public lbfgsb_hip_ctx {
         }
         return 0;
       }
-      if (prevfree)
-        HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
-      lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
-      index_valid = true;
-      iw_dirty = 0.0;
-      if (track)
-        HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CHK(freev_launch(track));
       // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
       // sets of sums with ONE host sync (it is wasted only if no variable is free)
       int npre = 0;
@@ -754,18 +774,9 @@ class Solver final : public lbfgsb_hip_ctx {
         std::memcpy(pre_res, h_res + 3, sizeof(double) * npre);
         pre_valid = true;
       }
-      chg_local = track ? *h_count : 0;
       cachyt += now_s() - cpu1;
       nintol += nseg;
-      nfree_g = (int64_t)h_res[0];
-      if (iter > 0 && cnstnd) {
-        nenter_g = (int64_t)h_res[1];
-        ileave_g = nglob + 1 - (int64_t)h_res[2];
-      } else {
-        nenter_g = 0;
-        ileave_g = nglob + 1;
-      }
-      wrk = (ileave_g < nglob + 1) || (nenter_g > 0) || updatd;
+      wrk = freev_land(track, updatd);
       if (ipr >= 99) {  // :2023-2057
         if (iter > 0 && cnstnd) {
           if (ipr >= 100 && chg_local > 0 && chg_local <= CHG_CAP) {
@@ -995,6 +1006,25 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
+  // the m x m half of matupd (:2324-2346): shift of Sy, Ss once the memory is full, the new row of Sy and
+  // column of Ss from the n-length sums, the two diagonal entries
+  void matupd_small(int col, int iupdat, const double *sy_row, const double *ss_col, double ss_diag,
+                    double dr) {
+    lbh::Mat SY{sy.data(), m}, SS{ss.data(), m};
+    if (iupdat > m) {  // :2324-2330
+      for (int j = 0; j < col - 1; ++j) {
+        for (int i = 0; i <= j; ++i) SS(i, j) = SS(i + 1, j + 1);
+        for (int i = j; i < col - 1; ++i) SY(i, j) = SY(i + 1, j + 1);
+      }
+    }
+    for (int j = 0; j < col - 1; ++j) {
+      SY(col - 1, j) = sy_row[j];
+      SS(j, col - 1) = ss_col[j];
+    }
+    SS(col - 1, col - 1) = ss_diag;
+    SY(col - 1, col - 1) = dr;
+  }
+
   // y, s and matupd (:812-857)
   int phase_update(Mainlb &L, Flow &flow) {
     MAINLB_VIEW(L);
@@ -1090,19 +1120,8 @@ class Solver final : public lbfgsb_hip_ctx {
       rr = h_res[2 * MCo];
     }
     theta = rr / dr;
-    lbh::Mat SY{sy.data(), m}, SS{ss.data(), m};
-    if (iupdat > m) {  // :2324-2330
-      for (int j = 0; j < col - 1; ++j) {
-        for (int i = 0; i <= j; ++i) SS(i, j) = SS(i + 1, j + 1);
-        for (int i = j; i < col - 1; ++i) SY(i, j) = SY(i + 1, j + 1);
-      }
-    }
-    for (int j = 0; j < col - 1; ++j) {
-      SY(col - 1, j) = wide() ? wsy[j] : h_res[j];
-      SS(j, col - 1) = wide() ? wss[j] : h_res[MCo + j];
-    }
-    SS(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
-    SY(col - 1, col - 1) = dr;
+    matupd_small(col, iupdat, wide() ? wsy.data() : h_res, wide() ? wss.data() : h_res + MCo,
+                 stp == 1.0 ? dtd : stp * stp * dtd, dr);
     info = lbh::formt(m, wt.data(), sy.data(), ss.data(), col, theta);  // :849
     if (info != 0) {
       if (ipr >= 1)
@@ -1218,6 +1237,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int64_t nfreev_skipped = 0;
 
 #include "solver_state.inl"     // state exchange, per-kernel doors, communicators
+#include "solver_doors.inl"     // routine doors (active, errclb, cauchy, freev, formk, cmprlb, subsm, lnsrlb, matupd)
 };
 
 }  // namespace

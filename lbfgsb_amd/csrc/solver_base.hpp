@@ -119,6 +119,24 @@ struct lbfgsb_hip_ctx {
   virtual int k_formk_gram(int col, int head, double *out) = 0;
   virtual int k_launch(int which, const void *x, const void *g, int col, int head) = 0;
   virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
+  // routine doors (solver_doors.inl): one routine of the reference each, on the state of the context
+  virtual int r_active(void *x, const void *l, const void *u, const int32_t *nbd, int32_t *out3) = 0;
+  virtual int r_errclb(const void *l, const void *u, const int32_t *nbd, double factr, char *task,
+                       int32_t *info, int64_t *k) = 0;
+  virtual int r_cauchy(const void *x, const void *l, const void *u, const int32_t *nbd, const void *g,
+                       double theta, int col, int head, double sbgnrm, void *xcp_out, int32_t *nseg,
+                       int32_t *info) = 0;
+  virtual int r_freev(int iter, int cnstnd, int updatd, int64_t *nfree, int64_t *nenter, int64_t *ileave,
+                      int32_t *wrk) = 0;
+  virtual int r_formk(int col, int head, double theta, int32_t *info) = 0;
+  virtual int r_cmprlb(const void *x, const void *g, double theta, int col, int head, int cnstnd, void *r_out,
+                       int32_t *info) = 0;
+  virtual int r_subsm(const void *x, const void *l, const void *u, const int32_t *nbd, const void *g,
+                      const void *r_in, double theta, int col, int head, void *xhat_out, int32_t *iword,
+                      int32_t *info) = 0;
+  virtual int r_lnsrlb(void *x, const void *l, const void *u, const int32_t *nbd, const void *g, double f,
+                       double *sc, int32_t *ic, char *task, char *csave, int32_t *isave2, double *dsave13) = 0;
+  virtual int r_matupd(const void *g, double stp, double dr, double dtd, int32_t *ip, double *theta_out) = 0;
   virtual int sync() = 0;
   // communicators (capi.hip): an initialised RCCL communicator / a host reducer for this context
   virtual int attach_rccl(ncclComm_t comm, int rank, int nranks) = 0;

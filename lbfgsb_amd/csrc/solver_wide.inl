@@ -83,10 +83,9 @@ int wide_formk(int col, int head) {
   return 0;
 }
 
-// cmprlb (:1548-1586) + subsm (:2676-2885) with r, W'r and the Newton direction as vectors (tbrk)
-int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta, int col,
-                  int head, bool cnstnd, int &iword, int &info) {
-  const int ipr = quiet ? -1 : print_level;
+// cmprlb (:1548-1586) with r as a vector: tbrk = r on the free rows, 0 elsewhere
+int wide_cmprlb(const T *x, const T *l, const T *u, const T *g, double theta, int col, int head, bool cnstnd,
+                int &info) {
   const bool plain = !cnstnd && col > 0;
   std::vector<double> a1(col, 0.0), a2(col, 0.0);
   if (!plain) {
@@ -100,6 +99,16 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
   lbk::launch_cmprlb_init<T>(q, n, x, g, z, iwhere, theta, plain ? 1 : 0, tbrk);
   tbrk_valid = false;
   if (!plain) CHK(wide_axpy(tbrk, a1.data(), a2.data(), col, head, 1.0, 1));
+  return 0;
+}
+
+// subsm (:2676-2885) with r (tbrk, from wide_cmprlb), W'r and the Newton direction as vectors.
+// xp_first: the safeguard copy xp = xcp (:2787) is taken from z before the projected step overwrites
+// it (contexts that mirror the reference's arrays, the routine doors); otherwise it is written from
+// the functional form of this call's Cauchy point, and only if the backtracking branch needs it.
+int wide_subsm(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta, int col,
+               int head, bool xp_first, int &iword, int &info) {
+  const int ipr = quiet ? -1 : print_level;
   double *wv = &wa8m[0];
   {
     std::vector<double> oy(col), os(col);
@@ -116,7 +125,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
   info = lbh::dtrsl(WN, col2, wv, 1);
   if (info != 0) return 0;
   CHK(wide_axpy(tbrk, wv, wv + col, col, head, theta, 1));  // :2770-2778
-  if (flags & LBFGSB_F_MIRROR_INDEX) CHK(write_xcp(xp, x, l, u, g));  // :2787
+  if (xp_first) HIPCHK(hipMemcpyAsync(xp, z, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));  // :2787
   lbk::launch_subsm_project<T>(q, n, z, tbrk, x, g, l, u, nbd, iwhere, 1.0 / theta);  // :2780-2827
   z_valid = true;
   CHK(fetch(2, 0, 0));
@@ -131,7 +140,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
     std::fprintf(rep.out, " Positive dir derivative in projection \n");
     std::fprintf(rep.out, " Using the backtracking step \n");
   }
-  if (!(flags & LBFGSB_F_MIRROR_INDEX)) CHK(write_xcp(xp, x, l, u, g));
+  if (!xp_first) CHK(write_xcp(xp, x, l, u, g));
   lbk::launch_subsm_alpha<T>(q, n, xp, tbrk, l, u, nbd, iwhere);
   CHK(fetch(0, 1, 0));
   const double alpha = std::min(1.0, h_res[0]);
@@ -144,4 +153,11 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
   lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, tbrk, l, u, iwhere, alpha, ibd);
   if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");
   return 0;
+}
+
+int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta, int col,
+                  int head, bool cnstnd, int &iword, int &info) {
+  CHK(wide_cmprlb(x, l, u, g, theta, col, head, cnstnd, info));
+  if (info != 0) return 0;
+  return wide_subsm(x, l, u, nbd, g, theta, col, head, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword, info);
 }

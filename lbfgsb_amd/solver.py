@@ -259,6 +259,69 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_projgr(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g), _p(out)))
         return float(out[0])
 
+    # ---- routine doors (include/lbfgsb_hip.h "Routine doors"): one routine of the reference each, on the
+    #      state of the context (import_state / export_state); vectors are device tensors ----
+    def r_active(self, x, l, u, nbd):
+        """active :965 -- x projected in place; -> (prjctd, cnstnd, boxed)"""
+        out = np.zeros(3, np.int32)
+        check(self.lib.lbfgsb_hip_active(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(out)))
+        return bool(out[0]), bool(out[1]), bool(out[2])
+
+    def r_errclb(self, l, u, nbd, factr, task=b"START"):
+        """errclb :1601 -- -> (task string, info, k)"""
+        t = np.frombuffer(task.ljust(60), dtype="S1").copy()
+        info, k = np.zeros(1, np.int32), np.zeros(1, np.int64)
+        check(self.lib.lbfgsb_hip_errclb(self.h, _p(l), _p(u), _p(nbd), float(factr), _p(t), _p(info), _p(k)))
+        return t.tobytes().decode().rstrip(), int(info[0]), int(k[0])
+
+    def r_cauchy(self, x, l, u, nbd, g, theta, col, head, sbgnrm, xcp_out=None):
+        """cauchy :1157 -- -> (nseg, info); xcp in the state's z (and in xcp_out)"""
+        nseg, info = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        check(self.lib.lbfgsb_hip_cauchy(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g), float(theta), int(col),
+                                         int(head), float(sbgnrm), _p(xcp_out) if xcp_out is not None else None,
+                                         _p(nseg), _p(info)))
+        return int(nseg[0]), int(info[0])
+
+    def r_freev(self, iter_, cnstnd, updatd):
+        """freev :1980 -- -> (nfree, nenter, ileave, wrk)"""
+        o = np.zeros(3, np.int64)
+        wrk = np.zeros(1, np.int32)
+        check(self.lib.lbfgsb_hip_freev(self.h, int(iter_), int(bool(cnstnd)), int(bool(updatd)), _p(o[0:1]),
+                                        _p(o[1:2]), _p(o[2:3]), _p(wrk)))
+        return int(o[0]), int(o[1]), int(o[2]), bool(wrk[0])
+
+    def r_formk(self, col, head, theta):
+        """formk :1681 (inner products from scratch) -- -> info; WN1, WN in the state"""
+        info = np.zeros(1, np.int32)
+        check(self.lib.lbfgsb_hip_formk(self.h, int(col), int(head), float(theta), _p(info)))
+        return int(info[0])
+
+    def r_cmprlb(self, x, g, theta, col, head, cnstnd, r_out):
+        """cmprlb :1548 -- r scattered to its rows in r_out -> info"""
+        info = np.zeros(1, np.int32)
+        check(self.lib.lbfgsb_hip_cmprlb(self.h, _p(x), _p(g), float(theta), int(col), int(head),
+                                         int(bool(cnstnd)), _p(r_out), _p(info)))
+        return int(info[0])
+
+    def r_subsm(self, x, l, u, nbd, g, r_in, theta, col, head, xhat_out=None):
+        """subsm :2676 -- -> (iword, info); the subspace minimiser in the state's z (and xhat_out)"""
+        iword, info = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        check(self.lib.lbfgsb_hip_subsm(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g), _p(r_in), float(theta),
+                                        int(col), int(head), _p(xhat_out) if xhat_out is not None else None,
+                                        _p(iword), _p(info)))
+        return int(iword[0]), int(info[0])
+
+    def r_lnsrlb(self, x, l, u, nbd, g, f, sc, ic, task, csave, isave2, dsave13):
+        """lnsrlb :2174 -- sc (8 doubles), ic (7 int32), task / csave (S1[60]), isave2, dsave13 in / out"""
+        check(self.lib.lbfgsb_hip_lnsrlb(self.h, _p(x), _p(l), _p(u), _p(nbd), _p(g), float(f), _p(sc), _p(ic),
+                                         _p(task), _p(csave), _p(isave2), _p(dsave13)))
+
+    def r_matupd(self, g, stp, dr, dtd, ip):
+        """mainlb :812-824 + matupd :2291 -- ip = (iupdat, col, head, itail) int32 in / out -> theta"""
+        th = np.zeros(1)
+        check(self.lib.lbfgsb_hip_matupd(self.h, _p(g), float(stp), float(dr), float(dtd), _p(ip), _p(th)))
+        return float(th[0])
+
     def set_w(self, ws: np.ndarray, wy: np.ndarray):
         """ws, wy: host arrays of shape (m, n) C-order == Fortran (n, m) column-major."""
         ws = np.ascontiguousarray(ws, self.real)

@@ -76,6 +76,46 @@ class Engine:
     available = staticmethod(available)  # type: ignore[assignment]
 
 
+class Routines:
+    """The oracle's routines one by one (lbo_active ... lbo_matupd, each following the reference routine
+    its header in lbfgsb_oracle.c cites): the CPU twins of the library's routine doors
+    (tests/test_gpu_routines.py).  Arrays are numpy (real / int32), scalars Python numbers; in/out
+    scalars are one-element arrays."""
+
+    def __init__(self, real=np.float64):
+        self.real = real
+        eng = Engine("oracle_r32" if real == np.float32 else "oracle")
+        L = self.lib = eng.lib
+        R = C.c_float if real == np.float32 else C.c_double
+        I, P = C.c_int, C.c_void_p
+        sig = {
+            "lbo_active": [I, P, P, P, P, P, P, P, P, P],
+            "lbo_errclb": [I, I, R, P, P, P, P, P, P],
+            "lbo_cauchy": [I, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, R, I, I, P, P, P, P, P, R, P, R],
+            "lbo_cmprlb": [I, I, P, P, P, P, P, P, P, P, P, P, R, I, I, I, I, P],
+            "lbo_freev": [I, P, P, P, P, P, P, P, I, I, I],
+            "lbo_formk": [I, I, P, I, I, P, I, I, P, P, I, P, P, P, R, I, I, P],
+            "lbo_formt": [I, P, P, P, I, R, P],
+            "lbo_matupd": [I, I, P, P, P, P, P, P, P, I, P, P, P, R, R, R, R],
+            "lbo_subsm": [I, I, I, P, P, P, P, P, P, P, P, P, R, P, P, I, I, P, P, P, P],
+            "lbo_lnsrlb": [I, P, P, P, P, R, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, I, I, P, P,
+                           P],
+        }
+        for name, args in sig.items():
+            fn = getattr(L, name)
+            fn.restype = None
+            fn.argtypes = args
+        L.lbo_ddot.restype = R
+        L.lbo_ddot.argtypes = [C.c_int64, P, P]
+
+    def __getattr__(self, name):
+        fn = getattr(self.lib, "lbo_" + name)
+
+        def call(*args):
+            return fn(*[_ptr(a) if isinstance(a, np.ndarray) else a for a in args])
+        return call
+
+
 # --------------------------------------------------------------------------
 # objectives (computed by the oracle's C code so that every engine is fed
 # bit-identical f, g)
