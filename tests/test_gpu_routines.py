@@ -297,6 +297,7 @@ CASES = [
     (102, 5000, 17, 24),
     (103, 2500, 40, 46),     # more pairs than the fused kernels hold: every W product in tiles
     (104, 4000, 10, 16),
+    (105, 150_000, 10, 9),   # many workgroups per reduction, thousands of breakpoints per walk
 ]
 
 
