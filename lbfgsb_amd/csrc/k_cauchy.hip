@@ -902,6 +902,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
     const T *__restrict__ u, const T *__restrict__ g, const T *__restrict__ tbrk,
     iw_t *iwhere, T *xcp, double tsum, double last_t, int64_t last_i, double *part) {
   double acc[1] = {0.0};
+  const double poison = tsum * 0.0;  // 0, or NaN if tsum is not finite (see xcp_row in kernels_common.hpp)
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], gv[W], tb[W], out[W];
@@ -929,19 +930,21 @@ __global__ __launch_bounds__(BLOCK) void cauchy_finish_kernel(
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      out[k] = xv[k];
+      out[k] = xv[k] + poison;
       if (tb[k] >= 0.0) {
         const double d = -gv[k];
         if (done[k]) {
           if (d > 0.0) {
-            out[k] = uv[k];
+            out[k] = uv[k] + poison;
             iw[k] = 2;
           } else {
-            out[k] = lv[k];
+            out[k] = lv[k] + poison;
             iw[k] = 1;
           }
         } else if (tsum != 0.0) {
           out[k] = xv[k] + tsum * d;
+        } else {
+          out[k] = xv[k];
         }
       }
     }

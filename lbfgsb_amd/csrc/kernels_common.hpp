@@ -344,21 +344,27 @@ __device__ __forceinline__ double brk_time(double xk, double lk, double uk, int 
 // The generalized Cauchy point is not stored as a vector on the main path: after the walk,
 // xcp(k) is a function of row k's own x, g, bounds and iwhere (cauchy :1341, :1425-1433, :1515):
 //   iwhere in {0,-1} (the row moves with d = -g and was not fixed):  x + tsum*d
-//   iwhere == 1 / 2 (at its lower/upper bound, before or by this walk): that bound
-//   otherwise (always fixed, or free with zero gradient): x
+//   iwhere == 1 / 2: the bound if the WALK fixed the row there (it started strictly inside: x > l,
+//     x < u), x itself if the scan found it at the bound (:1284-1291: x <= l, x >= u -- a line-search
+//     step of stpmx can leave x an ulp OUTSIDE the box, and the reference does not move it back)
+//   otherwise (always fixed): x
+// ... each of the non-moving cases + tsum * 0: the reference ends with xcp = xcp + tsum * d over ALL
+// rows (:1515) with d = 0 there, which changes nothing unless tsum is not finite -- d == 0 over all rows
+// with a projected gradient of a few ulps (x outside the box by an ulp) gives dtm = 0/0, tsum = NaN, and
+// the reference's Cauchy point is then NaN in EVERY component; so is this one.
 // Every consumer evaluates exactly the expression cauchy_finish_kernel stores (incl. the
 // rounding to T), so results do not depend on whether z was materialised.
 template <typename T>
 __device__ __forceinline__ double xcp_free(double xk, double gk, int iw, double tsum) {
-  if ((iw == 0 || iw == -1) && tsum != 0.0) return (double)(T)(xk + tsum * (-gk));
-  return xk;
+  if (iw == 0 || iw == -1) return tsum != 0.0 ? (double)(T)(xk + tsum * (-gk)) : xk;
+  return xk + tsum * 0.0;
 }
 template <typename T>
 __device__ __forceinline__ double xcp_row(double xk, double gk, int iw, double lk, double uk,
                                           double tsum) {
   if (tsum == 0.0) return xk;  // a walk that fixed a row has tsum >= its breakpoint > 0
-  if (iw == 1) return xk == lk ? xk : lk;
-  if (iw == 2) return xk == uk ? xk : uk;
+  if (iw == 1) return (xk > lk ? lk : xk) + tsum * 0.0;
+  if (iw == 2) return (xk < uk ? uk : xk) + tsum * 0.0;
   return xcp_free<T>(xk, gk, iw, tsum);
 }
 

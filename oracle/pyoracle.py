@@ -107,6 +107,8 @@ class Routines:
             fn.argtypes = args
         L.lbo_ddot.restype = R
         L.lbo_ddot.argtypes = [C.c_int64, P, P]
+        L.lbo_projgr.restype = R
+        L.lbo_projgr.argtypes = [I, P, P, P, P, P]
 
     def __getattr__(self, name):
         fn = getattr(self.lib, "lbo_" + name)

@@ -33,6 +33,14 @@ def _dev(torch, a):
 def nrm_close(a, b, rtol, what, floor=0.0):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
+    if b.size and a.shape == b.shape and not (np.isfinite(a).all() and np.isfinite(b).all()):
+        # non-finite values -- the reference's own arithmetic on degenerate problems (a linear objective:
+        # 0/0 in the line search once d = 0): the same kind in the same places, the rest as usual
+        assert np.array_equal(np.isnan(a), np.isnan(b)), what + ": NaN in different places"
+        inf = np.isinf(a) | np.isinf(b)
+        assert np.array_equal(a[inf], b[inf]), what + ": infinities differ"
+        keep = np.isfinite(a) & np.isfinite(b)
+        a, b = a[keep], b[keep]
     scale = max(float(np.max(np.abs(b))) if b.size else 0.0, floor)
     err = float(np.max(np.abs(a - b))) if b.size else 0.0
     assert err <= rtol * scale + 1e-300, "%s: max|diff| %.3e > %.1e * %.3e" % (what, err, rtol, scale)
@@ -64,6 +72,9 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), che
     gd, ed = got.dsave.copy(), exp.dsave.copy()
     gd[TIME_D] = ed[TIME_D] = 0
     for k in range(29):
+        if not (np.isfinite(gd[k]) and np.isfinite(ed[k])):   # (see nrm_close)
+            assert (np.isnan(gd[k]) and np.isnan(ed[k])) or gd[k] == ed[k], "dsave(%d): %r vs %r" % (k + 1, gd[k], ed[k])
+            continue
         s = max(abs(ed[k]), 1e-300)
         # (dsave(28:29) = dcsrch's width, width1 = stpmax - stpmin and twice that: stpmx again)
         tol = 1e-9 * (max(1.0, abs(ed[11])) if (stpmx_cond and k in (11, 27, 28)) else 1.0)
@@ -138,7 +149,11 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), che
             w8g, w8e = seg(got, "wa8m"), seg(exp, "wa8m")
             cs = float(np.max(np.abs(w8e[2 * m:4 * m])))
             nrm_close(w8g[2 * m:2 * m + 2 * col], w8e[2 * m:2 * m + 2 * col], 1e-9, "wa8m c", floor=cs * 1e-3 + 1e-300)
-            nrm_close(w8g[:2 * col], w8e[:2 * col], 1e-6, "wa8m wv")
+            # (wv comes out of two triangular solves with the factored K: beyond 1e-6 its error must be
+            #  explained the way wn's is -- cond(K) times the error of what went in; n = 6 with 13 pairs
+            #  stored makes K singular to working precision)
+            nrm_close(w8g[:2 * col], w8e[:2 * col], max(1e-6, 50.0 * cond_k * e_in), "wa8m wv",
+                      floor=1e-9 * max(1.0, float(np.max(np.abs(exp.x)))))   # (at convergence wv is rounding noise)
             nrm_close(w8g[4 * m:4 * m + 2 * col], w8e[4 * m:4 * m + 2 * col], rtol, "wa8m wbp")
             nrm_close(w8g[6 * m:6 * m + 2 * col], w8e[6 * m:6 * m + 2 * col], 1e-7, "wa8m v")
     iw_g = got.iwa[n:2 * n]

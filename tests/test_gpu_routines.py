@@ -361,3 +361,58 @@ def test_active_and_errclb_doors(oracle_built):
             assert (info_g, k_g) == (int(info[0]), int(k[0]) if info[0] else 0)
     finally:
         sol.close()
+
+
+def test_cauchy_door_reference_nan_point(oracle_built):
+    """The reference's own arithmetic on a degenerate state: x an ulp OUTSIDE the box (what a line-search
+    step of stpmx can leave behind), so that the projected gradient is a few ulps while no variable can
+    move -- d == 0, f1 = f2 = 0, dtm = 0/0, and xcp = x + tsum * d is NaN in EVERY component
+    (src/lbfgsb.f90:1357-1365, :1509-1515).  The door must return the same thing, not a tidier one; and a
+    variable found beyond its bound by the scan keeps its x in xcp, not the bound (:1284-1291)."""
+    import torch
+    import lbfgsb_amd
+    dev = torch.device("cuda", 0)
+    R = po.Routines()
+    n, m = 300, 4
+    rng = np.random.default_rng(5)
+    nbd = rng.integers(1, 4, n).astype(np.int32)
+    l, u = -np.ones(n), np.ones(n)
+    x = np.where(nbd == 3, u, l).astype(float)          # everybody on a bound ...
+    g = np.where(nbd == 3, -1.0, 1.0) * (0.5 + rng.random(n))   # ... pushed outwards
+    nbd[:40] = 0                                         # free variables with zero gradient
+    x[:40], g[:40] = rng.normal(0, 1, 40), 0.0
+    k = 77
+    nbd[k], x[k], g[k] = 1, np.nextafter(l[k], -np.inf), 0.3   # an ulp below its lower bound
+    for kind in ("nan", "finite"):
+        if kind == "finite":
+            g[5] = -0.25                                  # one variable moves: a finite Cauchy point
+        sbg = float(R.projgr(n, l, u, nbd, x, g))
+        assert sbg > 0.0
+        iw_o = np.where(nbd == 0, -1, 0).astype(np.int32)   # iwhere as active (:1024-1037) leaves it
+        xcp = np.zeros(n)
+        wk = [np.zeros(n, np.int32), np.zeros(n), np.zeros(n)]
+        pc = [np.zeros(2 * m) for _ in range(4)]
+        ws = np.zeros(m * n)
+        sy = np.zeros(m * m)
+        nseg, info = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        iw_ref = iw_o.copy()
+        R.cauchy(n, x, l, u, nbd, g, wk[0], iw_ref, wk[1], wk[2], xcp, m, ws, ws, sy, sy, 1.0, 0, 1, pc[0], pc[1],
+                 pc[2], pc[3], nseg, sbg, info, float(np.finfo(float).eps))
+        assert np.isnan(xcp).all() if kind == "nan" else np.isfinite(xcp).all()
+        sol = lbfgsb_amd.DeviceSolver(n, m, device=0, mirror_index=True)
+        try:
+            T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+            sol.set_iwhere(iw_o)
+            xcp_d = torch.zeros(n, dtype=torch.float64, device=dev)
+            ns_g, inf_g = sol.r_cauchy(T(x), T(l), T(u), T(nbd), T(g), 1.0, 0, 1, sbg, xcp_d)
+            got = xcp_d.cpu().numpy()
+            _, iwa = sol.export_state()
+        finally:
+            sol.close()
+        assert (ns_g, inf_g) == (int(nseg[0]), int(info[0]))
+        assert np.array_equal(iwa[n:2 * n], iw_ref)
+        if kind == "nan":
+            assert np.isnan(got).all(), "the reference's Cauchy point is NaN in every component here"
+        else:
+            assert np.array_equal(got, xcp), "finite case: bit for bit (no sums over rows with col = 0)"
+            assert got[k] == x[k] < l[k]      # found beyond its bound: x stays where it is
