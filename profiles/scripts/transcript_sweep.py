@@ -1,0 +1,62 @@
+"""Differential test of the PRINTED output (prn1lb / prn2lb / prn3lb, the iprint >= 99 reports of cauchy, freev and
+subsm, the iteration file): random problems of tests/test_gpu_fuzz.py run by the real reference (oracle/_ref, a
+built library that travels to the GPU box) and by the library through the reference-shaped host entry, same
+iprint, transcripts compared line by line (tests/test_gpu_fortran_drivers.py: compare -- words and integers
+exactly, floats to print precision, timing lines ignored).  Only problems whose trajectory does not part from
+the oracle's by rounding drift are compared (the one-step-replay harness tells).
+
+    python profiles/scripts/transcript_sweep.py [first] [count] > gpurun_out/transcripts.txt
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fuzz as tf  # noqa: E402
+import test_gpu_fortran_drivers as td  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+po.build(ref=False)
+WORKER = os.path.join(ROOT, "tests", "_iprint_worker.py")
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 90000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+# (iprint, nmax): vectors are dumped above 100 and every breakpoint is reported from 100 on
+LEVELS = [(0, 400), (1, 400), (5, 300), (99, 60), (100, 40), (101, 16)]
+ITERS = 25
+
+
+def transcript(engine, spec, iprint, cwd):
+    r = subprocess.run([sys.executable, WORKER, engine, spec, "0", "0", str(iprint), str(ITERS)], cwd=cwd,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (engine, spec, r.stderr[-1500:])
+    itf = os.path.join(cwd, "iterate.dat")
+    return r.stdout.splitlines(), (open(itf).read().splitlines() if os.path.exists(itf) else [])
+
+
+bad = done = skipped = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    iprint, nmax = LEVELS[seed % len(LEVELS)]
+    spec = "fuzz:%d:%d:1:13" % (seed, nmax)
+    p = tf.make(po, seed, nmax, 1, 13)
+    split, _ = tf.drive_with_replay(po, p, ITERS, final_check=False)
+    if split is not None:
+        skipped += 1
+        continue
+    with tempfile.TemporaryDirectory() as da, tempfile.TemporaryDirectory() as db:
+        try:
+            ref_out, ref_it = transcript("ref", spec, iprint, da)
+            gpu_out, gpu_it = transcript("gpu", spec, iprint, db)
+            td.compare(gpu_out, ref_out)
+            td.compare(gpu_it, ref_it)
+            done += 1
+        except AssertionError as e:
+            bad += 1
+            print("FAIL seed %d iprint %d (n=%d m=%d): %s" % (seed, iprint, p.n, p.m, str(e)[:600]), flush=True)
+print("transcripts compared %d  (skipped: trajectory drift %d)  failures %d  (%.0f s)"
+      % (done, skipped, bad, time.time() - t0))
+sys.exit(1 if bad else 0)

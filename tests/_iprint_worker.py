@@ -2,7 +2,9 @@
 src/lbfgsb.f90 iprint >= 99).  engine 'ref' = the real reference (oracle/_ref; used by
 tests/golden/make_golden.py in the build container only), 'gpu' = the product through the
 reference-shaped host entry.  problem 'rosen': driver1's Rosenbrock; 'quadmix': the bounded
-quadratic with all four bound types (variables leave and enter the free set)."""
+quadratic with all four bound types (variables leave and enter the free set); 'fuzz:SEED:NMAX:MLO:MHI' /
+'fam:NAME:SEED': a random problem of tests/test_gpu_fuzz.py (n, m arguments ignored) -- on the GPU box both
+engines can run side by side (oracle/_ref travels there as a built library)."""
 import os
 import sys
 
@@ -14,7 +16,18 @@ sys.path.insert(0, ROOT)
 
 def main(engine, problem, n, m, iprint, iters):
     from oracle import pyoracle as po
-    p = po.problem_rosenbrock(n, m) if problem == "rosen" else po.problem_quadratic(n, m, mixed_nbd=True)
+    if problem.startswith("fuzz:"):        # fuzz:SEED:NMAX:MLO:MHI -- a random problem of tests/test_gpu_fuzz.py
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_gpu_fuzz as tf
+        a = problem.split(":")
+        p = tf.make(po, int(a[1]), int(a[2]), int(a[3]), int(a[4]))
+    elif problem.startswith("fam:"):       # fam:NAME:SEED -- one of its FAMILIES
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_gpu_fuzz as tf
+        a = problem.split(":")
+        p = tf.FAMILIES[a[1]](po, int(a[2]))
+    else:
+        p = po.problem_rosenbrock(n, m) if problem == "rosen" else po.problem_quadratic(n, m, mixed_nbd=True)
     if engine == "ref":
         e = po.Engine("ref")
         s = po.State.fresh(p, e.int)
