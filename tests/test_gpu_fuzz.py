@@ -184,7 +184,7 @@ def _explain_divergence(po, p, prev, got, pp=False):
     # by design: at a NEW_X return a production context already holds the iwhere
     # pattern of the NEXT cauchy scan; xp / the enter-leave half of Indx2 are not materialised
     # ... and after a REJECTED first trial (FG_LNSRCH in, FG_LNSRCH out) the pattern of the rejected point
-    compare_states(got, s, p.n, p.m, po, skip=("xp",), check_lists=False,
+    compare_states(got, s, p.n, p.m, po, skip=("xp", "wbp"), check_lists=False,
                    check_iwhere=got.task_s.startswith("FG_LN") and not prev.task_s.startswith("FG_LN"),
                    stpmx_cond=True)
 
@@ -192,12 +192,12 @@ def _explain_divergence(po, p, prev, got, pp=False):
 LAST = {}   # how the last drive_with_replay run ended (for sweeps that classify the outcomes themselves)
 
 
-def drive_with_replay(po, p, max_iter, pp=False, final_check=True, **ctx):
+def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=False, **ctx):
     """Run p on the GPU (default context + ctx), call by call beside the oracle's trajectory.
     -> (split, n_calls): split = index of the first call that differs from the oracle's trajectory
     (None: equal to the end).  A split that one oracle call from the GPU's previous state does not
     reproduce raises.  pp: through the ping-pong entry (lbfgsb_hip_setulb_dev_pp).  final_check: after a
-    (reproduced) split the two final f must still agree to 1e-7."""
+    (reproduced) split the two final f must still agree to 1e-7.  replay_all: the one-step replay at EVERY call."""
     import torch
     import lbfgsb_amd as la
 
@@ -223,8 +223,17 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, **ctx):
             rg.append(row(t, sol.isave, sol.f[0]))
             k = len(rg) - 1
             cur = None
-            if split is None:
+            if split is None or replay_all:
                 cur = _state(po, p, sol, x, g)
+            if replay_all and prev is not None:
+                # EVERY call, not only the first that leaves the oracle's trajectory: one oracle call from the
+                # GPU's previous state must give the GPU's call
+                try:
+                    _explain_divergence(po, p, prev, cur, pp)
+                except AssertionError as e:
+                    raise AssertionError("%s (n=%d m=%d): call %d (%s) is NOT reproduced by one oracle call from "
+                                         "the GPU's previous state: %s" % (p.name, p.n, p.m, k, rg[k], e))
+            if split is None:
                 same = (k < len(ro) and ro[k][:5] == rg[k][:5]
                         and (abs(ro[k][5] - rg[k][5]) <= 1e-8 * max(1.0, abs(ro[k][5]))
                              or (np.isnan(ro[k][5]) and np.isnan(rg[k][5]))))

@@ -153,9 +153,14 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), che
             #  explained the way wn's is -- cond(K) times the error of what went in; n = 6 with 13 pairs
             #  stored makes K singular to working precision)
             nrm_close(w8g[:2 * col], w8e[:2 * col], max(1e-6, 50.0 * cond_k * e_in), "wa8m wv",
-                      floor=1e-9 * max(1.0, float(np.max(np.abs(exp.x)))))   # (at convergence wv is rounding noise)
-            nrm_close(w8g[4 * m:4 * m + 2 * col], w8e[4 * m:4 * m + 2 * col], rtol, "wa8m wbp")
-            nrm_close(w8g[6 * m:6 * m + 2 * col], w8e[6 * m:6 * m + 2 * col], 1e-7, "wa8m v")
+                      floor=1e-9 * max(1.0, float(np.max(np.abs(exp.x))), float(np.max(np.abs(exp.g)))))
+            # (floor: at convergence, and for n of a few variables, wv is rounding noise of sums of |g|-sized terms)
+            if "wbp" not in skip:
+                # (wbp = row of W of the LAST variable the walk fixed, v = M wbp: work vectors nothing reads
+                #  afterwards.  A production context crosses a WHOLE group of equal breakpoints in index order,
+                #  the reference in heap order -- same group, another last member)
+                nrm_close(w8g[4 * m:4 * m + 2 * col], w8e[4 * m:4 * m + 2 * col], rtol, "wa8m wbp")
+                nrm_close(w8g[6 * m:6 * m + 2 * col], w8e[6 * m:6 * m + 2 * col], 1e-7, "wa8m v")
     iw_g = got.iwa[n:2 * n]
     iw_e = exp.iwa[n:2 * n]
     if check_iwhere:
