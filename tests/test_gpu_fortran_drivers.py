@@ -149,3 +149,31 @@ def test_driver1_as_a_plain_c_program(tmp_path):
     assert mm, out
     assert int(mm.group(1)) == 23 and int(mm.group(2)) == 28, out
     assert abs(float(mm.group(3)) - 1.0834900834300614e-09) <= 1e-6 * 1.0834900834300614e-09, out
+
+
+@pytest.mark.parametrize("spec,iprint", [
+    ("fuzz:90001:400:1:13", 1), ("fuzz:90003:60:1:13", 99), ("fuzz:90004:40:1:13", 100), ("fuzz:90005:16:1:13", 101),
+    ("fam:linear:91003", 1), ("fam:linear:91002", 99), ("fam:rosenchain:91003", 100), ("fam:scaled:91000", 0),
+])
+def test_transcripts_against_the_live_reference(tmp_path, spec, iprint):
+    """Printed output on problems no golden file covers: the real reference (oracle/_ref, a built library that
+    travels to the GPU box) and the library through the reference-shaped host entry run the same random problem
+    at the same iprint; stdout and the iteration file are compared word for word, numbers to print precision
+    (profiles/scripts/transcript_sweep.py runs hundreds of these; the problems here are ones whose trajectory
+    does not leave the reference's by rounding drift)."""
+    from oracle import pyoracle as po
+    if not po.Engine.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    worker = os.path.join(HERE, "_iprint_worker.py")
+    outs = {}
+    for eng in ("ref", "gpu"):
+        cwd = tmp_path / eng
+        cwd.mkdir()
+        r = subprocess.run([os.sys.executable, worker, eng, spec, "0", "0", str(iprint), "25"], cwd=str(cwd),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (eng, r.stderr[-1500:])
+        itf = cwd / "iterate.dat"
+        outs[eng] = (r.stdout.splitlines(), itf.read_text().splitlines() if itf.exists() else [])
+    assert len(outs["ref"][0]) > 3
+    compare(outs["gpu"][0], outs["ref"][0])
+    compare(outs["gpu"][1], outs["ref"][1])
