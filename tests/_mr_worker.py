@@ -176,21 +176,72 @@ def fuzz_problem(po, seed):
     return po.Problem("mrfuzz%d" % seed, n, m, x0, l, u, nbd, 0.0, 0.0, fg, np.float64)
 
 
+def _assemble(po, p, parts, head):
+    """One caller state (pyoracle.State, the reference's wa / iwa layout for all n rows) out of the ranks'
+    exports of THEIR rows.  parts[r] = (x, g, wa, iwa) of rank r; head = (f, task, csave, lsave, isave, dsave),
+    identical on every rank.  The host matrices are replicated (rank 0's are taken).  Index -- which the next
+    freev reads to tell who enters and who leaves (:2012-2040) -- is put together from the ranks' local lists
+    (export_state: free rows ascending from the front, the others from the back, Indx2(1) = the local number
+    of free rows); the enter / leave halves of Indx2 are dead between calls and stay empty."""
+    n, m = p.n, p.m
+    off = po.wa_offsets(n, m)
+    wa = np.zeros(po.wa_len(n, m))
+    iwa = np.zeros(3 * n, np.int32)
+    row0 = 0
+    free_rows, act_rows = [], []
+    for r, (x, g, wl, il) in enumerate(parts):
+        nl = x.size
+        ol = po.wa_offsets(nl, m)
+        for name in ("ws", "wy"):
+            a = wl[ol[name][0]:ol[name][0] + m * nl].reshape(m, nl)
+            wa[off[name][0]:off[name][0] + m * n].reshape(m, n)[:, row0:row0 + nl] = a
+        for name in ("z", "r", "d", "t", "xp"):
+            wa[off[name][0] + row0:off[name][0] + row0 + nl] = wl[ol[name][0]:ol[name][0] + nl]
+        if r == 0:
+            for name in ("sy", "ss", "wt", "wn", "snd", "wa8m"):
+                wa[off[name][0]:off[name][0] + off[name][1]] = wl[ol[name][0]:ol[name][0] + ol[name][1]]
+        iwa[n + row0:n + row0 + nl] = il[nl:2 * nl]
+        if il[:nl].any():                     # a freev has run
+            nf = int(il[2 * nl])
+            free_rows.append(il[:nf] + row0)
+            act_rows.append(il[nl - 1:nf - 1 if nf > 0 else None:-1] + row0)
+        row0 += nl
+    if free_rows:
+        fr, ac = np.concatenate(free_rows), np.concatenate(act_rows)
+        assert fr.size + ac.size == n
+        iwa[:fr.size] = fr
+        iwa[n - 1:fr.size - 1 if fr.size > 0 else None:-1] = ac
+    f, task, csave, lsave, isave, dsave = head
+    return po.State(n, m, np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts]),
+                    np.array([f]), wa, iwa, task.copy(), csave.copy(), lsave.copy(), isave.copy(), dsave.copy())
+
+
 def run_fuzz(rank, world, port, first, count, iters, out_path):
-    """`count` random problems, rows cut over `world` ranks sharing cuda:0 (gloo host reducers);
-    the objective is evaluated per shard on the host and summed over the ranks."""
+    """`count` random problems, rows cut over `world` ranks sharing cuda:0 (gloo host reducers); the
+    objective is evaluated per shard on the host and summed over the ranks.  Rank 0 follows the oracle's
+    trajectory call by call; at the FIRST call that differs every rank hands over the state it exported
+    before and after that call, rank 0 puts the n rows together and ONE oracle call from the sharded run's
+    own previous state must reproduce the sharded run's call (tests/test_gpu_fuzz.py: _explain_divergence)."""
     import torch
     import torch.distributed as dist
     import lbfgsb_amd
     from oracle import pyoracle as po
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_fuzz import _explain_divergence
 
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
                             world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     results = {}
+
+    def row(t, isave, f):
+        return [t[:12], int(isave[29]), int(isave[33]), int(isave[32]), int(isave[37]), float(f)]
     for seed in range(first, first + count):
         p = fuzz_problem(po, seed)
+        ro = []
+        if rank == 0:
+            po.run(po.Engine("oracle"), p, max_iter=iters, snapshot=lambda k, s: ro.append(row(s.task_s, s.isave, s.f[0])))
         row0, n_loc = lbfgsb_amd.block_partition(p.n, world, rank)
         sol = lbfgsb_amd.DeviceSolver(n_loc, p.m, n_global=p.n, row0=row0, device=0)
         lbfgsb_amd.attach_host_group(sol, rank, world)
@@ -200,9 +251,36 @@ def run_fuzz(rank, world, port, first, count, iters, out_path):
         l = torch.from_numpy(p.l[sl].copy()).to(dev)
         u = torch.from_numpy(p.u[sl].copy()).to(dev)
         nbd = torch.from_numpy(p.nbd[sl].astype(np.int32)).to(dev)
-        rows = []
-        for _ in range(100000):
+        rows, prev, split, verdict = [], None, None, None
+        for k in range(100000):
             t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            rows.append(row(t, sol.isave, sol.f[0]))
+            flag = torch.zeros(1, dtype=torch.int32)
+            cur = None
+            if split is None:
+                torch.cuda.synchronize()
+                wa, iwa = sol.export_state()
+                cur = [x.cpu().numpy(), g.cpu().numpy(), wa, iwa]
+                head = (float(sol.f[0]), sol.task.copy(), sol.csave.copy(), sol.lsave.copy(), sol.isave.copy(),
+                        sol.dsave.copy())
+                if rank == 0:
+                    same = (k < len(ro) and ro[k][:5] == rows[k][:5]
+                            and abs(ro[k][5] - rows[k][5]) <= 1e-8 * max(1.0, abs(ro[k][5])))
+                    flag[0] = 0 if same else 1
+                dist.broadcast(flag, 0)
+                if int(flag[0]):
+                    split = k
+                    both = [None] * world
+                    dist.gather_object((prev, (cur, head)), both if rank == 0 else None, 0)
+                    if rank == 0:
+                        try:
+                            assert prev is not None, "diverged at the very first call"
+                            sp = _assemble(po, p, [b[0][0] for b in both], both[0][0][1])
+                            sc = _assemble(po, p, [b[1][0] for b in both], both[0][1][1])
+                            _explain_divergence(po, p, sp, sc)
+                            verdict = "reproduced"
+                        except AssertionError as e:
+                            verdict = "call %d (%s vs %s) NOT reproduced: %s" % (k, ro[k:k + 1], rows[k], str(e)[:300])
             if t.startswith("FG"):
                 xh = x.cpu().numpy()
                 gh = np.empty_like(xh)
@@ -210,14 +288,17 @@ def run_fuzz(rank, world, port, first, count, iters, out_path):
                 dist.all_reduce(ft)
                 g.copy_(torch.from_numpy(gh))
                 sol.f[0] = float(ft[0])
+                if cur is not None:   # the state the next call starts from: f, g as evaluated at the run's own x
+                    cur[1] = gh.copy()
+                    head = (float(ft[0]),) + head[1:]
             elif t.startswith("NEW_X"):
-                rows.append([int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
-                             int(sol.isave[37]), float(sol.f[0])])
                 if sol.isave[29] >= iters:
                     break
             else:
                 break
-        results[str(seed)] = {"rows": rows, "task": sol.task_s}
+            prev = (cur, head) if cur is not None else None
+        results[str(seed)] = {"rows": [r_[1:] for r_ in rows if r_[0].startswith("NEW_X")], "task": sol.task_s,
+                              "calls": len(rows), "oracle_calls": len(ro), "split": split, "verdict": verdict}
         sol.close()
     if rank == 0:
         with open(out_path, "w") as fh:

@@ -199,35 +199,23 @@ def test_sharded_checkpoint_and_resume(oracle_built, tmp_path, monkeypatch, worl
 @pytest.mark.parametrize("world,first,count", [(2, 100, 25), (3, 200, 25)])
 def test_sharded_random_problems_match_oracle(oracle_built, tmp_path, world, first, count):
     """Random separable problems (n < 2000, m < 13, all bound types) with the rows cut over 2 and
-    3 ranks, the objective evaluated per shard and summed: per iteration the integer columns
-    (iteration, nfg, nseg, nfree) and f must equal the single-rank oracle's -- the sharded
-    reductions, the merged breakpoint walk, the fix lists and the pending pair all have to agree
-    on every rank for that.  (Late divergence at rounding level is tolerated as in the fuzz test.)"""
-    po = oracle_built
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("_mr_worker", os.path.join(HERE, "_mr_worker.py"))
-    wk = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(wk)
+    3 ranks, the objective evaluated per shard and summed: call by call beside the single-rank oracle's
+    trajectory -- the sharded reductions, the merged breakpoint walk, the fix lists and the pending pair
+    all have to agree on every rank for that.  Where a sharded run leaves the trajectory (rounding drift:
+    factr = 0), the ranks' exported rows before and after that call are put together and ONE oracle call
+    from the run's own previous state must reproduce the call (task, every counter, iwhere exactly, floats
+    to 1e-10): the bar of tests/test_gpu_fuzz.py, no allowance."""
     iters = 40
     res = launch(world, "fuzz", first, count, iters, "-", str(tmp_path / "out.json"))
-    late = 0
+    splits = 0
     for seed in range(first, first + count):
-        p = wk.fuzz_problem(po, seed)
-        rows = []
-        so = po.run(po.Engine("oracle"), p, max_iter=iters,
-                    snapshot=lambda k, s: rows.append([int(s.isave[29]), int(s.isave[33]), int(s.isave[32]),
-                                                       int(s.isave[37]), float(s.f[0])])
-                    if s.task_s.startswith("NEW_X") else None)
-        got = res[str(seed)]["rows"]
-        k = 0
-        while (k < min(len(rows), len(got)) and rows[k][:4] == got[k][:4]
-               and abs(rows[k][4] - got[k][4]) <= 1e-9 * max(1.0, abs(rows[k][4]))):
-            k += 1
-        if k == len(rows) == len(got):
-            continue
-        late += 1
-        assert k >= 0.5 * len(rows), (seed, p.n, p.m, k, len(rows), len(got), rows[k - 1:k + 1], got[k - 1:k + 1])
-    assert late <= 0.2 * count
+        r = res[str(seed)]
+        if r["split"] is None:
+            assert r["calls"] == r["oracle_calls"], (seed, r["calls"], r["oracle_calls"])
+        else:
+            splits += 1
+            assert r["verdict"] == "reproduced", (seed, r["verdict"])
+    assert splits <= 0.2 * count, splits   # (a sanity bound on how often drift shows, not an allowance)
 
 
 def _fake_rccl():
