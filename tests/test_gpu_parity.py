@@ -1221,6 +1221,20 @@ def test_device_path_to_convergence_against_oracle(env, n, m, mixed, min_agree, 
     assert float(sol.f[0]) == pytest.approx(float(so.f[0]), rel=1e-11)
 
 
+@pytest.mark.parametrize("n,m,mixed", [(1000, 10, False), (4096, 10, True), (100003, 5, False)])
+def test_runs_to_convergence_under_the_replay_bar(env, n, m, mixed):
+    """The same three runs to CONVERGENCE (factr = pgtol = 0: the last iterations act on rounding noise) call by
+    call beside the oracle, both device-pointer entries: where a run leaves the oracle's trajectory -- the
+    `min_agree` of the test above -- ONE oracle call from the run's own previous state must reproduce the call
+    (tests/test_gpu_fuzz.py: drive_with_replay), and the final f still agrees to 1e-7."""
+    from test_gpu_fuzz import drive_with_replay
+    po = env["po"]
+    p = po.problem_quadratic(n, m, mixed_nbd=mixed)
+    for pp in (False, True):
+        split, ncalls = drive_with_replay(po, p, 10 ** 9, pp=pp)
+        assert ncalls > 100 and (split is None or split > 50), (split, ncalls)
+
+
 def test_parallel_gcp_with_pairs_stored(env):
     """LBFGSB_F_PARALLEL_GCP when pairs are stored (col > 0): a two-scale
     separable quadratic whose 2nd and 6th iterations each cross ~91 000 breakpoints with col = 1
