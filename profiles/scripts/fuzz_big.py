@@ -21,37 +21,10 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 97000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 
 
-def scaled_up(gen, factor):
-    """a family's problem with its n multiplied: the generators draw n first, from rng.integers(lo, hi)"""
-    def g(po_, seed):
-        real = np.random.default_rng
-
-        class Big:
-            def __init__(self, seed):
-                self.r = real(seed)
-                self.first = True
-
-            def integers(self, lo, hi=None, *a, **k):
-                v = self.r.integers(lo, hi, *a, **k)
-                if self.first and not a and not k:
-                    self.first = False
-                    return int(v) * factor
-                return v
-
-            def __getattr__(self, name):
-                return getattr(self.r, name)
-        np.random.default_rng = Big
-        try:
-            return gen(po_, seed)
-        finally:
-            np.random.default_rng = real
-    return g
-
-
-KINDS = [("make x300", lambda po_, s: scaled_up(lambda q, t: tf.make(q, t, 2000, 1, 9), 300)(po_, s)),
-         ("linear x300", scaled_up(tf.FAMILIES["linear"], 300)),
-         ("lattice x400", scaled_up(tf.FAMILIES["lattice"], 400)),
-         ("rosenchain x500", scaled_up(tf.FAMILIES["rosenchain"], 500))]
+KINDS = [("make x300", lambda po_, s: tf.scaled_up(lambda q, t: tf.make(q, t, 2000, 1, 9), 300)(po_, s)),
+         ("linear x300", tf.scaled_up(tf.FAMILIES["linear"], 300)),
+         ("lattice x400", tf.scaled_up(tf.FAMILIES["lattice"], 400)),
+         ("rosenchain x500", tf.scaled_up(tf.FAMILIES["rosenchain"], 500))]
 t0 = time.time()
 worst = 0
 for name, gen in KINDS:

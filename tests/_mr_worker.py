@@ -216,17 +216,20 @@ def _assemble(po, p, parts, head):
                     np.array([f]), wa, iwa, task.copy(), csave.copy(), lsave.copy(), isave.copy(), dsave.copy())
 
 
-def run_fuzz(rank, world, port, first, count, iters, out_path):
+def run_fuzz(rank, world, port, first, count, iters, out_path, family=None, scale=1, comm="gloo"):
     """`count` random problems, rows cut over `world` ranks sharing cuda:0 (gloo host reducers); the
     objective is evaluated per shard on the host and summed over the ranks.  Rank 0 follows the oracle's
     trajectory call by call; at the FIRST call that differs every rank hands over the state it exported
     before and after that call, rank 0 puts the n rows together and ONE oracle call from the sharded run's
-    own previous state must reproduce the sharded run's call (tests/test_gpu_fuzz.py: _explain_divergence)."""
+    own previous state must reproduce the sharded run's call (tests/test_gpu_fuzz.py: _explain_divergence).
+    family / scale: a problem of tests/test_gpu_fuzz.py's FAMILIES with its n multiplied (the objective is then
+    evaluated on the gathered x by every rank); comm = "fakerccl": through the library's communicator code path."""
     import torch
     import torch.distributed as dist
     import lbfgsb_amd
     from oracle import pyoracle as po
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as tf
     from test_gpu_fuzz import _explain_divergence
 
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
@@ -238,13 +241,23 @@ def run_fuzz(rank, world, port, first, count, iters, out_path):
     def row(t, isave, f):
         return [t[:12], int(isave[29]), int(isave[33]), int(isave[32]), int(isave[37]), float(f)]
     for seed in range(first, first + count):
-        p = fuzz_problem(po, seed)
+        if family:
+            gen = (lambda q, t_: tf.make(q, t_, 2000, 1, 9)) if family == "make" else tf.FAMILIES[family]
+            p = tf.scaled_up(gen, scale)(po, seed)
+        else:
+            p = fuzz_problem(po, seed)
         ro = []
         if rank == 0:
             po.run(po.Engine("oracle"), p, max_iter=iters, snapshot=lambda k, s: ro.append(row(s.task_s, s.isave, s.f[0])))
         row0, n_loc = lbfgsb_amd.block_partition(p.n, world, rank)
         sol = lbfgsb_amd.DeviceSolver(n_loc, p.m, n_global=p.n, row0=row0, device=0)
-        lbfgsb_amd.attach_host_group(sol, rank, world)
+        if comm == "fakerccl":
+            ids = [lbfgsb_amd.DeviceSolver.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, 0)
+            sol.init_rccl(ids[0], rank, world)
+            assert "libfake_rccl" in open("/proc/self/maps").read()
+        else:
+            lbfgsb_amd.attach_host_group(sol, rank, world)
         sl = slice(row0, row0 + n_loc)
         x = torch.from_numpy(p.x0[sl].copy()).to(dev)
         g = torch.zeros_like(x)
@@ -283,9 +296,17 @@ def run_fuzz(rank, world, port, first, count, iters, out_path):
                             verdict = "call %d (%s vs %s) NOT reproduced: %s" % (k, ro[k:k + 1], rows[k], str(e)[:300])
             if t.startswith("FG"):
                 xh = x.cpu().numpy()
-                gh = np.empty_like(xh)
-                ft = torch.tensor([p.fg(xh, gh, row0, row0 + n_loc)], dtype=torch.float64)
-                dist.all_reduce(ft)
+                if family:   # any objective: every rank evaluates it on the gathered x and keeps its rows
+                    xs_all = [None] * world
+                    dist.all_gather_object(xs_all, xh)
+                    xf = np.concatenate(xs_all)
+                    gf = np.empty_like(xf)
+                    ft = torch.tensor([p.fg(xf, gf)], dtype=torch.float64)
+                    gh = gf[sl].copy()
+                else:
+                    gh = np.empty_like(xh)
+                    ft = torch.tensor([p.fg(xh, gh, row0, row0 + n_loc)], dtype=torch.float64)
+                    dist.all_reduce(ft)
                 g.copy_(torch.from_numpy(gh))
                 sol.f[0] = float(ft[0])
                 if cur is not None:   # the state the next call starts from: f, g as evaluated at the run's own x
@@ -309,7 +330,9 @@ def run_fuzz(rank, world, port, first, count, iters, out_path):
 
 if __name__ == "__main__":
     a = sys.argv
-    if a[4] == "fuzz":   # rank world port "fuzz" first count iters - out
-        run_fuzz(int(a[1]), int(a[2]), int(a[3]), int(a[5]), int(a[6]), int(a[7]), a[9])
+    if a[4].startswith("fuzz"):   # rank world port "fuzz[:family:scale:comm]" first count iters - out
+        opt = a[4].split(":")
+        kw = dict(family=opt[1], scale=int(opt[2]), comm=opt[3]) if len(opt) == 4 else {}
+        run_fuzz(int(a[1]), int(a[2]), int(a[3]), int(a[5]), int(a[6]), int(a[7]), a[9], **kw)
     else:
         run(int(a[1]), int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]), int(a[7]), a[8], a[9])

@@ -157,6 +157,33 @@ FAMILIES = {"linear": fam_linear, "scaled": fam_scaled, "sqrt": fam_sqrt, "rosen
             "lattice": fam_lattice, "tiny": fam_tiny}
 
 
+def scaled_up(gen, factor):
+    """a family's problem with its n multiplied: the generators draw n first, from rng.integers(lo, hi)"""
+    def g(po_, seed):
+        real = np.random.default_rng
+
+        class Big:
+            def __init__(self, seed):
+                self.r = real(seed)
+                self.first = True
+
+            def integers(self, lo, hi=None, *a, **k):
+                v = self.r.integers(lo, hi, *a, **k)
+                if self.first and not a and not k:
+                    self.first = False
+                    return int(v) * factor
+                return v
+
+            def __getattr__(self, name):
+                return getattr(self.r, name)
+        np.random.default_rng = Big
+        try:
+            return gen(po_, seed)
+        finally:
+            np.random.default_rng = real
+    return g
+
+
 def _state(po, p, sol, x, g):
     """the caller arrays of a DEFAULT (production-path) context after a setulb return; export_state is
     read-only: it writes z and d out where the lean subspace pass left them implicit, nothing else"""
