@@ -180,7 +180,7 @@ void suite(int64_t n, const double *w, const double *vec, double *out, double *s
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const int64_t n = 100000000;   // multiple of 512
@@ -191,6 +191,17 @@ int main() {
   CK(hipMemset(w, 0, (size_t)n * 24 * 8));
   CK(hipMemset(out, 0, (size_t)n * 8 * 8));
   const double *vec = w + (size_t)n * 20;   // the 4 separate n-vectors of the tiled form
+  if (argc > 1 && argv[1][0] == 'r') {
+    // round 3: the stream mix of the iteration's two passes as they are now (uniform bounds, ping-pong entry):
+    // storing pass = 22 fp64 read streams (+ 1 B/row of iwhere) and 3 write streams, read-only pass = 22 read streams
+    for (int pass = 0; pass < 2; ++pass) {
+      suite<22, 3, false>(n, w, vec, out, sink);
+      suite<22, 5, false>(n, w, vec, out, sink);
+      suite<22, 0, false>(n, w, vec, out, sink);
+      printf("\n");
+    }
+    return 0;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     suite<24, 0, false>(n, w, vec, out, sink);
     suite<24, 0, true>(n, w, vec, out, sink);
