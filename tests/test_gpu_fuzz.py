@@ -412,3 +412,82 @@ def test_problem_families_against_oracle(oracle_built, family, first, count):
         split, _ = drive_with_replay(po, p, 60, pp=bool(seed & 1), final_check=False)
         splits += split is not None
     assert splits <= count * (0.6 if family == "linear" else 0.1), (family, splits, count)
+
+
+def _run_checkpointed(po, p, max_iter, pp, prob, seed, fg_prob=0.0):
+    """Drive p through a device-pointer entry; after a NEW_X return with probability `prob`, after an FG return
+    (f and g evaluated) with probability `fg_prob`, the state is
+    exported (wa, iwa + the small caller arrays), the context destroyed, and a NEW context imports it and
+    carries on (iterate and gradient in the first buffer pair).  -> per-call trace of what a caller sees."""
+    import torch
+    import lbfgsb_amd as la
+    rng = np.random.default_rng(seed)
+    TIME_D = [5, 6, 7, 8, 9]
+
+    def fresh(x0, g0):
+        xs = [torch.from_numpy(x0).cuda(), torch.full((p.n,), 5.0, dtype=torch.float64, device="cuda")]
+        gs = [torch.from_numpy(g0).cuda(), torch.full((p.n,), 9.0, dtype=torch.float64, device="cuda")]
+        return la.DeviceSolver(p.n, p.m), xs, gs
+    sol, xs, gs = fresh(p.x0.copy(), np.zeros(p.n))
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+    x, g, trace, nckpt = xs[0], gs[0], [], 0
+    try:
+        for _ in range(100000):
+            if pp:
+                t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                x, g = xs[cur], gs[cur]
+            else:
+                t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            ds = sol.dsave.copy()
+            ds[TIME_D] = 0
+            trace.append((t, sol.isave[21:44].copy(), ds.tobytes(), float(sol.f[0]), x.cpu().numpy().tobytes()))
+            ckpt = False
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+                ckpt = rng.random() < fg_prob      # (in the middle of a line search, f and g evaluated)
+            elif t.startswith("NEW_X"):
+                if sol.isave[29] >= max_iter:
+                    break
+                ckpt = rng.random() < prob
+            else:
+                break
+            if True:
+                if ckpt:
+                    torch.cuda.synchronize()
+                    wa, iwa = sol.export_state()
+                    keep = {nm: getattr(sol, nm).copy() for nm in ("task", "csave", "lsave", "isave", "dsave", "f")}
+                    xh, gh = x.cpu().numpy(), g.cpu().numpy()
+                    sol.close()
+                    sol, xs, gs = fresh(xh, gh)
+                    sol.import_state(wa, iwa, keep["isave"])
+                    for nm, v in keep.items():
+                        getattr(sol, nm)[:] = v
+                    x, g = xs[0], gs[0]
+                    nckpt += 1
+    finally:
+        sol.close()
+    return trace, nckpt
+
+
+@pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
+def test_checkpoint_resume_random_problems(oracle_built, pp):
+    """Checkpoint / resume on random problems (all state lives in the caller's arrays): a run
+    that is exported at random returns -- NEW_X, and FG in the middle of a line search -- its context destroyed
+    and a fresh one importing the state, must go on EXACTLY as the uninterrupted run: task, every counter, dsave,
+    f and x bit for bit at every call."""
+    po = oracle_built
+    total = 0
+    for seed in range(12000, 12040):
+        p = make(po, seed, 1500, 1, 25)
+        a, _ = _run_checkpointed(po, p, 40, pp, 0.0, seed)
+        b, nck = _run_checkpointed(po, p, 40, pp, 0.35, seed, fg_prob=0.25)
+        total += nck
+        assert len(a) == len(b), (p.name, p.n, p.m, len(a), len(b), nck)
+        for k, (ra, rb) in enumerate(zip(a, b)):
+            assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]), (p.name, k, ra[0], rb[0], ra[1], rb[1])
+            assert ra[3] == rb[3] and ra[2] == rb[2] and ra[4] == rb[4], (p.name, p.n, p.m, k, ra[0], ra[3], rb[3])
+    assert total >= 300
