@@ -491,3 +491,74 @@ def test_checkpoint_resume_random_problems(oracle_built, pp):
             assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]), (p.name, k, ra[0], rb[0], ra[1], rb[1])
             assert ra[3] == rb[3] and ra[2] == rb[2] and ra[4] == rb[4], (p.name, p.n, p.m, k, ra[0], ra[3], rb[3])
     assert total >= 300
+
+
+@pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
+def test_restart_on_a_used_context_random_problems(oracle_built, pp):
+    """task = 'START' on a context that is in the middle of ANOTHER run (other starting point, other bounds and
+    bound types, one of them with uniform bounds): nothing of the first run may leak into the second -- the
+    second run must be bit for bit the run of a fresh context (the reference keeps no state outside the
+    caller's arrays, src/lbfgsb.f90:246-284)."""
+    import torch
+    import lbfgsb_amd as la
+    po = oracle_built
+
+    def drive(sol, p, xs, gs, iters):
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        xs[0].copy_(torch.from_numpy(p.x0))
+        sol.task[:] = po.pad60("START")
+        # (the caller's small arrays as a new caller would hand them over: what a run leaves in isave(43:44) /
+        #  dsave(17:29) -- dcsrch's -- stays there until the next line search, in the reference as well)
+        sol.isave[:], sol.dsave[:], sol.lsave[:], sol.f[:] = 0, 0.0, 0, 0.0
+        sol.csave[:] = po.pad60("")
+        x, g, trace = xs[0], gs[0], []
+        for _ in range(100000):
+            if pp:
+                t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                x, g = xs[cur], gs[cur]
+            else:
+                t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            ds = sol.dsave.copy()
+            ds[[5, 6, 7, 8, 9]] = 0
+            trace.append((t, sol.isave[21:44].copy(), ds.tobytes(), float(sol.f[0]), x.cpu().numpy().tobytes()))
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+            elif t.startswith("NEW_X"):
+                if sol.isave[29] >= iters:
+                    break
+            else:
+                break
+        return trace
+    for seed in range(13000, 13030):
+        pa = make(po, seed, 1200, 1, 20)
+        rng = np.random.default_rng(seed)
+        # the second problem: same n and m, everything else new; every third one a plain box (uniform bounds)
+        pb = make(po, seed, 1200, 1, 20)
+        pb.x0 = rng.normal(0, 3, pa.n)
+        if seed % 3 == 0:
+            pb.l[:], pb.u[:], pb.nbd[:] = -1.0, 1.5, 2
+        else:
+            pb.l = rng.normal(-1, 1, pa.n)
+            pb.u = pb.l + np.abs(rng.normal(1.5, 1, pa.n))
+            pb.nbd = rng.integers(0, 4, pa.n).astype(np.int32)
+
+        def buffers():
+            xs = [torch.zeros(pa.n, dtype=torch.float64, device="cuda") for _ in range(2)]
+            gs = [torch.zeros(pa.n, dtype=torch.float64, device="cuda") for _ in range(2)]
+            return xs, gs
+        sol = la.DeviceSolver(pa.n, pa.m)
+        xs, gs = buffers()
+        fresh = drive(sol, pb, xs, gs, 25)
+        sol.close()
+        sol = la.DeviceSolver(pa.n, pa.m)
+        xs, gs = buffers()
+        drive(sol, pa, xs, gs, int(rng.integers(1, 12)))      # left in the middle: pending pair, speculative sums
+        again = drive(sol, pb, xs, gs, 25)
+        sol.close()
+        assert len(fresh) == len(again), (seed, len(fresh), len(again))
+        for k, (ra, rb) in enumerate(zip(fresh, again)):
+            assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[2:] == rb[2:], (seed, pa.n, pa.m, k, ra[0], rb[0])
