@@ -562,3 +562,60 @@ def test_restart_on_a_used_context_random_problems(oracle_built, pp):
         assert len(fresh) == len(again), (seed, len(fresh), len(again))
         for k, (ra, rb) in enumerate(zip(fresh, again)):
             assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[2:] == rb[2:], (seed, pa.n, pa.m, k, ra[0], rb[0])
+
+
+def test_caller_buffers_may_move_between_calls(oracle_built):
+    """The reference takes its arrays anew on every call (src/lbfgsb.f90:88-89): a caller may hand over x, g, l, u,
+    nbd at OTHER addresses than last time as long as the contents are what the previous call left.  30 random
+    problems (every third with uniform bounds), after ~30 % of the calls every array is copied to a new device
+    buffer and the old x, g are overwritten with NaN: every call bit for bit the run that never moves anything
+    (the library's speculative sums, implicit d = x - t, packed nbd and uniform-bound constants must follow)."""
+    import torch
+    import lbfgsb_amd as la
+    po = oracle_built
+
+    def run(p, move_prob, seed, iters=40):
+        rng = np.random.default_rng(seed)
+        sol = la.DeviceSolver(p.n, p.m)
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        keep, trace, moves = [], [], 0
+        try:
+            for _ in range(100000):
+                t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+                ds = sol.dsave.copy()
+                ds[[5, 6, 7, 8, 9]] = 0
+                trace.append((t, sol.isave[21:44].tobytes(), ds.tobytes(), float(sol.f[0]), x.cpu().numpy().tobytes()))
+                if t.startswith("FG"):
+                    xh = x.cpu().numpy()
+                    gh = np.empty_like(xh)
+                    sol.f[0] = p.fg(xh, gh)
+                    g.copy_(torch.from_numpy(gh))
+                elif t.startswith("NEW_X"):
+                    if sol.isave[29] >= iters:
+                        break
+                else:
+                    break
+                if rng.random() < move_prob:
+                    torch.cuda.synchronize()
+                    keep += [x, g, l, u, nbd]          # (the old buffers stay allocated: new addresses for sure)
+                    x2, g2, l, u, nbd = [t_.clone() for t_ in (x, g, l, u, nbd)]
+                    x.fill_(float("nan"))
+                    g.fill_(float("nan"))
+                    x, g = x2, g2
+                    moves += 1
+        finally:
+            sol.close()
+        return trace, moves
+    total = 0
+    for seed in range(14000, 14030):
+        p = make(po, seed, 1500, 1, 25)
+        if seed % 3 == 0:
+            p.l[:], p.u[:], p.nbd[:] = -1.0, 1.5, 2
+        a, _ = run(p, 0.0, seed)
+        b, mv = run(p, 0.3, seed)
+        total += mv
+        assert a == b, (seed, p.n, p.m, len(a), len(b), next((k for k, (ra, rb) in enumerate(zip(a, b)) if ra != rb), None))
+    assert total >= 300
