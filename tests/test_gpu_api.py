@@ -428,3 +428,66 @@ def test_ping_pong_entry_with_mirrored_lists_and_across_a_checkpoint():
         # (the exported wa of a production context is a VIEW of the state -- z, xp slots are dead storage there --
         #  so across the checkpoint the comparison is on what a caller sees: task, counters, scalars, f, x)
         same(tail, full[len(head):], "resumed", skip_first=True)
+
+
+def test_contexts_on_four_host_threads_do_not_interfere():
+    """include/lbfgsb_hip.h: one host thread per context, any number of contexts.  40 random problems run one after
+    the other, then again spread over four host threads that drive their contexts at the same time (ctypes
+    releases the GIL inside the library; every context has its own stream): every call of every run bit for
+    bit the serial one -- no state shared between contexts."""
+    import threading
+    import numpy as np
+    import torch
+    import lbfgsb_amd as la
+    from oracle import pyoracle as po
+    from test_gpu_fuzz import make
+
+    def run(p, pp, iters=30):
+        torch.cuda.set_device(0)
+        sol = la.DeviceSolver(p.n, p.m)
+        xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.zeros(p.n, dtype=torch.float64, device="cuda")]
+        gs = [torch.zeros_like(xs[0]), torch.zeros_like(xs[0])]
+        x, g = xs[0], gs[0]
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        trace = []
+        try:
+            for _ in range(100000):
+                if pp:
+                    t, c = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                    x, g = xs[c], gs[c]
+                else:
+                    t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+                ds = sol.dsave.copy()
+                ds[[5, 6, 7, 8, 9]] = 0
+                trace.append((t, sol.isave[21:44].tobytes(), ds.tobytes(), float(sol.f[0]), x.cpu().numpy().tobytes()))
+                if t.startswith("FG"):
+                    xh = x.cpu().numpy()
+                    gh = np.empty_like(xh)
+                    sol.f[0] = p.fg(xh, gh)
+                    g.copy_(torch.from_numpy(gh))
+                elif t.startswith("NEW_X"):
+                    if sol.isave[29] >= iters:
+                        break
+                else:
+                    break
+        finally:
+            sol.close()
+        return trace
+    probs = [make(po, s, 3000, 1, 25) for s in range(15000, 15040)]
+    serial = [run(p, i & 1) for i, p in enumerate(probs)]
+    out, errs = [None] * len(probs), []
+
+    def worker(k):
+        try:
+            for i in range(k, len(probs), 4):
+                out[i] = run(probs[i], i & 1)
+        except BaseException as e:   # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert [a == b for a, b in zip(serial, out)] == [True] * len(probs)
