@@ -71,6 +71,7 @@ PROTOTYPES = {
     "lbfgsb_hip_matupd": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp]),
 }
 
+E_NOGPU, E_ARG, E_ALLOC, E_COMM, E_STATE = -100, -101, -102, -103, -104   # status codes of include/lbfgsb_hip.h
 F_REAL32 = 1
 F_MIRROR_INDEX = 2
 F_NO_RETURN_SYNC = 4

@@ -25,6 +25,7 @@ int lbfgsb_hip_create(int64_t n_local, int64_t n_global, int64_t row0, int m, in
 void lbfgsb_hip_destroy(lbfgsb_hip_ctx *ctx) { delete ctx; }
 
 int lbfgsb_hip_rccl_unique_id(void *id128) {
+  if (!id128) return fail(LBFGSB_E_ARG, "rccl_unique_id: NULL argument");
   if (!g_rccl.load()) return fail(LBFGSB_E_COMM, "cannot load librccl");
   ncclUniqueId id;
   if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclGetUniqueId");
@@ -34,7 +35,7 @@ int lbfgsb_hip_rccl_unique_id(void *id128) {
 }
 
 int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, int nranks) {
-  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return fail(LBFGSB_E_ARG, "bad rank");
+  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(LBFGSB_E_ARG, "bad rank / NULL id");
   if (!g_rccl.load()) return fail(LBFGSB_E_COMM, "cannot load librccl");
   HIPCHK(hipSetDevice(ctx->device));
   ncclUniqueId id;
@@ -92,7 +93,7 @@ int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void 
                         const int32_t *nbd, void *g, double factr, double pgtol, int max_iter,
                         int max_fg, int iprint, lbfgsb_fg_fn fg, void *user, int builtin_kind,
                         double *f, char *task, int32_t *lsave, int32_t *isave, double *dsave) {
-  if (!ctx || !f || !task || !lsave || !isave || !dsave)
+  if (!ctx || !x || !l || !u || !nbd || !g || !f || !task || !lsave || !isave || !dsave)
     return fail(LBFGSB_E_ARG, "minimize: NULL argument");
   char csave[60];
   std::memset(csave, ' ', 60);
@@ -127,18 +128,18 @@ int lbfgsb_hip_minimize(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void 
 }
 
 int lbfgsb_hip_export_state(lbfgsb_hip_ctx *ctx, void *wa, int32_t *iwa) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !wa) return fail(LBFGSB_E_ARG, "export_state: NULL argument");   // (iwa may be NULL: wa only)
   return ctx->export_state(wa, iwa);
 }
 int lbfgsb_hip_import_state(lbfgsb_hip_ctx *ctx, const void *wa, const int32_t *iwa,
                             const int32_t *isave) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !wa || !iwa || !isave) return fail(LBFGSB_E_ARG, "import_state: NULL argument");
   return ctx->import_state(wa, iwa, isave);
 }
 
 int lbfgsb_hip_projgr(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const void *u,
                       const int32_t *nbd, const void *g, double *h_sbgnrm) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !x || !l || !u || !nbd || !g || !h_sbgnrm) return fail(LBFGSB_E_ARG, "projgr: NULL argument");
   return ctx->k_projgr(x, l, u, nbd, g, h_sbgnrm);
 }
 // ---- routine doors (solver_doors.inl) ----
@@ -194,16 +195,16 @@ int lbfgsb_hip_matupd(lbfgsb_hip_ctx *ctx, const void *g, double stp, double dr,
 }
 
 int lbfgsb_hip_wtv(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, double *h_out) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !v || !h_out) return fail(LBFGSB_E_ARG, "wtv: NULL argument");
   return ctx->k_wtv(v, col, head, h_out, false);
 }
 int lbfgsb_hip_wtv_launch_only(lbfgsb_hip_ctx *ctx, const void *v, int col, int head) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !v) return fail(LBFGSB_E_ARG, "wtv: NULL argument");
   return ctx->k_wtv(v, col, head, nullptr, true);
 }
 int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, int reps,
                         double *h_ms_per_launch) {
-  if (!ctx || reps < 1) return fail(LBFGSB_E_ARG, "wtv_time: bad arguments");
+  if (!ctx || !v || !h_ms_per_launch || reps < 1) return fail(LBFGSB_E_ARG, "wtv_time: bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
@@ -222,7 +223,7 @@ int lbfgsb_hip_wtv_time(lbfgsb_hip_ctx *ctx, const void *v, int col, int head, i
 }
 int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const void *g, int col,
                            int head, int reps, double *h_ms_per_launch) {
-  if (!ctx || reps < 1) return fail(LBFGSB_E_ARG, "kernel_time: bad arguments");
+  if (!ctx || !x || !g || !h_ms_per_launch || reps < 1) return fail(LBFGSB_E_ARG, "kernel_time: bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
@@ -240,7 +241,7 @@ int lbfgsb_hip_kernel_time(lbfgsb_hip_ctx *ctx, int which, const void *x, const 
   return 0;
 }
 int lbfgsb_hip_set_w(lbfgsb_hip_ctx *ctx, const void *h_ws, const void *h_wy) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !h_ws || !h_wy) return fail(LBFGSB_E_ARG, "set_w: NULL argument");
   return ctx->k_set_w(h_ws, h_wy);
 }
 int lbfgsb_hip_set_iwhere(lbfgsb_hip_ctx *ctx, const int32_t *h_iwhere) {
@@ -256,7 +257,7 @@ int lbfgsb_hip_sync(lbfgsb_hip_ctx *ctx) {
   return ctx->sync();
 }
 int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, double *h_f) {
-  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (!ctx || !x || !g) return fail(LBFGSB_E_ARG, "objective: NULL argument");   // (h_f may be NULL: deferred)
   return ctx->k_objective(kind, x, g, h_f);
 }
 int lbfgsb_hip_stats(lbfgsb_hip_ctx *ctx, int64_t *launches, int64_t *syncs,
@@ -389,6 +390,9 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
                             int32_t iprint, char *csave, void *lsave_, void *isave_, void *dsave,
                             const char *iteration_file, int32_t real_bytes, int32_t mirror, int int_bytes) {
   const bool r32 = real_bytes == 4;
+  if (!x || !l || !u || !nbd_ || !f || !g || !task || !csave || !lsave_ || !isave_ || !dsave)
+    return fail(LBFGSB_E_ARG, "setulb: NULL argument");
+  if (mirror && (!wa || !iwa_)) return fail(LBFGSB_E_ARG, "setulb: mirror = 1 needs wa and iwa");
   if (real_bytes != 4 && real_bytes != 8) return fail(LBFGSB_E_ARG, "real_bytes must be 4 or 8");
   if (int_bytes != 4 && int_bytes != 8) return fail(LBFGSB_E_ARG, "int_bytes must be 4 or 8");
   const bool i8 = int_bytes == 8;

@@ -1138,6 +1138,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int setulb_dev(void *x_, const void *l_, const void *u_, const int32_t *nbd, double *f,
                  void *g_, double factr, double pgtol, char *task, int iprint, char *csave,
                  int32_t *lsave, int32_t *isave_user, double *dsave) override {
+    if (!task) return fail(LBFGSB_E_ARG, "setulb: NULL argument");
     if (lbh::str60_eq(task, "START") || entry_mode == 0) {
       if (lbh::str60_eq(task, "START")) t = t_own, r = r_own;
       pp = false, entry_mode = 1;
@@ -1154,6 +1155,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int setulb_dev_pp(void *x0, void *x1, const void *l_, const void *u_, const int32_t *nbd, double *f,
                     void *g0, void *g1, double factr, double pgtol, char *task, int iprint, char *csave,
                     int32_t *lsave, int32_t *isave_user, double *dsave, int32_t *cur) override {
+    if (!task) return fail(LBFGSB_E_ARG, "setulb: NULL argument");
     if (!x0 || !x1 || !g0 || !g1 || x0 == x1 || g0 == g1)
       return fail(LBFGSB_E_ARG, "setulb_dev_pp needs two distinct x and two distinct g buffers");
     for (const void *p : {(const void *)x1, (const void *)g1})
@@ -1179,6 +1181,8 @@ class Solver final : public lbfgsb_hip_ctx {
   int drive(Mainlb &L, const void *l_, const void *u_, const int32_t *nbd, double *f, double factr,
             double pgtol, char *task, int iprint, char *csave, int32_t *lsave, int32_t *isave_user,
             double *dsave) {
+    if (!L.x || !L.g || !l_ || !u_ || !nbd || !f || !task || !csave || !lsave || !isave_user || !dsave)
+      return fail(LBFGSB_E_ARG, "setulb: NULL argument");   // (never a kernel launched on a null pointer)
     HIPCHK(hipSetDevice(device));
     print_level = iprint;
     quiet = rank != 0;

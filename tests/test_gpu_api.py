@@ -491,3 +491,44 @@ def test_contexts_on_four_host_threads_do_not_interfere():
         t.join()
     assert not errs, errs
     assert [a == b for a, b in zip(serial, out)] == [True] * len(probs)
+
+
+def test_null_arguments_are_refused_not_dereferenced():
+    """No entry of the C ABI launches a kernel on (or reads through) a null pointer: LBFGSB_E_ARG and a message,
+    the context stays usable."""
+    import numpy as np
+    import torch
+    import lbfgsb_amd as la
+    from lbfgsb_amd import capi
+    lib = la.load_library()
+    n, m = 1000, 5
+    sol = la.DeviceSolver(n, m)
+    try:
+        h = sol.h
+        x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        g = torch.zeros_like(x)
+        l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
+        nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+        P = lambda t: C.c_void_p(t.data_ptr())           # noqa: E731
+        A = lambda a: a.ctypes.data_as(C.c_void_p)       # noqa: E731
+        task, csave = np.frombuffer(b"START".ljust(60), dtype=np.uint8).copy(), np.zeros(60, np.uint8)
+        lsave, isave, dsave, f = np.zeros(4, np.int32), np.zeros(44, np.int32), np.zeros(29), np.zeros(1)
+        good = [h, P(x), P(l), P(u), P(nbd), A(f), P(g), 0.0, 0.0, A(task), -1, A(csave), A(lsave), A(isave), A(dsave)]
+        for k in (1, 2, 3, 4, 5, 6, 9, 11, 12, 13, 14):
+            args = list(good)
+            args[k] = None
+            assert lib.lbfgsb_hip_setulb_dev(*args) == capi.E_ARG, k
+            assert b"NULL" in lib.lbfgsb_hip_last_error()
+        out = np.zeros(1)
+        assert lib.lbfgsb_hip_projgr(h, None, P(l), P(u), P(nbd), P(g), A(out)) == capi.E_ARG
+        assert lib.lbfgsb_hip_wtv(h, None, 1, 1, A(out)) == capi.E_ARG
+        assert lib.lbfgsb_hip_objective(h, 0, None, P(g), A(out)) == capi.E_ARG
+        assert lib.lbfgsb_hip_export_state(h, None, None) == capi.E_ARG
+        assert lib.lbfgsb_hip_import_state(h, None, None, None) == capi.E_ARG
+        assert lib.lbfgsb_hip_cauchy(h, None, P(l), P(u), P(nbd), P(g), 1.0, 0, 1, 1.0, None, None, None) == capi.E_ARG
+        assert lib.lbfgsb_hip_setulb_host(n, m, None, None, None, None, None, None, 0.0, 0.0, None, None, None, -1,
+                                          None, None, None, None, None, 8, 0) == capi.E_ARG
+        # ... and the context still works
+        assert sol.setulb(x, l, u, nbd, g, 0.0, 0.0).startswith("FG_START")
+    finally:
+        sol.close()
