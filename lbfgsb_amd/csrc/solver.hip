@@ -1191,7 +1191,21 @@ class Solver final : public lbfgsb_hip_ctx {
     L.isave = isave_user + 21, L.dsave = dsave, L.ipr = quiet ? -1 : iprint;
     for (const void *p : {(const void *)L.x, (const void *)L.l, (const void *)L.u, (const void *)L.g})
       if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
-    if (lbh::str60_eq(task, "START")) nbd8_src = nullptr;  // (a new run may reuse the buffer)
+    if (lbh::str60_eq(task, "START")) {
+      nbd8_src = nullptr;  // (a new run may reuse the buffer)
+      // a host array handed to this entry by mistake would fault the GPU in the first kernel: every n-vector
+      // must be memory the device can address (device, managed, or pinned host memory)
+      const void *vec[] = {L.x, L.g, L.l, L.u, nbd, pp ? (const void *)xb[1] : (const void *)L.x,
+                           pp ? (const void *)gb[1] : (const void *)L.g};
+      for (const void *p : vec) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type == hipMemoryTypeUnregistered ||
+            at.devicePointer == nullptr) {
+          (void)hipGetLastError();
+          return fail(LBFGSB_E_ARG, "setulb_dev: x, g, l, u, nbd must be device-accessible memory (got a plain host pointer)");
+        }
+      }
+    }
     CHK(ensure_nbd8(nbd));
     if (ub_mask && !lbh::str60_eq(task, "START")) {  // other arrays than the ones START looked at
       if (L.l != ub_l) ub_mask &= ~1;

@@ -528,6 +528,13 @@ def test_null_arguments_are_refused_not_dereferenced():
         assert lib.lbfgsb_hip_cauchy(h, None, P(l), P(u), P(nbd), P(g), 1.0, 0, 1, 1.0, None, None, None) == capi.E_ARG
         assert lib.lbfgsb_hip_setulb_host(n, m, None, None, None, None, None, None, 0.0, 0.0, None, None, None, -1,
                                           None, None, None, None, None, 8, 0) == capi.E_ARG
+        # a plain host array where a device vector belongs (the classic slip with this entry): refused at START,
+        # not a GPU fault
+        host = np.zeros(n)
+        args = list(good)
+        args[1] = A(host)
+        assert lib.lbfgsb_hip_setulb_dev(*args) == capi.E_ARG
+        assert b"device-accessible" in lib.lbfgsb_hip_last_error()
         # ... and the context still works
         assert sol.setulb(x, l, u, nbd, g, 0.0, 0.0).startswith("FG_START")
     finally:
