@@ -59,7 +59,9 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
   bool ok = false;  // every symbol resolved
+  std::mutex mtx;   // (contexts are created from any number of host threads)
   bool load() {
+    std::lock_guard<std::mutex> lock(mtx);
     if (ok) return true;
     if (h) {  // an earlier attempt found a library without the symbols: try again from scratch
       dlclose(h);
