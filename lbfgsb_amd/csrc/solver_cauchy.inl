@@ -982,6 +982,73 @@
     double f1 = 0, nbreak = 0, nunb = 0, nunbnz = 0, bkmin = 0;
   } scan;
 
+  // The long stretch of a first-iteration walk (col = 0, records of 4 doubles: t, row, d, z, in order): the
+  // reference's steps :1416-1434, :1452-1453, :1483-1497 in its operation order, on values that live in
+  // registers, the records prefetched ahead.  -> 0: records used up; 1: the walk stops here; 2: all n variables
+  // fixed.  tie: the walk stops at a breakpoint equal to the last one it crossed.
+  struct WalkRaw {
+    double f1, f2, dtm, tsum, tj, lt;
+    int64_t nleft;
+  };
+  static __attribute__((noinline)) int walk_raw_col0(const double *raw, size_t &pos_io, size_t end, double theta,
+                                                     double clampv, bool all_n, bool bnded, WalkRaw &w,
+                                                     bool &tie) {
+    const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
+    const double inf = std::numeric_limits<double>::infinity();
+    double f1_ = w.f1, f2_ = w.f2, dtm_ = w.dtm, tsum_ = w.tsum, tj_ = w.tj, lt_ = w.lt;
+    int64_t nleft_ = w.nleft;
+    size_t pos = pos_io;
+    int code = 0;
+    bool tie_ = false;
+    while (pos < end) {
+      const double *rec = raw + pos * 4;
+      __builtin_prefetch(rec + 96);
+      const double mt = rec[0];
+      if (!(mt <= (tj_ + dtm_) * INFL && mt < inf)) {  // beyond reach: dtm < dt
+        tie_ = lt_ >= 0.0 && mt == lt_;
+        code = 1;
+        break;
+      }
+      const double dt = mt - tj_;
+      if (dtm_ < dt) {  // :1416
+        tie_ = lt_ >= 0.0 && mt == lt_;
+        code = 1;
+        break;
+      }
+      ++pos;
+      tsum_ = tsum_ + dt;
+      nleft_ = nleft_ - 1;
+      const double dibp = rec[2];
+      const double zibp = rec[3];
+      tj_ = mt;
+      lt_ = mt;
+      if (nleft_ == 0 && all_n) {  // all n variables fixed (:1436-1442)
+        dtm_ = dt;
+        code = 2;
+        break;
+      }
+      const double dibp2 = dibp * dibp;
+      f1_ = f1_ + dt * f2_ + dibp2 - theta * dibp * zibp;  // :1452-1453
+      f2_ = f2_ - theta * dibp2;
+      f2_ = std::max(clampv, f2_);  // :1483
+      if (nleft_ > 0) {
+        dtm_ = -f1_ / f2_;
+      } else if (bnded) {
+        f1_ = 0.0, f2_ = 0.0, dtm_ = 0.0;
+        code = 1;
+        break;
+      } else {
+        dtm_ = -f1_ / f2_;
+        code = 1;
+        break;
+      }
+    }
+    w = WalkRaw{f1_, f2_, dtm_, tsum_, tj_, lt_, nleft_};
+    pos_io = pos;
+    tie = tie_;
+    return code;
+  }
+
   int cauchy(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta,
              int col, int head, double sbgnrm, double epsmch, int &nseg, int &info) {
     double *p = &wa8m[0], *c = &wa8m[2 * m], *wbp = &wa8m[4 * m], *v = &wa8m[6 * m];
@@ -1126,57 +1193,17 @@
             // stay in registers -- with the records prefetched ahead (they were written by DMA: every
             // line is a cache miss, and the branch on dtm keeps the hardware prefetcher from running
             // ahead).  1.5 - 2 x the rate of the general loop below (profiles/scripts/walk_bench.cpp).
-            const double *const raw = pv.raw;
-            const double clampv = epsmch * f2_org;
-            const bool all_n = nbreak == nglob;
-            double f1_ = f1, f2_ = f2, dtm_ = dtm, tsum_ = tsum, tj_ = tj, lt_ = last_t;
-            int64_t nleft_ = nleft;
+            // (a function of its own, NOT inlined: inside this long routine the loop's seven running
+            //  values were spilled to the stack -- a store-to-load round trip on the chain f1 -> f1 of every
+            //  segment, 3.3 ns per record; on its own it keeps them in registers: 1.7 ns, the rate of
+            //  profiles/scripts/walk_bench.cpp)
+            WalkRaw w{f1, f2, dtm, tsum, tj, last_t, nleft};
             const size_t pos0 = pos;
-            int code = 0;  // 0: records used up; 1: the walk stops here; 2: all n variables fixed
             bool tie_ = false;
-            while (pos < end) {
-              const double *rec = raw + pos * 4;
-              __builtin_prefetch(rec + 96);
-              const double mt = rec[0];
-              if (!(mt <= (tj_ + dtm_) * INFL && mt < inf)) {  // beyond reach: dtm < dt
-                tie_ = lt_ >= 0.0 && mt == lt_;
-                code = 1;
-                break;
-              }
-              const double dt = mt - tj_;
-              if (dtm_ < dt) {  // :1416
-                tie_ = lt_ >= 0.0 && mt == lt_;
-                code = 1;
-                break;
-              }
-              ++pos;
-              tsum_ = tsum_ + dt;
-              nleft_ = nleft_ - 1;
-              const double dibp = rec[2];
-              const double zibp = rec[3];
-              tj_ = mt;
-              lt_ = mt;
-              if (nleft_ == 0 && all_n) {  // all n variables fixed (:1436-1442)
-                dtm_ = dt;
-                code = 2;
-                break;
-              }
-              const double dibp2 = dibp * dibp;
-              f1_ = f1_ + dt * f2_ + dibp2 - theta * dibp * zibp;  // :1452-1453
-              f2_ = f2_ - theta * dibp2;
-              f2_ = std::max(clampv, f2_);  // :1483
-              if (nleft_ > 0) {
-                dtm_ = -f1_ / f2_;
-              } else if (bnded) {
-                f1_ = 0.0, f2_ = 0.0, dtm_ = 0.0;
-                code = 1;
-                break;
-              } else {
-                dtm_ = -f1_ / f2_;
-                code = 1;
-                break;
-              }
-            }
+            const int code = walk_raw_col0(pv.raw, pos, end, theta, epsmch * f2_org, nbreak == nglob, bnded, w, tie_);
+            const double f1_ = w.f1, f2_ = w.f2, dtm_ = w.dtm, tsum_ = w.tsum, tj_ = w.tj, lt_ = w.lt;
+            const int64_t nleft_ = w.nleft;
+            const double *const raw = pv.raw;
             const int64_t took = (int64_t)(pos - pos0);
             f1 = f1_, f2 = f2_, dtm = dtm_, tsum = tsum_, tj = tj_, last_t = lt_, nleft = nleft_;
             iter += took;
