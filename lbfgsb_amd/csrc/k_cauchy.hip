@@ -154,21 +154,30 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_kernel(int64_t n, int64_t
       bits |= pred ? (1u << e) : 0u;
     }
     if (__ballot(bits != 0) == 0ull) continue;
+    // ONE atomic per wave and trip (positions lane-major inside the wave's slice): a first iteration selects
+    // nearly every row, and an atomic per wave AND element -- 1.5e6 of them on one address at n = 1e8 -- made
+    // this kernel 17.7 ms where its 2 GB of traffic take well under one.  The order of the output does not
+    // matter (it is sorted, ties by row number, before anything reads it).
+    const uint32_t c = (uint32_t)__popc(bits);
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(count, total);
+    base = __shfl(base, 63);
+    uint32_t pos = base + incl - c;
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
-      const bool pred = (bits >> e) & 1u;
-      const unsigned long long mask = __ballot(pred);
-      if (mask == 0ull) continue;
-      const int leader = __ffsll((long long)mask) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-      base = __shfl(base, leader);
-      if (pred) {
-        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if ((bits >> e) & 1u) {
         if (pos < cap) {
           keys[pos] = key_of(tv[e]);
           idx[pos] = (uint32_t)ri[e];
         }
+        ++pos;
       }
     }
   }
@@ -214,8 +223,34 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
       bits |= pred ? (1u << k) : 0u;
     }
     if (__ballot(bits != 0) == 0ull) return;
+    if (__ballot(true) == ~0ull) {
+      // a full wave: ONE atomic for all its candidates of this trip (see cauchy_window_kernel)
+      const uint32_t c = (uint32_t)__popc(bits);
+      uint32_t incl = c;
 #pragma unroll
-    for (int k = 0; k < W; ++k) {
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+      }
+      const uint32_t total = __shfl(incl, 63);
+      uint32_t base = 0;
+      if (lane == 63) base = atomicAdd(count, total);
+      base = __shfl(base, 63);
+      uint32_t pos = base + incl - c;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if ((bits >> k) & 1u) {
+          if (pos < cap) {
+            keys[pos] = key_of(tv[k]);
+            idx[pos] = (uint32_t)(i + k);
+          }
+          ++pos;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {  // (the ragged end of the rows: some lanes are not here)
       const bool pred = (bits >> k) & 1u;
       const unsigned long long mask = __ballot(pred);
       if (mask == 0ull) continue;
