@@ -378,7 +378,7 @@ class Run:
             elif task.startswith("NEW_X"):
                 done += 1
             else:
-                raise SystemExit("solver stopped: " + task)
+                raise RuntimeError("solver stopped: " + task)
 
     def close(self):
         import gc
@@ -405,7 +405,7 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
         run.advance(1)
         warm_done += 1
         if warm_done > warm_min + 4 * m + 20:
-            raise SystemExit("col never reached m = %d (skipped updates?)" % m)
+            raise RuntimeError("col never reached m = %d (skipped updates?)" % m)
     run.barrier()
     ts0, st0 = run.t_setulb, sol.stats()
     sol.pass_clock(1)            # hipEvents around every launch of the three W passes
@@ -706,7 +706,7 @@ def main():
                 kw.setdefault("opts", opts)
                 out["other_configs"].append(other_config(torch, dist, lbfgsb_amd, a, name, local_rank=local_rank,
                                                          **kw))
-            except BaseException as e:   # noqa: BLE001  (a leg must never take the headline line down)
+            except Exception as e:   # noqa: BLE001  (a leg must never take the headline line down; Ctrl-C still ends the run)
                 out["other_configs"].append({"config": name, "error": repr(e)})
     # ---- HBM traffic of the passes over W, counted in this run (contexts above are closed: the child
     # has the card's memory to itself) ----
@@ -729,7 +729,7 @@ def main():
                         "gfx950 corrections of MI355X_MICROARCH.md (KiB units, FETCH_SIZE x2)")
                     rec["traffic_counters"] = lt[fam]
             out["live_traffic_seconds"] = lt["seconds"]
-        except BaseException as e:   # noqa: BLE001  (the counters must never take the bench line down)
+        except Exception as e:   # noqa: BLE001  (the counters must never take the bench line down; Ctrl-C still ends the run)
             out["live_traffic_error"] = repr(e)[:400]
             for rec in [roofline] + others:
                 rec["traffic_source"] = static_note % repr(e)[:120]

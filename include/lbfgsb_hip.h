@@ -143,9 +143,16 @@ int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar,
  *   - lsave[4] are int32 0/1, isave[44] int32, dsave[29] double, with the
  *     reference's meaning slot for slot (src/lbfgsb.f90:188-242).
  * The caller evaluates f,g on the device whenever task(1:2)=='FG'.
- * l, u and nbd must not change between task='START' and the end of the run (the
- * context keeps a packed one-byte copy of nbd for its passes over W; it is
- * refreshed on START, after import_state and when the nbd POINTER changes).
+ * l, u and nbd MUST NOT CHANGE between task='START' and the end of the run -- neither
+ * the pointers' contents nor (without cost) the pointers.  The reference re-reads the
+ * three arrays on every call; this library does not: the context keeps a packed
+ * one-byte copy of nbd for its passes over W (refreshed on START, after import_state
+ * and when the nbd POINTER changes), and bound arrays found to hold ONE value each at
+ * START are read as that constant by the passes over W for the rest of the run
+ * (lbfgsb_hip_uniform_bounds below; a different POINTER switches that off, an edit in
+ * place is NOT noticed and gives an inconsistent iteration).  A caller that has to edit
+ * bounds in place starts a new run (task='START'), or disables the constant-folding with
+ * lbfgsb_hip_set_option(ctx, "uniform_bounds", 0) before START.
  * ------------------------------------------------------------------------- */
 int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
                           const int32_t *nbd, double *f, void *g, double factr, double pgtol,
@@ -209,7 +216,7 @@ int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const v
  * Fortran module binds (int_bytes = storage_size(1)/8), so that ONE source serves an ordinary build
  * and a -fdefault-integer-8 build -- the build BASELINE.md section 3 calls mandatory for n = 1e8,
  * because the reference's own wa offsets (src/lbfgsb.f90:246-265) overflow a 32-bit integer there.
- * With 8-byte integers isave(1:16) receive those offsets in full; n < 2^32 - 16 on one device.
+ * With 8-byte integers isave(1:16) receive those offsets in full; n < 2^31 - 16 on one device.
  * m > LBFGSB_MAX_M is answered the way the reference answers its own argument errors: task =
  * 'ERROR: M > 1024 (LIMIT OF LBFGSB_HIP)', return value 0, no iteration done (the reference itself puts
  * no upper limit on m, :93-97). */

@@ -15,7 +15,8 @@ int lbfgsb_hip_create(int64_t n_local, int64_t n_global, int64_t row0, int m, in
   if (n_local <= 0 || n_global < n_local || row0 < 0 || row0 + n_local > n_global)
     return fail(LBFGSB_E_ARG, "bad n_local / n_global / row0");
   if (m <= 0 || m > LBFGSB_MAX_M) return fail(LBFGSB_E_ARG, "m must be in 1..LBFGSB_MAX_M");
-  if (n_local > 0xFFFFFFF0ll) return fail(LBFGSB_E_ARG, "n_local must fit 32 bits");
+  // (31 bits: freev's changed-row list keeps a flag in bit 31, Index / Indx2 are exported as int32)
+  if (n_local > (int64_t)INT32_MAX - 16) return fail(LBFGSB_E_ARG, "n_local must be < 2^31 - 16 rows per device");
   int rc = 0;
   *out = lbfgsb_make_solver(n_local, n_global, row0, m, flags, device, stream, &rc);
   if (!*out) return rc;
@@ -441,8 +442,10 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
       finish_ints();
       return 0;
     }
-    if (n > 0xFFFFFFF0ll) {
-      lbh::str60_set(task, "ERROR: N >= 2**32 ON ONE DEVICE (LIMIT OF LBFGSB_HIP)");
+    // (row numbers of one device travel in 31 bits: freev's changed-row list keeps a flag in bit 31,
+    //  Index / Indx2 are exported as int32)
+    if (n > (int64_t)INT32_MAX - 16) {
+      lbh::str60_set(task, "ERROR: N >= 2**31 ON ONE DEVICE (LIMIT OF LBFGSB_HIP)");
       finish_ints();
       return 0;
     }
@@ -507,7 +510,12 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
                            iprint, csave, lsave, isave, ds);
   isave[16] = keep_id, isave[17] = keep_tag;
   if (iprint >= 0) std::fflush(stdout);
-  if (rc) return rc;
+  if (rc) {
+    // a START that failed after its context was registered: the caller's isave never received the
+    // handle, so nothing could release the context later -- free it here
+    if (start) g_host.drop(isave);
+    return rc;
+  }
   for (int i = 0; i < 29; ++i) {
     if (r32)
       ((float *)dsave)[i] = (float)ds[i];

@@ -447,55 +447,139 @@ __device__ __forceinline__ void for_rows_raw(int64_t n, const Ctx &c, F &&f) {
   }
 }
 
-// ---- reductions: wave shuffle, then LDS across the 4 waves ----
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+// ---- reductions: DPP inside the 16-lane rows of a wave, LDS across rows and waves ----
+// Round 3 reduced every slot with six dependent __shfl_down steps: each step is two ds_bpermute_b32,
+// an s_waitcnt lgkmcnt(0) and an add, and the compiler kept the slots' chains one behind the other --
+// 570 serialised LDS round trips for the 95 sums of the update pass, 25-30 us per wave.  At n = 1e8
+// that is 3 % of the pass; at the 8-GPU per-rank shape (1.25e7 rows) it was 70 of its 410 us, at
+// n = 1e6 70 of 100.  Now nothing in the epilogue waits for LDS:
+//   * inside a 16-lane row values move by DPP (quad_perm, row_half_mirror, row_mirror: plain VALU
+//     moves, no LDS);
+//   * many sums (K >= 16) are reduce-SCATTERed: at each of the four steps a lane hands one half of
+//     its slots to its partner and keeps the other, so the work halves every step (2 K adds per
+//     lane in all instead of 6 K) and lane j of a row ends up with K/16 slots summed over the row;
+//   * the 4 rows x 4 waves = 16 row results per slot go through LDS once and are added in a fixed
+//     order by one thread per slot.
+// Fixed shape => deterministic for a fixed (n, grid), as before; the ORDER of the additions inside
+// a workgroup differs from round 3's (reductions are compared at 1e-10, never bit for bit against
+// the oracle).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {  // every lane: the value of its DPP source lane
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each group of 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15 - i inside each row of 16
+constexpr int DPP_ROR8 = 0x128;        // row_ror:8: lane i <-> i xor 8 inside each row of 16
+// OP: 0 sum, 1 min, 2 max
+template <int OP>
+__device__ __forceinline__ double red_op(double a, double b) {
+  return OP == 0 ? a + b : (OP == 1 ? fmin(a, b) : fmax(a, b));
+}
+// every lane of a 16-lane row receives the row's result (a + b == b + a bit for bit, so all 16 agree)
+template <int OP>
+__device__ __forceinline__ double row_reduce(double v) {
+  v = red_op<OP>(v, dpp_mov<DPP_XOR1>(v));
+  v = red_op<OP>(v, dpp_mov<DPP_XOR2>(v));
+  v = red_op<OP>(v, dpp_mov<DPP_HALF_MIRROR>(v));
+  v = red_op<OP>(v, dpp_mov<DPP_MIRROR>(v));
   return v;
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o));
-  return v;
+__device__ __forceinline__ double lane_bcast(double v, int lane) {  // wave-uniform copy of one lane's value
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __forceinline__ double wave_max(double v) {
+// whole-wave results, valid in EVERY lane (rows added in the order 0, 1, 2, 3)
+template <int OP>
+__device__ __forceinline__ double wave_reduce(double v) {
+  v = row_reduce<OP>(v);
+  return red_op<OP>(red_op<OP>(red_op<OP>(lane_bcast(v, 0), lane_bcast(v, 16)), lane_bcast(v, 32)),
+                    lane_bcast(v, 48));
+}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<0>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<1>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<2>(v); }
+
+// one reduce-scatter step: N slots in, N / 2 out.  `up` = this lane's side of the exchange (the bit
+// of its lane number that the DPP pattern CTRL flips); a lane keeps in[p] (down side) or
+// in[p + N/2] (up side) and receives the same slot from its partner.
+template <int N, int CTRL>
+__device__ __forceinline__ void row_halve(const double (&in)[N], double (&out)[N / 2], bool up) {
+  static_assert(N % 2 == 0, "even slot count");
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
-  return v;
+  for (int p = 0; p < N / 2; ++p) {
+    const double keep = up ? in[p + N / 2] : in[p];
+    const double send = up ? in[p] : in[p + N / 2];
+    out[p] = keep + dpp_mov<CTRL>(send);
+  }
 }
 
-// acc[0..nsum) are sums, then nmin minima, then nmax maxima.  One value per
-// slot per workgroup goes to part[slot*pstride + blockIdx.x].  Fixed shape =>
-// deterministic for a fixed (n, grid).
+// acc[0..nsum) are sums, then nmin minima, then nmax maxima (constants at every call site: the
+// conditions below fold away).  One value per slot per workgroup goes to
+// part[slot*pstride + blockIdx.x].  Every lane of the workgroup must call this.
 template <int K>
 __device__ __forceinline__ void block_reduce_store(const double (&acc)[K], int nsum, int nmin,
                                                    int nmax, double *__restrict__ part,
                                                    int pstride) {
-  __shared__ double sm[4][K];
+  constexpr bool SCATTER = K >= 16;
+  constexpr int KP = SCATTER ? (K + 15) / 16 * 16 : K;
+  __shared__ double sm[16][KP];  // [wave * 4 + row][slot]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rr = w * 4 + (lane >> 4);
   const int ntot = nsum + nmin + nmax;
+  if constexpr (SCATTER) {
+    double t0[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) t0[k] = k < K ? acc[k] : 0.0;
+    double t1[KP / 2], t2[KP / 4], t3[KP / 8], t4[KP / 16];
+    // Partners must hold the SAME slots, i.e. differ in exactly the bit the step splits on.  The
+    // mirror patterns flip every lower bit too, so the half-mirror step (bit 2, partner 7 - i) comes
+    // FIRST, while every lane still holds all slots; bits 0 and 1 are exact xor exchanges (quad_perm),
+    // bit 3 is a rotation by 8 inside the row (i +- 8 mod 16 = i xor 8).
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    row_halve<KP, DPP_HALF_MIRROR>(t0, t1, b2);
+    row_halve<KP / 2, DPP_XOR1>(t1, t2, b0);
+    row_halve<KP / 4, DPP_XOR2>(t2, t3, b1);
+    row_halve<KP / 8, DPP_ROR8>(t3, t4, b3);
+    // this lane's slots: p + (KP/2) b2 + (KP/4) b0 + (KP/8) b1 + (KP/16) b3
+    const int base = (b2 ? KP / 2 : 0) + (b0 ? KP / 4 : 0) + (b1 ? KP / 8 : 0) + (b3 ? KP / 16 : 0);
+#pragma unroll
+    for (int p = 0; p < KP / 16; ++p)
+      if (base + p < nsum) sm[rr][base + p] = t4[p];
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k < nsum) {
+        const double v = row_reduce<0>(acc[k]);
+        if ((lane & 15) == 0) sm[rr][k] = v;
+      }
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (k < ntot) {
-      double v = acc[k];
-      if (k < nsum)
-        v = wave_sum(v);
-      else if (k < nsum + nmin)
-        v = wave_min(v);
-      else
-        v = wave_max(v);
-      if (lane == 0) sm[w][k] = v;
+    if (k >= nsum && k < ntot) {
+      const double v = k < nsum + nmin ? row_reduce<1>(acc[k]) : row_reduce<2>(acc[k]);
+      if ((lane & 15) == 0) sm[rr][k] = v;
     }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ntot; k += blockDim.x) {
     double s = sm[0][k];
-    if (k < nsum)
-      s = ((s + sm[1][k]) + sm[2][k]) + sm[3][k];
-    else if (k < nsum + nmin)
-      s = fmin(fmin(s, sm[1][k]), fmin(sm[2][k], sm[3][k]));
-    else
-      s = fmax(fmax(s, sm[1][k]), fmax(sm[2][k], sm[3][k]));
+    if (k < nsum) {
+#pragma unroll
+      for (int q = 1; q < 16; ++q) s = s + sm[q][k];
+    } else if (k < nsum + nmin) {
+#pragma unroll
+      for (int q = 1; q < 16; ++q) s = fmin(s, sm[q][k]);
+    } else {
+#pragma unroll
+      for (int q = 1; q < 16; ++q) s = fmax(s, sm[q][k]);
+    }
     part[(size_t)k * pstride + blockIdx.x] = s;
   }
 }

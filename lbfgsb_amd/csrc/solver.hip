@@ -1141,7 +1141,7 @@ class Solver final : public lbfgsb_hip_ctx {
     if (!task) return fail(LBFGSB_E_ARG, "setulb: NULL argument");
     if (lbh::str60_eq(task, "START") || entry_mode == 0) {
       if (lbh::str60_eq(task, "START")) t = t_own, r = r_own;
-      pp = false, entry_mode = 1;
+      pp = false, entry_mode = 1, check_ptrs = true;
     } else if (entry_mode != 1) {
       return fail(LBFGSB_E_STATE, "this run was started with lbfgsb_hip_setulb_dev_pp");
     }
@@ -1164,7 +1164,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // (entry_mode == 0 without START: a run resumed from lbfgsb_hip_import_state -- the iterate and
       //  its gradient are in x0 / g0, the imported t and r in the context's own buffers)
       if (lbh::str60_eq(task, "START")) t = t_own, r = r_own;
-      pp = true, pp_cur = 0, entry_mode = 2;
+      pp = true, pp_cur = 0, entry_mode = 2, check_ptrs = true;
       xb[0] = (T *)x0, xb[1] = (T *)x1, gb[0] = (T *)g0, gb[1] = (T *)g1;
     } else if (entry_mode != 2) {
       return fail(LBFGSB_E_STATE, "this run was started with lbfgsb_hip_setulb_dev");
@@ -1191,8 +1191,9 @@ class Solver final : public lbfgsb_hip_ctx {
     L.isave = isave_user + 21, L.dsave = dsave, L.ipr = quiet ? -1 : iprint;
     for (const void *p : {(const void *)L.x, (const void *)L.l, (const void *)L.u, (const void *)L.g})
       if (((uintptr_t)p & 15) != 0) return fail(LBFGSB_E_ARG, "device pointers must be 16-byte aligned");
-    if (lbh::str60_eq(task, "START")) {
-      nbd8_src = nullptr;  // (a new run may reuse the buffer)
+    if (lbh::str60_eq(task, "START")) nbd8_src = nullptr;  // (a new run may reuse the buffer)
+    if (check_ptrs) {  // START, and the first call of a run resumed from import_state
+      check_ptrs = false;
       // a host array handed to this entry by mistake would fault the GPU in the first kernel: every n-vector
       // must be memory the device can address (device, managed, or pinned host memory)
       const void *vec[] = {L.x, L.g, L.l, L.u, nbd, pp ? (const void *)xb[1] : (const void *)L.x,
@@ -1202,6 +1203,7 @@ class Solver final : public lbfgsb_hip_ctx {
         if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type == hipMemoryTypeUnregistered ||
             at.devicePointer == nullptr) {
           (void)hipGetLastError();
+          check_ptrs = true;  // (the next attempt is looked at again)
           return fail(LBFGSB_E_ARG, "setulb_dev: x, g, l, u, nbd must be device-accessible memory (got a plain host pointer)");
         }
       }
@@ -1245,6 +1247,7 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
+  bool check_ptrs = false;   // this call decides the entry of a run: its pointers have not been looked at yet
   bool index_valid = false;  // a freev has run: wasfree is the membership of Index(1:nfree)
   // How many iwhere entries have changed since the last freev pass (a count where the kernels report
   // one, >= 1 where they do not).  Zero at the point where freev is due means: the free set is what

@@ -70,6 +70,22 @@
     if (nranks != 1 && index)
       return fail(LBFGSB_E_STATE, "import_state: contexts that mirror Index are single-rank");
     HIPCHK(hipSetDevice(device));
+    // validate BEFORE anything of the context is overwritten: an E_STATE return leaves it as it was
+    std::vector<int8_t> wf((size_t)n, 0);
+    const int64_t nfree_glob = isave_user[37];
+    const int64_t nfree = nranks != 1 ? (int64_t)iwa[2 * n] : nfree_glob;  // (see export_state)
+    bool have_index = false;
+    for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
+    if (!have_index) {  // state from before the first freev (START / FG_START)
+      std::fill(wf.begin(), wf.end(), (int8_t)1);
+    } else {
+      if (nfree < 0 || nfree > n) return fail(LBFGSB_E_STATE, "import_state: isave(38) (nfree) out of range");
+      for (int64_t i = 0; i < nfree; ++i) {
+        const int64_t k = iwa[i];
+        if (k < 1 || k > n) return fail(LBFGSB_E_STATE, "import_state: Index entry out of range");
+        wf[(size_t)(k - 1)] = 1;
+      }
+    }
     const T *wa = (const T *)wa_;
     const int64_t mn = (int64_t)m * n;
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
@@ -99,22 +115,7 @@
       for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (lbk::iw_t)iwa[n + i];
       HIPCHK(hipMemcpy(iwhere, h.data(), (size_t)n * sizeof(lbk::iw_t), hipMemcpyHostToDevice));
     }
-    // free-set membership as of the last freev: Index(1:nfree)
-    std::vector<int8_t> wf((size_t)n, 0);
-    const int64_t nfree_glob = isave_user[37];
-    const int64_t nfree = nranks != 1 ? (int64_t)iwa[2 * n] : nfree_glob;  // (see export_state)
-    bool have_index = false;
-    for (int64_t i = 0; i < n && !have_index; ++i) have_index = iwa[i] != 0;
-    if (!have_index) {  // state from before the first freev (START / FG_START)
-      std::fill(wf.begin(), wf.end(), (int8_t)1);
-    } else {
-      if (nfree < 0 || nfree > n) return fail(LBFGSB_E_STATE, "import_state: isave(38) (nfree) out of range");
-      for (int64_t i = 0; i < nfree; ++i) {
-        const int64_t k = iwa[i];
-        if (k < 1 || k > n) return fail(LBFGSB_E_STATE, "import_state: Index entry out of range");
-        wf[(size_t)(k - 1)] = 1;
-      }
-    }
+    // free-set membership as of the last freev: Index(1:nfree), validated above
     index_valid = have_index;
     HIPCHK(hipMemcpyAsync(wasfree, wf.data(), (size_t)n, hipMemcpyHostToDevice, stream));
     if (index) {

@@ -1089,11 +1089,29 @@ def test_minimize_wrapper_matches_reverse_communication(env):
         return (torch.from_numpy(p.x0.copy()).cuda(), torch.from_numpy(p.l).cuda(),
                 torch.from_numpy(p.u).cuda(), torch.from_numpy(p.nbd.astype(np.int32)).cuda(),
                 torch.zeros(n, dtype=torch.float64, device="cuda"))
+    # the same run driven by hand through the reverse-communication entry
+    hand = la.DeviceSolver(n, m)
+    xh, lh, uh, nbdh, gh = tensors()
+    while True:
+        th = hand.setulb(xh, lh, uh, nbdh, gh, 0.0, 0.0)
+        if th.startswith("FG"):
+            hand.f[0] = hand.objective(0, xh, gh)
+        elif not th.startswith("NEW_X"):
+            break
     sol = la.DeviceSolver(n, m)
     x, l, u, nbd, g = tensors()
     t = sol.minimize(x, l, u, nbd, g, builtin=0, factr=0.0, pgtol=0.0)
+    # the wrapper IS the hand-driven loop: same task, same counters, same point
+    assert t == th
+    assert int(sol.isave[29]) == int(hand.isave[29]) and int(sol.isave[33]) == int(hand.isave[33])
+    assert float(sol.f[0]) == pytest.approx(float(hand.f[0]), rel=1e-13)
+    assert np.max(np.abs(x.cpu().numpy() - xh.cpu().numpy())) <= 1e-12
+    hand.close()
+    # ... and the oracle's run: with factr = 0 the LAST iterations act on the rounding noise of f (the
+    # stop test is "f did not decrease"), so how many of them there are depends on the order of the sums;
+    # the point they stop at does not
     assert t == ref.task_s
-    assert int(sol.isave[29]) == int(ref.isave[29]) and int(sol.isave[33]) == int(ref.isave[33])
+    assert abs(int(sol.isave[29]) - int(ref.isave[29])) <= 4 and abs(int(sol.isave[33]) - int(ref.isave[33])) <= 6
     assert float(sol.f[0]) == pytest.approx(float(ref.f[0]), rel=1e-10)
     assert np.max(np.abs(x.cpu().numpy() - ref.x)) <= 1e-7
     sol.close()
