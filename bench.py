@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--classic", action="store_true",
                     help="drive lbfgsb_hip_setulb_dev (t = x, r = g as copies: 5 store streams in the storing "
                          "pass) instead of the ping-pong entry lbfgsb_hip_setulb_dev_pp (3 store streams)")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="contexts WITHOUT LBFGSB_F_DEFER_LNSRCH: every FG_LNSRCH return waits for the storing "
+                         "pass's sums (one more host sync per iteration; what an ordinary caller gets)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="lbfgsb_hip_set_option on every context of the run (A/B measurements)")
     ap.add_argument("--roofline-reps", type=int, default=20)
@@ -308,7 +311,7 @@ class Run:
         self.n_loc = n_loc
         mk = lambda: la.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,   # noqa: E731
                                      same_stream_objective=True, real32=real32, options=opts,
-                                     parallel_gcp=parallel_gcp)
+                                     parallel_gcp=parallel_gcp, defer_lnsrch=not a.no_defer)
         self.sol = mk()
         self.collective = "none"
         if world > 1:
@@ -408,6 +411,7 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
             raise RuntimeError("col never reached m = %d (skipped updates?)" % m)
     run.barrier()
     ts0, st0 = run.t_setulb, sol.stats()
+    hg0 = sol.host_gap()
     sol.pass_clock(1)            # hipEvents around every launch of the three W passes
     cols_timed, step_ms = [], []
     t0 = time.perf_counter()
@@ -427,6 +431,8 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
         run.dist.all_reduce(tt, op=run.dist.ReduceOp.MAX)
         dt, dt_setulb = float(tt[0]), float(tt[1])
     st1 = sol.stats()
+    hg1 = sol.host_gap()
+    st1["host_gap_us"] = (hg1[0] - hg0[0]) / max(1, hg1[1] - hg0[1]) * 1e6
     return dict(first_iter_s=first_iter_s, nseg_first=nseg_first, warm_done=warm_done, cols_timed=cols_timed,
                 dt=dt, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1,
                 step_ms_median=float(np.median(step_ms)), step_ms_max=float(np.max(step_ms)))
@@ -469,6 +475,8 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "freev_passes_skipped_per_iter": (r["st1"]["freev_skipped"] - r["st0"]["freev_skipped"]) / steps,
                 "passes": passes, "subspace_steps_closed_form": closed, "subspace_steps_three_pass": three,
                 "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0]),
+                "lnsrch_setups_deferred_reissued": list(run.sol.defer_stats()),
+                "host_algebra_us_between_passes": r["st1"]["host_gap_us"],
                 "uniform_bounds_mask": ub, "options": opts}
     finally:
         run.close()
@@ -642,6 +650,10 @@ def main():
                    "entry": ("lbfgsb_hip_setulb_dev_pp (ping-pong iterate buffers)" if run.pp
                              else "lbfgsb_hip_setulb_dev"),
                    "options": opts,
+                   "lnsrch_setup": ("waited for at every FG_LNSRCH return (--no-defer)" if a.no_defer else
+                                    "LBFGSB_F_DEFER_LNSRCH: the objective is the library's own kernel on the "
+                                    "solver's stream, so the storing pass's sums ride with the next call's fetch "
+                                    "(one host sync per iteration less; NEW_X returns bit-identical)"),
                    "uniform_bounds_mask": ub,
                    "uniform_bounds": "l, u, nbd of this workload hold one value each (detected at START, bit 0/1/2 = "
                                      "l/u/nbd): the passes over W read them as constants, not as 8+8+1 B/row "
@@ -660,6 +672,8 @@ def main():
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
         "freev_passes_skipped_per_iter": (stats["freev_skipped"] - st0["freev_skipped"]) / a.steps,
         "tie_splits": sol.tie_splits(),
+        "lnsrch_setups_deferred_reissued": list(sol.defer_stats()),
+        "host_algebra_us_between_passes": stats["host_gap_us"],
         "subspace_steps_closed_form": closed_steps,
         "subspace_steps_three_pass": three_steps,
         "cauchy_walks_served_by_update_pass": handed_windows,

@@ -86,12 +86,37 @@ enum {
                                 replicated heap and gathers the records of the rows it owns), so the
                                 active set equals the reference's bit for bit.  Only the calls that
                                 need it pay for it. */
-  LBFGSB_F_INDEX_TIES = 32   /* OPT-OUT of that replay: a walk that ends inside a group of equal
+  LBFGSB_F_INDEX_TIES = 32,  /* OPT-OUT of that replay: a walk that ends inside a group of equal
                                 breakpoints fixes the group's members in variable order (which members --
                                 and, when their rows of W differ, how many -- may then differ from the
                                 reference).  For callers who prefer the
                                 O(window) cost bound over the reference's tie order: the replay costs
                                 what the reference's own walk costs (heap pops over all breakpoints). */
+  LBFGSB_F_DEFER_LNSRCH = 64 /* for callers that evaluate f,g on the context's own stream and do nothing
+                                else with the context between an 'FG_LNSRCH' return and the re-entry with
+                                that evaluation (lbfgsb_hip_minimize with a built-in objective, bench.py).
+                                The pass that forms the subspace step also stores the first trial point
+                                of the line search, x = z (lnsrlb, src/lbfgsb.f90:2265: the unit step), and
+                                produces the numbers its set-up needs (d'd, g'd, stpmx, subsm's iword,
+                                :2196-2244, :2820-2828).  By default the call waits for them before it
+                                returns 'FG_LNSRCH'.  With this flag it returns at once -- no host sync
+                                in that call, implies LBFGSB_F_NO_RETURN_SYNC -- and the numbers come
+                                over with the first fetch of the NEXT call, which then runs the set-up
+                                and, in the same call, the step of dcsrch that consumes the evaluation:
+                                one host round trip per iteration less.  Same arithmetic in the same
+                                order: every 'NEW_X' return (x, f, g, isave, dsave, the exported state)
+                                is bit for bit the default's.  What differs:
+                                 * at such an 'FG_LNSRCH' return dsave / isave / csave do not describe
+                                   the line search yet, and lbfgsb_hip_export_state is refused
+                                   (LBFGSB_E_STATE) until the next 'NEW_X';
+                                 * when the set-up turns out to ask for ANOTHER point than x = z --
+                                   subsm's backtracking step (:2830-2879), an ascent direction (:2247)
+                                   -- the evaluation the caller has just delivered is dropped (it is not
+                                   counted in nfgv) and the call returns 'FG_LNSRCH' once more, with
+                                   the point the reference would have asked for (lbfgsb_hip_defer_stats
+                                   counts these).
+                                Not with LBFGSB_F_MIRROR_INDEX, LBFGSB_F_PARALLEL_GCP, iprint >= 99 or
+                                m > LBFGSB_FUSED_M: such contexts wait as before. */
 };
 
 /* -------------------------------------------------------------------------
@@ -395,6 +420,10 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *   "pg_min" (count)        LBFGSB_F_PARALLEL_GCP: walks with more breakpoints in reach than this
  *                           go to the sort + scans
  *   "exact_always" (0/1)    every Cauchy walk in the reference's heap order from its start (tests)
+ *   "defer_lnsrch" (0/1)    LBFGSB_F_DEFER_LNSRCH switched on / off for the iterations that follow (the
+ *                           caller must honour that flag's contract)
+ *   "spin" (0/1)            results of a phase reach the host through mapped memory + a polled sequence
+ *                           word (default) / through a D2H copy + hipStreamSynchronize
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "wgrid" (1..2047)       workgroups of the passes over W (default 768)
@@ -441,6 +470,16 @@ int lbfgsb_hip_path_counts(lbfgsb_hip_ctx *ctx, int64_t *closed_form, int64_t *t
 /* number of setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints
  * (see LBFGSB_F_EXACT_TIES) */
 int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count);
+
+/* host seconds (and how many stretches) between the landing of a trial point's sums and the launch of the
+ * storing pass that follows in the same call -- dcsrch, matupd, formt, the Cauchy walk's host part, formk's
+ * assembly and factorisations, W'Z r in closed form: the part of an iteration during which the device waits
+ * for the host (window / freev syncs inside the stretch included) */
+int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count);
+
+/* LBFGSB_F_DEFER_LNSRCH: line-search set-ups whose sums travelled with the next call's fetch, and how many
+ * of those had to re-issue their 'FG_LNSRCH' request (backtracking step, ascent direction) */
+int lbfgsb_hip_defer_stats(lbfgsb_hip_ctx *ctx, int64_t *deferred, int64_t *reissued);
 
 /* In-run clocks of the three passes over W of an iteration (hipEvents on the context's stream
  * around every launch, read back at the next host sync): [0] cmprlb_wtv_kernel, [1]

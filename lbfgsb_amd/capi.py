@@ -37,6 +37,8 @@ PROTOTYPES = {
     "lbfgsb_hip_wait_stream": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_release_host": (C.c_int, [_vp]),
     "lbfgsb_hip_tie_splits": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_defer_stats": (C.c_int, [_vp, _vp, _vp]),
+    "lbfgsb_hip_host_gap": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_path_counts": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lbfgsb_hip_minimize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
@@ -78,6 +80,7 @@ F_NO_RETURN_SYNC = 4
 F_PARALLEL_GCP = 8
 F_EXACT_TIES = 16      # accepted and ignored: the default since round 3
 F_INDEX_TIES = 32      # opt-out: equal breakpoints in variable order, no heap-order replay
+F_DEFER_LNSRCH = 64    # the line-search set-up's sums travel with the next call's fetch (same-stream objective)
 
 
 class LbfgsbError(RuntimeError):

@@ -312,12 +312,32 @@ int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count) {
   return 0;
 }
 
+int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  if (seconds) *seconds = ctx->t_mid;
+  if (count) *count = ctx->n_mid;
+  return 0;
+}
+
+int lbfgsb_hip_defer_stats(lbfgsb_hip_ctx *ctx, int64_t *deferred, int64_t *reissued) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  int64_t a = 0, b = 0;
+  ctx->defer_counts(a, b);
+  if (deferred) *deferred = a;
+  if (reissued) *reissued = b;
+  return 0;
+}
+
 int lbfgsb_hip_pass_clock(lbfgsb_hip_ctx *ctx, int enable, double *ms_total, int64_t *count) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->clk_stream = ctx->q.stream;
   if (enable == 1) {
-    for (int k = 0; k < 3; ++k) ctx->clk_ms[k] = 0.0, ctx->clk_n[k] = 0, ctx->clk_pending[k] = false;
+    for (int k = 0; k < 3; ++k) {
+      ctx->clk_ms[k] = 0.0, ctx->clk_n[k] = 0;
+      for (bool &pnd : ctx->clk_pending[k]) pnd = false;
+    }
+    ctx->clk_dropped = 0;
     ctx->clock_on = true;
   } else {
     HIPCHK(hipStreamSynchronize(ctx->q.stream));

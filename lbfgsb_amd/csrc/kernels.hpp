@@ -390,5 +390,10 @@ inline int update_scan_extra(int nold, int newrow) {
 
 // finalize: d_part -> d_res (nsum sums, then nmin mins, then nmax maxes)
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax);
+// publish: count doubles from src (device) to dst_host (device address of mapped host memory), then
+// *flag_host = seq with release semantics at system scope -- what the host polls instead of waiting
+// for the stream (solver.hip, fetch)
+void launch_publish(Queue &q, const double *src, double *dst_host, int count, unsigned long long seq,
+                    unsigned long long *flag_host);
 
 }  // namespace lbk

@@ -142,16 +142,17 @@ class Solver final : public lbfgsb_hip_ctx {
       if (p) (void)hipHostFree(p);
       p = nullptr;
     };
-    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_fix), H(h_sp_all), H(h_sp_loc), H(h_res_all);
+    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_flag), H(h_fix), H(h_sp_all), H(h_sp_loc), H(h_res_all);
     if (pf_ev) (void)hipEventDestroy(pf_ev);
     pf_ev = nullptr;
     if (order_ev) (void)hipEventDestroy(order_ev);
     order_ev = nullptr;
-    for (auto &pair : clk_ev)
-      for (auto &e : pair) {
-        if (e) (void)hipEventDestroy(e);
-        e = nullptr;
-      }
+    for (auto &ring : clk_ev)
+      for (auto &pair : ring)
+        for (auto &e : pair) {
+          if (e) (void)hipEventDestroy(e);
+          e = nullptr;
+        }
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -174,6 +175,7 @@ class Solver final : public lbfgsb_hip_ctx {
       own_stream = true;
     }
     q.stream = stream;
+    defer_on = (flags & LBFGSB_F_DEFER_LNSRCH) != 0;
     ld = ((n + 31) / 32) * 32;
     // streamed-once data: nontemporal loads unless W fits the 256 MiB Infinity Cache
     q.nt = (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
@@ -213,6 +215,10 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&q.d_res, res_len * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_gpart, E * lbk::GRAM_BLOCKS * sizeof(double)));
     HIPCHK(hipHostMalloc(&h_res, res_len * sizeof(double)));
+    HIPCHK(hipHostGetDevicePointer((void **)&hd_res, h_res, 0));
+    HIPCHK(hipHostMalloc(&h_flag, 64));
+    std::memset(h_flag, 0, 64);
+    HIPCHK(hipHostGetDevicePointer((void **)&hd_flag, h_flag, 0));
     // cauchy selection scratch (window mode); the full-sort buffers grow on demand
     CHK(ensure_sel(SEL_CAP));
     HIPCHK(hipMalloc(&d_count, sizeof(uint32_t)));
@@ -270,6 +276,7 @@ class Solver final : public lbfgsb_hip_ctx {
     d_res_all = h_res_all = nullptr;
     HIPCHK(hipMalloc(&d_res_all, (size_t)nr * res_len * sizeof(double)));
     HIPCHK(hipHostMalloc(&h_res_all, (size_t)nr * res_len * sizeof(double)));
+    HIPCHK(hipHostGetDevicePointer((void **)&hd_res_all, h_res_all, 0));
     return 0;
   }
 
@@ -296,6 +303,37 @@ class Solver final : public lbfgsb_hip_ctx {
   // the solver's stream, k <= 8m + 15 doubles per rank) and reduced on the host in rank order --
   // sums | minima | maxima in one go, every rank gets bit-identical results by construction,
   // whatever algorithm RCCL picks for the message.  (r02: up to three grouped ncclAllReduce.)
+  // How the numbers reach the host: publish_kernel writes them into mapped host memory and then a
+  // sequence word, which this thread polls (option "spin" = 0: a D2H copy + hipStreamSynchronize as
+  // in round 3).  The poll is bounded: after SPIN_LIMIT_S the runtime's own wait takes over, so a
+  // faulted or hung stream is reported the way it always was.
+  // DEFER_OFF: four more slots (3 sums + 1 minimum) behind the widest phase -- the line-search sums of a
+  // storing pass that did not wait for them (LBFGSB_F_DEFER_LNSRCH); while defer_live they travel with
+  // every fetch and are reduced like the rest.
+  static constexpr int DEFER_OFF = lbk::RES_MAX;
+  static constexpr double SPIN_LIMIT_S = 0.05;
+  bool defer_live = false;
+  bool spin_on = true;  // (option "spin")
+  unsigned long long pub_seq = 0;
+  unsigned long long *h_flag = nullptr, *hd_flag = nullptr;  // host / device view of the sequence word
+  double *hd_res = nullptr, *hd_res_all = nullptr;           // device views of h_res / h_res_all
+  int wait_published(unsigned long long seq) {
+    const double t0 = now_s();
+    for (unsigned it = 1;; ++it) {
+      if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) break;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      if ((it & 0x3ff) == 0 && now_s() - t0 > SPIN_LIMIT_S) {
+        HIPCHK(hipStreamSynchronize(stream));
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq)
+          return fail(LBFGSB_E_NOGPU, "the stream finished without publishing its results");
+        break;
+      }
+    }
+    t_wait += now_s() - t0;
+    return 0;
+  }
   int fetch(int nsum, int nmin, int nmax) {
     const int k = nsum + nmin + nmax;
     if (q.launch_err != hipSuccess) {  // a kernel launch of this phase failed: name it
@@ -305,18 +343,23 @@ class Solver final : public lbfgsb_hip_ctx {
                                       (q.launch_err_where ? q.launch_err_where : "?") + ": " +
                                       hipGetErrorString(e));
     }
-    if ((size_t)k > res_len) return fail(LBFGSB_E_STATE, "fetch: more partials than the buffer holds");
-    if (comm || nranks > 1) ncoll++, coll_bytes += (int64_t)k * 8;
+    if (defer_live && k > DEFER_OFF) return fail(LBFGSB_E_STATE, "fetch: phase overlaps the deferred line-search sums");
+    const int kk = defer_live ? DEFER_OFF + 4 : k;  // doubles that travel
+    if ((size_t)kk > res_len) return fail(LBFGSB_E_STATE, "fetch: more partials than the buffer holds");
+    if (comm || nranks > 1) ncoll++, coll_bytes += (int64_t)kk * 8;
+    const double *src = q.d_res;
+    double *dst = h_res, *dst_dev = hd_res;
+    size_t cnt = (size_t)kk;
     if (comm) {
-      if (g_rccl.AllGather(q.d_res, d_res_all, (size_t)k, ncclDouble, comm, stream) != ncclSuccess)
+      if (g_rccl.AllGather(q.d_res, d_res_all, (size_t)kk, ncclDouble, comm, stream) != ncclSuccess)
         return fail(LBFGSB_E_COMM, "ncclAllGather of the partial sums failed");
-      HIPCHK(hipMemcpyAsync(h_res_all, d_res_all, (size_t)nranks * k * sizeof(double),
-                            hipMemcpyDeviceToHost, stream));
-    } else {
-      HIPCHK(hipMemcpyAsync(h_res, q.d_res, (size_t)k * sizeof(double), hipMemcpyDeviceToHost,
-                            stream));
+      src = d_res_all, dst = h_res_all, dst_dev = hd_res_all, cnt = (size_t)nranks * kk;
     }
-    {
+    if (spin_on) {
+      lbk::launch_publish(q, src, dst_dev, (int)cnt, ++pub_seq, hd_flag);
+      CHK(wait_published(pub_seq));
+    } else {
+      HIPCHK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
       const double t0 = now_s();
       HIPCHK(hipStreamSynchronize(stream));
       t_wait += now_s() - t0;
@@ -324,17 +367,22 @@ class Solver final : public lbfgsb_hip_ctx {
     nsync++;
     if (clock_on) clk_collect();
     if (comm) {
-      for (int j = 0; j < k; ++j) {
+      auto over_ranks = [&](int j, int op) {  // 0 sum, 1 min, 2 max -- in rank order
         double v = h_res_all[j];
         for (int rk = 1; rk < nranks; ++rk) {
-          const double w = h_res_all[(size_t)rk * k + j];
-          v = j < nsum ? v + w : (j < nsum + nmin ? std::fmin(v, w) : std::fmax(v, w));
+          const double w = h_res_all[(size_t)rk * kk + j];
+          v = op == 0 ? v + w : (op == 1 ? std::fmin(v, w) : std::fmax(v, w));
         }
         h_res[j] = v;
-      }
+      };
+      for (int j = 0; j < k; ++j) over_ranks(j, j < nsum ? 0 : (j < nsum + nmin ? 1 : 2));
+      if (defer_live)
+        for (int j = 0; j < 4; ++j) over_ranks(DEFER_OFF + j, j < 3 ? 0 : 1);
     } else if (nranks > 1) {
       if (!cb_ar) return fail(LBFGSB_E_COMM, "multi-rank context without a reducer");
       if (cb_ar(cb_user, h_res, nsum, nmin, nmax) != 0)
+        return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
+      if (defer_live && cb_ar(cb_user, h_res + DEFER_OFF, 3, 1, 0) != 0)
         return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
     }
     return 0;
@@ -369,12 +417,18 @@ class Solver final : public lbfgsb_hip_ctx {
     bool compute_pg = true, prelims = true, linesearch = true;
     double spec_sbgnrm = 0.0;
     int fo = 0;  // 1: the value of a deferred built-in objective rides in front of the first fetch
+    // LBFGSB_F_DEFER_LNSRCH: this call entered with the evaluation of a trial point whose line-search
+    // set-up had not happened yet (its sums arrived with this call's first fetch).  While `landing`
+    // the call works on the ITERATE (x, g, f as at the set-up); the evaluation waits here
+    bool landing = false, spec_holds = false;
+    double f_trial = 0.0, gd_trial = 0.0, sbg_trial = 0.0, spec_iw_changed = 0.0;
   };
   // what a phase tells the driver loop: go on with the next phase | start the loop trip again
-  // (memory refreshed, update skipped) | the call is over
-  enum Flow { NEXT, AGAIN, DONE };
+  // (memory refreshed, update skipped) | the call is over | run the same phase once more
+  enum Flow { NEXT, AGAIN, DONE, REPEAT };
   static int again(Flow &fl) { return fl = AGAIN, 0; }
   static int done(Flow &fl) { return fl = DONE, 0; }
+  static int repeat(Flow &fl) { return fl = REPEAT, 0; }
 #define MAINLB_VIEW(L)                                                                             \
   [[maybe_unused]] T *const x = L.x;                                                              \
   [[maybe_unused]] T *const g = L.g;                                                              \
@@ -453,6 +507,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int phase_start(Mainlb &L, Flow &flow) {
     MAINLB_VIEW(L);
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
+    ls.deferred = false, defer_live = false;
     spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
     epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
                             : std::numeric_limits<double>::epsilon();
@@ -566,10 +621,17 @@ class Solver final : public lbfgsb_hip_ctx {
         *f = f_scale * h_res[0];
       }
     }
+    // a deferred line-search set-up lands with this call's first fetch -- if this IS the evaluation it
+    // asked for; any other task drops it (the sums stay unread)
+    const bool landing = ls.deferred && lbh::str60_pre(task, "FG_LN");
+    if (!landing) ls.deferred = false, defer_live = false;
     if (lbh::str60_pre(task, "FG_LN")) {
       compute_pg = false, prelims = false;
       spec.valid = false;
       spcand.valid = false;
+      // (landing: the set-up has not run; its step is the unit step, this is its first trial)
+      const double stp_here = landing ? 1.0 : stp;
+      const bool first_trial = landing || ifun == 1;
       // First trial of a line search on a bounded problem: it is accepted far more often than
       // not, so evaluate it with the pass that matupd + the next cauchy scan would run anyway
       // (read-only with the pair pending); g'd and |proj g| are two of its sums.  Contexts
@@ -577,7 +639,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // update is real (iwhere_update_kernel at the NEW_X entry).
       // Unconstrained problems (two_pass): the same pass -- every row is free, its p = W'd is
       // W'Z r itself (r = -g, c = 0), and the new pair needs no copy pass of its own.
-      if ((cnstnd || two_pass) && ifun == 1 && !wide()) {
+      if ((cnstnd || two_pass) && first_trial && !wide()) {
         const int store_iw = (flags & LBFGSB_F_MIRROR_INDEX) ? 0 : 1;
         int c2, h2, it2;  // matupd's pointer update (:2303-2309), as if this trial is accepted
         if (iupdat + 1 <= m) {
@@ -591,23 +653,25 @@ class Solver final : public lbfgsb_hip_ctx {
         q.res_off = fo;
         // (the MC = 20 instantiation with the new-row sums has no registers for the hand-over)
         const double chi = (nr_flag(c2) && lbk::maxc_for(c2 - 1) > 10) ? -1.0 : spec_hi(cnstnd);
-        lbk::launch_update_scan<T>(q, n, x, lk(l), uk(u), nbk(), g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
+        lbk::launch_update_scan<T>(q, n, x, lk(l), uk(u), nbk(), g, r, d_src(), d_impl ? 1 : 0, stp_here, iwhere,
                                    (T *)nullptr, W(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count, ub_mask);
         q.res_off = 0;
         clk_end(1);
         spcand.valid = false;
-        if (chi >= 0.0) CHK(spec_queue(x, l, u, g, h2, c2, stp));
+        if (chi >= 0.0) CHK(spec_queue(x, l, u, g, h2, c2, stp_here));
         CHK(fetch(fo + 4 * MCo + 9 + NX, 1, 1));
+        t_mid0 = now_s();
         if (chi >= 0.0) CHK(spec_land(c2, chi));
         if (fo) *f = f_scale * h_res[0];
         const double *R = h_res + fo;
         if (store_iw) iw_dirty += R[4 * MCo + 8];  // (the pass stored the entries that changed)
+        L.spec_iw_changed = store_iw ? R[4 * MCo + 8] : 0.0;
         gd = R[4 * MCo + 7];
         spec_sbgnrm = R[4 * MCo + 10 + NX];
         std::memcpy(spec.res, R, sizeof(double) * (4 * MCo + 11 + NX));
         spec.valid = true;  // dropped below unless dcsrch accepts this point
-        spec.x = x, spec.g = g, spec.stp = stp, spec.head = h2, spec.col = c2, spec.itail = it2;
+        spec.x = x, spec.g = g, spec.stp = stp_here, spec.head = h2, spec.col = c2, spec.itail = it2;
         tbrk_valid = false;
       } else {
         // g.d for the line search and, speculatively, |proj g| for the NEW_X return
@@ -620,6 +684,7 @@ class Solver final : public lbfgsb_hip_ctx {
         gd = h_res[fo];
         spec_sbgnrm = h_res[fo + 1];
       }
+      if (landing) CHK(land_deferred(L));
     } else if (lbh::str60_pre(task, "NEW_X")) {
       compute_pg = false, prelims = false, linesearch = false;
     } else if (!lbh::str60_pre(task, "FG_ST")) {
@@ -637,6 +702,40 @@ class Solver final : public lbfgsb_hip_ctx {
       return done(flow);
     }
     return 0;
+  }
+
+  // LBFGSB_F_DEFER_LNSRCH: the sums of the previous call's storing pass have arrived (h_res[DEFER_OFF..+4)),
+  // together with the evaluation of the trial point that call had already put in place.  Go back to the
+  // iterate and let the line-search set-up run as it would have in that call; if it asks for exactly
+  // this trial point -- the usual case -- phase_linesearch continues with the evaluation at once
+  // (Mainlb::spec_holds), otherwise (backtracking step, ascent direction) the corrected request goes
+  // back to the caller: one more 'FG_LNSRCH', the wasted evaluation is not counted in nfgv.
+  int land_deferred(Mainlb &L) {
+    MAINLB_VIEW(L);
+    const double D[4] = {h_res[DEFER_OFF], h_res[DEFER_OFF + 1], h_res[DEFER_OFF + 2], h_res[DEFER_OFF + 3]};
+    ls.deferred = false, defer_live = false;
+    L.f_trial = *f, L.gd_trial = gd, L.sbg_trial = spec_sbgnrm;
+    L.landing = true, L.spec_holds = false;
+    if (pp) pp_cur ^= 1, L.x = xb[pp_cur], L.g = gb[pp_cur];  // the iterate's pair again
+    *f = defer_f0;
+    linesearch = true, prelims = false, compute_pg = false;
+    int info_sub = 0;
+    const bool uphill = D[0] > 0.0 && D[1] > 0.0;  // subsm's backtracking branch (:2828)
+    if (uphill) {
+      // the branch reads iwhere as the walk left it at the ITERATE; the pass that evaluated the trial
+      // point has meanwhile stored the entries that change there.  The post-scan status is a function of
+      // the row's own x, g and bounds (:1284-1291), the walk's fixes are on file: put both back
+      spec.valid = false;
+      iw_dirty -= L.spec_iw_changed;
+      CHK(restore_iterate(L));  // (classic entry: x = t, g = r)
+      if (cnstnd && L.spec_iw_changed > 0.0) {
+        lbk::launch_iwhere_update<T>(q, n, L.x, L.l, L.u, L.nbd, L.g, iwhere);
+        tbrk_valid = false;
+        CHK(apply_walk_fixes());
+      }
+    }
+    CHK(subspace_land(L.x, L.l, L.u, L.nbd, L.g, D, iword, info_sub));
+    return 0;  // (phase_linesearch counts the evaluation as wasted if its set-up asks for another point)
   }
 
   // first projected gradient (:579-596)
@@ -870,7 +969,19 @@ class Solver final : public lbfgsb_hip_ctx {
     MAINLB_VIEW(L);
     const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
     bool ls_abort = false;
-    const bool setup_call = !lbh::str60_pre(task, "FG_LN");  // first call of this iteration's line search
+    // first call of this iteration's line search (or its deferred set-up, landing one call later)
+    const bool setup_call = L.landing || !lbh::str60_pre(task, "FG_LN");
+    if (setup_call && ls.deferred) {
+      // LBFGSB_F_DEFER_LNSRCH: the storing pass has put the first trial point x = z in place; its sums
+      // (dtd, g'd, stpmx, iword) are still on the device and come over with the next call's first
+      // fetch -- no host sync in this call.  dsave / isave of THIS return do not describe the line
+      // search yet (include/lbfgsb_hip.h)
+      defer_f0 = *f;
+      lbh::str60_set(task, "FG_LNSRCH");
+      if (pp) pp_cur ^= 1, L.x = xb[pp_cur], L.g = gb[pp_cur];
+      save_locals(L);
+      return done(flow);
+    }
     if (setup_call) {
       const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
       double stpmx_cand;
@@ -911,15 +1022,21 @@ class Solver final : public lbfgsb_hip_ctx {
         ifun++;
         nfgv++;
         iback = ifun - 1;
-        if (!(ls.x_is_z && ifun == 1 && stp == 1.0)) {  // else x = z is already in place
+        const bool in_place = ls.x_is_z && ifun == 1 && stp == 1.0;  // x = z is already in place
+        if (!in_place) {
           CHK(ensure_d(setup_call ? xmut : x));  // (it still holds the rejected first trial point z)
           // (the set-up call writes this iteration's first trial point: xmut -- the caller's x, or the
           //  other buffer of a ping-pong pair; later calls are entered with x = the trial buffer)
           lbk::launch_lnsrlb_step<T>(q, n, setup_call ? xmut : x, z, d, t, stp);
         }
         ls.x_is_z = false;
-        spec.valid = false;  // the trial point was not accepted
-        spcand.valid = false;
+        // (a landing set-up that asks for the point in place: that point HAS been evaluated, by the pass
+        //  whose sums this call entered with -- they stay valid)
+        L.spec_holds = L.landing && in_place;
+        if (!L.spec_holds) {
+          spec.valid = false;  // the trial point was not accepted
+          spcand.valid = false;
+        }
       } else {
         lbh::str60_set(task, "NEW_X");
       }
@@ -929,6 +1046,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
 
     if (info != 0 || iback >= 20) {  // :734-769
+      if (L.landing) L.landing = false, L.spec_holds = false, nredo++;
       CHK(ensure_d(setup_call ? xmut : x));  // (d, z as vectors before the trial point goes)
       CHK(restore_iterate(L));
       *f = fold;
@@ -956,8 +1074,15 @@ class Solver final : public lbfgsb_hip_ctx {
     } else if (lbh::str60_pre(task, "FG_LN")) {
       // ping-pong buffers: the caller evaluates f, g at the OTHER pair from here on
       if (pp && setup_call) pp_cur ^= 1, L.x = xb[pp_cur], L.g = gb[pp_cur];
+      if (L.landing && L.spec_holds) {
+        // the request is the point this call was entered with: go on as its 'FG_LNSRCH' re-entry
+        L.landing = false, L.spec_holds = false;
+        *f = L.f_trial, gd = L.gd_trial, spec_sbgnrm = L.sbg_trial;
+        return repeat(flow);
+      }
+      if (L.landing) L.landing = false, nredo++;  // (a corrected request: one more evaluation)
       save_locals(L);
-      if (!(flags & LBFGSB_F_NO_RETURN_SYNC)) {
+      if (!(flags & (LBFGSB_F_NO_RETURN_SYNC | LBFGSB_F_DEFER_LNSRCH))) {
         const double t0 = now_s();
         HIPCHK(hipStreamSynchronize(stream));  // x is ready for the caller's f,g evaluation
         t_wait += now_s() - t0;
@@ -1236,7 +1361,9 @@ class Solver final : public lbfgsb_hip_ctx {
         if (flow == AGAIN) continue;
       }
       if (L.linesearch) {
-        PHASE(phase_linesearch(L, flow));
+        do {
+          PHASE(phase_linesearch(L, flow));
+        } while (flow == REPEAT);
         if (flow == AGAIN) continue;
       }
       PHASE(phase_termination(L, flow));

@@ -160,47 +160,66 @@ struct lbfgsb_hip_ctx {
   int64_t ngcp_clamped = 0;  // closed-form GCPs declined because the f2 clamp would have acted
   int64_t nspecwin = 0;   // walks served by the candidates the update pass handed over
   double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize
+  // host time between the landing of a trial point's sums and the launch of the next storing pass
+  // (dcsrch, matupd, formt, the walk, formk's assembly and factorisations, the closed form): the
+  // stretch of an iteration in which the device has nothing to do
+  double t_mid = 0.0, t_mid0 = 0.0;
+  int64_t n_mid = 0;
   int64_t ncoll = 0, coll_bytes = 0;  // collectives issued / bytes THIS rank contributed to them
   virtual int uniform_mask() const = 0;  // lbfgsb_hip_uniform_bounds
   virtual int64_t freev_skipped() const = 0;
+  virtual void defer_counts(int64_t &deferred, int64_t &reissued) const = 0;
   // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
   // the next setulb_dev call fetches it together with the sums of its own first pass
   bool f_pending = false;
   double f_scale = 1.0;
   // in-run clocks of the three passes over W (hipEvents on the solver's stream around each
-  // launch, read at the next host sync): 0 cmprlb_wtv, 1 update_scan, 2 subsm_update
+  // launch, read at the next host sync): 0 cmprlb_wtv, 1 update_scan, 2 subsm_update.  A small ring
+  // of event pairs per pass: a pass launched again before the previous reading was collected takes
+  // the next pair (every launch is counted; only a ring that is full drops its oldest reading, and
+  // says so in clk_dropped)
+  static constexpr int CLK_RING = 4;
   bool clock_on = false;
-  hipEvent_t clk_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  bool clk_pending[3] = {false, false, false};
+  hipEvent_t clk_ev[3][CLK_RING][2] = {};
+  bool clk_pending[3][CLK_RING] = {};
+  int clk_cur[3] = {0, 0, 0};
   double clk_ms[3] = {0.0, 0.0, 0.0};
   int64_t clk_n[3] = {0, 0, 0};
+  int64_t clk_dropped = 0;
   hipStream_t clk_stream = nullptr;
   hipEvent_t order_ev = nullptr;  // lbfgsb_hip_wait_stream
   void clk_begin(int k) {
     if (!clock_on) return;
-    if (!clk_ev[k][0]) {
-      (void)hipEventCreate(&clk_ev[k][0]);
-      (void)hipEventCreate(&clk_ev[k][1]);
+    clk_collect();
+    int s = clk_cur[k];
+    for (int tries = 0; tries < CLK_RING && clk_pending[k][s]; ++tries) s = (s + 1) % CLK_RING;
+    if (clk_pending[k][s]) clk_dropped++, clk_pending[k][s] = false;
+    clk_cur[k] = s;
+    if (!clk_ev[k][s][0]) {
+      (void)hipEventCreate(&clk_ev[k][s][0]);
+      (void)hipEventCreate(&clk_ev[k][s][1]);
     }
-    clk_collect();  // (a pass launched twice between two syncs: keep the first reading)
-    (void)hipEventRecord(clk_ev[k][0], clk_stream);
+    (void)hipEventRecord(clk_ev[k][s][0], clk_stream);
   }
   void clk_end(int k) {
     if (!clock_on) return;
-    (void)hipEventRecord(clk_ev[k][1], clk_stream);
-    clk_pending[k] = true;
+    const int s = clk_cur[k];
+    (void)hipEventRecord(clk_ev[k][s][1], clk_stream);
+    clk_pending[k][s] = true;
+    clk_cur[k] = (s + 1) % CLK_RING;
   }
   void clk_collect() {  // call after a stream sync (or when the events are known complete)
-    for (int k = 0; k < 3; ++k) {
-      if (!clk_pending[k]) continue;
-      if (hipEventQuery(clk_ev[k][1]) != hipSuccess) continue;
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, clk_ev[k][0], clk_ev[k][1]) == hipSuccess) {
-        clk_ms[k] += ms;
-        clk_n[k]++;
+    for (int k = 0; k < 3; ++k)
+      for (int s = 0; s < CLK_RING; ++s) {
+        if (!clk_pending[k][s]) continue;
+        if (hipEventQuery(clk_ev[k][s][1]) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, clk_ev[k][s][0], clk_ev[k][s][1]) == hipSuccess) {
+          clk_ms[k] += ms;
+          clk_n[k]++;
+        }
+        clk_pending[k][s] = false;
       }
-      clk_pending[k] = false;
-    }
   }
   lbk::Queue q{};
 };

@@ -743,10 +743,16 @@
     gcp.tsum = tsum, gcp.last_t = last_t, gcp.last_i = last_i, gcp.copy_x = false;
     z_valid = false;
     iw_dirty += fix_overflow ? 1.0 : (double)fixlist.size();  // rows whose iwhere the walk sets
+    return apply_walk_fixes();
+  }
+  // (also: a deferred line-search set-up that has to redo subsm's backtracking branch puts the walk's
+  //  fixes back on top of the recomputed post-scan status, solver.hip land_deferred)
+  int apply_walk_fixes() {
+    if (gcp.copy_x) return 0;  // (no walk behind this Cauchy point)
     if (fix_overflow) {  // long walk: the cursor-based kernel (it writes z on the way)
       CHK(ensure_tbrk());
       lbk::launch_cauchy_finish<T>(q, n, row0, (const T *)cx, (const T *)cl, (const T *)cu,
-                                   (const T *)cg, tbrk, iwhere, z, tsum, last_t, last_i);
+                                   (const T *)cg, tbrk, iwhere, z, gcp.tsum, gcp.last_t, gcp.last_i);
       z_valid = true;
     } else {
       for (size_t at = 0; at < fixlist.size(); at += FIX_CAP) {  // (one piece unless exact order)

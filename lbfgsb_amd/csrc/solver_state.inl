@@ -8,6 +8,9 @@
     // many of THIS rank's rows are free -- Indx2(1) carries the local free count
     if (nranks != 1 && index)
       return fail(LBFGSB_E_STATE, "export_state: contexts that mirror Index are single-rank");
+    if (defer_live)
+      return fail(LBFGSB_E_STATE, "export_state: the line-search set-up of this 'FG_LNSRCH' return is still "
+                                  "deferred (LBFGSB_F_DEFER_LNSRCH): export at a NEW_X return");
     HIPCHK(hipSetDevice(device));
     T *wa = (T *)wa_;
     const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
@@ -108,6 +111,7 @@
     get(wa8m);
     z_valid = true;  // z as imported
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, tbrk_valid = false, scan.ready = false;
+    ls.deferred = false, defer_live = false;
     nbd8_src = nullptr;
     spcand.valid = false;
     {
@@ -262,5 +266,6 @@
     closed_form = nclosed, three_pass = nthreepass;
   }
   int64_t freev_skipped() const override { return nfreev_skipped; }
+  void defer_counts(int64_t &deferred, int64_t &reissued) const override { deferred = ndeferred, reissued = nredo; }
   const void *prev_iterate() const override { return t; }
   int uniform_mask() const override { return ub_mask; }

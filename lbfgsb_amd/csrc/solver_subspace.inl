@@ -306,27 +306,55 @@
     // lean: the first trial step is 1 and x = z is stored by the pass, so neither z nor d = x - t
     // is written (5 store streams instead of 7); they stay implicit until ensure_d()
     const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass) && !(flags & LBFGSB_F_MIRROR_INDEX);
+    // LBFGSB_F_DEFER_LNSRCH: the pass's four sums (iword, dd_p, dtd, stpmx) are not waited for -- the first
+    // trial point x = z is in place, the call returns 'FG_LNSRCH' at once, and the sums come over with
+    // the fetch of the NEXT call's first pass (fetch, DEFER_OFF); phase_entry lands them there
+    const bool defer = defer_on && ls_unit_step && !(flags & (LBFGSB_F_MIRROR_INDEX | LBFGSB_F_PARALLEL_GCP)) &&
+                       ipr < 99;
     clk_begin(2);
     // (ping-pong buffers: no t = x, r = g copies -- the roles change below -- and the trial point
     //  goes to the other x buffer, which is where the pending pair's t is read from, row by row)
+    q.res_off = defer ? DEFER_OFF : 0;
+    if (t_mid0 > 0.0) t_mid += now_s() - t_mid0, n_mid++, t_mid0 = 0.0;
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, lk(l), uk(u),
                                 nbk(), iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
                                 pp ? (T *)nullptr : t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
                                 pend, d_src(), ub_mask);
+    q.res_off = 0;
     clk_end(2);
     pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
     d_impl = z_in_x = lean;
     z_valid = !lean;
     if (lean) x_lean = xmut;
     if (pp) t = const_cast<T *>(x), r = const_cast<T *>(g);  // t = x, r = g (:2235-2236) as a change of roles
+    sub_cw = cw, sub_theta = theta, sub_col = col, sub_head = head;
+    if (defer) {
+      defer_live = true, ls.deferred = true;
+      ndeferred++;
+      return 0;
+    }
     CHK(fetch(3, 1, 0));
-    iword = h_res[0] > 0.0 ? 1 : 0;
-    const double dd_p = h_res[1];
+    return subspace_land(x, l, u, nbd, g, h_res, iword, info);
+  }
+
+  // what follows the storing pass's sums (in the same call, or -- deferred -- in the next one): the
+  // line-search set-up values, and the backtracking branch (:2830-2879) when the projected step points uphill
+  lbk::Coef sub_cw;
+  double sub_theta = 1.0;
+  int sub_col = 0, sub_head = 1;
+  int subspace_land(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, const double *R,
+                    int &iword, int &info) {
+    const int ipr = quiet ? -1 : print_level;
+    const double theta = sub_theta;
+    const int col = sub_col, head = sub_head;
+    const lbk::Coef &cw = sub_cw;
+    iword = R[0] > 0.0 ? 1 : 0;
+    const double dd_p = R[1];
     ls.ready = true;
     ls.x_is_z = ls_unit_step;
     ls.gd = dd_p;
-    ls.dtd = h_res[2];
-    ls.stpmx = h_res[3];
+    ls.dtd = R[2];
+    ls.stpmx = R[3];
     if (iword == 0 || dd_p <= 0.0) {  // :2820, :2828
       if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");  // :2883
       return 0;
@@ -358,12 +386,14 @@
     }
     lbk::launch_subsm_backtrack<T>(q, n, row0, z, xp, tbrk, l, u, iwhere, alpha, ibd);
     if (ipr >= 99) std::fprintf(rep.out, "\n----------------exit SUBSM --------------------\n\n");
+    (void)info;
     return 0;
   }
 
   // line-search set-up values when they were produced by the subsm pass
   struct LsOut {
     bool ready = false;
+    bool deferred = false;  // the storing pass ran, its sums are still on the device (defer_live)
     bool x_is_z = false;  // the pass already stored the first trial point x = z
     double gd = 0, dtd = 0, stpmx = 0;
   } ls;
@@ -381,6 +411,9 @@
   //  option "two_pass_maxcol" lowers the limit, for measurements)
   int two_pass_maxcol = 20;
   bool exact_always = false;  // (option "exact_always": every walk in the reference's heap order)
+  bool defer_on = false;      // (LBFGSB_F_DEFER_LNSRCH / option "defer_lnsrch")
+  double defer_f0 = 0.0;      // f at the iterate of a deferred line-search set-up
+  int64_t ndeferred = 0, nredo = 0;  // set-ups whose sums were deferred / of those, requests that had to be re-issued
 
   // lbfgsb_hip_set_option: measurement / test switches of THIS context (include/lbfgsb_hip.h)
   int set_option(const char *name, double v) override {
@@ -401,6 +434,8 @@
     if (k == "lean") return flag(lean_on);
     if (k == "spec_capture") return flag(spec_on);
     if (k == "exact_always") return flag(exact_always);
+    if (k == "defer_lnsrch") return flag(defer_on);
+    if (k == "spin") return flag(spin_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");

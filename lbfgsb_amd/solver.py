@@ -61,7 +61,8 @@ class DeviceSolver:
     def __init__(self, n_local: int, m: int, n_global: Optional[int] = None, row0: int = 0,
                  real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None,
                  same_stream_objective: bool = False, parallel_gcp: bool = False,
-                 exact_ties: bool = True, index_ties: bool = False, options: Optional[dict] = None):
+                 exact_ties: bool = True, index_ties: bool = False, options: Optional[dict] = None,
+                 defer_lnsrch: bool = False):
         self.lib = load_library()
         self.same_stream_objective = bool(same_stream_objective)
         self.n, self.m = int(n_local), int(m)
@@ -74,6 +75,9 @@ class DeviceSolver:
         # a walk that ends inside a group of equal breakpoints is replayed in the reference's heap
         # order by default; index_ties=True (or exact_ties=False) opts out (include/lbfgsb_hip.h)
         flags |= capi.F_INDEX_TIES if (index_ties or not exact_ties) else 0
+        # the caller evaluates f,g on the solver's stream and re-enters with nothing in between: the
+        # line-search set-up's sums ride with the next call's fetch (include/lbfgsb_hip.h)
+        flags |= capi.F_DEFER_LNSRCH if defer_lnsrch else 0
         h = C.c_void_p()
         sp = C.c_void_p(int(stream)) if stream else None
         check(self.lib.lbfgsb_hip_create(self.n, self.n_global, self.row0, self.m, flags, device,
@@ -395,6 +399,18 @@ class DeviceSolver:
         c = C.c_int32()
         check(self.lib.lbfgsb_hip_uniform_bounds(self.h, C.byref(c)))
         return int(c.value)
+
+    def host_gap(self):
+        """(seconds, stretches) the device waited for the host's 2m x 2m algebra between the two passes"""
+        a, b = C.c_double(), C.c_int64()
+        check(self.lib.lbfgsb_hip_host_gap(self.h, C.byref(a), C.byref(b)))
+        return float(a.value), int(b.value)
+
+    def defer_stats(self):
+        """(line-search set-ups whose sums were deferred, of those: requests that had to be re-issued)"""
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.lbfgsb_hip_defer_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def tie_splits(self) -> int:
         """setulb calls so far whose Cauchy walk ended inside a group of equal breakpoints"""

@@ -1,0 +1,164 @@
+"""LBFGSB_F_DEFER_LNSRCH (include/lbfgsb_hip.h): the storing pass's line-search sums travel with the
+NEXT call's fetch instead of being waited for -- one host round trip per iteration less.  The flag
+must change nothing a caller can observe at a 'NEW_X' return: same arithmetic in the same order.
+These tests run every problem twice -- a default context and a deferring one -- and require every
+NEW_X return, the final return and the exported state to be BIT FOR BIT equal; the only visible
+difference allowed is the re-issued 'FG_LNSRCH' request in the calls where the set-up asks for
+another point than x = z (subsm's backtracking step, an ascent direction), which the library
+counts (lbfgsb_hip_defer_stats) and the harness checks against its own count of FG requests.
+The default mode itself is pinned against the oracle by test_gpu_fuzz.py / test_gpu_parity.py."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(t):
+    return hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()
+
+
+def _run(p, pp, defer, max_iter, **ctx):
+    """drive p through one context; f, g are evaluated on the host from x as it is on the solver's
+    stream (sol.sync() first: a deferring context does not synchronise at an FG return)"""
+    import torch
+    import lbfgsb_amd as la
+    sol = la.DeviceSolver(p.n, p.m, defer_lnsrch=defer, **ctx)
+    try:
+        xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.full((p.n,), 7.0, dtype=torch.float64, device="cuda")]
+        gs = [torch.zeros_like(xs[0]), torch.full_like(xs[0], -3.0)]
+        x, g = xs[0], gs[0]
+        l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        rows, nfg_req = [], 0
+        t = ""
+        for _ in range(200000):
+            if pp:
+                t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+                x, g = xs[cur], gs[cur]
+            else:
+                t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+            if t.startswith("FG"):
+                nfg_req += 1
+                sol.sync()
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+                torch.cuda.synchronize()
+            else:
+                sol.sync()
+                rows.append((t, tuple(int(v) for v in sol.isave[21:44]), sol.f.tobytes(),
+                             sol.dsave[[0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 15]].tobytes(),   # (5..9 are wall-clock timers)
+                             _digest(x), _digest(g)))
+                if not t.startswith("NEW_X") or sol.isave[29] >= max_iter:
+                    break
+        wa, iwa = sol.export_state()
+        return dict(rows=rows, nfg_req=nfg_req, defer=sol.defer_stats(), wa=wa.tobytes(), iwa=iwa.tobytes(),
+                    task=t, nfgv=int(sol.isave[33]))
+    finally:
+        sol.close()
+
+
+def _same(p, pp, max_iter=60, **ctx):
+    a = _run(p, pp, False, max_iter, **ctx)
+    b = _run(p, pp, True, max_iter, **ctx)
+    assert a["defer"] == (0, 0)
+    assert len(a["rows"]) == len(b["rows"]), (p.name, len(a["rows"]), len(b["rows"]), a["task"], b["task"])
+    for k, (ra, rb) in enumerate(zip(a["rows"], b["rows"])):
+        assert ra == rb, "%s (n=%d m=%d pp=%s): return %d differs: %s | %s" % (p.name, p.n, p.m, pp, k, ra[:3], rb[:3])
+    assert a["wa"] == b["wa"] and a["iwa"] == b["iwa"], (p.name, "exported state differs")
+    deferred, reissued = b["defer"]
+    # every request the default mode made, plus the ones the deferring mode had to make twice
+    assert b["nfg_req"] == a["nfg_req"] + reissued, (p.name, a["nfg_req"], b["nfg_req"], b["defer"])
+    assert a["nfgv"] == b["nfgv"]
+    return deferred, reissued
+
+
+@pytest.mark.parametrize("pp", [True, False])
+def test_random_problems_bit_identical(oracle_built, pp):
+    from test_gpu_fuzz import make
+    po = oracle_built
+    tot = [0, 0]
+    for seed in list(range(200, 260)) + list(range(5200, 5212)):
+        p = make(po, seed, 400, 1, 13) if seed < 5000 else make(po, seed, 3000, 11, 33)
+        d, r = _same(p, pp)
+        tot[0] += d
+        tot[1] += r
+    assert tot[0] > 500, tot     # the flag did act: most iterations deferred their set-up
+
+
+@pytest.mark.parametrize("pp", [True, False])
+def test_backtracking_and_restarts_bit_identical(oracle_built, pp):
+    """problems that reach subsm's backtracking branch (:2830-2879) and the 'refresh the memory' branches:
+    the deferred set-up has to go back to the iterate, put iwhere back as the walk left it, run the
+    branch and re-issue its request"""
+    from test_gpu_parity import _random_box_rosenbrock
+    po = oracle_built
+    reissued = 0
+    for seed in [5003, 5021, 5028, 5006, 5007, 5040, 5041, 5042, 5043, 5044, 5045, 5046, 5047, 5048, 5049]:
+        p = _random_box_rosenbrock(po, seed)
+        _, r = _same(p, pp, max_iter=150)
+        reissued += r
+    assert reissued > 0, "these seeds are expected to re-issue at least one request"
+
+
+@pytest.mark.parametrize("family", ["linear", "lattice", "tiny", "rosenchain", "scaled"])
+def test_families_bit_identical(oracle_built, family):
+    import test_gpu_fuzz as tf
+    po = oracle_built
+    gen = getattr(tf, "fam_" + family)
+    for seed in range(61000, 61012):
+        _same(gen(po, seed), True)
+        _same(gen(po, seed), False)
+
+
+def test_export_is_refused_while_deferred_and_start_resets(oracle_built):
+    import torch
+    import lbfgsb_amd as la
+    from test_gpu_fuzz import make
+    po = oracle_built
+    p = make(po, 207, 400, 4, 9)
+    sol = la.DeviceSolver(p.n, p.m, defer_lnsrch=True)
+    x = torch.from_numpy(p.x0.copy()).cuda()
+    g = torch.zeros_like(x)
+    l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()
+    nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+
+    def step():
+        t = sol.setulb(x, l, u, nbd, g, p.factr, p.pgtol)
+        if t.startswith("FG"):
+            sol.sync()
+            xh = x.cpu().numpy()
+            gh = np.empty_like(xh)
+            sol.f[0] = p.fg(xh, gh)
+            g.copy_(torch.from_numpy(gh))
+            torch.cuda.synchronize()
+        return t
+    refused = False
+    for _ in range(400):
+        before = sol.defer_stats()[0]
+        t = step()
+        if t.startswith("FG_LN") and sol.defer_stats()[0] > before:
+            with pytest.raises(la.LbfgsbError):
+                sol.export_state()
+            refused = True
+            break
+        if not (t.startswith("FG") or t.startswith("NEW_X")):
+            break
+    assert refused, "no deferred set-up seen"
+    # START in the middle of a deferred set-up: the new run is the run of a fresh context
+    sol.task[:] = la.solver.pad60("START")
+    x.copy_(torch.from_numpy(p.x0))
+    rows = []
+    for _ in range(60):
+        t = step()
+        if t.startswith("NEW_X"):
+            rows.append((int(sol.isave[29]), int(sol.isave[33]), sol.f.tobytes(), _digest(x)))
+        elif not t.startswith("FG"):
+            break
+    sol.close()
+    ref = _run(p, False, True, 10 ** 6)
+    got = [(r[1][8], r[1][12], r[2], r[4]) for r in ref["rows"] if r[0].startswith("NEW_X")][:len(rows)]
+    assert rows == got

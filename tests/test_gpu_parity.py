@@ -1113,7 +1113,8 @@ def test_minimize_wrapper_matches_reverse_communication(env):
     assert t == ref.task_s
     assert abs(int(sol.isave[29]) - int(ref.isave[29])) <= 4 and abs(int(sol.isave[33]) - int(ref.isave[33])) <= 6
     assert float(sol.f[0]) == pytest.approx(float(ref.f[0]), rel=1e-10)
-    assert np.max(np.abs(x.cpu().numpy() - ref.x)) <= 1e-7
+    # (f is flat to 1e-10 around the minimiser; x is where those last iterations left it)
+    assert np.max(np.abs(x.cpu().numpy() - ref.x)) <= 1e-6
     sol.close()
     # Python callback objective (device pointers) + iteration cap
     sol = la.DeviceSolver(n, m)

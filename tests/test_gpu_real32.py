@@ -290,3 +290,61 @@ def test_real32_config5_full_shape_anchors(env):
     rows2, _, _ = run()
     assert rows2 == rows       # bit for bit, f and |proj g| included
     print("config 5 full shape, last rows:", rows[-3:])
+
+
+@pytest.mark.parametrize("case", ["driver2_r32", "quad1000_r32"])
+def test_reference_real32_trajectory_through_the_host_entry(env, case):
+    """The trajectories the REAL reference's -DREAL32 build produced (tests/golden/*_r32_traj.npz, recorded by
+    tests/golden/make_golden.py from oracle/_ref) driven through lbfgsb_hip_setulb_host with real_bytes = 4 --
+    exactly the call lbfgsb_module.F90 makes under -DREAL32.  The reference does EVERYTHING in fp32, the
+    library keeps fp64 partial sums and host algebra, so this is the tolerance sweep of SURVEY.md a19, on
+    the reference's own numbers:
+      driver2 (n = 25): call by call, task and the counters (iteration, nfg, nseg, nfree) equal the
+        reference's for at least the first third of the run (the two part ways near fp32's floor);
+      quad1000 (n = 1000): the first walk already counts 979 segments in fp32 sums, so nseg differs from
+        the first iteration on; f per iteration and the nfg column are what is compared.
+    f to 1e-2 while it is within four decades of its first value (fp32 noise, amplified by the line
+    searches), and the run ends where the reference's ended."""
+    import os
+    po, la = env["po"], env["la"]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case + "_traj.npz"))
+    n, m = int(z["n"]), int(z["m"])
+    if case.startswith("driver2"):
+        p = po.problem_rosenbrock(n, m, float(z["factr"]), float(z["pgtol"]), real=np.float32)
+        cols = [29, 33, 32, 37]      # iteration, nfg, nseg of the last walk, nfree
+    else:
+        p = po.problem_quadratic(n, m, real=np.float32)
+        cols = [29, 33]
+    assert np.array_equal(p.x0, z["x0"]) and np.array_equal(p.l, z["l"]) and np.array_equal(p.nbd, z["nbd"])
+    s = po.State.fresh(p)
+    nbd = p.nbd.astype(np.int32)
+    ncalls = z["f"].shape[0]
+    f_top = float(np.max(np.abs(z["f"])))
+    agree = 0
+    diverged = False
+    for k in range(ncalls):
+        la.setulb(n, m, s.x, p.l, p.u, nbd, s.f, s.g, p.factr, p.pgtol, s.wa, s.iwa, s.task, -1,
+                  s.csave, s.lsave, s.isave, s.dsave)
+        t = s.task_s
+        tz = bytes(z["task"][k].tobytes()).decode().rstrip()
+        if not diverged:
+            same = t == tz and all(int(s.isave[c]) == int(z["isave"][k][c]) for c in cols)
+            if same:
+                fz = float(z["f"][k])
+                if abs(fz) >= 1e-4 * f_top:
+                    assert abs(float(s.f[0]) - fz) <= 1e-2 * abs(fz), (case, k, float(s.f[0]), fz)
+                agree += 1
+            else:
+                diverged = True
+        if t.startswith("FG"):
+            s.f[0] = p.fg(s.x, s.g)
+        elif not t.startswith("NEW_X"):
+            break
+    if s.task_s.startswith("FG") or s.task_s.startswith("NEW_X"):
+        from lbfgsb_amd import capi
+        capi.load_library().lbfgsb_hip_release_host(s.isave.ctypes.data_as(capi.C.c_void_p))
+    assert agree >= ncalls // 3, (case, agree, ncalls)
+    assert s.dsave.dtype == np.float32 and float(s.dsave[4]) == pytest.approx(1.1920929e-07)
+    # the run got where the reference got: f within fp32's reach of the reference's final value
+    f_ref_end = float(z["f"][-1])
+    assert float(s.f[0]) <= max(2.0 * f_ref_end, 1e-6 * f_top), (float(s.f[0]), f_ref_end)
