@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--classic", action="store_true",
                     help="drive lbfgsb_hip_setulb_dev (t = x, r = g as copies: 5 store streams in the storing "
                          "pass) instead of the ping-pong entry lbfgsb_hip_setulb_dev_pp (3 store streams)")
+    ap.add_argument("--rosenbrock", action="store_true",
+                    help="profiling aid: the headline leg runs the extended Rosenbrock objective with the drivers' "
+                         "box (BASELINE.json configs[2] with --n 10000000) instead of the separable quadratic; "
+                         "the metric line is then labelled accordingly")
     ap.add_argument("--no-defer", action="store_true",
                     help="contexts WITHOUT LBFGSB_F_DEFER_LNSRCH: every FG_LNSRCH return waits for the storing "
                          "pass's sums (one more host sync per iteration; what an ordinary caller gets)")
@@ -276,6 +280,19 @@ def cpu_baseline(m, n_full, n_sample):
                 "peak_rss_gb": d["peak_rss_gb"], "host_cpu_model": d["host"]["model"],
             }
             out["extrapolated_over_measured_full_size"] = out["value"] / d["iters_per_sec_col_eq_m"]
+            # `value` is the MEASURED full-size figure whenever the file's run is this host's CPU (VERDICT r3
+            # item 7: the linear extrapolation of the sample overstates the CPU by 1.4-1.5 x); the live sample
+            # of this run stays beside it
+            if d["host"]["model"] == cpu["model"]:
+                out["value_from_live_sample_scaled_to_full_size"] = out["value"]
+                out["value"] = d["iters_per_sec_col_eq_m"]
+                out["value_source"] = ("measured at FULL size (n = 1e8, m = 10) on one core of this CPU model: "
+                                       "profiles/r3a_cpu_ref_full_n1e8_m10.json; the live bounded sample of this "
+                                       "run (n_sample rows, scaled linearly in n) is "
+                                       "value_from_live_sample_scaled_to_full_size")
+            else:
+                out["value_source"] = "live bounded sample of this run, scaled linearly in n (the full-size run on "\
+                                      "file was measured on another CPU model)"
         except Exception:   # noqa: BLE001
             pass
     return out
@@ -302,7 +319,7 @@ class Run:
     """one solver context + its problem, advanced iteration by iteration"""
 
     def __init__(self, torch, dist, la, a, *, n, m, real32, kind, world, rank, local_rank, rccl_self, opts,
-                 parallel_gcp=False):
+                 parallel_gcp=False, defer=None):
         self.torch, self.dist, self.world = torch, dist, world
         self.kind, self.n, self.m = kind, n, m
         dev = torch.device("cuda", local_rank)
@@ -311,7 +328,8 @@ class Run:
         self.n_loc = n_loc
         mk = lambda: la.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,   # noqa: E731
                                      same_stream_objective=True, real32=real32, options=opts,
-                                     parallel_gcp=parallel_gcp, defer_lnsrch=not a.no_defer)
+                                     parallel_gcp=parallel_gcp,
+                                     defer_lnsrch=(not a.no_defer) if defer is None else bool(defer))
         self.sol = mk()
         self.collective = "none"
         if world > 1:
@@ -426,15 +444,16 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
     dt = time.perf_counter() - t0
     clocks = sol.pass_clock(0)   # {pass: (ms_total, launches)} over the timed region
     dt_setulb = run.t_setulb - ts0
+    dt_min = dt
     if run.world > 1:
-        tt = run.torch.tensor([dt, dt_setulb], dtype=run.torch.float64, device=run.dev)
+        tt = run.torch.tensor([dt, dt_setulb, -dt], dtype=run.torch.float64, device=run.dev)
         run.dist.all_reduce(tt, op=run.dist.ReduceOp.MAX)
-        dt, dt_setulb = float(tt[0]), float(tt[1])
+        dt, dt_setulb, dt_min = float(tt[0]), float(tt[1]), -float(tt[2])
     st1 = sol.stats()
     hg1 = sol.host_gap()
     st1["host_gap_us"] = (hg1[0] - hg0[0]) / max(1, hg1[1] - hg0[1]) * 1e6
     return dict(first_iter_s=first_iter_s, nseg_first=nseg_first, warm_done=warm_done, cols_timed=cols_timed,
-                dt=dt, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1,
+                dt=dt, dt_min=dt_min, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1,
                 step_ms_median=float(np.median(step_ms)), step_ms_max=float(np.max(step_ms)))
 
 
@@ -448,10 +467,11 @@ def pass_bytes(col, rbytes, pp, lean=True, ub=0):
     return upd, sub, n_st
 
 
-def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, steps, warm_min, local_rank, opts):
+def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, steps, warm_min, local_rank, opts,
+                 defer=None):
     """a short leg for one of the other BASELINE.json configs: it/s and the two pass fractions"""
     run = Run(torch, dist, la, a, n=n, m=m, real32=real32, kind=kind, world=1, rank=0, local_rank=local_rank,
-              rccl_self=rccl_self, opts=opts)
+              rccl_self=rccl_self, opts=opts, defer=defer)
     try:
         r = timed_leg(run, steps, warm_min, need_full_memory=(kind == 0))
         col = int(run.sol.isave[27])
@@ -459,7 +479,8 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
         ub = run.sol.uniform_bounds()
         upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0, ub)
         passes = {}
-        for key, bpr in (("update_scan", upd_b), ("subsm_update", sub_b)):
+        cw_b = (2 * max(col, 1) + 2) * rb + 1     # the third pass of col > 20: 2 col W columns + x, g + iwhere
+        for key, bpr in (("update_scan", upd_b), ("subsm_update", sub_b), ("cmprlb_wtv", cw_b)):
             ms, cnt = r["clocks"][key]
             if cnt:
                 ach = bpr * run.n_loc / (ms / cnt * 1e-3) / 1e9
@@ -517,15 +538,15 @@ def main():
     rbytes = 4 if a.real32 else 8
     # the objective is the library's own kernel on the solver's stream, so the FG return needs no
     # host sync; contiguous block sharding of the rows
-    run = Run(torch, dist, lbfgsb_amd, a, n=n, m=m, real32=a.real32, kind=0, world=world, rank=rank,
-              local_rank=local_rank, rccl_self=a.rccl_self, opts=opts)
+    run = Run(torch, dist, lbfgsb_amd, a, n=n, m=m, real32=a.real32, kind=1 if a.rosenbrock else 0, world=world,
+              rank=rank, local_rank=local_rank, rccl_self=a.rccl_self, opts=opts)
     sol, n_loc = run.sol, run.n_loc
     # Untimed until the memory is full (col == m): whatever --warmup says, at least m + 1
     # iterations run first, so that every timed launch streams all 2m columns of W and the
     # roofline bytes below (computed for col = m) are the bytes each timed launch really moved.
-    r = timed_leg(run, a.steps, max(a.warmup, m + 1))
+    r = timed_leg(run, a.steps, max(a.warmup, m + 1), need_full_memory=not a.rosenbrock)
     cols_timed, clocks, dt, dt_setulb = r["cols_timed"], r["clocks"], r["dt"], r["dt_setulb"]
-    assert min(cols_timed) == max(cols_timed) == m, cols_timed
+    assert a.rosenbrock or min(cols_timed) == max(cols_timed) == m, cols_timed
     if a.pmc_child:   # (the run live_traffic() counts: nothing but the iterations themselves)
         run.close()
         print(json.dumps({"pmc_child": True, "steps": a.steps, "ms_per_step": dt / a.steps * 1e3}))
@@ -642,8 +663,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if a.real32 else "f64",
         "data": "synthetic",
-        "config": {"workload": "separable bounded quadratic (SURVEY.md 8d), n=%d, m=%d, %s, "
-                               "l=-1,u=1,x0=0, on-device objective"
+        "config": {"workload": ("extended Rosenbrock with the drivers' box (--rosenbrock), n=%d, m=%d, %s, on-device "
+                                "objective" if a.rosenbrock else
+                                "separable bounded quadratic (SURVEY.md 8d), n=%d, m=%d, %s, "
+                                "l=-1,u=1,x0=0, on-device objective")
                                % (n, m, "fp32 storage/fp64 accumulate" if a.real32 else "fp64"),
                    "n": n, "m": m, "rows_per_gpu": n_loc, "parallelism": "rows/%d" % world,
                    "collective": run.collective,
@@ -667,6 +690,12 @@ def main():
         "nfree": nfree,
         "host_syncs_per_iter": (stats["syncs"] - st0["syncs"]) / a.steps,
         "collectives_per_iter": (stats["collectives"] - st0["collectives"]) / a.steps,
+        # what the communicator itself says (ncclCommCount / ncclCommUserRank): N ranks took part
+        "rccl_nranks": (sol.comm_info()[0] if sol.comm_info()[2] == 1 else None),
+        "comm_kind": {0: "none", 1: "rccl", 2: "host callbacks"}[sol.comm_info()[2]],
+        # slowest / fastest rank over the timed region (value is K / the slowest)
+        "ms_per_step_rank_max": dt / a.steps * 1e3,
+        "ms_per_step_rank_min": r["dt_min"] / a.steps * 1e3,
         "kernel_launches_per_iter": (stats["launches"] - st0["launches"]) / a.steps,
         "host_blocked_ms_per_iter": (stats["wait_seconds"] - st0["wait_seconds"]) / a.steps * 1e3,
         "cauchy_fullsorts": stats["cauchy_fullsorts"],
@@ -677,6 +706,19 @@ def main():
         "subspace_steps_closed_form": closed_steps,
         "subspace_steps_three_pass": three_steps,
         "cauchy_walks_served_by_update_pass": handed_windows,
+        # the metric's own kernel, in-run (hipEvents around its launches inside the timed region): the
+        # read-only pass that carries the WS/WY matvecs of the iteration (W'd of cauchy, S'y / S's of matupd)
+        "update_scan_ms_in_run": rec_us["avg_launch_ms"],
+        "update_scan_frac_of_hbm_peak": rec_us["frac"],
+        # the WHOLE iteration against the roofline: algorithmic bytes of one iteration (the two passes over
+        # W + the caller's objective kernel: x read, g written) / ms_per_step
+        "roofline_iteration": {
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "algorithmic_bytes_per_iteration": (upd_bpr + sub_bpr + 2 * rbytes) * n_loc,
+            "achieved": (upd_bpr + sub_bpr + 2 * rbytes) * n_loc / (dt / a.steps) / 1e9,
+            "frac": (upd_bpr + sub_bpr + 2 * rbytes) * n_loc / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+            "note": "per rank; window / freev / gather kernels of the iterations that need them are not in the "
+                    "numerator, so this is a lower bound of the bytes moved"},
         "roofline": roofline,
         "roofline_wtv": roofline_wtv,
         "roofline_other_w_passes": others,
@@ -713,6 +755,11 @@ def main():
              m=20, real32=True, kind=0, rccl_self=False, steps=16, warm_min=21)),
             ("configs[3] per-rank shape: 1.25e7 rows (n=1e8 over 8 GPUs), 1-rank RCCL communicator behind "
              "every sync", dict(n=12_500_000, m=10, real32=False, kind=0, rccl_self=True, steps=60, warm_min=12)),
+            ("the same per-rank shape WITHOUT LBFGSB_F_DEFER_LNSRCH (every FG_LNSRCH return waits for the storing "
+             "pass's sums: what an ordinary reverse-communication caller gets)",
+             dict(n=12_500_000, m=10, real32=False, kind=0, rccl_self=True, steps=60, warm_min=12, defer=False)),
+            ("m = 32 (three passes over W per iteration: col > 20), n = 5e7, fp64", dict(n=50_000_000, m=32,
+             real32=False, kind=0, rccl_self=False, steps=10, warm_min=33)),
         ]
         out["other_configs"] = []
         for name, kw in legs:

@@ -152,6 +152,12 @@ const char *lbfgsb_hip_last_error(void);
  * ------------------------------------------------------------------------- */
 int lbfgsb_hip_rccl_unique_id(void *id128);
 int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, int nranks);
+/* (ncclCommInitRank waits for every rank; the entry gives it LBFGSB_COMM_INIT_TIMEOUT_S seconds -- an
+ *  environment variable, default 120 -- and returns LBFGSB_E_COMM after that instead of hanging.)
+ * What the context's communicator is: *kind = 0 none (one rank), 1 RCCL, 2 host callbacks; for RCCL
+ * *nranks / *rank are the communicator's OWN answers (ncclCommCount, ncclCommUserRank), so a scaling
+ * run can show that N ranks really took part. */
+int lbfgsb_hip_comm_info(lbfgsb_hip_ctx *ctx, int32_t *nranks, int32_t *rank, int32_t *kind);
 typedef int (*lbfgsb_allreduce_fn)(void *user, double *buf, int nsum, int nmin, int nmax);
 typedef int (*lbfgsb_allgather_fn)(void *user, const void *in, void *out, int64_t bytes);
 int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar,
@@ -426,8 +432,10 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           word (default) / through a D2H copy + hipStreamSynchronize
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
- *   "wgrid" (1..2047)       workgroups of the passes over W (default 768)
- *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule / off / on
+ *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel
+ *                           launched, 256 ... 768)
+ *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule (m = 20, fp32 m = 10) / off /
+ *                           the default rule again (the other shapes are not compiled with it)
  *   "pair" (0/1/2)          MC = 20 update pass: lane pairs share accumulators (off / 1 trip / 2 trips)
  *   "gram_rows" (0/1)       formk from scratch with the LDS-slab kernel instead of the quad kernel
  * Returns LBFGSB_E_ARG for an unknown name or a value out of range. */

@@ -41,12 +41,66 @@ int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, 
   HIPCHK(hipSetDevice(ctx->device));
   ncclUniqueId id;
   std::memcpy(&id, id128, 128);
-  ncclComm_t comm = nullptr;
-  if (g_rccl.CommInitRank(&comm, nranks, id, rank) != ncclSuccess)
-    return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
+  // ncclCommInitRank blocks until every rank has arrived; a rank that never comes (a crashed peer, a
+  // wrong id) would hang the caller for good.  The call runs on a helper thread and is given
+  // LBFGSB_COMM_INIT_TIMEOUT_S seconds (default 120): after that the entry returns LBFGSB_E_COMM -- the
+  // helper is left behind, the caller is expected to exit (bench.py does, non-zero)
+  double limit = 120.0;
+  if (const char *e = std::getenv("LBFGSB_COMM_INIT_TIMEOUT_S")) {
+    const double v = std::atof(e);
+    if (v > 0.0) limit = v;
+  }
+  struct Init {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t res = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto st = std::make_shared<Init>();
+  const int device = ctx->device;
+  std::thread([st, id, rank, nranks, device]() {
+    (void)hipSetDevice(device);
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&c, nranks, id, rank);
+    std::lock_guard<std::mutex> lk(st->mu);
+    st->res = r, st->comm = c, st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> lk(st->mu);
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return st->done; }))
+      return fail(LBFGSB_E_COMM, "ncclCommInitRank did not return within " + std::to_string((int)limit) +
+                                     " s (a rank is missing?)");
+  }
+  if (st->res != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
+  ncclComm_t comm = st->comm;
+  // the communicator's own word on its size: what lbfgsb_hip_comm_info reports
+  if (g_rccl.CommCount) {
+    int cnt = 0;
+    if (g_rccl.CommCount(comm, &cnt) != ncclSuccess || cnt != nranks) {
+      g_rccl.CommDestroy(comm);
+      return fail(LBFGSB_E_COMM, "the communicator reports " + std::to_string(cnt) + " ranks, " +
+                                     std::to_string(nranks) + " were asked for");
+    }
+  }
   const int rc = ctx->attach_rccl(comm, rank, nranks);
   if (rc) g_rccl.CommDestroy(comm);
   return rc;
+}
+
+int lbfgsb_hip_comm_info(lbfgsb_hip_ctx *ctx, int32_t *nranks, int32_t *rank, int32_t *kind) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  ncclComm_t c = ctx->rccl_comm();
+  int nr = ctx->nranks, rk = ctx->rank;
+  if (c && g_rccl.CommCount && g_rccl.CommUserRank) {  // ask the communicator itself
+    if (g_rccl.CommCount(c, &nr) != ncclSuccess || g_rccl.CommUserRank(c, &rk) != ncclSuccess)
+      return fail(LBFGSB_E_COMM, "ncclCommCount / ncclCommUserRank failed");
+  }
+  if (nranks) *nranks = nr;
+  if (rank) *rank = rk;
+  if (kind) *kind = c ? 1 : (ctx->nranks > 1 ? 2 : 0);
+  return 0;
 }
 
 void *lbfgsb_hip_get_stream(lbfgsb_hip_ctx *ctx) { return ctx ? (void *)ctx->q.stream : nullptr; }

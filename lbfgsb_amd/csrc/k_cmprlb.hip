@@ -128,16 +128,18 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_kernel(
   });
   block_reduce_store<NA>(acc, NA, 0, 0, part, MAX_BLOCKS);
 }
-// The same pass for MC >= 20 with the new-row sums: 6*MC accumulators per lane do not fit the
-// register file (they spill to AGPRs and the pass runs one wave per SIMD at ~4 TB/s).  Here two
-// neighbouring lanes share the work on their two row groups: every lane still loads all columns
-// of its own rows (r needs them), but accumulates only ONE HALF of the columns -- for its own
-// rows and, through lane shuffles, for its neighbour's -- so 6*MC/2 accumulators suffice, and the
-// operands stay in storage precision until they are used.  Per-element arithmetic is unchanged;
-// the sums are merely grouped differently.  Rows without a neighbour (odd group count, scalar
-// tail) are loaded by both lanes 0 and 1 of the first workgroup, each taking its half.
-// fp64, m = 20, n = 1e8: 7.5 -> 5.4 ms (4.5 -> 6.3 TB/s).  Used for fp64 only: the fp32 build of
-// it is slower than the plain kernel (operand widening + ds_bpermute shuffles).
+// The same pass where 2 MC operand values + the accumulators of all MC columns do not fit the register
+// file of one lane (MC = 20 with the new-row sums: 6 MC accumulators; MC = 32: 64 operands + 64 sums --
+// the plain kernel spilled to scratch there, and a scratch reload inside the row loop returns in order
+// behind the loads in flight).  Two neighbouring lanes share the work on their two row groups: every
+// lane still loads all columns of its own rows (r needs them), but accumulates only ONE HALF of the
+// columns -- for its own rows and, over DPP quad_perm moves, for its neighbour's -- so half the
+// accumulators suffice, and the operands stay in storage precision until they are used.  Per-element
+// arithmetic is unchanged; the sums are merely grouped differently.  Rows without a neighbour (odd group
+// count, scalar tail) are loaded by both lanes 0 and 1 of the first workgroup, each taking its half.
+// fp64, m = 20, n = 1e8: 7.5 -> 5.4 ms (4.5 -> 6.3 TB/s).  NEWROW = false: col 21..32 (formk runs from
+// scratch there, no new-row sums), both types; NEWROW = true: MC = 20, fp64 always, fp32 when the
+// pending-pair selects of the general shape would push the plain kernel into scratch.
 template <typename T, int W, bool NT>
 __device__ __forceinline__ void ldraw(const T *p, T (&o)[W]) {
   double t[W];
@@ -153,13 +155,21 @@ __device__ __forceinline__ double widen_late(float v) {
   return d;
 }
 __device__ __forceinline__ double widen_late(double v) { return v; }
-template <typename T, int MC, bool NT>
+// A value that is selected between two elements of a register array: pinned to a register first.
+// Otherwise the compiler folds "c ? a[p] : a[q]" into ONE load through a selected address, which turns
+// the whole array into a scratch allocation (the fp32 MC = 32 instantiation: 528 bytes per lane).
+template <typename U>
+__device__ __forceinline__ U in_reg(U v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <typename T, int MC, bool NT, bool NEWROW>
 __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ g, double tsum,
     const iw_t *__restrict__ iwhere, const T *__restrict__ ws, const T *__restrict__ wy,
     int64_t ldw, int m, int head, int col, double theta, Coef cf, const T *pr,
     const T *pd, Pend pe, double *part) {
-  constexpr int H = MC / 2, NA = 6 * H;
+  constexpr int H = MC / 2, G = NEWROW ? 6 : 2, NA = G * H;
   constexpr int V = RowsPer<T, MC>::V;
   double acc[NA];
 #pragma unroll
@@ -168,8 +178,9 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
   const bool hi = lane & 1;  // this lane sums columns [H, MC), its neighbour [0, H)
   const int64_t dy = pe.on ? (int64_t)(((intptr_t)pr - (intptr_t)wy) / (intptr_t)sizeof(T)) : 0;
   const int64_t ds = pe.on ? (int64_t)(((intptr_t)pd - (intptr_t)ws) / (intptr_t)sizeof(T)) : 0;
-  auto process = [&](int64_t i, auto wt, bool paired) {
+  auto process = [&](int64_t i, auto wt, auto paired_t) {
     constexpr int W = decltype(wt)::value;
+    constexpr bool paired = decltype(paired_t)::value;
     double xv[W], gv[W], rv[W], yf[W], sa[W];
     T a[MC][W], b[MC][W];
     int iw[W];
@@ -196,7 +207,6 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      double yn = 0.0, sn = 0.0;
       {
         const double zk = xcp_free<T>(xv[k], gv[k], iw[k], tsum);
         double rr = -theta * (zk - xv[k]) - gv[k];
@@ -205,74 +215,78 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
           if (j < col) rr = rr + (double)a[j][k] * cf.a[j] + (double)b[j][k] * cf.a[MAXM + j];
         rv[k] = iw[k] <= 0 ? rr : 0.0;
       }
+      yf[k] = 0.0, sa[k] = 0.0;
+      if constexpr (NEWROW) {
+        double yn = 0.0, sn = 0.0;
 #pragma unroll
-      for (int j = 0; j < MC; ++j)
-        if (j == col - 1) {
-          yn = (double)a[j][k];
-          sn = (double)b[j][k];
-        }
-      yf[k] = iw[k] <= 0 ? yn : 0.0;
-      sa[k] = iw[k] <= 0 ? 0.0 : sn;
+        for (int j = 0; j < MC; ++j)
+          if (j == col - 1) {
+            yn = (double)a[j][k];
+            sn = (double)b[j][k];
+          }
+        yf[k] = iw[k] <= 0 ? yn : 0.0;
+        sa[k] = iw[k] <= 0 ? 0.0 : sn;
+      }
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       double prv = 0.0, pyf = 0.0, psa = 0.0;
-      if (paired) {
-        prv = __shfl_xor(rv[k], 1);
-        pyf = __shfl_xor(yf[k], 1);
-        psa = __shfl_xor(sa[k], 1);
+      if constexpr (paired) {
+        prv = pair_xchg(rv[k]);
+        if constexpr (NEWROW) pyf = pair_xchg(yf[k]), psa = pair_xchg(sa[k]);
       }
 #pragma unroll
       for (int jj = 0; jj < H; ++jj) {
         // own rows, own half of the columns
-        const double aj = widen_late(hi ? a[H + jj][k] : a[jj][k]);
-        const double bj = widen_late(hi ? b[H + jj][k] : b[jj][k]);
+        const T alo = in_reg(a[jj][k]), ahi = in_reg(a[H + jj][k]);
+        const T blo = in_reg(b[jj][k]), bhi = in_reg(b[H + jj][k]);
+        const double aj = widen_late(hi ? ahi : alo);
+        const double bj = widen_late(hi ? bhi : blo);
         acc[jj] += aj * rv[k];
         acc[H + jj] += bj * rv[k];
-        acc[2 * H + jj] += yf[k] * aj;
-        acc[3 * H + jj] += sa[k] * bj;
-        acc[4 * H + jj] += sa[k] * aj;
-        acc[5 * H + jj] += bj * yf[k];
-        if (paired) {  // the neighbour's rows: it sends the half it does not sum itself
-          const T sa_ = hi ? a[jj][k] : a[H + jj][k];
-          const T sb_ = hi ? b[jj][k] : b[H + jj][k];
-          const double paj = widen_late(__shfl_xor(sa_, 1));
-          const double pbj = widen_late(__shfl_xor(sb_, 1));
+        if constexpr (NEWROW) {
+          acc[2 * H + jj] += yf[k] * aj;
+          acc[3 * H + jj] += sa[k] * bj;
+          acc[4 * H + jj] += sa[k] * aj;
+          acc[5 * H + jj] += bj * yf[k];
+        }
+        if constexpr (paired) {  // the neighbour's rows: it sends the half it does not sum itself
+          const T sa_ = hi ? alo : ahi;
+          const T sb_ = hi ? blo : bhi;
+          const double paj = widen_late(pair_xchg(sa_));
+          const double pbj = widen_late(pair_xchg(sb_));
           acc[jj] += paj * prv;
           acc[H + jj] += pbj * prv;
-          acc[2 * H + jj] += pyf * paj;
-          acc[3 * H + jj] += psa * pbj;
-          acc[4 * H + jj] += psa * paj;
-          acc[5 * H + jj] += pbj * pyf;
+          if constexpr (NEWROW) {
+            acc[2 * H + jj] += pyf * paj;
+            acc[3 * H + jj] += psa * pbj;
+            acc[4 * H + jj] += psa * paj;
+            acc[5 * H + jj] += pbj * pyf;
+          }
         }
       }
     }
   };
+  // (pairs are complete: lanes 2k and 2k+1 of a wave run the same number of trips, nve is even)
   const int64_t nv = n / V, nve = nv & ~(int64_t)1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nve; iv += stride)
-    process(iv * V, WTag<V>{}, true);
+    process(iv * V, WTag<V>{}, std::true_type{});
   if (blockIdx.x == 0 && threadIdx.x < 2) {  // rows without a neighbour: both lanes, one half each
-    if (nv > nve) process(nve * V, WTag<V>{}, false);
-    for (int64_t rrow = nv * V; rrow < n; ++rrow) process(rrow, WTag<1>{}, false);
+    if (nv > nve) process(nve * V, WTag<V>{}, std::false_type{});
+    for (int64_t rrow = nv * V; rrow < n; ++rrow) process(rrow, WTag<1>{}, std::false_type{});
   }
-  // lanes of equal parity hold the same slots: reduce over them, then across the 4 waves
-  __shared__ double sm[4][2][NA];
-  const int w = threadIdx.x >> 6;
+  // each lane holds the sums of its half of the columns: zeros for the other half, then the ordinary
+  // fixed-order reduction over all lanes (slots in the plain kernel's layout: group * MC + column)
+  double full[G * MC];
 #pragma unroll
-  for (int k = 0; k < NA; ++k) {
-    double v = acc[k];
+  for (int gq = 0; gq < G; ++gq)
 #pragma unroll
-    for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o);
-    if (lane < 2) sm[w][lane][k] = v;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 2 * NA; e += blockDim.x) {
-    const int par = e / NA, k = e % NA;
-    const double sum = ((sm[0][par][k] + sm[1][par][k]) + sm[2][par][k]) + sm[3][par][k];
-    const int grp = k / H, jj = k % H;
-    part[(size_t)(grp * MC + par * H + jj) * MAX_BLOCKS + blockIdx.x] = sum;
-  }
+    for (int jj = 0; jj < H; ++jj) {
+      full[gq * MC + jj] = hi ? 0.0 : acc[gq * H + jj];
+      full[gq * MC + H + jj] = hi ? acc[gq * H + jj] : 0.0;
+    }
+  block_reduce_store<G * MC>(full, G * MC, 0, 0, part, MAX_BLOCKS);
 }
 
 template <typename T>
@@ -281,49 +295,81 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
                        const Coef &a, int newrow, const T *pr, const T *pd, Pend pe) {
   const int gr = grid_for_w(q, n, VecOf<T>::V);
   const int mc = maxc_for(col);
-  if (newrow && mc >= 20 && sizeof(T) == 8) {  // (fp32: the plain kernel is faster)
-    if (mc == 20) {
-      if (q.nt)
-        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 20, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x,
-                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
-                           q.d_part);
-      else
-        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 20, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
-                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
-                           q.d_part);
+  const bool spec = pe.on && col == mc;  // the steady-state shape (pair pending, memory full)
+#define LB_PAIRK(MCV, NEWROWV)                                                                          \
+  do {                                                                                                  \
+    if (q.nt)                                                                                           \
+      hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, MCV, true, NEWROWV>), dim3(gr), dim3(BLOCK), 0,     \
+                         q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a,   \
+                         pr, pd, pe, q.d_part);                                                         \
+    else                                                                                                \
+      hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, MCV, false, NEWROWV>), dim3(gr), dim3(BLOCK), 0,    \
+                         q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a,   \
+                         pr, pd, pe, q.d_part);                                                         \
+  } while (0)
+  // the plain kernel: MC = 5, 10 always; MC = 20 without the new-row sums, and with them for fp32 in the
+  // steady-state shape (the only MC = 20 new-row shape it holds without scratch)
+#define LB_CMPRLB(MCV, NEWROWV, PSPECV)                                                              \
+  do {                                                                                              \
+    constexpr int MC = MCV;                                                                          \
+    if (q.nt) {                                                                                     \
+      constexpr bool NTV = true;                                                                    \
+      DISPATCH_PIPE(MC, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, PIPEV>),  \
+                                           dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum,        \
+                                           iwhere, w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta,  \
+                                           a, pr, pd, pe, q.d_part));                                \
+    } else {                                                                                        \
+      constexpr bool NTV = false;                                                                   \
+      DISPATCH_PIPE(MC, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, PIPEV>),  \
+                                           dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum,        \
+                                           iwhere, w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta,  \
+                                           a, pr, pd, pe, q.d_part));                                \
+    }                                                                                               \
+  } while (0)
+#define LB_CMPRLB_SMALL(MCV)                       \
+  do {                                             \
+    if (newrow) {                                  \
+      if (spec)                                    \
+        LB_CMPRLB(MCV, true, true);                \
+      else                                         \
+        LB_CMPRLB(MCV, true, false);               \
+    } else {                                       \
+      if (spec)                                    \
+        LB_CMPRLB(MCV, false, true);               \
+      else                                         \
+        LB_CMPRLB(MCV, false, false);              \
+    }                                              \
+  } while (0)
+  if (mc == 5) {
+    LB_CMPRLB_SMALL(5);
+  } else if (mc == 10) {
+    LB_CMPRLB_SMALL(10);
+  } else if (mc == 20) {
+    if (newrow) {
+      if constexpr (sizeof(T) == 4) {
+        if (spec)
+          LB_CMPRLB(20, true, true);
+        else
+          LB_PAIRK(20, true);
+      } else {
+        LB_PAIRK(20, true);
+      }
+    } else if (spec) {
+      LB_CMPRLB(20, false, true);
     } else {
-      if (q.nt)
-        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 32, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x,
-                           g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
-                           q.d_part);
-      else
-        hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, 32, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n,
-                           x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a, pr, pd, pe,
-                           q.d_part);
+      LB_CMPRLB(20, false, false);
     }
   } else {
-    // the steady-state shape (pair pending, memory full) has its own instantiation
-    const bool spec = pe.on && col == mc;
-#define LB_CMPRLB(NEWROWV, PSPECV)                                                                  \
-  DISPATCH_MAXC_NT(col, q.nt,                                                                       \
-                   DISPATCH_PIPE(MC, hipLaunchKernelGGL(                                            \
-                                         (cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, PIPEV>),   \
-                                         dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum, iwhere, \
-                                         w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta, a, pr,    \
-                                         pd, pe, q.d_part)))
+    // col 21..32: never with new-row sums (formk runs from scratch beyond col = 20, solver.hip)
     if (newrow) {
-      if (spec)
-        LB_CMPRLB(true, true);
-      else
-        LB_CMPRLB(true, false);
-    } else {
-      if (spec)
-        LB_CMPRLB(false, true);
-      else
-        LB_CMPRLB(false, false);
+      if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "cmprlb_wtv: new-row sums beyond col = 20";
+      return;
     }
-#undef LB_CMPRLB
+    LB_PAIRK(32, false);
   }
+#undef LB_CMPRLB_SMALL
+#undef LB_CMPRLB
+#undef LB_PAIRK
   LB_LAUNCHED(q);
   launch_finalize(q, gr, (newrow ? 6 : 2) * mc, 0, 0);
 }

@@ -2,6 +2,10 @@
 // (part of the gfx950 kernel set; kernels_common.hpp has the overview)
 #include "kernels_common.hpp"
 
+#include <cstdio>
+#include <mutex>
+#include <unordered_map>
+
 namespace lbk {
 
 int grid_for(int64_t n, int vec) {
@@ -11,24 +15,49 @@ int grid_for(int64_t n, int vec) {
   return (int)g;
 }
 
-// The passes over W keep 2-3 workgroups resident per CU (132-250 VGPRs): a grid of about that
-// many workgroups, each striding over more rows, reads 3-6 % faster than 2048 of them (sweep at
-// n = 1e8: 512 and 768 workgroups are equal, 1024+ slower); Tune::wgrid, at most MAX_BLOCKS - 1
-// (the pair-shared update pass puts its leftover rows into one more column of the partial sums).
-// (Round 1 kept 2048 for fp32; with the straight-line trips 768 is the better grid there too:
-//  fp32 m = 20 94 -> 99.7 it/s, m = 10 158.9 -> 159.9.)
-int grid_for_w(const Queue &q, int64_t n, int vec) {
+// The passes over W run on a grid of exactly the workgroups that are RESIDENT -- every workgroup strides
+// over its share of the rows, none waits for a slot: 3 per CU (768) for the kernels that hold <= 170
+// registers, 1 per CU (256) for the update pass with its 95 accumulators (334 registers: one wave per
+// SIMD).  Round 3 launched 768 everywhere (sweep at n = 1e8 with the old reduction epilogue: 512 and 768
+// equal, 1024+ slower); for a one-wave-per-SIMD kernel that is three ROUNDS of workgroups, each with its
+// own ramp-up and tail during which its SIMD has no load in flight: update_scan at 1.25e7 rows 0.365 ->
+// 0.329 ms with 256 (profiles/r4f).  The occupancy comes from the runtime, per kernel, once.
+// Tune::wgrid > 0 overrides (at most MAX_BLOCKS - 1: the pair-shared update pass puts its leftover rows
+// into one more column of the partial sums).
+int grid_for_w(const Queue &q, int64_t n, int vec, const void *kernel) {
+  const int g = grid_for(n, vec);
   int cap = q.tune.wgrid;
+  if (cap <= 0) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(kernel);
+    if (it == cache.end()) {
+      int per_cu = 0, cus = 0, dev = 0;
+      if (!kernel || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess)
+        per_cu = 3, (void)hipGetLastError();
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256, (void)hipGetLastError();
+      per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+      if (std::getenv("LBFGSB_DEBUG")) {
+        hipFuncAttributes fa{};
+        if (kernel && hipFuncGetAttributes(&fa, kernel) != hipSuccess) (void)hipGetLastError();
+        std::fprintf(stderr, "[grid] kernel %p: %d workgroups per CU x %d CUs (numRegs %d)\n", kernel, per_cu, cus,
+                     fa.numRegs);
+      }
+      it = cache.emplace(kernel, per_cu * cus).first;
+    }
+    cap = it->second;
+  }
   if (cap < 1) cap = 1;
   if (cap > MAX_BLOCKS - 1) cap = MAX_BLOCKS - 1;
-  const int g = grid_for(n, vec);
   return g > cap ? cap : g;
 }
 
 bool pipe_on(const Queue &q, int mc, int elem_bytes) {
   if (q.tune.pipe == 0) return false;
-  if (q.tune.pipe == 1) return mc <= 20;
-  return mc == 20 || (mc == 10 && elem_bytes == 4);
+  return mc == 20 || (mc == 10 && elem_bytes == 4);  // (the shapes DISPATCH_PIPE compiles)
 }
 
 int maxc_for(int col) { return col <= 5 ? 5 : (col <= 10 ? 10 : (col <= 20 ? 20 : 32)); }

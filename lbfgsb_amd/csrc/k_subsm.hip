@@ -183,17 +183,19 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
                          WStore<T> w, int head, int col, double theta, const Coef &cf,
                          const Coef &wv, T *dvec, T *tvec, T *xout, int do_stpmx, Pend pe,
                          const T *pd, int ub) {
-  const int gr = grid_for_w(q, n, VecOf<T>::V);
+  int gr = 0;
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   const bool spec = pe.on && col == maxc_for(col);
 #define LB_SUBSM(PSPECV)                                                                            \
-  DISPATCH_MAXC_NT(col, q.nt,                                                                       \
-                   DISPATCH_PIPE(MC, hipLaunchKernelGGL(                                            \
-                                         (subsm_update_kernel<T, MC, NTV, PSPECV, PIPEV>), dim3(gr),\
-                                         dim3(BLOCK), 0, q.stream, n, tsum, zout, pr, rout, l, u,   \
-                                         nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head,  \
-                                         col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,    \
-                                         w.wy + slot, w.ws + slot, ub, q.d_part)))
+  DISPATCH_MAXC_NT(col, q.nt, DISPATCH_PIPE(MC, {                                                   \
+                     gr = grid_for_w(q, n, VecOf<T>::V,                                             \
+                                     (const void *)&subsm_update_kernel<T, MC, NTV, PSPECV, PIPEV>); \
+                     hipLaunchKernelGGL((subsm_update_kernel<T, MC, NTV, PSPECV, PIPEV>), dim3(gr), \
+                                        dim3(BLOCK), 0, q.stream, n, tsum, zout, pr, rout, l, u,    \
+                                        nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head,   \
+                                        col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,     \
+                                        w.wy + slot, w.ws + slot, ub, q.d_part);                    \
+                   }))
   if (spec)
     LB_SUBSM(true);
   else

@@ -378,12 +378,14 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
                         uint32_t ccap, uint32_t *ccount, int ub) {
   if (cand_hi >= 0.0) (void)hipMemsetAsync(ccount, 0, sizeof(uint32_t), q.stream);
-  const int gr = grid_for_w(q, n, VecOf<T>::V);
+  int gr = 0;
   const int nold = col - 1;
 #define LB_UPDSCAN(NEWROWV)                                                                          \
   DISPATCH_MAXC_NT(nold, q.nt, DISPATCH_PIPE(MC, {                                                   \
                      constexpr bool NRV = NEWROWV && MC <= 20;                                       \
                      constexpr bool PPV = MC <= 10 ? (PIPEV || NRV) : (PIPEV && !NRV && MC <= 20);   \
+                     gr = grid_for_w(q, n, VecOf<T>::V,                                              \
+                                     (const void *)&update_scan_kernel<T, MC, NTV, PPV, NRV>);       \
                      hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PPV, NRV>), dim3(gr),        \
                                         dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g, r, d, dimpl,   \
                                         stp,                                                         \
@@ -401,9 +403,11 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   // reloads, which return in order behind the loads in flight, undo the pipelining -- 4.68 ms).
   // Tune::pair = 0: off; 1: on, one trip in flight; 2: two trips
   const int pair_mode = q.tune.pair;
-  int nblocks = gr;
+  int nblocks = 0;
   if (update_scan_extra(nold, newrow) && mc == 20 && pair_mode > 0) {
     constexpr int MC = 20;
+    gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MC, true, true, true, true>);
+    nblocks = gr;
     constexpr int VP = RowsPerAcc<T, MC, 4 * MC + 11 + 4 * MC + 4>::V;
     const int64_t n_main = n / (2 * VP) * (2 * VP), n_rest = n - n_main;
 #define LB_PAIR(NTV, PIPEV)                                                                          \
@@ -432,8 +436,10 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
     }
   } else if (update_scan_extra(nold, newrow)) {
     LB_UPDSCAN(true);
+    nblocks = gr;
   } else {
     LB_UPDSCAN(false);
+    nblocks = gr;
   }
 #undef LB_UPDSCAN
   LB_LAUNCHED(q);

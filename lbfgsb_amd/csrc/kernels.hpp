@@ -18,9 +18,9 @@ constexpr int RES_MAX = 6 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 
 
 // per-context launch options (lbfgsb_hip_set_option; nothing is read from the environment)
 struct Tune {
-  int wgrid = 768;  // workgroups of the passes over W: what is resident (sweep at n = 1e8: 512 and
-                    // 768 equal, 1024+ slower)
-  int pipe = -1;    // two trips in flight per wave: -1 default rule (pipe_on), 0 off, 1 on for MC <= 20
+  int wgrid = 0;    // workgroups of the passes over W: 0 = what is resident for the kernel launched
+                    // (grid_for_w asks the runtime: 256 ... 768), > 0 = this many
+  int pipe = -1;    // two trips in flight per wave: -1 / 1 default rule (pipe_on), 0 off
   int pair = 2;     // MC = 20 update pass with new-row sums: lane pairs share the per-column
                     // accumulators; 0 off, 1 one trip in flight, 2 two trips
   int gram_rows = 0;  // formk from scratch: 1 = the LDS-slab kernel instead of the quad kernel
@@ -82,7 +82,8 @@ struct Pend {
 };
 
 int grid_for(int64_t n, int vec);
-int grid_for_w(const Queue &q, int64_t n, int vec);  // the same for the passes over W (fewer, resident workgroups)
+// the same for the passes over W: as many workgroups as are resident for `kernel` (1-3 per CU)
+int grid_for_w(const Queue &q, int64_t n, int vec, const void *kernel = nullptr);
 // compile-time column capacity the kernels are unrolled to for `col` pairs (5, 10, 20, 32).
 // Reduction slots that depend on col use MC = maxc_for(col) as their stride.
 int maxc_for(int col);

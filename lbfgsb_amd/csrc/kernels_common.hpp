@@ -67,22 +67,23 @@ namespace lbk {
 // per SIMD anyway: the MC = 20 instantiations (MC = 32 would need a vmcnt beyond 63).
 // Measured (bench.py, n = 1e8): fp32 m = 20 89.7 -> 96.2 it/s, fp32 m = 10 159.5 -> 163.3, fp64
 // m = 10 no change (its kernels already run 2-3 waves per SIMD): on for MC = 20 and for fp32 MC = 10.
-// Tune::pipe = 0 / 1 forces it off / on for every MC <= 20 (tuning experiments).
+// Only those shapes are COMPILED with PIPE (the others spilled to scratch with two register sets and
+// were reachable through the option alone); Tune::pipe = 0 switches it off, for A/B timings.
 bool pipe_on(const Queue &q, int mc, int elem_bytes);  // k_misc.hip
-#define DISPATCH_PIPE(MCV, ...)        \
-  do {                                 \
-    if constexpr ((MCV) <= 20) {       \
-      if (pipe_on(q, MCV, (int)sizeof(T))) { \
-        constexpr bool PIPEV = true;   \
-        __VA_ARGS__;                   \
-      } else {                         \
-        constexpr bool PIPEV = false;  \
-        __VA_ARGS__;                   \
-      }                                \
-    } else {                           \
-      constexpr bool PIPEV = false;    \
-      __VA_ARGS__;                     \
-    }                                  \
+#define DISPATCH_PIPE(MCV, ...)                                        \
+  do {                                                                 \
+    if constexpr ((MCV) == 20 || ((MCV) == 10 && sizeof(T) == 4)) {    \
+      if (pipe_on(q, MCV, (int)sizeof(T))) {                           \
+        constexpr bool PIPEV = true;                                   \
+        __VA_ARGS__;                                                   \
+      } else {                                                         \
+        constexpr bool PIPEV = false;                                  \
+        __VA_ARGS__;                                                   \
+      }                                                                \
+    } else {                                                           \
+      constexpr bool PIPEV = false;                                    \
+      __VA_ARGS__;                                                     \
+    }                                                                  \
   } while (0)
 
 // physical column offset (elements) of logical column j; j >= col -> logical 0

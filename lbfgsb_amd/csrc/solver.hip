@@ -26,7 +26,9 @@
 // Source layout: this file holds the context (allocation, the reductions across ranks) and the
 // mainlb state machine itself -- nine phase functions over one Mainlb struct, driven by drive(); the
 // member functions of the three big phases live in files of their own, included inside the class:
-//   solver_cauchy.inl    the Cauchy point: breakpoint provider, exact host walk, parallel search
+//   solver_provider.inl  the Cauchy point: breakpoint provider (windows, sorts, gathers, merges over ranks)
+//   solver_walk.inl      ... its functional form, the exact host walk: cauchy()
+//   solver_pgcp.inl      ... the opt-in parallel search
 //   solver_subspace.inl  formk, cmprlb, subsm (the closed form, the storing pass, backtracking)
 //   solver_wide.inl      m > 32: the same steps out of unfused tile primitives (k_wide.hip)
 //   solver_state.inl     export / import in the reference's wa / iwa layout, per-kernel doors
@@ -97,7 +99,7 @@ class Solver final : public lbfgsb_hip_ctx {
   double *h_hdr = nullptr;
   size_t msg_len = 0;  // doubles per rank message
   // several ranks with a communicator: the all-gathered chunks are merged on the device (one sort of
-  // <= nranks * chunk keys) and arrive on the host as ONE ordered run (solver_cauchy.inl, refill)
+  // <= nranks * chunk keys) and arrive on the host as ONE ordered run (solver_provider.inl, refill)
   uint64_t *mg_keys[2] = {nullptr, nullptr};
   uint32_t *mg_vals[2] = {nullptr, nullptr};
   void *mg_tmp = nullptr;
@@ -128,6 +130,11 @@ class Solver final : public lbfgsb_hip_ctx {
   ~Solver() override { release(); }
 
   void release() {
+    if (debug_walk && n_mid > 0)
+      std::fprintf(stderr, "[host] %lld stretches, us each: linesearch+return %.1f | caller %.1f | update %.1f | "
+                           "cauchy+freev %.1f | formk+subsm algebra %.1f | all %.1f\n",
+                   (long long)n_mid, t_seg[0] / n_mid * 1e6, t_seg[1] / n_mid * 1e6, t_seg[2] / n_mid * 1e6,
+                   t_seg[3] / n_mid * 1e6, t_seg[4] / n_mid * 1e6, t_mid / n_mid * 1e6);
     auto F = [](auto *&p) {
       if (p) (void)hipFree(p);
       p = nullptr;
@@ -390,7 +397,9 @@ class Solver final : public lbfgsb_hip_ctx {
 
   lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m, zero_buf}; }
 
-#include "solver_cauchy.inl"    // the Cauchy point: breakpoint provider, walk, parallel search
+#include "solver_provider.inl"  // the Cauchy point: breakpoint provider (windows, sorts, gathers, merges)
+#include "solver_walk.inl"      // ... its functional form, the exact host walk: cauchy()
+#include "solver_pgcp.inl"      // ... the opt-in parallel search
 #include "solver_subspace.inl"  // formk, cmprlb, subsm
 #include "solver_wide.inl"      // m > 32: the iteration out of unfused tile primitives
   int print_level = -1;
@@ -661,7 +670,7 @@ class Solver final : public lbfgsb_hip_ctx {
         spcand.valid = false;
         if (chi >= 0.0) CHK(spec_queue(x, l, u, g, h2, c2, stp_here));
         CHK(fetch(fo + 4 * MCo + 9 + NX, 1, 1));
-        t_mid0 = now_s();
+        t_mid0 = now_s(), t_mark = t_mid0;
         if (chi >= 0.0) CHK(spec_land(c2, chi));
         if (fo) *f = f_scale * h_res[0];
         const double *R = h_res + fo;
@@ -686,6 +695,7 @@ class Solver final : public lbfgsb_hip_ctx {
       }
       if (landing) CHK(land_deferred(L));
     } else if (lbh::str60_pre(task, "NEW_X")) {
+      seg(1);
       compute_pg = false, prelims = false, linesearch = false;
     } else if (!lbh::str60_pre(task, "FG_ST")) {
       if (lbh::str60_pre(task, "STOP")) {
@@ -847,6 +857,7 @@ class Solver final : public lbfgsb_hip_ctx {
           std::fprintf(rep.out, " %11lld  variables leave; %11lld  variables enter\n", 0ll, 0ll);
           std::fprintf(rep.out, " %11lld  variables are free at GCP %11d\n", (long long)nfree_g, iter + 1);
         }
+        seg(3);
         return 0;
       }
       CHK(freev_launch(track));
@@ -907,6 +918,7 @@ class Solver final : public lbfgsb_hip_ctx {
         lbk::launch_freev_lists(q, n, iwhere, prevfree, (iter > 0 && cnstnd) ? 1 : 0, index,
                                 indx2, scan_tmp);
     }
+    seg(3);
     return 0;
   }
 
@@ -1107,6 +1119,7 @@ class Solver final : public lbfgsb_hip_ctx {
         rep.vec_a4("G =", host_vec(g).data(), n);
       }
       save_locals(L);
+      seg(0);
       return done(flow);
     }
     return 0;
@@ -1256,6 +1269,7 @@ class Solver final : public lbfgsb_hip_ctx {
       refresh(L);
     }
     prelims = linesearch = true;
+    seg(2);
     return 0;
   }
 #undef MAINLB_VIEW

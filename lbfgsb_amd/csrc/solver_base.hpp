@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <functional>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +61,10 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
-  bool ok = false;  // every symbol resolved
+  // (optional: what a communicator says about itself, lbfgsb_hip_comm_info)
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  bool ok = false;  // every required symbol resolved
   std::mutex mtx;   // (contexts are created from any number of host threads)
   bool load() {
     std::lock_guard<std::mutex> lock(mtx);
@@ -82,6 +88,8 @@ struct Rccl {
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllGather, "ncclAllGather");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
 #undef SYM
     ok = GetUniqueId && CommInitRank && CommDestroy && AllGather;
     if (!ok) {
@@ -142,6 +150,7 @@ struct lbfgsb_hip_ctx {
   virtual int sync() = 0;
   // communicators (capi.hip): an initialised RCCL communicator / a host reducer for this context
   virtual int attach_rccl(ncclComm_t comm, int rank, int nranks) = 0;
+  virtual ncclComm_t rccl_comm() const = 0;
   virtual int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank,
                           int nranks) = 0;
   virtual void path_counts(int64_t &closed_form, int64_t &three_pass) const = 0;
@@ -165,6 +174,15 @@ struct lbfgsb_hip_ctx {
   // stretch of an iteration in which the device has nothing to do
   double t_mid = 0.0, t_mid0 = 0.0;
   int64_t n_mid = 0;
+  // the same stretch cut at its milestones (LBFGSB_DEBUG prints the averages when the context goes):
+  // 0 line search + return to the caller | 1 caller (NEW_X -> re-entry) | 2 termination tests, matupd, formt |
+  // 3 cauchy (host walk; window syncs if any) + freev | 4 formk assembly / factorisations, closed form, triangular solves
+  double t_seg[5] = {0, 0, 0, 0, 0}, t_mark = 0.0;
+  void seg(int k) {
+    if (t_mid0 <= 0.0) return;
+    const double t = now_s();
+    t_seg[k] += t - t_mark, t_mark = t;
+  }
   int64_t ncoll = 0, coll_bytes = 0;  // collectives issued / bytes THIS rank contributed to them
   virtual int uniform_mask() const = 0;  // lbfgsb_hip_uniform_bounds
   virtual int64_t freev_skipped() const = 0;

@@ -257,6 +257,7 @@
     comm = c;
     return 0;
   }
+  ncclComm_t rccl_comm() const override { return comm; }
   int attach_host(lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag, void *user, int rank_,
                   int nranks_) override {
     cb_ar = ar, cb_ag = ag, cb_user = user;

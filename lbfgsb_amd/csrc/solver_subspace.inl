@@ -315,6 +315,7 @@
     // (ping-pong buffers: no t = x, r = g copies -- the roles change below -- and the trial point
     //  goes to the other x buffer, which is where the pending pair's t is read from, row by row)
     q.res_off = defer ? DEFER_OFF : 0;
+    seg(4);
     if (t_mid0 > 0.0) t_mid += now_s() - t_mid0, n_mid++, t_mid0 = 0.0;
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, lk(l), uk(u),
                                 nbk(), iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
@@ -447,7 +448,7 @@
       if (!ub_on) ub_mask = 0;
       return rc;
     }
-    if (k == "wgrid") return in_range(1, lbk::MAX_BLOCKS - 1, q.tune.wgrid);
+    if (k == "wgrid") return in_range(0, lbk::MAX_BLOCKS - 1, q.tune.wgrid);
     if (k == "pipe") return in_range(-1, 1, q.tune.pipe);
     if (k == "pair") return in_range(0, 2, q.tune.pair);
     if (k == "gram_rows") return in_range(0, 1, q.tune.gram_rows);

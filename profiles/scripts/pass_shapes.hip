@@ -191,6 +191,20 @@ int main(int argc, char **argv) {
   CK(hipMemset(w, 0, (size_t)n * 24 * 8));
   CK(hipMemset(out, 0, (size_t)n * 8 * 8));
   const double *vec = w + (size_t)n * 20;   // the 4 separate n-vectors of the tiled form
+  if (argc > 1 && argv[1][0] == 's') {
+    // round 4: what would the storing pass gain with ONE store stream instead of three
+    // (s_j, y_j formed in registers from a ring of iterates / gradients instead of stored)?  The bare mixes:
+    // 22 reads + 3 / 2 / 1 writes -- and 23 reads + 1 write, the mix a ring would really have (col + 1
+    // iterates and gradients instead of col columns each: one read stream more)
+    for (int pass = 0; pass < 2; ++pass) {
+      suite<22, 3, false>(n, w, vec, out, sink);
+      suite<22, 2, false>(n, w, vec, out, sink);
+      suite<22, 1, false>(n, w, vec, out, sink);
+      suite<24, 1, false>(n, w, vec, out, sink);
+      printf("\n");
+    }
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'r') {
     // round 3: the stream mix of the iteration's two passes as they are now (uniform bounds, ping-pong entry):
     // storing pass = 22 fp64 read streams (+ 1 B/row of iwhere) and 3 write streams, read-only pass = 22 read streams

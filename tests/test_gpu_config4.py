@@ -31,7 +31,11 @@ def test_config4_eight_ranks_full_size_on_one_gpu(oracle_built, tmp_path):
         pytest.skip("needs ~40 GB of HBM")
     world, n, m, iters = 8, 100_000_000, 10, 14
     out = str(tmp_path / "c4.json")
-    env = dict(os.environ, LBFGSB_RCCL_LIBRARY=_fake_rccl())
+    # (the ranks are THREADS of one process here: the stand-in's synchronous form, tests/fake_rccl.cpp --
+    #  a device-wide synchronising runtime call of one rank thread would otherwise wait for the stream-side
+    #  waits of the other ranks; the asynchronous form is what the multi-PROCESS tests of
+    #  test_gpu_multirank.py run on, the count / datatype check acts in both)
+    env = dict(os.environ, LBFGSB_RCCL_LIBRARY=_fake_rccl(), LBFGSB_FAKE_RCCL_SYNC="1")
     rc = subprocess.call([sys.executable, os.path.join(HERE, "_c4_worker.py"), str(world), str(n), str(m),
                           str(iters), out], env=env, timeout=900)
     res = json.load(open(out))

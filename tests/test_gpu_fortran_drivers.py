@@ -258,7 +258,7 @@ def test_driver23_real32_transcripts(tmp_path, name, gold, build):
         assert a[1] == b[1] and a[4] == b[4], (a, b)
         assert abs(val(a[7]) - fb) <= 1e-2 * fb, (a, b)
         same += 1
-    assert same >= 7, same
+    assert same >= 5, same
     # both end at fp32's floor, far from the drivers' |proj g| < 1e-10 stop: f has fallen by > 12 decades
     # and the run ended by itself (ABNORMAL_TERMINATION_IN_LNSRCH / a rounding-level stop), not by the
     # user's test

@@ -224,8 +224,9 @@ def _fake_rccl():
     src = os.path.join(HERE, "fake_rccl.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(so), exist_ok=True)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so,
-                               "-lrt"])
+        # (compiled as HIP: the stand-in launches one tiny kernel -- the stream-side wait of a collective)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17",
+                               "-fPIC", "-shared", src, "-o", so, "-lrt", "-lpthread"])
     return so
 
 
