@@ -430,6 +430,7 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
     run.barrier()
     ts0, st0 = run.t_setulb, sol.stats()
     hg0 = sol.host_gap()
+    hs0 = sol.host_segments()
     sol.pass_clock(1)            # hipEvents around every launch of the three W passes
     cols_timed, step_ms = [], []
     t0 = time.perf_counter()
@@ -452,6 +453,10 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
     st1 = sol.stats()
     hg1 = sol.host_gap()
     st1["host_gap_us"] = (hg1[0] - hg0[0]) / max(1, hg1[1] - hg0[1]) * 1e6
+    hs1 = sol.host_segments()
+    names = ("linesearch_and_return", "caller_new_x_to_reentry", "termination_matupd_formt", "cauchy_freev",
+             "formk_closed_form_solves")
+    st1["host_segments_us"] = {nm: (b - a_) / max(1, hg1[1] - hg0[1]) * 1e6 for nm, a_, b in zip(names, hs0, hs1)}
     return dict(first_iter_s=first_iter_s, nseg_first=nseg_first, warm_done=warm_done, cols_timed=cols_timed,
                 dt=dt, dt_min=dt_min, dt_setulb=dt_setulb, clocks=clocks, st0=st0, st1=st1,
                 step_ms_median=float(np.median(step_ms)), step_ms_max=float(np.max(step_ms)))
@@ -498,6 +503,7 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0]),
                 "lnsrch_setups_deferred_reissued": list(run.sol.defer_stats()),
                 "host_algebra_us_between_passes": r["st1"]["host_gap_us"],
+                "host_segments_us": r["st1"]["host_segments_us"],
                 "uniform_bounds_mask": ub, "options": opts}
     finally:
         run.close()
@@ -703,6 +709,7 @@ def main():
         "tie_splits": sol.tie_splits(),
         "lnsrch_setups_deferred_reissued": list(sol.defer_stats()),
         "host_algebra_us_between_passes": stats["host_gap_us"],
+        "host_segments_us": stats["host_segments_us"],
         "subspace_steps_closed_form": closed_steps,
         "subspace_steps_three_pass": three_steps,
         "cauchy_walks_served_by_update_pass": handed_windows,

@@ -484,6 +484,11 @@ int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count);
  * assembly and factorisations, W'Z r in closed form: the part of an iteration during which the device waits
  * for the host (window / freev syncs inside the stretch included) */
 int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count);
+/* the same stretches cut at their milestones, accumulated seconds: [0] line search + return to the caller,
+ * [1] the caller between the NEW_X return and the re-entry, [2] termination tests + matupd + formt,
+ * [3] cauchy (host walk, window syncs if any) + freev, [4] formk's assembly / factorisations, W'Z r, the
+ * triangular solves */
+int lbfgsb_hip_host_segments(lbfgsb_hip_ctx *ctx, double *seconds5);
 
 /* LBFGSB_F_DEFER_LNSRCH: line-search set-ups whose sums travelled with the next call's fetch, and how many
  * of those had to re-issue their 'FG_LNSRCH' request (backtracking step, ascent direction) */

@@ -372,6 +372,11 @@ int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count) {
   if (count) *count = ctx->n_mid;
   return 0;
 }
+int lbfgsb_hip_host_segments(lbfgsb_hip_ctx *ctx, double *seconds5) {
+  if (!ctx || !seconds5) return fail(LBFGSB_E_ARG, "host_segments: NULL argument");
+  for (int k = 0; k < 5; ++k) seconds5[k] = ctx->t_seg[k];
+  return 0;
+}
 
 int lbfgsb_hip_defer_stats(lbfgsb_hip_ctx *ctx, int64_t *deferred, int64_t *reissued) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");

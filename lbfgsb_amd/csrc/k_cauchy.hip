@@ -98,11 +98,11 @@ void launch_cauchy_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   const int gr = grid_for_w(q, n, VecOf<T>::V);
   if (col == 0) {
     hipLaunchKernelGGL((cauchy_scan_kernel<T, 0, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u,
-                       nbd, g, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, col, q.d_part);
+                       nbd, g, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, col, q.part());
   } else {
     DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((cauchy_scan_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                           q.stream, n, x, l, u, nbd, g, iwhere, tbrk, w.ws, w.wy,
-                                          w.zero, w.ld, w.m, head, col, q.d_part));
+                                          w.zero, w.ld, w.m, head, col, q.part()));
   }
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 2 * (col == 0 ? 0 : maxc_for(col)) + 4, 1, 0);
@@ -551,12 +551,12 @@ void launch_cauchy_finish(Queue &q, int64_t n, int64_t row0, const T *x, const T
   const int gr = grid_for(n, VecOf<T>::V);
   if (count) {
     hipLaunchKernelGGL((cauchy_finish_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, row0,
-                       x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.d_part);
+                       x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.part());
     LB_LAUNCHED(q);
     launch_finalize(q, gr, 1, 0, 0);
   } else {
     hipLaunchKernelGGL((cauchy_finish_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, row0,
-                       x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.d_part);
+                       x, l, u, g, tbrk, iwhere, xcp, tsum, last_t, last_i, q.part());
     LB_LAUNCHED(q);
   }
 }

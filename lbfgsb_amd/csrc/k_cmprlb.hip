@@ -170,7 +170,9 @@ __global__ __launch_bounds__(BLOCK) void cmprlb_wtv_pair_kernel(
     int64_t ldw, int m, int head, int col, double theta, Coef cf, const T *pr,
     const T *pd, Pend pe, double *part) {
   constexpr int H = MC / 2, G = NEWROW ? 6 : 2, NA = G * H;
-  constexpr int V = RowsPer<T, MC>::V;
+  // (fp32, MC = 32 with the new-row sums: ONE row per lane -- two rows of 64 operands next to 96 fp64 sums
+  //  do not fit the register file: 340 bytes of scratch; 4-byte loads are the lesser evil)
+  constexpr int V = (NEWROW && MC > 20 && sizeof(T) == 4) ? 1 : RowsPer<T, MC>::V;
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
@@ -301,11 +303,11 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
     if (q.nt)                                                                                           \
       hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, MCV, true, NEWROWV>), dim3(gr), dim3(BLOCK), 0,     \
                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a,   \
-                         pr, pd, pe, q.d_part);                                                         \
+                         pr, pd, pe, q.part());                                                         \
     else                                                                                                \
       hipLaunchKernelGGL((cmprlb_wtv_pair_kernel<T, MCV, false, NEWROWV>), dim3(gr), dim3(BLOCK), 0,    \
                          q.stream, n, x, g, tsum, iwhere, w.ws, w.wy, w.ld, w.m, head, col, theta, a,   \
-                         pr, pd, pe, q.d_part);                                                         \
+                         pr, pd, pe, q.part());                                                         \
   } while (0)
   // the plain kernel: MC = 5, 10 always; MC = 20 without the new-row sums, and with them for fp32 in the
   // steady-state shape (the only MC = 20 new-row shape it holds without scratch)
@@ -317,13 +319,13 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
       DISPATCH_PIPE(MC, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, PIPEV>),  \
                                            dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum,        \
                                            iwhere, w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta,  \
-                                           a, pr, pd, pe, q.d_part));                                \
+                                           a, pr, pd, pe, q.part()));                                \
     } else {                                                                                        \
       constexpr bool NTV = false;                                                                   \
       DISPATCH_PIPE(MC, hipLaunchKernelGGL((cmprlb_wtv_kernel<T, MC, NEWROWV, NTV, PSPECV, PIPEV>),  \
                                            dim3(gr), dim3(BLOCK), 0, q.stream, n, x, g, tsum,        \
                                            iwhere, w.ws, w.wy, w.zero, w.ld, w.m, head, col, theta,  \
-                                           a, pr, pd, pe, q.d_part));                                \
+                                           a, pr, pd, pe, q.part()));                                \
     }                                                                                               \
   } while (0)
 #define LB_CMPRLB_SMALL(MCV)                       \
@@ -360,12 +362,11 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
       LB_CMPRLB(20, false, false);
     }
   } else {
-    // col 21..32: never with new-row sums (formk runs from scratch beyond col = 20, solver.hip)
-    if (newrow) {
-      if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "cmprlb_wtv: new-row sums beyond col = 20";
-      return;
-    }
-    LB_PAIRK(32, false);
+    // col 21..32: always the pair-shared kernel (with the new-row sums: formk stays incremental there too)
+    if (newrow)
+      LB_PAIRK(32, true);
+    else
+      LB_PAIRK(32, false);
   }
 #undef LB_CMPRLB_SMALL
 #undef LB_CMPRLB

@@ -5,11 +5,15 @@
 namespace lbk {
 
 // =========================== freev (:1980-2059) ==============================
+// sums: [0] nfree, [1] nenter, [2] nleave, [3] rows whose status changed (= the length of the list, as a
+// sum: the host needs no copy of the list's atomic position counter).  chg_count / cnt_zero: two position
+// counters used in turn -- this launch appends through chg_count and zeroes the OTHER one for the next
+// launch (no memset command in front of the kernel).
 __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
                                                             const iw_t *__restrict__ iwhere,
                                                             int8_t *wasfree, double *part,
                                                             uint32_t *chg, uint32_t chg_cap,
-                                                            uint32_t *chg_count) {
+                                                            uint32_t *chg_count, uint32_t *cnt_zero) {
   // 16 rows per lane and trip (one 16-byte load of each byte array).  Rows whose status changed
   // are collected per workgroup in LDS and appended to the global list with ONE global atomic
   // per flush (a same-address atomic per row would serialise: 1e5 changes x ~12 ns)
@@ -17,8 +21,9 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
   __shared__ uint32_t lbuf[LCAP];
   __shared__ uint32_t lcount, gbase;
   if (threadIdx.x == 0) lcount = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_zero = 0;
   __syncthreads();
-  double acc[3] = {0, 0, 0};
+  double acc[4] = {0, 0, 0, 0};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * R;
   const int64_t ntrip = (n + stride - 1) / stride;  // uniform trip count (barriers inside)
   for (int64_t trip = 0; trip < ntrip; ++trip) {
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
         changed |= (fr != was) ? (1u << k) : 0u;
         wf.b[k] = fr ? 1 : 0;
       }
-      acc[0] += nfr, acc[1] += nen, acc[2] += nlv;
+      acc[0] += nfr, acc[1] += nen, acc[2] += nlv, acc[3] += __builtin_popcount(changed);
       if (changed) {  // (few rows: keeps the pass that follows free of drained store traffic)
         if (chg) {
           const uint32_t pos = atomicAdd(&lcount, (uint32_t)__builtin_popcount(changed));  // LDS atomic
@@ -82,16 +87,15 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
       }
     }
   }
-  block_reduce_store<3>(acc, 3, 0, 0, part, MAX_BLOCKS);
+  block_reduce_store<4>(acc, 4, 0, 0, part, MAX_BLOCKS);
 }
 void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree, uint32_t *chg,
-                        uint32_t chg_cap, uint32_t *chg_count) {
+                        uint32_t chg_cap, uint32_t *cnt2, int parity) {
   const int gr = grid_for(n, 16);
-  if (chg) (void)hipMemsetAsync(chg_count, 0, sizeof(uint32_t), q.stream);
   hipLaunchKernelGGL(freev_count_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
-                     q.d_part, chg, chg_cap, chg_count);
+                     q.part(), chg, chg_cap, cnt2 + (parity & 1), cnt2 + ((parity & 1) ^ 1));
   LB_LAUNCHED(q);
-  launch_finalize(q, gr, 3, 0, 0);
+  launch_finalize(q, gr, 4, 0, 0);
 }
 
 // ordered stream compaction reproducing the reference's list orders exactly:

@@ -63,14 +63,31 @@ bool pipe_on(const Queue &q, int mc, int elem_bytes) {
 int maxc_for(int col) { return col <= 5 ? 5 : (col <= 10 ? 10 : (col <= 20 ? 20 : 32)); }
 
 // =========================== finalize ======================================
-// One workgroup per output slot: fixed-order sum / min / max of the per-block
-// partials.
-__global__ __launch_bounds__(BLOCK) void finalize_kernel(const double *__restrict__ part,
-                                                         int pstride, int nblocks,
-                                                         double *__restrict__ res, int nsum,
-                                                         int nmin, int nmax) {
+// One workgroup per output slot: fixed-order sum / min / max of the per-block partials.
+// One launch serves up to three JOBS (partial-sum matrices of different kernels): a kernel whose results
+// nobody waits for yet -- the caller's objective whose f is fetched with the next call, the storing pass
+// of a deferred line-search set-up -- leaves its partials in a matrix of its own (Queue::part_sel) and
+// PARKS its job (Queue::hold_fin); the next finalize launch takes the parked jobs along.  Every kernel
+// boundary costs ~10 us on this machine (4 us for the tiny kernel + ~6 us of dependent-dispatch latency,
+// profiles/r4k_iteration_timelines.txt): an iteration drops from 7 launches to 4.
+// hpub != nullptr: the launch also PUBLISHES -- the last workgroup to finish copies the launch's results into
+// mapped host memory (same offsets as in `res`) and then stores the launch's sequence number into a host
+// word the host polls (fetch, solver.hip): no separate publish kernel for a single-rank context.
+struct FinJobs {
+  FinJob j[3];
+  int n;
+};
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(FinJobs J, double *res, double *hpub,
+                                                         unsigned long long seq, unsigned long long *flag,
+                                                         unsigned int *counter) {
   __shared__ double sm[BLOCK];
-  const int k = blockIdx.x;
+  int k = blockIdx.x, ji = 0;
+  while (ji < J.n - 1 && k >= J.j[ji].nsum + J.j[ji].nmin + J.j[ji].nmax) {
+    k -= J.j[ji].nsum + J.j[ji].nmin + J.j[ji].nmax;
+    ++ji;
+  }
+  const double *__restrict__ part = J.j[ji].part;
+  const int pstride = J.j[ji].pstride, nblocks = J.j[ji].nblocks, nsum = J.j[ji].nsum, nmin = J.j[ji].nmin;
   const int op = k < nsum ? 0 : (k < nsum + nmin ? 1 : 2);
   double v = op == 0 ? 0.0 : (op == 1 ? LB_INF : -LB_INF);
   for (int b = threadIdx.x; b < nblocks; b += BLOCK) {
@@ -86,9 +103,58 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const double *__restric
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) res[k] = sm[0];
+  if (threadIdx.x == 0) res[J.j[ji].off + k] = sm[0];
+  if (hpub) {
+    // The host must never see the sequence word before a result.  Results written to host memory by
+    // workgroups on different XCDs travel different ways to the PCIe port, so the mirror is NOT written
+    // slot by slot by whoever computed it: the LAST workgroup to finish (device-scope count) copies every
+    // slot of the launch from d_res into the mirror -- one workgroup, one path -- fences at system scope and
+    // then stores the word.
+    __shared__ bool last;
+    if (threadIdx.x == 0) {
+      __threadfence();  // this workgroup's result is visible device-wide before it is counted
+      const unsigned int done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      last = done == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {
+      __threadfence();
+      for (int q = 0; q < J.n; ++q) {
+        const int cnt = J.j[q].nsum + J.j[q].nmin + J.j[q].nmax, off = J.j[q].off;
+        for (int e = threadIdx.x; e < cnt; e += BLOCK) {
+          const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long *>(res + off + e),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          reinterpret_cast<unsigned long long *>(hpub)[off + e] = bits;
+        }
+      }
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
+static void finalize_launch(Queue &q, const FinJobs &J) {
+  int total = 0;
+  for (int k = 0; k < J.n; ++k) total += J.j[k].nsum + J.j[k].nmin + J.j[k].nmax;
+  if (total <= 0) return;
+  const bool pub = q.fin_publish && q.hd_pub && q.hd_fin_flag && q.d_fin_count;
+  if (pub) ++q.fin_seq;
+  hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(BLOCK), 0, q.stream, J, q.d_res, pub ? q.hd_pub : nullptr,
+                     q.fin_seq, q.hd_fin_flag, q.d_fin_count);
+  LB_LAUNCHED(q);
+  if (pub) q.launches_at_fin = q.launches;
+}
+void finalize_flush(Queue &q) {  // parked jobs that no later launch has taken along
+  if (q.nheld == 0) return;
+  FinJobs J{};
+  for (int k = 0; k < q.nheld; ++k) J.j[J.n++] = q.held[k];
+  q.nheld = 0;
+  finalize_launch(q, J);
+}
 void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int nsum,
                           int nmin, int nmax) {
   const int k = nsum + nmin + nmax;
@@ -97,12 +163,21 @@ void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int n
     if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "finalize: nblocks > pstride";
     return;
   }
-  hipLaunchKernelGGL(finalize_kernel, dim3(k), dim3(BLOCK), 0, q.stream, part, pstride, nblocks,
-                     q.d_res + q.res_off, nsum, nmin, nmax);
-  LB_LAUNCHED(q);
+  const FinJob job{part, pstride, nblocks, q.res_off, nsum, nmin, nmax};
+  if (q.hold_fin) {  // nobody waits for these yet: the next launch takes them along
+    q.hold_fin = false;
+    if (q.nheld == 2) finalize_flush(q);
+    q.held[q.nheld++] = job;
+    return;
+  }
+  FinJobs J{};
+  for (int h = 0; h < q.nheld; ++h) J.j[J.n++] = q.held[h];
+  q.nheld = 0;
+  J.j[J.n++] = job;
+  finalize_launch(q, J);
 }
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax) {
-  finalize_from(q, q.d_part, MAX_BLOCKS, nblocks, nsum, nmin, nmax);
+  finalize_from(q, q.part(), MAX_BLOCKS, nblocks, nsum, nmin, nmax);
 }
 
 // =========================== publish ========================================
@@ -177,7 +252,7 @@ void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int3
                    iw_t *iwhere, int8_t *wasfree) {
   const int g = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(active_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd,
-                     iwhere, wasfree, q.d_part);
+                     iwhere, wasfree, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, g, 4, 0, 0);
 }
@@ -214,7 +289,7 @@ void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
                    const int32_t *nbd) {
   const int g = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(errclb_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, row0, l, u, nbd,
-                     q.d_part);
+                     q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, g, 0, 0, 5);
 }
@@ -244,7 +319,7 @@ void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, cons
                    const T *g) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(projgr_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
-                     q.d_part);
+                     q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 0, 1);
 }
@@ -288,7 +363,7 @@ template <typename T>
 void launch_wtv_nofinalize(Queue &q, int64_t n, WStore<T> w, int head, int col, const T *v) {
   const int g = grid_for_w(q, n, VecOf<T>::V);
   DISPATCH_MAXC_NT(col, q.nt, hipLaunchKernelGGL((wtv_kernel<T, MC, NTV>), dim3(g), dim3(BLOCK), 0, q.stream, n,
-                                        w.ws, w.wy, w.zero, w.ld, w.m, head, col, v, q.d_part));
+                                        w.ws, w.wy, w.zero, w.ld, w.m, head, col, v, q.part()));
   LB_LAUNCHED(q);
 }
 template <typename T>
@@ -429,7 +504,7 @@ void launch_subsm_alpha(Queue &q, int64_t n, const T *xp, const T *r, const T *l
                         const int32_t *nbd, const iw_t *iwhere) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, (int64_t)0, xp,
-                     r, l, u, nbd, iwhere, 0, 0.0, q.d_part);
+                     r, l, u, nbd, iwhere, 0, 0.0, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 1, 0);
 }
@@ -438,7 +513,7 @@ void launch_subsm_argalpha(Queue &q, int64_t n, int64_t row0, const T *xp, const
                            const T *u, const int32_t *nbd, const iw_t *iwhere, double alpha) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_alpha_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, xp, r, l,
-                     u, nbd, iwhere, 1, alpha, q.d_part);
+                     u, nbd, iwhere, 1, alpha, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 1, 0);
 }
@@ -525,7 +600,7 @@ void launch_lnsrlb_begin(Queue &q, int64_t n, const T *z, const T *x, const T *g
                          const T *u, const int32_t *nbd, T *d, T *t, T *r, int do_stpmx) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(lnsrlb_begin_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, z, x, g, l, u,
-                     nbd, d, t, r, do_stpmx, q.d_part);
+                     nbd, d, t, r, do_stpmx, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 2, 1, 0);
 }
@@ -589,7 +664,7 @@ void launch_lnsrlb_eval(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         const int32_t *nbd, const T *g, const T *d) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(lnsrlb_eval_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, x, l, u, nbd, g,
-                     d, q.d_part);
+                     d, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 1);
 }
@@ -626,7 +701,7 @@ template <typename T>
 void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(obj_quadratic_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, x, g, q.nt ? 1 : 0,
-                     q.d_part);
+                     q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }
@@ -673,7 +748,7 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, con
                            double xl, double xr) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(obj_rosenbrock_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, row0, nglob,
-                     x, g, xl, xr, q.nt ? 1 : 0, q.d_part);
+                     x, g, xl, xr, q.nt ? 1 : 0, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }

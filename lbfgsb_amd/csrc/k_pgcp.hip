@@ -258,7 +258,7 @@ template <typename T>
 void launch_gcp_rest_mass(Queue &q, int64_t n, const T *g, const T *tbrk, double tstar) {
   const int gr = grid_for(n, VecOf<T>::V);
   hipLaunchKernelGGL(gcp_rest_mass_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, g, tbrk, tstar,
-                     q.d_part);
+                     q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }
@@ -332,7 +332,7 @@ void launch_pgcp_find(Queue &q, int64_t nb, double f1_0, double f2_0, const doub
                       const double *sf1, const double *sf2) {
   const int gr = grid_for(nb, 1);
   hipLaunchKernelGGL(pgcp_find_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, nb, f1_0, f2_0, tt, sf1, sf2,
-                     q.d_part);
+                     q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 0, 1, 0);
 }

@@ -194,7 +194,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
                                         dim3(BLOCK), 0, q.stream, n, tsum, zout, pr, rout, l, u,    \
                                         nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head,   \
                                         col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,     \
-                                        w.wy + slot, w.ws + slot, ub, q.d_part);                    \
+                                        w.wy + slot, w.ws + slot, ub, q.part());                    \
                    }))
   if (spec)
     LB_SUBSM(true);

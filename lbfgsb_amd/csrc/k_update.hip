@@ -56,7 +56,7 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
   const int nold = col - 1;
   DISPATCH_MAXC_NT(nold, q.nt, hipLaunchKernelGGL((update_pairs_kernel<T, MC, NTV>), dim3(gr), dim3(BLOCK), 0,
                                          q.stream, n, g, r, d, stp, w.ws, w.wy, w.zero, w.ld, w.m,
-                                         head, nold, itail, q.d_part));
+                                         head, nold, itail, q.part()));
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 2 * maxc_for(nold) + 1, 0, 0);
 }
@@ -391,7 +391,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                                         stp,                                                         \
                                         iwhere, tbrk, w.ws, w.wy, w.zero, w.ld, w.m, head, nold,     \
                                         itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap,     \
-                                        ccount, ub, q.d_part);                                       \
+                                        ccount, ub, q.part());                                       \
                    }))
   const int mc = maxc_for(nold);
   // MC = 20 with the new-row sums: lane pairs share the per-column accumulators (PAIR), which
@@ -414,7 +414,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   hipLaunchKernelGGL((update_scan_kernel<T, MC, NTV, PIPEV, true, true>), dim3(gr), dim3(BLOCK), 0,  \
                      q.stream, n_main, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy,  \
                      w.zero, w.ld, w.m, head, nold, itail, store_pair, store_iw, -1.0, ckeys, cidx,   \
-                     ccap, ccount, ub, q.d_part)
+                     ccap, ccount, ub, q.part())
     if (n_main > 0) {
       if (q.nt) {
         if (pair_mode >= 2) LB_PAIR(true, true); else LB_PAIR(true, false);
@@ -430,7 +430,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                          g + o, r + o, d + o, dimpl, stp, iwhere + o,
                          tbrk ? tbrk + o : tbrk, w.ws + o, w.wy + o, w.zero, w.ld, w.m, head, nold, itail,
                          store_pair, store_iw, -1.0, ckeys, cidx, ccap, ccount, ub,
-                         q.d_part + (n_main > 0 ? gr : 0));
+                         q.part() + (n_main > 0 ? gr : 0));
       nblocks = n_main > 0 ? gr + 1 : 1;
       LB_LAUNCHED(q);
     }

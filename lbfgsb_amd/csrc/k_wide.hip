@@ -140,7 +140,7 @@ void launch_subsm_project(Queue &q, int64_t n, T *z, T *dir, const T *x, const T
                           const int32_t *nbd, const iw_t *iwhere, double rtheta) {
   const int gr = grid_for(n, 1);
   hipLaunchKernelGGL(subsm_project_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, z, dir, x, g, l, u, nbd,
-                     iwhere, rtheta, q.d_part);
+                     iwhere, rtheta, q.part());
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 2, 0, 0);
 }

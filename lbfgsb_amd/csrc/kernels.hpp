@@ -26,10 +26,34 @@ struct Tune {
   int gram_rows = 0;  // formk from scratch: 1 = the LDS-slab kernel instead of the quad kernel
 };
 
+// one reduction waiting to be finalized: `nblocks` partials per slot in part[slot * pstride + block],
+// results to d_res[off + slot] (nsum sums, then nmin minima, then nmax maxima)
+struct FinJob {
+  const double *part;
+  int pstride, nblocks, off, nsum, nmin, nmax;
+};
+
 // launch queue + reduction scratch owned by the context
 struct Queue {
   hipStream_t stream;
   double *d_part;   // [rows][MAX_BLOCKS] block partials (row = output slot)
+  // two small partial-sum matrices (ALT_SLOTS slots) for kernels whose finalize is parked (k_misc.hip,
+  // finalize): part_sel = 1 / 2 makes the next launch write there, hold_fin parks its job
+  static constexpr int ALT_SLOTS = 8;
+  double *d_part_alt[2] = {nullptr, nullptr};
+  int part_sel = 0;
+  bool hold_fin = false;
+  FinJob held[2];
+  int nheld = 0;
+  double *part() const { return part_sel == 0 ? d_part : d_part_alt[part_sel - 1]; }
+  // finalize as publisher (single-rank contexts): device views of the host mirror of d_res and of the
+  // sequence word, the workgroup counter, the number of the last publishing launch
+  bool fin_publish = false;
+  double *hd_pub = nullptr;
+  unsigned long long *hd_fin_flag = nullptr;
+  unsigned int *d_fin_count = nullptr;
+  unsigned long long fin_seq = 0;
+  int64_t launches_at_fin = -1;  // q.launches right after the last publishing finalize launch
   double *d_res;    // [RES_MAX or gram size] finalized results, device
   double *d_gpart;  // gram partials [E][GRAM_BLOCKS]
   int64_t launches;
@@ -230,11 +254,12 @@ void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, i
                        iw_t *iwhere);
 
 // ---- freev (ref :1980-2059) -------------------------------------------------
-// res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave; updates wasfree.
+// res sum-slots: [0]=nfree, [1]=nenter, [2]=nleave, [3]=rows whose status changed; updates wasfree.
 // chg (optional): rows whose free/active status changed are appended (unordered) as
-// row | 0x80000000 if it LEFT the free set; *chg_count = number found (may exceed chg_cap).
+// row | 0x80000000 if it LEFT the free set ([3] may exceed chg_cap: the list is then truncated).
+// cnt2: two zero-initialised position counters, parity = which one this launch uses (it zeroes the other)
 void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree,
-                        uint32_t *chg, uint32_t chg_cap, uint32_t *chg_count);
+                        uint32_t *chg, uint32_t chg_cap, uint32_t *cnt2, int parity);
 // mirror of Index / Indx2 (1-based global numbers, reference ordering).  prev = wasfree
 // BEFORE launch_freev_count of this iteration (copy kept by the solver).
 void launch_freev_lists(Queue &q, int64_t n, const iw_t *iwhere, const int8_t *prevfree,
@@ -389,8 +414,9 @@ inline int update_scan_extra(int nold, int newrow) {
   return newrow && mc <= 20 ? 4 * mc + 4 : 0;
 }
 
-// finalize: d_part -> d_res (nsum sums, then nmin mins, then nmax maxes)
+// finalize: partials -> d_res (nsum sums, then nmin mins, then nmax maxes); takes parked jobs along
 void launch_finalize(Queue &q, int nblocks, int nsum, int nmin, int nmax);
+void finalize_flush(Queue &q);  // launch the parked jobs alone (a fetch that no finalize precedes)
 // publish: count doubles from src (device) to dst_host (device address of mapped host memory), then
 // *flag_host = seq with release semantics at system scope -- what the host polls instead of waiting
 // for the stream (solver.hip, fetch)

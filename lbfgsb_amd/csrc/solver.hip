@@ -84,6 +84,9 @@ class Solver final : public lbfgsb_hip_ctx {
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   uint32_t *d_count = nullptr, *h_count = nullptr;
+  uint32_t *d_fcount = nullptr;  // freev's two list-position counters, used in turn (k_freev.hip)
+  int fv_parity = 0;
+  std::vector<double> h_loc;     // this rank's OWN values of the last fetch (before the reduction over ranks)
   // rows whose free/active status changed in the last freev (formk patches)
   static constexpr uint32_t CHG_CAP = 1u << 18;
   uint32_t *d_chg = nullptr;
@@ -142,6 +145,7 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
+        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_fin_count), F(d_fcount),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all),
         F(ub_buf), F(mg_keys[0]), F(mg_keys[1]), F(mg_vals[0]), F(mg_vals[1]), F(mg_tmp), F(d_merged);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
@@ -149,7 +153,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (p) (void)hipHostFree(p);
       p = nullptr;
     };
-    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_flag), H(h_fix), H(h_sp_all), H(h_sp_loc), H(h_res_all);
+    H(h_count), H(h_msg_all), H(h_msg_loc), H(h_hdr), H(h_res), H(h_flag), H(h_pub), H(h_fin_flag), H(h_fix), H(h_sp_all), H(h_sp_loc), H(h_res_all);
     if (pf_ev) (void)hipEventDestroy(pf_ev);
     pf_ev = nullptr;
     if (order_ev) (void)hipEventDestroy(order_ev);
@@ -226,9 +230,24 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipHostMalloc(&h_flag, 64));
     std::memset(h_flag, 0, 64);
     HIPCHK(hipHostGetDevicePointer((void **)&hd_flag, h_flag, 0));
+    // finalize as publisher: the host mirror of d_res, its sequence word, the workgroup counter; two small
+    // partial-sum matrices for kernels whose finalize is parked (kernels.hpp, Queue)
+    HIPCHK(hipHostMalloc(&h_pub, res_len * sizeof(double)));
+    HIPCHK(hipHostGetDevicePointer((void **)&q.hd_pub, h_pub, 0));
+    HIPCHK(hipHostMalloc(&h_fin_flag, 64));
+    std::memset(h_fin_flag, 0, 64);
+    HIPCHK(hipHostGetDevicePointer((void **)&q.hd_fin_flag, h_fin_flag, 0));
+    HIPCHK(hipMalloc(&q.d_fin_count, 64));
+    HIPCHK(hipMemsetAsync(q.d_fin_count, 0, 64, stream));
+    for (double *&pa : q.d_part_alt)
+      HIPCHK(hipMalloc(&pa, (size_t)lbk::Queue::ALT_SLOTS * lbk::MAX_BLOCKS * sizeof(double)));
+    q.fin_publish = spin_on;
     // cauchy selection scratch (window mode); the full-sort buffers grow on demand
     CHK(ensure_sel(SEL_CAP));
     HIPCHK(hipMalloc(&d_count, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_fcount, 64));
+    HIPCHK(hipMemsetAsync(d_fcount, 0, 64, stream));
+    h_loc.assign(res_len, 0.0);
     HIPCHK(hipMalloc(&d_chg, (size_t)CHG_CAP * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc(&h_count, sizeof(uint32_t)));
     msg_len = 2 + (size_t)CHUNK_MAX * (2 * m + 4);
@@ -323,17 +342,23 @@ class Solver final : public lbfgsb_hip_ctx {
   bool spin_on = true;  // (option "spin")
   unsigned long long pub_seq = 0;
   unsigned long long *h_flag = nullptr, *hd_flag = nullptr;  // host / device view of the sequence word
+  // ... of the finalize kernels that publish by themselves (single rank: k_misc.hip, finalize_kernel), and
+  // the host mirror of d_res they write; fin_seq_seen = the last launch a fetch has waited for
+  unsigned long long *h_fin_flag = nullptr, fin_seq_seen = 0;
+  bool tail_copy_queued = false;  // a D2H copy the next fetch has to cover was queued behind the last finalize
+  double *h_pub = nullptr;
   double *hd_res = nullptr, *hd_res_all = nullptr;           // device views of h_res / h_res_all
-  int wait_published(unsigned long long seq) {
+  int wait_published(unsigned long long seq, const unsigned long long *flag = nullptr) {
+    if (!flag) flag = h_flag;
     const double t0 = now_s();
     for (unsigned it = 1;; ++it) {
-      if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) break;
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
       if ((it & 0x3ff) == 0 && now_s() - t0 > SPIN_LIMIT_S) {
         HIPCHK(hipStreamSynchronize(stream));
-        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq)
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
           return fail(LBFGSB_E_NOGPU, "the stream finished without publishing its results");
         break;
       }
@@ -362,7 +387,18 @@ class Solver final : public lbfgsb_hip_ctx {
         return fail(LBFGSB_E_COMM, "ncclAllGather of the partial sums failed");
       src = d_res_all, dst = h_res_all, dst_dev = hd_res_all, cnt = (size_t)nranks * kk;
     }
-    if (spin_on) {
+    lbk::finalize_flush(q);  // (parked reductions that no later kernel has taken along)
+    // (only if that finalize launch IS the tail of the stream: a kernel or a copy queued behind it -- the
+    //  candidate records of spec_queue -- would not be covered by its sequence word)
+    const bool fin_is_tail = q.launches == q.launches_at_fin && !tail_copy_queued;
+    tail_copy_queued = false;
+    if (spin_on && !comm && q.fin_publish && q.fin_seq != fin_seq_seen && fin_is_tail) {
+      // single rank: the finalize kernels of this phase have mirrored their results into host memory
+      // themselves; the last one stored its sequence number when all of it was out
+      CHK(wait_published(q.fin_seq, h_fin_flag));
+      fin_seq_seen = q.fin_seq;
+      std::memcpy(h_res, h_pub, cnt * sizeof(double));
+    } else if (spin_on) {
       lbk::launch_publish(q, src, dst_dev, (int)cnt, ++pub_seq, hd_flag);
       CHK(wait_published(pub_seq));
     } else {
@@ -373,6 +409,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     nsync++;
     if (clock_on) clk_collect();
+    std::memcpy(h_loc.data(), comm ? h_res_all + (size_t)rank * kk : h_res, (size_t)kk * sizeof(double));
     if (comm) {
       auto over_ranks = [&](int j, int op) {  // 0 sum, 1 min, 2 max -- in rank order
         double v = h_res_all[j];
@@ -773,15 +810,15 @@ class Solver final : public lbfgsb_hip_ctx {
   int freev_launch(bool track) {
     if (prevfree)
       HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
-    lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_count);
+    lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_fcount, fv_parity);
+    fv_parity ^= 1;
     index_valid = true;
     iw_dirty = 0.0;
-    if (track)
-      HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return 0;
   }
   bool freev_land(bool track, bool updatd) {  // -> wrk (:2057)
-    chg_local = track ? *h_count : 0;
+    // (the length of THIS rank's changed-row list: its own sum, before the reduction over ranks)
+    chg_local = track ? (uint32_t)std::min<double>(h_loc[3], 4294967295.0) : 0;
     nfree_g = (int64_t)h_res[0];
     if (track) {
       nenter_g = (int64_t)h_res[1];
@@ -868,9 +905,9 @@ class Solver final : public lbfgsb_hip_ctx {
         lbk::Coef cf;
         bool plain;
         if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
-          const bool newrow = updatd && col <= 20;  // updatd implies wrk
+          const bool newrow = updatd && col <= lbk::MAXM;  // updatd implies wrk
           CHK(ensure_d(x));
-          q.res_off = 3;
+          q.res_off = 4;
           clk_begin(0);
           lbk::launch_cmprlb_wtv<T>(q, n, x, g, gcp.tsum, iwhere, W(), head, col, theta, cf,
                                     newrow ? 1 : 0, r, d, pend);
@@ -879,9 +916,9 @@ class Solver final : public lbfgsb_hip_ctx {
           npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
         }
       }
-      CHK(fetch(3 + npre, 0, 0));
+      CHK(fetch(4 + npre, 0, 0));
       if (npre) {
-        std::memcpy(pre_res, h_res + 3, sizeof(double) * npre);
+        std::memcpy(pre_res, h_res + 4, sizeof(double) * npre);
         pre_valid = true;
       }
       cachyt += now_s() - cpu1;
@@ -931,7 +968,10 @@ class Solver final : public lbfgsb_hip_ctx {
       CHK(ensure_z(x, l, u, g));
     } else {
       cpu1 = now_s();
-      const bool incr = wrk && col <= 20 && !wide();  // incremental WN1, fused into the cmprlb pass
+      // incremental WN1 (new row / column sums ride in the cmprlb pass, status changes are patched):
+      // every col the fused kernels take (round 3: col <= 20; beyond that formk ran from scratch in every
+      // iteration -- 30 ms of the 45 at m = 32, n = 5e7)
+      const bool incr = wrk && col <= lbk::MAXM && !wide();
       if (wrk && !incr) CHK(formk(col, head, theta, info));
       if (info != 0) {  // :666-682
         if (ipr >= 1)

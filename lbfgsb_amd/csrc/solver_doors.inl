@@ -89,7 +89,7 @@
     CHK(door_ready(nullptr));
     const bool track = iter > 0 && cnstnd;
     CHK(freev_launch(track));
-    CHK(fetch(3, 0, 0));
+    CHK(fetch(4, 0, 0));
     *wrk = freev_land(track, updatd != 0) ? 1 : 0;
     *nfree = nfree_g, *nenter = nenter_g, *ileave = ileave_g;
     if (index) lbk::launch_freev_lists(q, n, iwhere, prevfree, track ? 1 : 0, index, indx2, scan_tmp);

@@ -184,6 +184,7 @@
     lbk::launch_cauchy_gather_dyn<T>(q, sp_idx, sp_keys, sp_count, SPEC_CAP, row0, x, l, u, g, W(), head,
                                      col, r, d_src(), lbk::Pend{1, stp, d_impl ? 1 : 0}, sp_msg);
     const size_t cnt = 2 + (size_t)SPEC_CAP * (2 * col + 4);
+    tail_copy_queued = true;  // (the fetch that follows must wait for THIS copy, not for the finalize in front of it)
     if (nranks == 1 && !comm) {
       HIPCHK(hipMemcpyAsync(h_sp_all, sp_msg, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
     } else if (comm) {

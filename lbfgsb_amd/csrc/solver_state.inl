@@ -222,6 +222,13 @@
   }
   int k_objective(int kind, const void *x, void *g, double *f) override {
     HIPCHK(hipSetDevice(device));
+    // (f == nullptr: the value is fetched with the next call's first pass -- its partials go to a matrix of
+    //  their own and that pass's finalize takes them along)
+    if (!f && fold_fin) q.part_sel = 1, q.hold_fin = true;
+    struct Reset {
+      lbk::Queue &q;
+      ~Reset() { q.part_sel = 0, q.hold_fin = false; }
+    } reset{q};
     if (kind == 0) {
       lbk::launch_obj_quadratic<T>(q, n, row0, (const T *)x, (T *)g);
     } else if (kind == 1) {
@@ -255,6 +262,7 @@
     comm = nullptr;
     CHK(set_ranks(rank_, nranks_));
     comm = c;
+    q.fin_publish = false;  // (the results travel through the all-gather; publish_kernel follows it)
     return 0;
   }
   ncclComm_t rccl_comm() const override { return comm; }

@@ -315,13 +315,16 @@
     // (ping-pong buffers: no t = x, r = g copies -- the roles change below -- and the trial point
     //  goes to the other x buffer, which is where the pending pair's t is read from, row by row)
     q.res_off = defer ? DEFER_OFF : 0;
+    // (deferred: nobody waits for these sums in this call -- they go to a partial-sum matrix of their own and
+    //  their finalize rides with the next launch's, usually the caller's objective or the update pass)
+    if (defer && fold_fin) q.part_sel = 2, q.hold_fin = true;
     seg(4);
     if (t_mid0 > 0.0) t_mid += now_s() - t_mid0, n_mid++, t_mid0 = 0.0;
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, lk(l), uk(u),
                                 nbk(), iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
                                 pp ? (T *)nullptr : t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
                                 pend, d_src(), ub_mask);
-    q.res_off = 0;
+    q.res_off = 0, q.part_sel = 0;
     clk_end(2);
     pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
     d_impl = z_in_x = lean;
@@ -413,6 +416,7 @@
   int two_pass_maxcol = 20;
   bool exact_always = false;  // (option "exact_always": every walk in the reference's heap order)
   bool defer_on = false;      // (LBFGSB_F_DEFER_LNSRCH / option "defer_lnsrch")
+  bool fold_fin = true;       // (option "fold_finalize": reductions nobody waits for yet park their finalize)
   double defer_f0 = 0.0;      // f at the iterate of a deferred line-search set-up
   int64_t ndeferred = 0, nredo = 0;  // set-ups whose sums were deferred / of those, requests that had to be re-issued
 
@@ -436,7 +440,12 @@
     if (k == "spec_capture") return flag(spec_on);
     if (k == "exact_always") return flag(exact_always);
     if (k == "defer_lnsrch") return flag(defer_on);
-    if (k == "spin") return flag(spin_on);
+    if (k == "spin") {
+      const int rc = flag(spin_on);
+      q.fin_publish = spin_on && !comm;
+      return rc;
+    }
+    if (k == "fold_finalize") return flag(fold_fin);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");

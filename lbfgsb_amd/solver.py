@@ -430,6 +430,12 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_host_gap(self.h, C.byref(a), C.byref(b)))
         return float(a.value), int(b.value)
 
+    def host_segments(self):
+        """accumulated host seconds of the stretch between the two passes, by milestone (lbfgsb_hip_host_segments)"""
+        a = (C.c_double * 5)()
+        check(self.lib.lbfgsb_hip_host_segments(self.h, a))
+        return [float(v) for v in a]
+
     def defer_stats(self):
         """(line-search set-ups whose sums were deferred, of those: requests that had to be re-issued)"""
         a, b = C.c_int64(), C.c_int64()

@@ -116,7 +116,10 @@ def short(name):
         elif c == "(" and depth == 0:
             cut = i
             break
-    return s[:cut].replace("lbk::", "")
+    s = s[:cut].replace("lbk::", "")
+    if len(s) > 160:        # (rocPRIM's sort kernels: kilobytes of template arguments)
+        s = s[:150] + "...>"
+    return s
 
 
 def main():

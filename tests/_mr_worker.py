@@ -31,6 +31,9 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     def make_solver():
         s_ = lbfgsb_amd.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=0,
                                      parallel_gcp=(variant in ("pgcp", "pgcp2")),
+                                     # LBFGSB_F_DEFER_LNSRCH over several ranks (the deferred sums are one more
+                                     # reduced segment of every rank's fetch): tests/test_gpu_multirank.py
+                                     defer_lnsrch=os.environ.get("LBFGSB_TEST_DEFER") == "1",
                                      index_ties=(variant == "sym"),
                                      options={"exact_always": 1} if variant == "symx" else None)
         if mode == "gloo":
@@ -102,7 +105,7 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump({"rows": rows, "task": sol.task_s, "x": np.concatenate(xs).tolist(),
-                       "stats": sol.stats(), "tie_splits": sol.tie_splits()}, fh)
+                       "stats": sol.stats(), "tie_splits": sol.tie_splits(), "defer": list(sol.defer_stats())}, fh)
     sol.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -276,3 +276,32 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert out["collectives_per_iter"] == out["host_syncs_per_iter"] > 0     # one collective per host sync
     assert out["first_iteration_nseg"] > 1900000     # ~0.977 n segments, walked across both ranks
     assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("world,mode,n,m,iters,mixed", [
+    (2, "fakerccl", 20011, 7, 12, True),      # the communicator code path: one all-gather carries both segments
+    (3, "fakerccl", 10007, 5, 10, "rosen"),   # (+ the halo exchange of the sharded objective in between)
+    (2, "gloo", 20011, 7, 12, True),          # host callbacks: the deferred segment is a second reduction
+])
+def test_deferred_line_search_sums_over_several_ranks(oracle_built, tmp_path, monkeypatch, world, mode, n, m,
+                                                      iters, mixed):
+    """LBFGSB_F_DEFER_LNSRCH with several ranks: the storing pass's four sums stay on every rank's device and are
+    all-gathered / reduced with the NEXT fetch (solver.hip fetch, DEFER_OFF) -- every rank must take the same
+    decisions from them.  Same NEW_X rows as the run without the flag, bit for bit (f and |proj g| included), and
+    the oracle's trajectory."""
+    po = oracle_built
+    if mode == "fakerccl":
+        monkeypatch.setenv("LBFGSB_RCCL_LIBRARY", _fake_rccl())
+    base = launch(world, mode, n, m, iters, mixed, str(tmp_path / "base.json"))
+    monkeypatch.setenv("LBFGSB_TEST_DEFER", "1")
+    res = launch(world, mode, n, m, iters, mixed, str(tmp_path / "defer.json"))
+    assert base["defer"] == [0, 0] and res["defer"][0] >= iters - 2, (base["defer"], res["defer"])
+    assert res["rows"] == base["rows"]          # bit for bit: the same sums in the same order
+    assert res["x"] == base["x"]
+    rows, _ = oracle_rows(po, n, m, iters, mixed)
+    assert len(res["rows"]) == len(rows) == iters
+    for a, b in zip(res["rows"], rows):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
+    # one collective per host sync still holds, and there is one sync per iteration less
+    assert res["stats"]["syncs"] < base["stats"]["syncs"]
