@@ -430,6 +430,10 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           caller must honour that flag's contract)
  *   "spin" (0/1)            results of a phase reach the host through mapped memory + a polled sequence
  *                           word (default) / through a D2H copy + hipStreamSynchronize
+ *   "fold_finalize" (0/1)   reductions nobody waits for yet (a deferred f, a deferred set-up) leave their
+ *                           finalize to the next launch (default 1)
+ *   "eager_patch" (0/1)     formk's patch sums are queued behind freev's counting pass and fetched with its
+ *                           counts (default 1) / after a host round trip of their own
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel

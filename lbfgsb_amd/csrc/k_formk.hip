@@ -495,8 +495,12 @@ void launch_formk_gram(Queue &q, int64_t n, WStore<T> w, int head, int col,
 // chg[k] = local row | (left ? 0x80000000 : 0).  Output layout = the Gram's (E entries for
 // `upcl` columns): P_yy (i>=j), P_ss (i>=j), P_sy (all i,j).
 template <typename T>
+// cnt_ptr != nullptr: the length of the list is read from the device (the eager chain that follows freev's
+// counting pass without a host round trip); a list longer than `cnt` (= the capacity the chain serves) is not
+// patched at all and slot E of the output says so (1.0), so that the host -- every rank's -- takes the
+// ordinary route.
 __global__ __launch_bounds__(BLOCK) void formk_patch_kernel(const uint32_t *__restrict__ chg,
-                                                            uint32_t cnt,
+                                                            uint32_t cnt, const uint32_t *cnt_ptr,
                                                             const T *__restrict__ ws,
                                                             const T *__restrict__ wy, int64_t ldw,
                                                             int m, int head, int upcl,
@@ -506,6 +510,12 @@ __global__ __launch_bounds__(BLOCK) void formk_patch_kernel(const uint32_t *__re
   __shared__ double sgn[R];
   const int tri = upcl * (upcl + 1) / 2;
   const int E = 2 * upcl * upcl + upcl;
+  if (cnt_ptr) {
+    const uint32_t have = *cnt_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) gpart[(size_t)E * GRAM_BLOCKS] = have > cnt ? 1.0 : 0.0;
+    if (blockIdx.x > 0 && threadIdx.x == 0) gpart[(size_t)E * GRAM_BLOCKS + blockIdx.x] = 0.0;
+    cnt = have > cnt ? 0u : have;
+  }
   constexpr int NE = (2 * MAXM * MAXM + MAXM + BLOCK - 1) / BLOCK;
   int ca[NE], cb[NE];
   double acc[NE];
@@ -567,16 +577,29 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
   int gr = (int)((cnt + 63) / 64);
   if (gr < 1) gr = 1;
   if (gr > 256) gr = 256;
-  hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cnt, w.ws, w.wy,
-                     w.ld, w.m, head, upcl, q.d_gpart);
+  hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cnt,
+                     (const uint32_t *)nullptr, w.ws, w.wy, w.ld, w.m, head, upcl, q.d_gpart);
   LB_LAUNCHED(q);
   finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * upcl * upcl + upcl, 0, 0);
+}
+// the eager form: list length on the device, at most `cap` rows served (a fixed grid of cap / 64 workgroups:
+// one tile each, the same association of the sums as the ordinary launch for a list of that length);
+// E + 1 sums: the patch, then the "not served" flag
+template <typename T>
+void launch_formk_patch_dev(Queue &q, const uint32_t *chg, const uint32_t *cnt_ptr, uint32_t cap, WStore<T> w,
+                            int head, int upcl) {
+  const int gr = (int)((cap + 63) / 64);
+  hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cap, cnt_ptr, w.ws, w.wy,
+                     w.ld, w.m, head, upcl, q.d_gpart);
+  LB_LAUNCHED(q);
+  finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * upcl * upcl + upcl + 1, 0, 0);
 }
 
 // =========================== explicit instantiations =========================
 #define INSTANTIATE(T) \
   template void launch_formk_gram<T>(Queue &, int64_t, WStore<T>, int, int, const iw_t *); \
-  template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int);
+  template void launch_formk_patch<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int); \
+  template void launch_formk_patch_dev<T>(Queue &, const uint32_t *, const uint32_t *, uint32_t, WStore<T>, int, int);
 INSTANTIATE(double)
 INSTANTIATE(float)
 #undef INSTANTIATE

@@ -43,6 +43,35 @@ __global__ __launch_bounds__(BLOCK) void sort_u32_small_kernel(uint32_t *keys, u
   for (int k = threadIdx.x; k < npow2; k += BLOCK)
     if ((uint32_t)k < cnt) keys[k] = sm[k];
 }
+// the same with the list's length still on the device (freev's position counter, which may exceed what was
+// stored): lists of up to SMALL_SORT rows are sorted in place, longer ones are left alone -- the eager patch
+// chain of formk (solver_subspace.inl) then reports "not served" and the host takes the ordinary route
+__global__ __launch_bounds__(BLOCK) void sort_u32_small_dev_kernel(uint32_t *keys, const uint32_t *cnt_ptr) {
+  __shared__ uint32_t sm[SMALL_SORT];
+  const uint32_t cnt = *cnt_ptr;
+  if (cnt <= 1 || cnt > (uint32_t)SMALL_SORT) return;  // (uniform)
+  int npow2 = 2;
+  while ((uint32_t)npow2 < cnt) npow2 <<= 1;
+  for (int k = threadIdx.x; k < npow2; k += BLOCK) sm[k] = (uint32_t)k < cnt ? keys[k] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int k = threadIdx.x; k < npow2 / 2; k += BLOCK) {
+        const int lo = 2 * k - (k & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint32_t a = sm[lo], b = sm[hi];
+        if ((a > b) == up) sm[lo] = b, sm[hi] = a;
+      }
+      __syncthreads();
+    }
+  for (int k = threadIdx.x; k < npow2; k += BLOCK)
+    if ((uint32_t)k < cnt) keys[k] = sm[k];
+}
+void launch_sort_u32_small_dev(Queue &q, uint32_t *keys, const uint32_t *cnt_ptr) {
+  hipLaunchKernelGGL(sort_u32_small_dev_kernel, dim3(1), dim3(BLOCK), 0, q.stream, keys, cnt_ptr);
+  LB_LAUNCHED(q);
+}
+int small_sort_cap() { return SMALL_SORT; }
 uint32_t *launch_sort_u32(Queue &q, void *d_temp, size_t temp_bytes, uint32_t *keys, uint32_t *scratch,
                           uint32_t count) {
   if (count <= 1) return keys;

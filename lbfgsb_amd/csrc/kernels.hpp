@@ -288,6 +288,14 @@ void launch_cmprlb_wtv(Queue &q, int64_t n, const T *x, const T *g, double tsum,
 // set) for the first upcl logical columns; res layout as launch_formk_gram with col = upcl.
 template <typename T>
 void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w, int head, int upcl);
+// the same queued right behind freev's counting pass, the list's length still on the device (*cnt_ptr): lists of
+// up to `cap` rows (<= small_sort_cap(), sorted by launch_sort_u32_small_dev first) are patched, longer ones
+// are not; res = the 2 upcl^2 + upcl sums, then one more: 1.0 if the list was too long
+template <typename T>
+void launch_formk_patch_dev(Queue &q, const uint32_t *chg, const uint32_t *cnt_ptr, uint32_t cap, WStore<T> w,
+                            int head, int upcl);
+void launch_sort_u32_small_dev(Queue &q, uint32_t *keys, const uint32_t *cnt_ptr);
+int small_sort_cap();
 
 // ---- subsm (ref :2676-2885) --------------------------------------------------
 // update (cmprlb's r recomputed, :2770-2816, :2824-2827) + the line-search set-up of mainlb

@@ -224,7 +224,7 @@ class Solver final : public lbfgsb_hip_ctx {
     res_len = std::max<size_t>(lbk::RES_MAX, E) + 8;
     HIPCHK(hipMalloc(&q.d_part, (size_t)lbk::RES_MAX * lbk::MAX_BLOCKS * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_res, res_len * sizeof(double)));
-    HIPCHK(hipMalloc(&q.d_gpart, E * lbk::GRAM_BLOCKS * sizeof(double)));
+    HIPCHK(hipMalloc(&q.d_gpart, (E + 1) * lbk::GRAM_BLOCKS * sizeof(double)));  // (+ the eager patch's flag slot)
     HIPCHK(hipHostMalloc(&h_res, res_len * sizeof(double)));
     HIPCHK(hipHostGetDevicePointer((void **)&hd_res, h_res, 0));
     HIPCHK(hipHostMalloc(&h_flag, 64));
@@ -898,6 +898,26 @@ class Solver final : public lbfgsb_hip_ctx {
         return 0;
       }
       CHK(freev_launch(track));
+      // formk's patch sums (:1801-1851) do not depend on anything the host still has to decide either -- only
+      // on the list freev's pass has just written and on W: in the two-pass iteration (no cmprlb launch
+      // below) the sort of the list and the patch kernel are queued right behind the counting pass with
+      // the list's length read on the device, and ONE fetch brings freev's counts and the patch
+      // (eager.*; lists longer than the one-workgroup sort serves fall back to the ordinary route in
+      // formk_incremental).  Same kernels, same order of the sums: bit-identical to that route.
+      eager.valid = false;
+      int neager = 0;
+      {
+        const int upcl = updatd ? col - 1 : col;
+        if (eager_on && track && closed_cand && upcl > 0 && !wide()) {
+          const uint32_t *cnt_ptr = d_fcount + ((fv_parity ^ 1) & 1);  // the counter freev_launch just used
+          lbk::launch_sort_u32_small_dev(q, d_chg, cnt_ptr);
+          q.res_off = 4;
+          lbk::launch_formk_patch_dev<T>(q, d_chg, cnt_ptr, (uint32_t)lbk::small_sort_cap(), W(), head, upcl);
+          q.res_off = 0;
+          neager = 2 * upcl * upcl + upcl + 1;
+          eager.upcl = upcl, eager.head = head;
+        }
+      }
       // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
       // sets of sums with ONE host sync (it is wasted only if no variable is free)
       int npre = 0;
@@ -916,7 +936,12 @@ class Solver final : public lbfgsb_hip_ctx {
           npre = (newrow ? 6 : 2) * lbk::maxc_for(col);
         }
       }
-      CHK(fetch(4 + npre, 0, 0));
+      CHK(fetch(4 + npre + neager, 0, 0));
+      if (neager) {  // (never together with npre: closed_cand)
+        eager.P.assign(h_res + 4, h_res + 4 + neager - 1);
+        eager.valid = h_res[4 + neager - 1] == 0.0;  // (summed over the ranks: every rank's list was served)
+        neager_served += eager.valid;
+      }
       if (npre) {
         std::memcpy(pre_res, h_res + 4, sizeof(double) * npre);
         pre_valid = true;
@@ -1428,6 +1453,14 @@ class Solver final : public lbfgsb_hip_ctx {
   }
 
   int64_t nfree_g = 0, nenter_g = 0, ileave_g = 0;
+  // formk's patch sums fetched together with freev's counts (phase_cauchy_freev)
+  struct Eager {
+    bool valid = false;
+    int upcl = 0, head = 0;
+    std::vector<double> P;
+  } eager;
+  bool eager_on = true;  // (option "eager_patch")
+  int64_t neager_served = 0;
   bool check_ptrs = false;   // this call decides the entry of a run: its pointers have not been looked at yet
   bool index_valid = false;  // a freev has run: wasfree is the membership of Index(1:nfree)
   // How many iwhere entries have changed since the last freev pass (a count where the kernels report

@@ -34,7 +34,12 @@
     const int64_t nchg = nenter_g + (nglob + 1 - ileave_g);
     bool patched = false;
     std::vector<double> P;
-    if (nchg > 0 && upcl > 0) {
+    if (nchg > 0 && upcl > 0 && eager.valid && eager.upcl == upcl && eager.head == head) {
+      P = eager.P;  // (came with freev's counts: same kernels, same sums)
+      patched = true;
+      eager.valid = false;
+    } else if (nchg > 0 && upcl > 0) {
+      eager.valid = false;
       if (nchg > (int64_t)CHG_CAP) return formk_scratch(col, head);  // whole Gram is cheaper
       // (the list was appended with an atomic counter: put it in ascending order first, so that the
       //  patch sums -- and with them WN1, the subspace step, the whole trajectory -- are
@@ -446,6 +451,7 @@
       return rc;
     }
     if (k == "fold_finalize") return flag(fold_fin);
+    if (k == "eager_patch") return flag(eager_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");

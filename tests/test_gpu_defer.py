@@ -162,3 +162,26 @@ def test_export_is_refused_while_deferred_and_start_resets(oracle_built):
     ref = _run(p, False, True, 10 ** 6)
     got = [(r[1][8], r[1][12], r[2], r[4]) for r in ref["rows"] if r[0].startswith("NEW_X")][:len(rows)]
     assert rows == got
+
+
+@pytest.mark.parametrize("pp,defer", [(True, False), (False, False), (True, True)])
+def test_launch_plumbing_options_change_nothing(oracle_built, pp, defer):
+    """The round-4 changes to HOW results travel -- the finalize that publishes by itself (`spin`), parked
+    finalize jobs (`fold_finalize`), formk's patch queued behind freev's counting pass (`eager_patch`) -- must
+    not change a single bit of WHAT is computed: every return of a run with all three switched off (the
+    round-3 plumbing: one finalize per kernel, a D2H copy + stream sync per phase, the patch after a host round
+    trip of its own) equals the default's, on random problems whose free sets change from iteration to
+    iteration (so that the patch really runs)."""
+    from test_gpu_fuzz import make, fam_rosenchain
+    po = oracle_built
+    old = {"spin": 0, "fold_finalize": 0, "eager_patch": 0}
+    for seed in list(range(700, 724)) + list(range(5300, 5306)):
+        p = make(po, seed, 400, 1, 13) if seed < 5000 else make(po, seed, 3000, 11, 33)
+        a = _run(p, pp, defer, 60, options=old)
+        b = _run(p, pp, defer, 60)
+        assert a["rows"] == b["rows"] and a["wa"] == b["wa"] and a["iwa"] == b["iwa"], (p.name, p.n, p.m)
+    for seed in range(62000, 62008):
+        p = fam_rosenchain(po, seed)
+        a = _run(p, pp, defer, 80, options=old)
+        b = _run(p, pp, defer, 80)
+        assert a["rows"] == b["rows"] and a["wa"] == b["wa"], (p.name, p.n, p.m)
