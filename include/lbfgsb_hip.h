@@ -434,6 +434,10 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           finalize to the next launch (default 1)
  *   "eager_patch" (0/1)     formk's patch sums are queued behind freev's counting pass and fetched with its
  *                           counts (default 1) / after a host round trip of their own
+ *   "spec_freev" (0/1)      while the free set changes from iteration to iteration, freev's counting pass and
+ *                           the patch are queued speculatively behind the evaluation of a trial point and
+ *                           used if the point is accepted and the next walk fixes no row (default 0: measured,
+ *                           does not pay)
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel

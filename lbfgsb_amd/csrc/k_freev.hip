@@ -9,6 +9,10 @@ namespace lbk {
 // sum: the host needs no copy of the list's atomic position counter).  chg_count / cnt_zero: two position
 // counters used in turn -- this launch appends through chg_count and zeroes the OTHER one for the next
 // launch (no memset command in front of the kernel).
+// WRITE = false: counts and the list only, wasfree untouched -- the pass run SPECULATIVELY behind the
+// evaluation of a trial point (solver.hip, phase_entry); if its result is used, freev_apply_kernel brings
+// wasfree up to date from the list
+template <bool WRITE>
 __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
                                                             const iw_t *__restrict__ iwhere,
                                                             int8_t *wasfree, double *part,
@@ -64,7 +68,9 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
           for (int k = 0; k < R; ++k)
             if ((changed >> k) & 1u) lbuf[w++] = (uint32_t)(i + k) | (wf.b[k] ? 0u : 0x80000000u);
         }
-        if (full) {
+        if (!WRITE) {
+          // (speculative pass: nothing stored)
+        } else if (full) {
           *reinterpret_cast<v4i *>(wasfree + i) = wf.v;
         } else {
 #pragma unroll
@@ -90,12 +96,31 @@ __global__ __launch_bounds__(BLOCK) void freev_count_kernel(int64_t n,
   block_reduce_store<4>(acc, 4, 0, 0, part, MAX_BLOCKS);
 }
 void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree, uint32_t *chg,
-                        uint32_t chg_cap, uint32_t *cnt2, int parity) {
+                        uint32_t chg_cap, uint32_t *cnt2, int parity, int write) {
   const int gr = grid_for(n, 16);
-  hipLaunchKernelGGL(freev_count_kernel, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
-                     q.part(), chg, chg_cap, cnt2 + (parity & 1), cnt2 + ((parity & 1) ^ 1));
+  if (write)
+    hipLaunchKernelGGL(freev_count_kernel<true>, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
+                       q.part(), chg, chg_cap, cnt2 + (parity & 1), cnt2 + ((parity & 1) ^ 1));
+  else
+    hipLaunchKernelGGL(freev_count_kernel<false>, dim3(gr), dim3(BLOCK), 0, q.stream, n, iwhere, wasfree,
+                       q.part(), chg, chg_cap, cnt2 + (parity & 1), cnt2 + ((parity & 1) ^ 1));
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 4, 0, 0);
+}
+// wasfree brought up to date from the list of a speculative counting pass (<= cap entries, length on the device)
+__global__ __launch_bounds__(BLOCK) void freev_apply_kernel(const uint32_t *__restrict__ chg,
+                                                            const uint32_t *__restrict__ cnt_ptr, uint32_t cap,
+                                                            int8_t *wasfree) {
+  uint32_t cnt = *cnt_ptr;
+  if (cnt > cap) cnt = cap;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const uint32_t e = chg[k];
+    wasfree[e & 0x7FFFFFFFu] = (e & 0x80000000u) ? 0 : 1;
+  }
+}
+void launch_freev_apply(Queue &q, const uint32_t *chg, const uint32_t *cnt_ptr, uint32_t cap, int8_t *wasfree) {
+  hipLaunchKernelGGL(freev_apply_kernel, dim3(8), dim3(BLOCK), 0, q.stream, chg, cnt_ptr, cap, wasfree);
+  LB_LAUNCHED(q);
 }
 
 // ordered stream compaction reproducing the reference's list orders exactly:

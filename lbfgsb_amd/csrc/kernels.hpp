@@ -258,8 +258,10 @@ void launch_cauchy_fix(Queue &q, const int64_t *list, int count, int64_t row0, i
 // chg (optional): rows whose free/active status changed are appended (unordered) as
 // row | 0x80000000 if it LEFT the free set ([3] may exceed chg_cap: the list is then truncated).
 // cnt2: two zero-initialised position counters, parity = which one this launch uses (it zeroes the other)
+// write = 0: counts and list only (speculative pass); launch_freev_apply then updates wasfree from the list
 void launch_freev_count(Queue &q, int64_t n, const iw_t *iwhere, int8_t *wasfree,
-                        uint32_t *chg, uint32_t chg_cap, uint32_t *cnt2, int parity);
+                        uint32_t *chg, uint32_t chg_cap, uint32_t *cnt2, int parity, int write = 1);
+void launch_freev_apply(Queue &q, const uint32_t *chg, const uint32_t *cnt_ptr, uint32_t cap, int8_t *wasfree);
 // mirror of Index / Indx2 (1-based global numbers, reference ordering).  prev = wasfree
 // BEFORE launch_freev_count of this iteration (copy kept by the solver).
 void launch_freev_lists(Queue &q, int64_t n, const iw_t *iwhere, const int8_t *prevfree,

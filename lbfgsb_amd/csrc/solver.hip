@@ -221,7 +221,9 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     // reduction scratch
     const size_t E = (size_t)2 * m * m + m;
-    res_len = std::max<size_t>(lbk::RES_MAX, E) + 8;
+    // (the widest phase or a from-scratch Gram; behind DEFER_OFF the four deferred sums, behind SPEC_OFF the
+    //  speculative freev counts + formk patch of a trial point: 4 + E + 1)
+    res_len = std::max<size_t>(std::max<size_t>(lbk::RES_MAX, E) + 8, (size_t)SPEC_OFF + 4 + E + 1 + 8);
     HIPCHK(hipMalloc(&q.d_part, (size_t)lbk::RES_MAX * lbk::MAX_BLOCKS * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_res, res_len * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_gpart, (E + 1) * lbk::GRAM_BLOCKS * sizeof(double)));  // (+ the eager patch's flag slot)
@@ -337,6 +339,10 @@ class Solver final : public lbfgsb_hip_ctx {
   // storing pass that did not wait for them (LBFGSB_F_DEFER_LNSRCH); while defer_live they travel with
   // every fetch and are reduced like the rest.
   static constexpr int DEFER_OFF = lbk::RES_MAX;
+  // SPEC_OFF: the sums of a SPECULATIVE freev + formk-patch chain queued behind the evaluation of a trial point
+  // (phase_entry): spec_live_len slots, all sums, fetched and reduced with that evaluation's fetch
+  static constexpr int SPEC_OFF = DEFER_OFF + 8;
+  int spec_live_len = 0;
   static constexpr double SPIN_LIMIT_S = 0.05;
   bool defer_live = false;
   bool spin_on = true;  // (option "spin")
@@ -376,7 +382,8 @@ class Solver final : public lbfgsb_hip_ctx {
                                       hipGetErrorString(e));
     }
     if (defer_live && k > DEFER_OFF) return fail(LBFGSB_E_STATE, "fetch: phase overlaps the deferred line-search sums");
-    const int kk = defer_live ? DEFER_OFF + 4 : k;  // doubles that travel
+    if (spec_live_len && k > DEFER_OFF) return fail(LBFGSB_E_STATE, "fetch: phase overlaps the speculative sums");
+    const int kk = spec_live_len ? SPEC_OFF + spec_live_len : (defer_live ? DEFER_OFF + 4 : k);  // doubles that travel
     if ((size_t)kk > res_len) return fail(LBFGSB_E_STATE, "fetch: more partials than the buffer holds");
     if (comm || nranks > 1) ncoll++, coll_bytes += (int64_t)kk * 8;
     const double *src = q.d_res;
@@ -422,11 +429,14 @@ class Solver final : public lbfgsb_hip_ctx {
       for (int j = 0; j < k; ++j) over_ranks(j, j < nsum ? 0 : (j < nsum + nmin ? 1 : 2));
       if (defer_live)
         for (int j = 0; j < 4; ++j) over_ranks(DEFER_OFF + j, j < 3 ? 0 : 1);
+      for (int j = 0; j < spec_live_len; ++j) over_ranks(SPEC_OFF + j, 0);
     } else if (nranks > 1) {
       if (!cb_ar) return fail(LBFGSB_E_COMM, "multi-rank context without a reducer");
       if (cb_ar(cb_user, h_res, nsum, nmin, nmax) != 0)
         return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
       if (defer_live && cb_ar(cb_user, h_res + DEFER_OFF, 3, 1, 0) != 0)
+        return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
+      if (spec_live_len && cb_ar(cb_user, h_res + SPEC_OFF, spec_live_len, 0, 0) != 0)
         return fail(LBFGSB_E_COMM, "host all-reduce callback failed");
     }
     return 0;
@@ -554,6 +564,7 @@ class Solver final : public lbfgsb_hip_ctx {
     MAINLB_VIEW(L);
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
     ls.deferred = false, defer_live = false;
+    sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
     spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
     epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
                             : std::numeric_limits<double>::epsilon();
@@ -706,7 +717,43 @@ class Solver final : public lbfgsb_hip_ctx {
         clk_end(1);
         spcand.valid = false;
         if (chi >= 0.0) CHK(spec_queue(x, l, u, g, h2, c2, stp_here));
+        // freev (:1980-2059) and formk's patch sums (:1801-1851) of the NEXT iteration, speculatively: if this
+        // trial point is accepted and the walk that follows fixes no row, iwhere is final as this pass has
+        // just left it -- the counting pass (without its wasfree stores), the sort of its list and the
+        // patch are queued right here and their sums come with this fetch (sfv.*; used in phase_cauchy_freev).
+        // Only while the free set is changing from iteration to iteration (sfv_hot); otherwise the regular
+        // route finds "nothing changed" without any pass at all.
+        sfv.valid = false;
+        const int sf_upcl = c2 - 1;
+        const bool do_sfv = spec_freev_on && sfv_hot && cnstnd && store_iw && index_valid && !index && two_pass &&
+                            c2 <= two_pass_maxcol && sf_upcl > 0 && chi < 0.0 && print_level < 99 &&
+                            !(flags & LBFGSB_F_PARALLEL_GCP);
+        if (do_sfv) {
+          const int par = fv_parity;
+          q.res_off = SPEC_OFF;
+          q.hold_fin = fold_fin;  // (its four sums ride with the patch's finalize: one launch less)
+          lbk::launch_freev_count(q, n, iwhere, wasfree, d_chg, CHG_CAP, d_fcount, par, 0);
+          q.hold_fin = false;
+          fv_parity ^= 1;
+          lbk::launch_sort_u32_small_dev(q, d_chg, d_fcount + (par & 1));
+          q.res_off = SPEC_OFF + 4;
+          lbk::launch_formk_patch_dev<T>(q, d_chg, d_fcount + (par & 1), (uint32_t)lbk::small_sort_cap(), W(), h2,
+                                         sf_upcl);
+          q.res_off = 0;
+          spec_live_len = 4 + 2 * sf_upcl * sf_upcl + sf_upcl + 1;
+          sfv.parity = par & 1, sfv.upcl = sf_upcl, sfv.head = h2, sfv.col = c2, sfv.iter = iter + 1, sfv.x = x;
+        }
         CHK(fetch(fo + 4 * MCo + 9 + NX, 1, 1));
+        if (do_sfv) {
+          const int nl = spec_live_len;
+          spec_live_len = 0;
+          const double *S = h_res + SPEC_OFF;
+          for (int j = 0; j < 4; ++j) sfv.cnt[j] = S[j];
+          sfv.loc3 = h_loc[SPEC_OFF + 3];
+          sfv.P.assign(S + 4, S + nl - 1);
+          sfv.served = S[nl - 1] == 0.0;  // (summed over the ranks: every rank's list fitted the chain)
+          sfv.valid = true;
+        }
         t_mid0 = now_s(), t_mark = t_mid0;
         if (chi >= 0.0) CHK(spec_land(c2, chi));
         if (fo) *f = f_scale * h_res[0];
@@ -807,10 +854,12 @@ class Solver final : public lbfgsb_hip_ctx {
   // generalized Cauchy point + freev (:599-646)
   // freev's counting pass (:1980-2059), in two halves so that another pass can be queued between
   // the launch and the one host sync that brings its three counts (h_res[0..2])
-  int freev_launch(bool track) {
+  int freev_launch(bool track, bool park_finalize = false) {
     if (prevfree)
       HIPCHK(hipMemcpyAsync(prevfree, wasfree, (size_t)n, hipMemcpyDeviceToDevice, stream));
+    q.hold_fin = park_finalize && fold_fin;  // (the patch chain that follows finalizes both)
     lbk::launch_freev_count(q, n, iwhere, wasfree, track ? d_chg : nullptr, CHG_CAP, d_fcount, fv_parity);
+    q.hold_fin = false;
     fv_parity ^= 1;
     index_valid = true;
     iw_dirty = 0.0;
@@ -897,7 +946,29 @@ class Solver final : public lbfgsb_hip_ctx {
         seg(3);
         return 0;
       }
-      CHK(freev_launch(track));
+      if (sfv.valid && sfv.served && track && closed_cand && !index && fixlist.empty() && !fix_overflow &&
+          sfv.iter == iter && sfv.x == x && sfv.col == col && sfv.head == head && sfv.upcl == (updatd ? col - 1 : col)) {
+        // the speculative chain behind the accepted trial point holds: the walk fixed nothing, so iwhere is what
+        // that counting pass saw.  Its counts are freev's, its patch is formk's; wasfree is brought up to date
+        // from its list (<= the chain's capacity on every rank: sfv.served) -- no pass, no host sync here
+        sfv.valid = false;
+        nsfv_used++;
+        if (sfv.cnt[3] > 0.0)
+          lbk::launch_freev_apply(q, d_chg, d_fcount + sfv.parity, (uint32_t)lbk::small_sort_cap(), wasfree);
+        iw_dirty = 0.0;
+        h_res[0] = sfv.cnt[0], h_res[1] = sfv.cnt[1], h_res[2] = sfv.cnt[2];
+        h_loc[3] = sfv.loc3;
+        cachyt += now_s() - cpu1;
+        nintol += nseg;
+        wrk = freev_land(track, updatd);
+        sfv_hot = sfv.cnt[3] > 0.0;
+        eager.valid = true, eager.upcl = sfv.upcl, eager.head = sfv.head, eager.P = sfv.P;
+        seg(3);
+        return 0;
+      }
+      sfv.valid = false;
+      const bool will_eager = eager_on && track && closed_cand && (updatd ? col - 1 : col) > 0 && !wide();
+      CHK(freev_launch(track, will_eager));
       // formk's patch sums (:1801-1851) do not depend on anything the host still has to decide either -- only
       // on the list freev's pass has just written and on W: in the two-pass iteration (no cmprlb launch
       // below) the sort of the list and the patch kernel are queued right behind the counting pass with
@@ -908,7 +979,7 @@ class Solver final : public lbfgsb_hip_ctx {
       int neager = 0;
       {
         const int upcl = updatd ? col - 1 : col;
-        if (eager_on && track && closed_cand && upcl > 0 && !wide()) {
+        if (will_eager) {
           const uint32_t *cnt_ptr = d_fcount + ((fv_parity ^ 1) & 1);  // the counter freev_launch just used
           lbk::launch_sort_u32_small_dev(q, d_chg, cnt_ptr);
           q.res_off = 4;
@@ -949,6 +1020,7 @@ class Solver final : public lbfgsb_hip_ctx {
       cachyt += now_s() - cpu1;
       nintol += nseg;
       wrk = freev_land(track, updatd);
+      sfv_hot = track && (nenter_g > 0 || ileave_g < nglob + 1);  // the free set is moving: speculate next time
       if (ipr >= 99) {  // :2023-2057
         if (iter > 0 && cnstnd) {
           if (ipr >= 100 && chg_local > 0 && chg_local <= CHG_CAP) {
@@ -1275,6 +1347,7 @@ class Solver final : public lbfgsb_hip_ctx {
       const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
                          spec.head == head && spec.col == col && spec.itail == itail;
       const int NX = lbk::update_scan_extra(col - 1, nr_flag(col));
+      if (!reuse) sfv.valid = false;
       if (reuse) {
         std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
         if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
@@ -1461,6 +1534,20 @@ class Solver final : public lbfgsb_hip_ctx {
   } eager;
   bool eager_on = true;  // (option "eager_patch")
   int64_t neager_served = 0;
+  // the same chain queued SPECULATIVELY behind the evaluation of a trial point (phase_entry)
+  struct SpecFreev {
+    bool valid = false, served = false;
+    double cnt[4] = {0, 0, 0, 0}, loc3 = 0.0;
+    int parity = 0, upcl = 0, head = 0, col = 0, iter = 0;
+    const void *x = nullptr;
+    std::vector<double> P;
+  } sfv;
+  // Off unless option "spec_freev" = 1: measured on BASELINE configs[2] (Rosenbrock n = 1e7, where the free set
+  // changes in most iterations) the chain is used in a quarter of the iterations only -- 2.6 -> 2.4 syncs --
+  // and its three extra launches per iteration cost more than that saves: 980 -> 955 it/s
+  bool spec_freev_on = false;
+  bool sfv_hot = false;       // the last freev found the free set changed
+  int64_t nsfv_used = 0;
   bool check_ptrs = false;   // this call decides the entry of a run: its pointers have not been looked at yet
   bool index_valid = false;  // a freev has run: wasfree is the membership of Index(1:nfree)
   // How many iwhere entries have changed since the last freev pass (a count where the kernels report

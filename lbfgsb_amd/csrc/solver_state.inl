@@ -112,6 +112,7 @@
     z_valid = true;  // z as imported
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, tbrk_valid = false, scan.ready = false;
     ls.deferred = false, defer_live = false;
+    sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
     nbd8_src = nullptr;
     spcand.valid = false;
     {

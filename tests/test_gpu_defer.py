@@ -167,21 +167,23 @@ def test_export_is_refused_while_deferred_and_start_resets(oracle_built):
 @pytest.mark.parametrize("pp,defer", [(True, False), (False, False), (True, True)])
 def test_launch_plumbing_options_change_nothing(oracle_built, pp, defer):
     """The round-4 changes to HOW results travel -- the finalize that publishes by itself (`spin`), parked
-    finalize jobs (`fold_finalize`), formk's patch queued behind freev's counting pass (`eager_patch`) -- must
-    not change a single bit of WHAT is computed: every return of a run with all three switched off (the
+    finalize jobs (`fold_finalize`), formk's patch queued behind freev's counting pass (`eager_patch`), the same
+    chain queued speculatively behind the evaluation of a trial point (`spec_freev`) -- must not change a single
+    bit of WHAT is computed: every return of a run with all four switched off (the
     round-3 plumbing: one finalize per kernel, a D2H copy + stream sync per phase, the patch after a host round
     trip of its own) equals the default's, on random problems whose free sets change from iteration to
     iteration (so that the patch really runs)."""
     from test_gpu_fuzz import make, fam_rosenchain
     po = oracle_built
-    old = {"spin": 0, "fold_finalize": 0, "eager_patch": 0}
+    old = {"spin": 0, "fold_finalize": 0, "eager_patch": 0, "spec_freev": 0}
+    new = {"spec_freev": 1}     # (opt-in; everything else is on by default)
     for seed in list(range(700, 724)) + list(range(5300, 5306)):
         p = make(po, seed, 400, 1, 13) if seed < 5000 else make(po, seed, 3000, 11, 33)
         a = _run(p, pp, defer, 60, options=old)
-        b = _run(p, pp, defer, 60)
+        b = _run(p, pp, defer, 60, options=new)
         assert a["rows"] == b["rows"] and a["wa"] == b["wa"] and a["iwa"] == b["iwa"], (p.name, p.n, p.m)
     for seed in range(62000, 62008):
         p = fam_rosenchain(po, seed)
         a = _run(p, pp, defer, 80, options=old)
-        b = _run(p, pp, defer, 80)
+        b = _run(p, pp, defer, 80, options=new)
         assert a["rows"] == b["rows"] and a["wa"] == b["wa"], (p.name, p.n, p.m)
