@@ -438,6 +438,9 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           the patch are queued speculatively behind the evaluation of a trial point and
  *                           used if the point is accepted and the next walk fixes no row (default 0: measured,
  *                           does not pay)
+ *   "skip_reuse" (0/1)      after a skipped BFGS update, cauchy's n-loop sums come from the pass that evaluated
+ *                           the accepted point (+ a one-column scan when the memory is full) (default 1) /
+ *                           from a scan over all of W
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel
@@ -501,6 +504,11 @@ int lbfgsb_hip_host_segments(lbfgsb_hip_ctx *ctx, double *seconds5);
 /* LBFGSB_F_DEFER_LNSRCH: line-search set-ups whose sums travelled with the next call's fetch, and how many
  * of those had to re-issue their 'FG_LNSRCH' request (backtracking step, ascent direction) */
 int lbfgsb_hip_defer_stats(lbfgsb_hip_ctx *ctx, int64_t *deferred, int64_t *reissued);
+
+/* Skipped BFGS updates (src/lbfgsb.f90:822-830) whose next cauchy n-loop (:1270-1330) was taken from the
+ * pass that had evaluated the accepted point instead of a scan of its own over all of W (option
+ * "skip_reuse", default 1) */
+int lbfgsb_hip_skip_stats(lbfgsb_hip_ctx *ctx, int64_t *scans_reused);
 
 /* In-run clocks of the three passes over W of an iteration (hipEvents on the context's stream
  * around every launch, read back at the next host sync): [0] cmprlb_wtv_kernel, [1]

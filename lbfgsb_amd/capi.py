@@ -61,6 +61,7 @@ PROTOTYPES = {
     "lbfgsb_hip_comm_stats": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_uniform_bounds": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_freev_skipped": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_skip_stats": (C.c_int, [_vp, _vp]),
     # routine doors
     "lbfgsb_hip_active": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_errclb": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),

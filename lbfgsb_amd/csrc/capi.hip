@@ -338,6 +338,12 @@ int lbfgsb_hip_freev_skipped(lbfgsb_hip_ctx *ctx, int64_t *count) {
   return 0;
 }
 
+int lbfgsb_hip_skip_stats(lbfgsb_hip_ctx *ctx, int64_t *scans_reused) {
+  if (!ctx || !scans_reused) return fail(LBFGSB_E_ARG, "skip_stats: NULL argument");
+  *scans_reused = ctx->skip_scans_reused();
+  return 0;
+}
+
 int lbfgsb_hip_uniform_bounds(lbfgsb_hip_ctx *ctx, int32_t *mask) {
   if (!ctx || !mask) return fail(LBFGSB_E_ARG, "uniform_bounds: NULL argument");
   *mask = ctx->uniform_mask();

@@ -89,10 +89,33 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(FinJobs J, double *res,
   const double *__restrict__ part = J.j[ji].part;
   const int pstride = J.j[ji].pstride, nblocks = J.j[ji].nblocks, nsum = J.j[ji].nsum, nmin = J.j[ji].nmin;
   const int op = k < nsum ? 0 : (k < nsum + nmin ? 1 : 2);
-  double v = op == 0 ? 0.0 : (op == 1 ? LB_INF : -LB_INF);
-  for (int b = threadIdx.x; b < nblocks; b += BLOCK) {
-    const double p = part[(size_t)k * pstride + b];
-    v = op == 0 ? v + p : (op == 1 ? fmin(v, p) : fmax(v, p));
+  const double ident = op == 0 ? 0.0 : (op == 1 ? LB_INF : -LB_INF);
+  double v = ident;
+  if (nblocks <= 8 * BLOCK) {
+    for (int b = threadIdx.x; b < nblocks; b += BLOCK) {
+      const double p = part[(size_t)k * pstride + b];
+      v = op == 0 ? v + p : (op == 1 ? fmin(v, p) : fmax(v, p));
+    }
+  } else {
+    // very many partials (a pass launched with one trip per workgroup): eight independent chains per
+    // thread, so that eight loads are in flight instead of one (fixed association all the same)
+    double c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = ident;
+    int b = threadIdx.x;
+    for (; b + 7 * BLOCK < nblocks; b += 8 * BLOCK) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const double p = part[(size_t)k * pstride + b + e * BLOCK];
+        c[e] = op == 0 ? c[e] + p : (op == 1 ? fmin(c[e], p) : fmax(c[e], p));
+      }
+    }
+    for (int e = 0; b < nblocks; b += BLOCK, ++e) {
+      const double p = part[(size_t)k * pstride + b];
+      c[e & 7] = op == 0 ? c[e & 7] + p : (op == 1 ? fmin(c[e & 7], p) : fmax(c[e & 7], p));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v = op == 0 ? v + c[e] : (op == 1 ? fmin(v, c[e]) : fmax(v, c[e]));
   }
   sm[threadIdx.x] = v;
   __syncthreads();

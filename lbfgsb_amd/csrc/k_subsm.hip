@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
     int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
-    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part) {
+    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part, int pstride) {
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
       if (xout) st<W>(xout + i, zv);
     }
   });
-  block_reduce_store<4>(acc, 3, 1, 0, part, MAX_BLOCKS);
+  block_reduce_store<4>(acc, 3, 1, 0, part, pstride);
 }
 template <typename T>
 void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr, T *rout, const T *l,
@@ -186,6 +186,8 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
   int gr = 0;
   const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col-1
   const bool spec = pe.on && col == maxc_for(col);
+  double *part = q.part();
+  const int pstride = MAX_BLOCKS;
 #define LB_SUBSM(PSPECV)                                                                            \
   DISPATCH_MAXC_NT(col, q.nt, DISPATCH_PIPE(MC, {                                                   \
                      gr = grid_for_w(q, n, VecOf<T>::V,                                             \
@@ -194,7 +196,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
                                         dim3(BLOCK), 0, q.stream, n, tsum, zout, pr, rout, l, u,    \
                                         nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld, w.m, head,   \
                                         col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd,     \
-                                        w.wy + slot, w.ws + slot, ub, q.part());                    \
+                                        w.wy + slot, w.ws + slot, ub, part, pstride);               \
                    }))
   if (spec)
     LB_SUBSM(true);
@@ -202,7 +204,7 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
     LB_SUBSM(false);
 #undef LB_SUBSM
   LB_LAUNCHED(q);
-  launch_finalize(q, gr, 3, 1, 0);
+  finalize_from(q, part, pstride, gr, 3, 1, 0);
 }
 
 // The Newton direction as a vector (free rows; 0 elsewhere), for the backtracking branch only.

@@ -992,9 +992,11 @@ class Solver final : public lbfgsb_hip_ctx {
       // the cmprlb pass does not depend on freev's counts: launch it now and fetch both
       // sets of sums with ONE host sync (it is wasted only if no variable is free)
       int npre = 0;
+      double p_walk[2 * lbk::MAXM];  // (wa(1:2m) as the walk left it: cmprlb_coef puts M c there)
       if (col > 0 && !closed_cand && !wide()) {
         lbk::Coef cf;
         bool plain;
+        std::memcpy(p_walk, wa8m.data(), sizeof(double) * 2 * col);
         if (cmprlb_coef(col, theta, cnstnd, cf, plain)) {
           const bool newrow = updatd && col <= lbk::MAXM;  // updatd implies wrk
           CHK(ensure_d(x));
@@ -1020,6 +1022,8 @@ class Solver final : public lbfgsb_hip_ctx {
       cachyt += now_s() - cpu1;
       nintol += nseg;
       wrk = freev_land(track, updatd);
+      // no free variable: the reference goes straight to the line search (:648-651), wa(1:2m) stays cauchy's p
+      if (npre && nfree_g == 0) std::memcpy(wa8m.data(), p_walk, sizeof(double) * 2 * col);
       sfv_hot = track && (nenter_g > 0 || ileave_g < nglob + 1);  // the free set is moving: speculate next time
       if (ipr >= 99) {  // :2023-2057
         if (iter > 0 && cnstnd) {
@@ -1300,6 +1304,45 @@ class Solver final : public lbfgsb_hip_ctx {
     SY(col - 1, col - 1) = dr;
   }
 
+  // The BFGS update is skipped (:822-830) but the pass that evaluated the accepted point has run all the
+  // same: the n-loop of the cauchy() that follows (:1270-1330) is a function of x, g, the bounds and the
+  // columns of W, and the pass read every column that stays -- all of them while the memory is filling
+  // (c2 = col + 1, same head); with the memory full it left out the OLDEST pair (it would have been
+  // dropped), whose two products come from a one-column scan: 70 bytes per row instead of the 8 + 16 col + ...
+  // of cauchy_scan_kernel over all columns.  f1, the breakpoint counts and bkmin do not depend on W at all.
+  bool skip_reuse_on = true;  // option "skip_reuse"
+  int64_t nskip_reused = 0;
+  int scan_from_skipped(Mainlb &L) {
+    MAINLB_VIEW(L);
+    const int c2 = spec.col, nold = c2 - 1;
+    const bool full = c2 == col;  // (the pass ran with head + 1)
+    if (!(full ? (col == m && spec.head == head % m + 1) : (c2 == col + 1 && spec.head == head))) return 0;
+    const int MCo = lbk::maxc_for(nold);
+    const int NX = lbk::update_scan_extra(nold, nr_flag(c2));
+    const double *R = spec.res;
+    const int shift = full ? 1 : 0;
+    if (full) {
+      const int MC1 = lbk::maxc_for(1);
+      lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, 1);
+      CHK(fetch(2 * MC1 + 4, 1, 0));
+      scan.p[0] = h_res[0], scan.p[col] = h_res[MC1];
+      tbrk_valid = true;
+      if (flags & LBFGSB_F_MIRROR_INDEX) iw_dirty += 1.0;  // (the evaluation held its iwhere stores back)
+    } else if ((flags & LBFGSB_F_MIRROR_INDEX) && R[4 * MCo + 8] > 0.0) {
+      lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere), iw_dirty += 1.0;
+    }
+    for (int j = shift; j < col; ++j) {
+      scan.p[j] = R[2 * MCo + 1 + j - shift];
+      scan.p[col + j] = R[3 * MCo + 2 + j - shift];
+    }
+    scan.f1 = R[4 * MCo + 3], scan.nbreak = R[4 * MCo + 4];
+    scan.nunb = R[4 * MCo + 5], scan.nunbnz = R[4 * MCo + 6];
+    scan.bkmin = R[4 * MCo + 9 + NX];
+    scan.ready = true;
+    nskip_reused++;
+    return 0;
+  }
+
   // y, s and matupd (:812-857)
   int phase_update(Mainlb &L, Flow &flow) {
     MAINLB_VIEW(L);
@@ -1315,6 +1358,9 @@ class Solver final : public lbfgsb_hip_ctx {
     if (dr <= epsmch * ddum) {
       nskip++;
       updatd = false;
+      if (debug_walk) std::fprintf(stderr, "[update] iter %d skipped: dr %g ddum %g\n", iter, dr, ddum);
+      if (skip_reuse_on && spec.valid && spec.x == x && spec.g == g && spec.stp == stp && !wide())
+        CHK(scan_from_skipped(L));
       spec.valid = false;
       spcand.valid = false;
       if (ipr >= 1)
@@ -1347,6 +1393,7 @@ class Solver final : public lbfgsb_hip_ctx {
       const bool reuse = spec.valid && spec.x == x && spec.g == g && spec.stp == stp &&
                          spec.head == head && spec.col == col && spec.itail == itail;
       const int NX = lbk::update_scan_extra(col - 1, nr_flag(col));
+      if (debug_walk) std::fprintf(stderr, "[update] iter %d stp %g reuse %d\n", iter, stp, (int)reuse);
       if (!reuse) sfv.valid = false;
       if (reuse) {
         std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));

@@ -186,6 +186,7 @@ struct lbfgsb_hip_ctx {
   int64_t ncoll = 0, coll_bytes = 0;  // collectives issued / bytes THIS rank contributed to them
   virtual int uniform_mask() const = 0;  // lbfgsb_hip_uniform_bounds
   virtual int64_t freev_skipped() const = 0;
+  virtual int64_t skip_scans_reused() const = 0;
   virtual void defer_counts(int64_t &deferred, int64_t &reissued) const = 0;
   // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):
   // the next setulb_dev call fetches it together with the sums of its own first pass

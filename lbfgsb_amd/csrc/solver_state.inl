@@ -276,6 +276,7 @@
     closed_form = nclosed, three_pass = nthreepass;
   }
   int64_t freev_skipped() const override { return nfreev_skipped; }
+  int64_t skip_scans_reused() const override { return nskip_reused; }
   void defer_counts(int64_t &deferred, int64_t &reissued) const override { deferred = ndeferred, reissued = nredo; }
   const void *prev_iterate() const override { return t; }
   int uniform_mask() const override { return ub_mask; }

@@ -453,6 +453,7 @@
     if (k == "fold_finalize") return flag(fold_fin);
     if (k == "eager_patch") return flag(eager_on);
     if (k == "spec_freev") return flag(spec_freev_on);
+    if (k == "skip_reuse") return flag(skip_reuse_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");

@@ -168,6 +168,7 @@
     if (!scan.ready && wide()) {
       CHK(wide_cauchy_scan(x, l, u, nbd, g, head, col));
     } else if (!scan.ready) {
+      if (debug_walk) std::fprintf(stderr, "[cauchy] own scan pass (col %d, theta %g)\n", col, theta);
       lbk::launch_cauchy_scan<T>(q, n, x, l, u, nbd, g, iwhere, tbrk, W(), head, col);
       iw_dirty += 1.0;  // (this scan does not count the entries it changes)
       tbrk_valid = true;

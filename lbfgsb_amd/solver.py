@@ -455,5 +455,8 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_comm_stats(self.h, C.byref(nc), C.byref(nb)))
         fs = C.c_int64()
         check(self.lib.lbfgsb_hip_freev_skipped(self.h, C.byref(fs)))
+        sr = C.c_int64()
+        check(self.lib.lbfgsb_hip_skip_stats(self.h, C.byref(sr)))
         return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value, wait_seconds=w.value,
-                    collectives=nc.value, collective_bytes=nb.value, freev_skipped=fs.value)
+                    collectives=nc.value, collective_bytes=nb.value, freev_skipped=fs.value,
+                    skip_scans_reused=sr.value)

@@ -288,6 +288,7 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
                 break
             prev = cur
         fgp, fo = float(sol.f[0]), float(so.f[0])
+        LAST["stats"] = sol.stats()
     finally:
         sol.close()
     LAST.update(f_oracle=fo, f_gpu=fgp, task_oracle=so.task_s, task_gpu=rg[-1][0], calls_gpu=len(rg))
@@ -320,6 +321,48 @@ def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, m
             splits.append((seed, split, ncalls))
     print("%d of %d runs left the oracle's trajectory, each reproduced by a one-step oracle replay "
           "(seed, first differing call, calls): %s" % (len(splits), count, splits))
+
+
+def fam_cubic(po, seed):
+    """f = sum a_i x_i^3 (+ a small linear term) from a start in the convex half towards lower bounds in the
+    concave half: a few updates succeed, then y's < 0 with the step ending on stpmx -- the BFGS update is
+    skipped (src/lbfgsb.f90:822-830) iteration after iteration with the memory full (m <= 5)"""
+    rng = np.random.default_rng(seed)
+    n, m = int(rng.integers(2, 1200)), int(rng.integers(1, 6))
+    a = rng.uniform(0.5, 2.0, n)
+    l = -rng.uniform(0.5, 2.0, n)
+    u = rng.uniform(2.5, 4.0, n)
+    x0 = rng.uniform(1.0, 2.5, n)
+    nbd = np.full(n, 2, np.int32)
+    nbd[rng.random(n) < 0.2] = 1
+
+    def fg(x, g):
+        g[:] = 3 * a * x * x + 0.01
+        return float(np.sum(a * x ** 3 + 0.01 * x))
+    return po.Problem("cubic%d" % seed, n, m, x0, l, u, nbd, 0.0, 0.0, fg, np.float64)
+
+
+FAMILIES["cubic"] = fam_cubic
+
+
+def test_skipped_updates_take_the_scan_from_the_evaluation_pass(oracle_built):
+    """After a skipped BFGS update the next cauchy n-loop's sums come from the pass that evaluated the
+    accepted point (all old columns while the memory fills; all but the oldest, plus a one-column scan, once
+    it is full) -- option skip_reuse.  Every call against one oracle step from the GPU's previous state."""
+    po = oracle_built
+    reused = same = 0
+    for seed in range(9200, 9230):
+        p = fam_cubic(po, seed)
+        drive_with_replay(po, p, 40, pp=bool(seed & 1), replay_all=True)
+        reused += LAST["stats"]["skip_scans_reused"]
+        # the same run with a scan of its own after every skipped update: same decisions
+        a = dict(LAST)
+        drive_with_replay(po, p, 40, pp=bool(seed & 1), options={"skip_reuse": 0.0})
+        assert LAST["stats"]["skip_scans_reused"] == 0
+        # (two orders of summation: a run may end a call apart where the line search gives up on rounding noise)
+        same += (a["task_gpu"] == LAST["task_gpu"] and a["calls_gpu"] == LAST["calls_gpu"] and
+                 abs(a["f_gpu"] - LAST["f_gpu"]) <= 1e-9 * max(1.0, abs(a["f_gpu"])))
+    assert reused > 100 and same >= 26, (reused, same)
 
 
 def test_random_problems_parallel_gcp_search(oracle_built):

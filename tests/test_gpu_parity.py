@@ -152,9 +152,18 @@ def compare_states(got, exp, n, m, po, rtol=RTOL, check_lists=True, skip=(), che
             # (wv comes out of two triangular solves with the factored K: beyond 1e-6 its error must be
             #  explained the way wn's is -- cond(K) times the error of what went in; n = 6 with 13 pairs
             #  stored makes K singular to working precision)
-            nrm_close(w8g[:2 * col], w8e[:2 * col], max(1e-6, 50.0 * cond_k * e_in), "wa8m wv",
-                      floor=1e-9 * max(1.0, float(np.max(np.abs(exp.x))), float(np.max(np.abs(exp.g)))))
-            # (floor: at convergence, and for n of a few variables, wv is rounding noise of sums of |g|-sized terms)
+            wv_tol = max(1e-6, 50.0 * cond_k * e_in)
+            kinv = float(np.linalg.norm(np.linalg.inv(np.triu(ew)), 2)) ** 2
+            nseg_ = float(exp.isave[32])
+            gmax = float(np.max(np.abs(exp.g)))
+            wmax = max(float(np.max(np.abs(seg(exp, "ws")))), float(np.max(np.abs(seg(exp, "wy")))))
+            nrm_close(w8g[:2 * col], w8e[:2 * col], wv_tol, "wa8m wv",
+                      floor=max(1e-9 * max(1.0, float(np.max(np.abs(exp.x))), gmax),
+                                (4.0 + nseg_) * np.finfo(np.float64).eps * n * gmax * wmax * max(1.0, kinv) / wv_tol))
+            # (floor: at convergence, and for n of a few variables, wv is rounding noise of sums of |g|-sized terms
+            #  -- W'Z r: n products |r_i| |w_ij| <= gmax wmax each, summed in another order: 4 eps n gmax wmax,
+            #  carried through the two triangular solves: |K^-1| <= |factor^-1|^2; c = W'(xcp - x) behind it is
+            #  accumulated over the walk's segments from a p that starts at n gmax wmax and cancels: + nseg)
             if "wbp" not in skip:
                 # (wbp = row of W of the LAST variable the walk fixed, v = M wbp: work vectors nothing reads
                 #  afterwards.  A production context crosses a WHOLE group of equal breakpoints in index order,
