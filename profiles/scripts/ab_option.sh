@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of one context option on the headline (n = 1e8) and the per-rank shape (1.25e7 rows, 1-rank RCCL):
 #   bash profiles/scripts/ab_option.sh OUTDIR OPTION [values...]      e.g.  ab_option.sh gpurun_out/ab eager_patch 0 1 0 1
+# (AB_ROSEN=1: configs[2], extended Rosenbrock n = 1e7, as well)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/$1; OPT=$2; shift 2
 mkdir -p $O
@@ -11,6 +12,9 @@ for v in "$@"; do
   k=$((k+1))
   python3 bench.py --steps 20 $COMMON --opt $OPT=$v > $O/n1e8_${OPT}${v}_$k.json 2> $O/n1e8_${OPT}${v}_$k.err
   python3 bench.py --rows 12500000 --rccl-self --steps 40 $COMMON --opt $OPT=$v > $O/n125e5_${OPT}${v}_$k.json 2> $O/n125e5_${OPT}${v}_$k.err
+  if [ -n "$AB_ROSEN" ]; then
+    python3 bench.py --rosenbrock --n 10000000 --steps 16 $COMMON --opt $OPT=$v > $O/rosen1e7_${OPT}${v}_$k.json 2> $O/rosen1e7_${OPT}${v}_$k.err
+  fi
 done
 python3 - "$O" <<'PY'
 import json, sys, os, glob
