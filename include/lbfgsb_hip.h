@@ -340,10 +340,23 @@ int lbfgsb_hip_formk_gram(lbfgsb_hip_ctx *ctx, int col, int head, double *h_out)
  * code (cauchy is the function the iteration calls; freev and matupd share their halves with
  * the iteration; cmprlb, subsm and matupd's n-length sums run through the unfused tile functions
  * that carry m > 32, valid for every m); the fused passes of the hot path are covered call by
- * call by the one-step parity tests.  The reference's n-length level-1 BLAS call sites
- * (dcopy / dscal / daxpy / ddot in mainlb, lnsrlb, matupd) have no kernels of their own in this
- * library -- each is a term of one of these routines' passes -- and therefore no doors.
+ * call by the one-step parity tests.
  * ------------------------------------------------------------------------- */
+
+/* The reference's n-length level-1 BLAS call sites (src/lbfgsb_blas_module.F90:37-277: dcopy / dscal /
+ * daxpy / ddot as called from mainlb, lnsrlb, matupd) are terms of the fused passes inside an iteration;
+ * the three primitives SURVEY.md 8(b)(4) names have doors of their own all the same.  Device vectors of
+ * n_local values of the context's real kind, on the context's stream; no state of the context is read
+ * or changed, any number of ranks.
+ *   vec_sub    out = a - b            (src/lbfgsb.f90:720-722 d = z - x, :812-816 y = g - r); out may be a or b
+ *   vec_scale  v = alpha v            (dscal, :822 s = stp d); alpha is rounded to the context's kind first
+ *   dot        *h_result = a'b        (ddot, :816 / :2196 / :2244 / :2335) accumulated in fp64 in the library's
+ *              fixed order -- not the reference's groups of five (src/lbfgsb_blas_module.F90:187-202): equal
+ *              to it within rounding -- and summed over all ranks of the context (one all-gather, a host
+ *              sync); the other two return with the stream synchronised */
+int lbfgsb_hip_vec_sub(lbfgsb_hip_ctx *ctx, const void *a, const void *b, void *out);
+int lbfgsb_hip_vec_scale(lbfgsb_hip_ctx *ctx, double alpha, void *v);
+int lbfgsb_hip_dot(lbfgsb_hip_ctx *ctx, const void *a, const void *b, double *h_result);
 
 /* active, src/lbfgsb.f90:965-1040: x projected onto the box IN PLACE, iwhere initialised;
  * h_flags[0..2] = prjctd, cnstnd, boxed */

@@ -62,6 +62,9 @@ PROTOTYPES = {
     "lbfgsb_hip_uniform_bounds": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_freev_skipped": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_skip_stats": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_vec_sub": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "lbfgsb_hip_vec_scale": (C.c_int, [_vp, C.c_double, _vp]),
+    "lbfgsb_hip_dot": (C.c_int, [_vp, _vp, _vp, _vp]),
     # routine doors
     "lbfgsb_hip_active": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_errclb": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),

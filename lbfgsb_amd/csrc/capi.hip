@@ -198,6 +198,18 @@ int lbfgsb_hip_projgr(lbfgsb_hip_ctx *ctx, const void *x, const void *l, const v
   return ctx->k_projgr(x, l, u, nbd, g, h_sbgnrm);
 }
 // ---- routine doors (solver_doors.inl) ----
+int lbfgsb_hip_vec_sub(lbfgsb_hip_ctx *ctx, const void *a, const void *b, void *out) {
+  if (!ctx || !a || !b || !out) return fail(LBFGSB_E_ARG, "vec_sub: NULL argument");
+  return ctx->r_vec_sub(a, b, out);
+}
+int lbfgsb_hip_vec_scale(lbfgsb_hip_ctx *ctx, double alpha, void *v) {
+  if (!ctx || !v) return fail(LBFGSB_E_ARG, "vec_scale: NULL argument");
+  return ctx->r_vec_scale(alpha, v);
+}
+int lbfgsb_hip_dot(lbfgsb_hip_ctx *ctx, const void *a, const void *b, double *h_result) {
+  if (!ctx || !a || !b || !h_result) return fail(LBFGSB_E_ARG, "dot: NULL argument");
+  return ctx->r_dot(a, b, h_result);
+}
 int lbfgsb_hip_active(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u, const int32_t *nbd,
                       int32_t *h_flags) {
   if (!ctx || !x || !l || !u || !nbd || !h_flags) return fail(LBFGSB_E_ARG, "active: NULL argument");

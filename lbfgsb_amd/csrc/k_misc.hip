@@ -347,6 +347,66 @@ void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u, cons
   launch_finalize(q, gr, 0, 0, 1);
 }
 
+// =========================== level-1 doors ===================================
+// The reference's n-length level-1 BLAS call sites (src/lbfgsb_blas_module.F90:37-277 as called from
+// src/lbfgsb.f90:720-722 d = z - x, :812-822 y = g - r / s = stp d, :816 / :2196 / :2244 / :2335 the dots) are
+// terms of the fused passes in an iteration; these three kernels exist for the doors of SURVEY.md 8(b)(4)
+// (lbfgsb_hip_vec_sub / _vec_scale / _dot) and for callers that want the same primitives on the
+// context's stream and -- the dot -- reduced over its ranks.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void vec_sub_kernel(int64_t n, const T *a, const T *b, T *out) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double av[W], bv[W];
+    ld<W>(a + i, av);
+    ld<W>(b + i, bv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) av[k] = av[k] - bv[k];  // (REAL32: exact in fp64, rounded once by the store)
+    st<W>(out + i, av);
+  });
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void vec_scale_kernel(int64_t n, double alpha, T *v) {
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double vv[W];
+    ld<W>(v + i, vv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) vv[k] = alpha * vv[k];
+    st<W>(v + i, vv);
+  });
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *a, const T *b, double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double av[W], bv[W];
+    ld<W>(a + i, av);
+    ld<W>(b + i, bv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[0] += av[k] * bv[k];
+  });
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_vec_sub(Queue &q, int64_t n, const T *a, const T *b, T *out) {
+  hipLaunchKernelGGL(vec_sub_kernel<T>, dim3(grid_for(n, VecOf<T>::V)), dim3(BLOCK), 0, q.stream, n, a, b, out);
+  LB_LAUNCHED(q);
+}
+template <typename T>
+void launch_vec_scale(Queue &q, int64_t n, double alpha, T *v) {
+  hipLaunchKernelGGL(vec_scale_kernel<T>, dim3(grid_for(n, VecOf<T>::V)), dim3(BLOCK), 0, q.stream, n, alpha, v);
+  LB_LAUNCHED(q);
+}
+template <typename T>
+void launch_dot(Queue &q, int64_t n, const T *a, const T *b) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(dot_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, n, a, b, q.part());
+  LB_LAUNCHED(q);
+  launch_finalize(q, gr, 1, 0, 0);
+}
+
 // =========================== W'v ============================================
 // The WS/WY correction-pair matvec: out[j] = sum_i Wy(i,j) v_i,
 // out[col+j] = sum_i Ws(i,j) v_i.  Algorithmic bytes (2 col + 1) n s.
@@ -794,6 +854,9 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
   template void launch_active<T>(Queue &, int64_t, T *, const T *, const T *, const int32_t *, iw_t *, int8_t *); \
   template void launch_errclb<T>(Queue &, int64_t, int64_t, const T *, const T *, const int32_t *); \
   template void launch_projgr<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *); \
+  template void launch_vec_sub<T>(Queue &, int64_t, const T *, const T *, T *); \
+  template void launch_vec_scale<T>(Queue &, int64_t, double, T *); \
+  template void launch_dot<T>(Queue &, int64_t, const T *, const T *); \
   template void launch_wtv<T>(Queue &, int64_t, WStore<T>, int, int, const T *); \
   template void launch_wtv_nofinalize<T>(Queue &, int64_t, WStore<T>, int, int, const T *); \
   template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *, const T *, const iw_t *, double, T *); \

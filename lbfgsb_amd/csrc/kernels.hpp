@@ -129,6 +129,13 @@ void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u,
 template <typename T>
 void launch_projgr(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                    const int32_t *nbd, const T *g);
+// level-1 doors (k_misc.hip): out = a - b; v = alpha v; sum slot 0 = a'b
+template <typename T>
+void launch_vec_sub(Queue &q, int64_t n, const T *a, const T *b, T *out);
+template <typename T>
+void launch_vec_scale(Queue &q, int64_t n, double alpha, T *v);
+template <typename T>
+void launch_dot(Queue &q, int64_t n, const T *a, const T *b);
 
 // ---- W'v (the WS/WY correction-pair matvec) -------------------------------
 // res sum-slots [0..col) = Wy' v, [MC..MC+col) = Ws' v (logical column order)

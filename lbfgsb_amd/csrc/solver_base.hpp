@@ -131,6 +131,9 @@ struct lbfgsb_hip_ctx {
   virtual int k_objective(int kind, const void *x, void *g, double *f) = 0;
   // routine doors (solver_doors.inl): one routine of the reference each, on the state of the context
   virtual int r_active(void *x, const void *l, const void *u, const int32_t *nbd, int32_t *out3) = 0;
+  virtual int r_vec_sub(const void *a, const void *b, void *out) = 0;
+  virtual int r_vec_scale(double alpha, void *v) = 0;
+  virtual int r_dot(const void *a, const void *b, double *out) = 0;
   virtual int r_errclb(const void *l, const void *u, const int32_t *nbd, double factr, char *task,
                        int32_t *info, int64_t *k) = 0;
   virtual int r_cauchy(const void *x, const void *l, const void *u, const int32_t *nbd, const void *g,

@@ -28,6 +28,29 @@
     return sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon() : std::numeric_limits<double>::epsilon();
   }
 
+  // level-1 BLAS, src/lbfgsb_blas_module.F90:37-277 at its n-length call sites (d = z - x :720-722, y = g - r
+  // :812-816, s = stp d :822, the dots of :816 / :2196 / :2244 / :2335): plain vectors, no state of the context
+  // involved, any number of ranks -- the dot is reduced over the ranks like every other sum (one all-gather)
+  int r_vec_sub(const void *a, const void *b, void *out) override {
+    HIPCHK(hipSetDevice(device));
+    lbk::launch_vec_sub<T>(q, n, (const T *)a, (const T *)b, (T *)out);
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int r_vec_scale(double alpha, void *v) override {
+    HIPCHK(hipSetDevice(device));
+    lbk::launch_vec_scale<T>(q, n, (double)(T)alpha, (T *)v);  // (REAL32: the factor as the reference holds it)
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int r_dot(const void *a, const void *b, double *out) override {
+    HIPCHK(hipSetDevice(device));
+    lbk::launch_dot<T>(q, n, (const T *)a, (const T *)b);
+    CHK(fetch(1, 0, 0));
+    *out = h_res[0];
+    return 0;
+  }
+
   // active :965-1040 -- x projected onto the box in place, iwhere initialised; out3 = prjctd, cnstnd, boxed
   int r_active(void *x, const void *l, const void *u, const int32_t *nbd, int32_t *out3) override {
     CHK(door_ready(nbd));

@@ -282,6 +282,20 @@ class DeviceSolver:
 
     # ---- routine doors (include/lbfgsb_hip.h "Routine doors"): one routine of the reference each, on the
     #      state of the context (import_state / export_state); vectors are device tensors ----
+    def r_vec_sub(self, a, b, out):
+        """out = a - b (level-1 door; src/lbfgsb.f90:720-722, :812-816)"""
+        check(self.lib.lbfgsb_hip_vec_sub(self.h, _p(a), _p(b), _p(out)))
+
+    def r_vec_scale(self, alpha, v):
+        """v = alpha v (dscal, :822)"""
+        check(self.lib.lbfgsb_hip_vec_scale(self.h, float(alpha), _p(v)))
+
+    def r_dot(self, a, b):
+        """a'b in fp64, summed over the context's ranks (ddot, :816 / :2196 / :2244 / :2335)"""
+        out = np.zeros(1, np.float64)
+        check(self.lib.lbfgsb_hip_dot(self.h, _p(a), _p(b), _p(out)))
+        return float(out[0])
+
     def r_active(self, x, l, u, nbd):
         """active :965 -- x projected in place; -> (prjctd, cnstnd, boxed)"""
         out = np.zeros(3, np.int32)

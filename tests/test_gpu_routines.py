@@ -416,3 +416,45 @@ def test_cauchy_door_reference_nan_point(oracle_built):
         else:
             assert np.array_equal(got, xcp), "finite case: bit for bit (no sums over rows with col = 0)"
             assert got[k] == x[k] < l[k]      # found beyond its bound: x stays where it is
+
+
+@pytest.mark.parametrize("real", [np.float64, np.float32])
+def test_level1_doors(oracle_built, real):
+    """vec_sub / vec_scale / dot (src/lbfgsb_blas_module.F90:37-277 at the n-length call sites
+    of src/lbfgsb.f90:720-722, :812-822).  Differences and scalings are one rounding each: bit-exact against
+    numpy in the context's real kind, in place too.  The dot against the oracle's ddot (sequential, groups of
+    five): other order of summation, 1e-12 (fp64 accumulation; REAL32: the reference accumulates in REAL32) of
+    sum |a_i b_i|."""
+    import torch
+    import lbfgsb_amd
+    twin = po.Routines(real)     # (sets lbo_ddot's prototype)
+    tdt = torch.float32 if real == np.float32 else torch.float64
+    for seed, n in enumerate((1, 2, 3, 5, 63, 64, 255, 1000, 4097, 1_000_003)):
+        rng = np.random.default_rng(100 + seed)
+        a = (rng.normal(0, 1, n) * 10.0 ** rng.uniform(-6, 6, n)).astype(real)
+        b = (rng.normal(0, 1, n) * 10.0 ** rng.uniform(-6, 6, n)).astype(real)
+        sol = lbfgsb_amd.DeviceSolver(n, 3, device=0, real32=real == np.float32)
+        try:
+            da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+            out = torch.full((n,), 9.0, dtype=tdt, device="cuda")
+            torch.cuda.synchronize()             # (the doors run on the context's stream, torch on its own)
+            sol.r_vec_sub(da, db, out)
+            assert np.array_equal(out.cpu().numpy(), a - b)
+            out.copy_(da)
+            torch.cuda.synchronize()
+            sol.r_vec_sub(out, db, out)          # in place
+            assert np.array_equal(out.cpu().numpy(), a - b)
+            alpha = 0.2992887057956888
+            out.copy_(db)
+            torch.cuda.synchronize()
+            sol.r_vec_scale(alpha, out)
+            assert np.array_equal(out.cpu().numpy(), real(alpha) * b)
+            got = sol.r_dot(da, db)
+            ref = float(twin.lib.lbo_ddot(n, a.ctypes.data, b.ctypes.data))
+            exact = float(np.sum(a.astype(np.longdouble) * b.astype(np.longdouble)))
+            scale = float(np.sum(np.abs(a.astype(np.float64) * b.astype(np.float64))))
+            assert abs(got - exact) <= 1e-12 * scale, (n, got, exact)
+            assert abs(got - ref) <= (1e-12 if real == np.float64 else 4e-7 * max(1.0, np.sqrt(n))) * scale, (n, got, ref)
+            assert sol.r_dot(da, da) >= 0.0
+        finally:
+            sol.close()
