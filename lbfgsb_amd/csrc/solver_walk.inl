@@ -78,13 +78,14 @@
   struct WalkRaw {
     double f1, f2, dtm, tsum, tj, lt;
     int64_t nleft;
+    double lt2;  // the breakpoint crossed before the last one (-1: none)
   };
   static __attribute__((noinline)) int walk_raw_col0(const double *raw, size_t &pos_io, size_t end, double theta,
                                                      double clampv, bool all_n, bool bnded, WalkRaw &w,
                                                      bool &tie) {
     const double INFL = 1.0 + 16.0 * std::numeric_limits<double>::epsilon();
     const double inf = std::numeric_limits<double>::infinity();
-    double f1_ = w.f1, f2_ = w.f2, dtm_ = w.dtm, tsum_ = w.tsum, tj_ = w.tj, lt_ = w.lt;
+    double f1_ = w.f1, f2_ = w.f2, dtm_ = w.dtm, tsum_ = w.tsum, tj_ = w.tj, lt_ = w.lt, lt2_ = w.lt2;
     int64_t nleft_ = w.nleft;
     size_t pos = pos_io;
     int code = 0;
@@ -110,6 +111,7 @@
       const double dibp = rec[2];
       const double zibp = rec[3];
       tj_ = mt;
+      lt2_ = lt_;
       lt_ = mt;
       if (nleft_ == 0 && all_n) {  // all n variables fixed (:1436-1442)
         dtm_ = dt;
@@ -132,7 +134,7 @@
         break;
       }
     }
-    w = WalkRaw{f1_, f2_, dtm_, tsum_, tj_, lt_, nleft_};
+    w = WalkRaw{f1_, f2_, dtm_, tsum_, tj_, lt_, nleft_, lt2_};
     pos_io = pos;
     tie = tie_;
     return code;
@@ -243,9 +245,15 @@
     }
 
     // Equal breakpoints are delivered in index order, the reference pops them in heap order
-    // (hpsolb :2079); the two differ in effect only if the walk ends INSIDE such a group.  That
-    // is detected (tie_split), counted, and the walk is then replayed from its start in the
-    // reference's own order (exact_init / refill_exact) -- unless LBFGSB_F_INDEX_TIES opts out.
+    // (hpsolb :2079); the two differ in effect only if SOME order of a group's members makes the walk
+    // end inside the group: the derivative f1 at the group's breakpoint, plus the members' jumps taken in
+    // that order, turns positive before the last member (then dtm < 0 = dt, :1416).  The jumps
+    // dibp^2 - theta dibp zibp + dibp w'Mc do not depend on the order (c stands still while dt = 0), so a
+    // group can do that only if f1 on arrival + the sum of its POSITIVE jumps is positive.  With B = theta I
+    // every jump is positive: only the group the walk ends in or right behind.  That is detected (tie_split:
+    // the walk stops at a breakpoint equal to the last one it crossed; grp_sens: a crossed group of two or
+    // more could have stopped it), counted, and the walk is then replayed from its start in the reference's
+    // own order (exact_init / refill_exact) -- unless LBFGSB_F_INDEX_TIES opts out.
     const bool can_exact = !(flags & LBFGSB_F_INDEX_TIES);
     // (a replay would print the walk twice: under iprint >= 99 the walk runs in that order from the
     //  start; option "exact_always": every walk in that order, for tests)
@@ -254,6 +262,10 @@
     const double f1_start = f1, f2_start = f2, dtm_start = dtm;
     for (;;) {  // at most two trips: the second one in exact order
     bool tie_split = false;
+    bool grp_sens = false;
+    double t_prev = -1.0;  // the breakpoint crossed before the last one
+    double grp_t = -1.0, grp_f1_in = 0.0, grp_pos = 0.0;  // (col > 0) the group being crossed
+    int64_t grp_n = 0;
     if (nbreak != 0) {
       int64_t nleft = nbreak;
       int64_t iter = 1;
@@ -287,7 +299,7 @@
             //  values were spilled to the stack -- a store-to-load round trip on the chain f1 -> f1 of every
             //  segment, 3.3 ns per record; on its own it keeps them in registers: 1.7 ns, the rate of
             //  profiles/scripts/walk_bench.cpp)
-            WalkRaw w{f1, f2, dtm, tsum, tj, last_t, nleft};
+            WalkRaw w{f1, f2, dtm, tsum, tj, last_t, nleft, t_prev};
             const size_t pos0 = pos;
             bool tie_ = false;
             const int code = walk_raw_col0(pv.raw, pos, end, theta, epsmch * f2_org, nbreak == nglob, bnded, w, tie_);
@@ -295,7 +307,7 @@
             const int64_t nleft_ = w.nleft;
             const double *const raw = pv.raw;
             const int64_t took = (int64_t)(pos - pos0);
-            f1 = f1_, f2 = f2_, dtm = dtm_, tsum = tsum_, tj = tj_, last_t = lt_, nleft = nleft_;
+            f1 = f1_, f2 = f2_, dtm = dtm_, tsum = tsum_, tj = tj_, last_t = lt_, nleft = nleft_, t_prev = w.lt2;
             iter += took;
             if (pv.rank_of)
               for (size_t k = pos0; k < pos; ++k) pv.taken[pv.rank_of[k]]++;
@@ -334,6 +346,7 @@
             const double dibp = rec[2];
             const double zibp = rec[3];
             tj = mt;
+            t_prev = last_t;
             last_t = mt;
             last_i = (int64_t)rec[1];
             if (!fix_overflow) {
@@ -446,6 +459,7 @@
         iter = iter + 1;
         const double dibp = rec[2];
         const double zibp = rec[3];
+        t_prev = last_t;
         last_t = tj;
         last_i = rec_gi;
         if (pv.exact || fixlist.size() < FIX_CAP)
@@ -473,6 +487,7 @@
         }
         nseg = nseg + 1;
         const double dibp2 = dibp * dibp;
+        const double f1_arrival = f1 + dt * f2;  // (the derivative at this breakpoint, nothing fixed yet)
         f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;  // :1452-1453
         f2 = f2 - theta * dibp2;
         if (col > 0) {
@@ -492,6 +507,15 @@
           f1 = f1 + dibp * wmc;
           f2 = f2 + 2.0 * dibp * wmp - dibp2 * wmw;
         }
+        {  // the group of equal breakpoints this one belongs to: could another order have ended the walk in it?
+          const double jump = f1 - f1_arrival;
+          if (grp_n > 0 && tj == grp_t) {
+            grp_n++, grp_pos += std::max(jump, 0.0);
+          } else {
+            grp_t = tj, grp_n = 1, grp_f1_in = f1_arrival, grp_pos = std::max(jump, 0.0);
+          }
+          if (grp_n >= 2 && grp_f1_in + grp_pos > -1e-12 * (std::fabs(grp_f1_in) + grp_pos)) grp_sens = true;
+        }
         f2 = std::max(epsmch * f2_org, f2);  // :1483
         if (nleft > 0) {
           dtm = -f1 / f2;
@@ -506,7 +530,10 @@
         }
       }
     }
-    if (tie_split && !exact_run) {
+    // (no pair stored: the jumps are positive, only the last group counts -- two or more crossed at last_t and
+    //  the derivative non-negative behind them: dtm <= 0, or the 0 the all-breakpoints-crossed exit leaves)
+    if (col == 0 && last_t >= 0.0 && t_prev == last_t && dtm <= 1e-9 * last_t) grp_sens = true;
+    if ((tie_split || grp_sens) && !exact_run) {
       ntiesplit++;
       if (can_exact) {  // replay from the start of the walk, in the reference's order
         exact_run = true;

@@ -289,6 +289,7 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
             prev = cur
         fgp, fo = float(sol.f[0]), float(so.f[0])
         LAST["stats"] = sol.stats()
+        LAST["tie_splits"] = sol.tie_splits()
     finally:
         sol.close()
     LAST.update(f_oracle=fo, f_gpu=fgp, task_oracle=so.task_s, task_gpu=rg[-1][0], calls_gpu=len(rg))
@@ -455,6 +456,21 @@ def test_problem_families_against_oracle(oracle_built, family, first, count):
         split, _ = drive_with_replay(po, p, 60, pp=bool(seed & 1), final_check=False)
         splits += split is not None
     assert splits <= count * (0.6 if family == "linear" else 0.1), (family, splits, count)
+
+
+def test_walk_stopping_right_behind_a_tie_group(oracle_built):
+    """lattice 70219 (found by profiles/scripts/fuzz_shapes.py, round 4): in iteration 3 the walk, taking equal
+    breakpoints in index order, crosses a whole group of them and stops right BEHIND it (derivative positive,
+    dtm < 0) -- the reference's heap order puts another member first and stops INSIDE the group, one variable
+    fewer fixed (nseg 12 vs 13).  No order of a group's members can end the walk inside it unless the derivative
+    on arrival plus the group's positive jumps is positive: such groups (grp_sens, solver_walk.inl) send the walk
+    through the reference's own order, like a walk that stops in front of an equal breakpoint."""
+    po = oracle_built
+    p = FAMILIES["lattice"](po, 70219)
+    split, _ = drive_with_replay(po, p, 60, pp=True, final_check=False)
+    assert split is None and LAST["tie_splits"] >= 1, (split, LAST)
+    split, _ = drive_with_replay(po, p, 60, pp=False, final_check=False, replay_all=True)
+    assert split is None
 
 
 def _run_checkpointed(po, p, max_iter, pp, prob, seed, fg_prob=0.0):
