@@ -36,5 +36,7 @@ for seed in range(first, first + count):
     if (seed - first) % 100 == 99:
         print("... %d problems, %d splits (each reproduced one-step), %d failures, %.0f s"
               % (total, splits, bad, time.time() - t0), flush=True)
-print("problems %d  splits reproduced %d  failures %d  (%.0f s)" % (total, splits, bad, time.time() - t0))
+print("problems %d  splits reproduced %d  (of them line-search branch flips at one ulp of g'd, "
+      "tests/test_gpu_fuzz.py _line_search_branch_flip: %d %s)  failures %d  (%.0f s)"
+      % (total, splits, len(tf.FLIPS), tf.FLIPS[:4], bad, time.time() - t0))
 sys.exit(1 if bad else 0)
