@@ -616,8 +616,10 @@ def main():
                 "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col,
                 "stores": stores}
     rec_us = pass_record("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
-                         "first trial point: W'd of cauchy, S'y / S's of matupd, formk's new row)"
-                         % (tname, mc, nts), upd_bpr, "none", "update_scan" + ubs)
+                         "first trial point: W'd of cauchy, S'y / S's of matupd, formk's new row%s)"
+                         % (tname, mc, nts, "; col - 1 > 20: two launches of the <20> kernel over half of the columns "
+                            "each + a merge, timed together, priced at the bytes of ONE pass" if mc > 20 else ""),
+                         upd_bpr, "none", "update_scan" + ubs)
     entry = "ping-pong entry" if run.pp else "classic entry"
     if run.pp:
         st_txt = "trial x + Ws/Wy column (3 of %d streams; t = x, r = g are a change of roles)" % (2 * col + 7)
@@ -765,7 +767,7 @@ def main():
             ("the same per-rank shape WITHOUT LBFGSB_F_DEFER_LNSRCH (every FG_LNSRCH return waits for the storing "
              "pass's sums: what an ordinary reverse-communication caller gets)",
              dict(n=12_500_000, m=10, real32=False, kind=0, rccl_self=True, steps=60, warm_min=12, defer=False)),
-            ("m = 32 (three passes over W per iteration: col > 20), n = 5e7, fp64", dict(n=50_000_000, m=32,
+            ("m = 32 (two passes over W per iteration; the update pass split over the columns: col > 21), n = 5e7, fp64", dict(n=50_000_000, m=32,
              real32=False, kind=0, rccl_self=False, steps=10, warm_min=33)),
         ]
         out["other_configs"] = []

@@ -433,7 +433,8 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  * behaves as created unless this is called.  Names (value):
  *   "two_pass" (0/1)        the two-pass iteration with W'Z r in closed form; 0 = always the
  *                           cmprlb_wtv pass (three passes over W)
- *   "two_pass_maxcol" (0..20)  largest col that takes the two-pass iteration
+ *   "two_pass_maxcol" (0..32)  largest col that takes the two-pass iteration (default 32; beyond 21 pairs the update
+ *                           pass runs as two launches over half of the columns each; 20 = three passes there)
  *   "lean" (0/1)            z and d = x - t left implicit by the storing pass
  *   "spec_capture" (0/1)    the update pass hands the next walk's first breakpoints over
  *   "pg_min" (count)        LBFGSB_F_PARALLEL_GCP: walks with more breakpoints in reach than this

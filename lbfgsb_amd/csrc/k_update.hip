@@ -371,15 +371,72 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   }
   block_reduce_store<NA>(acc, X + NX, 1, 1, part, MAX_BLOCKS);
 }
+// ---- 20 < nold <= 32 with formk's new-row sums: the split pass ----
+// Eight sums per column pair are 256 fp64 accumulators at MC = 32 -- no sharing between two lanes brings that
+// into the register file next to the 64 operands of a row.  The pass runs as TWO launches of the MC = 20
+// kernel over half of the columns each (a sub-range of the ring of pairs is again a ring: head' = head + j0):
+// W is still read once, the row vectors (x, g, r, d, bounds: ~10 % of the bytes) twice -- against a third
+// pass over W (cmprlb_wtv) in the iteration, which this saves.  The sums that do not depend on the columns
+// (y'y, the line search's g'd, cauchy's f1 and counts, the new pair's own dots) are taken from the first launch,
+// which also stores iwhere; the second finds iwhere already final (the n-loop's update is idempotent).
+// One finalize for both; update_split_merge_kernel puts the results into the layout of a single MC = 32 launch.
+__device__ __forceinline__ int split_src(int k, int c0, int c1, int sa, int sb, int ma, int mb) {
+  // (ma, mb: the column capacity each half ran with -- 20, or 10 for a second half of exactly 10 columns)
+  constexpr int MO = 32, XO = 4 * MO + 9, NXO = 4 * MO + 4;
+  const int xa = 4 * ma + 9, xb = 4 * mb + 9;
+  // slot `base(mi)` + j of a half's own layout, for logical column j of the whole
+  auto colmap = [&](int j, int basea, int baseb) {
+    return j < c0 ? sa + basea + j : (j < c0 + c1 ? sb + baseb + (j - c0) : -1);
+  };
+  if (k < MO) return colmap(k, 0, 0);                                          // Sy(col, .)
+  if (k < 2 * MO) return colmap(k - MO, ma, mb);                               // Ss(., col)
+  if (k == 2 * MO) return sa + 2 * ma;                                         // y'y
+  if (k < 3 * MO + 1) return colmap(k - (2 * MO + 1), 2 * ma + 1, 2 * mb + 1);  // p (Wy half)
+  if (k == 3 * MO + 1) return sa + 3 * ma + 1;
+  if (k < 4 * MO + 2) return colmap(k - (3 * MO + 2), 3 * ma + 2, 3 * mb + 2);  // p (Ws half)
+  if (k < XO) return sa + 4 * ma + 2 + (k - (4 * MO + 2));  // new Ws column . d, f1, counts, g'd, #iwhere changed
+  const int k2 = k - XO;
+  if (k2 < 4 * MO) return colmap(k2 % MO, xa + (k2 / MO) * ma, xb + (k2 / MO) * mb);  // the four new-row vectors
+  if (k2 < NXO) return sa + xa + 4 * ma + (k2 - 4 * MO);                       // their four scalars
+  return sa + xa + 4 * ma + 4 + (k2 - NXO);                                    // bkmin, |proj g|
+}
+__global__ __launch_bounds__(BLOCK) void update_split_merge_kernel(double *res, int sa, int sb, int dst, int c0,
+                                                                   int c1, int ma, int mb) {
+  constexpr int NO = 4 * 32 + 11 + 4 * 32 + 4;
+  for (int k = threadIdx.x; k < NO; k += BLOCK) {
+    const int s = split_src(k, c0, c1, sa, sb, ma, mb);
+    res[dst + k] = s >= 0 ? res[s] : 0.0;
+  }
+}
+
 template <typename T>
 void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u, const nb_t *nbd,
                         const T *g, const T *r, const T *d, int dimpl, double stp, iw_t *iwhere,
                         T *tbrk, WStore<T> w, int head, int col, int itail, int store_pair,
                         int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
                         uint32_t ccap, uint32_t *ccount, int ub) {
+  const int nold = col - 1;
+  if (newrow && maxc_for(nold) > 20 && maxc_for(nold) <= MAXM) {  // the split pass (see above)
+    if (!q.d_part_split || q.part_sel != 0 || store_pair) {
+      if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "update_scan: split pass";
+      return;
+    }
+    const int c0 = (nold + 1) / 2, c1 = nold - c0, dst = q.res_off;
+    q.res_off = SPLIT_A;
+    q.hold_fin = true;  // (one finalize launch for both halves)
+    launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w, head, c0 + 1, itail, 0, store_iw,
+                          1, -1.0, ckeys, cidx, ccap, ccount, ub);
+    q.res_off = SPLIT_B, q.part_sel = 3;
+    launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, (T *)nullptr, w,
+                          (head - 1 + c0) % w.m + 1, c1 + 1, itail, 0, 0, 1, -1.0, ckeys, cidx, ccap, ccount, ub);
+    q.res_off = dst, q.part_sel = 0;
+    hipLaunchKernelGGL(update_split_merge_kernel, dim3(1), dim3(BLOCK), 0, q.stream, q.d_res, SPLIT_A, SPLIT_B, dst,
+                       c0, c1, maxc_for(c0), maxc_for(c1));
+    LB_LAUNCHED(q);
+    return;
+  }
   if (cand_hi >= 0.0) (void)hipMemsetAsync(ccount, 0, sizeof(uint32_t), q.stream);
   int gr = 0;
-  const int nold = col - 1;
 #define LB_UPDSCAN(NEWROWV)                                                                          \
   DISPATCH_MAXC_NT(nold, q.nt, DISPATCH_PIPE(MC, {                                                   \
                      constexpr bool NRV = NEWROWV && MC <= 20;                                       \

@@ -14,7 +14,11 @@ constexpr int BLOCK = 256;        // 4 wave64 per workgroup
 constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 workgroups, grid-stride beyond that
 constexpr int GRAM_BLOCKS = 1024;
 constexpr int MAXM = 32;          // LBFGSB_MAX_M
-constexpr int RES_MAX = 6 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 8*20+15 of update_scan(newrow)
+constexpr int RES_MAX = 8 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 8*MC+15 of update_scan(newrow)
+// update pass with formk's new-row sums at 20 < col - 1 <= 32 (k_update.hip): two launches over half of the columns
+// each; their results land at d_res[SPLIT_A..), d_res[SPLIT_B..) and are merged into the one-launch layout
+constexpr int SPLIT_SLOTS = 8 * 20 + 16, SPLIT_A = RES_MAX + 16, SPLIT_B = SPLIT_A + SPLIT_SLOTS;
+constexpr int SPLIT_END = SPLIT_B + SPLIT_SLOTS;
 
 // per-context launch options (lbfgsb_hip_set_option; nothing is read from the environment)
 struct Tune {
@@ -45,7 +49,8 @@ struct Queue {
   bool hold_fin = false;
   FinJob held[2];
   int nheld = 0;
-  double *part() const { return part_sel == 0 ? d_part : d_part_alt[part_sel - 1]; }
+  double *d_part_split = nullptr;  // [SPLIT_SLOTS][MAX_BLOCKS]: the second half of a split update pass (part_sel = 3)
+  double *part() const { return part_sel == 0 ? d_part : (part_sel == 3 ? d_part_split : d_part_alt[part_sel - 1]); }
   // finalize as publisher (single-rank contexts): device views of the host mirror of d_res and of the
   // sequence word, the workgroup counter, the number of the last publishing launch
   bool fin_publish = false;
@@ -428,7 +433,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out);
 
 inline int update_scan_extra(int nold, int newrow) {
   const int mc = maxc_for(nold);
-  return newrow && mc <= 20 ? 4 * mc + 4 : 0;
+  return newrow && mc <= MAXM ? 4 * mc + 4 : 0;  // (mc = 32: the split pass, k_update.hip)
 }
 
 // finalize: partials -> d_res (nsum sums, then nmin mins, then nmax maxes); takes parked jobs along

@@ -6,8 +6,9 @@
 // launch from the k_*.hip files; every 2m x 2m operation is host code from
 // host_dense.hpp.  One host thread per context, one HIP stream per context.
 //
-// One steady-state iteration on a bounded problem with col <= 20 pairs stored (DESIGN.md 4a
-// has the why) -- two passes over W:
+// One steady-state iteration on a bounded problem with col <= 32 pairs stored (DESIGN.md 4a
+// has the why) -- two passes over W (beyond 21 pairs the first one is two launches over half of
+// the columns each, k_update.hip "the split pass"):
 //   FG_LNSRCH entry : update_scan as the evaluation of the first trial point  [read-only, 1 sync]
 //                     (g'd and |proj g| for dcsrch; if accepted also matupd's sums, the next
 //                      cauchy scan's sums and formk's new row) -- later trials: lnsrlb_eval
@@ -18,8 +19,8 @@
 //     subsm+lnsrlb  : W'Z r in closed form on the host (subspace_closed_form); subsm_update:
 //                     Newton step, projection, line-search set-up, first trial x, commits the
 //                     pending pair                                            [stores, 1 sync]
-// Fallback with a third pass (cmprlb_wtv: r, W'r, formk's new row): col > 20, few free variables,
-// long walks.  Other paths (col = 0, restarts, unconstrained): projgr, cauchy_scan,
+// Fallback with a third pass (cmprlb_wtv: r, W'r, formk's new row): few free variables, long walks,
+// option two_pass_maxcol.  Other paths (col = 0, restarts, unconstrained): projgr, cauchy_scan,
 // cauchy_finish, formk_gram, update_pairs, lnsrlb_begin/step, pair_commit, xcp_fill,
 // subsm_dir/backtrack.
 //
@@ -145,7 +146,7 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_fin_count), F(d_fcount),
+        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_part_split), F(q.d_fin_count), F(d_fcount),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all),
         F(ub_buf), F(mg_keys[0]), F(mg_keys[1]), F(mg_vals[0]), F(mg_vals[1]), F(mg_tmp), F(d_merged);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
@@ -224,6 +225,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // (the widest phase or a from-scratch Gram; behind DEFER_OFF the four deferred sums, behind SPEC_OFF the
     //  speculative freev counts + formk patch of a trial point: 4 + E + 1)
     res_len = std::max<size_t>(std::max<size_t>(lbk::RES_MAX, E) + 8, (size_t)SPEC_OFF + 4 + E + 1 + 8);
+    res_len = std::max<size_t>(res_len, (size_t)lbk::SPLIT_END + 8);  // (the two halves of a split update pass)
     HIPCHK(hipMalloc(&q.d_part, (size_t)lbk::RES_MAX * lbk::MAX_BLOCKS * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_res, res_len * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_gpart, (E + 1) * lbk::GRAM_BLOCKS * sizeof(double)));  // (+ the eager patch's flag slot)
@@ -243,6 +245,8 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMemsetAsync(q.d_fin_count, 0, 64, stream));
     for (double *&pa : q.d_part_alt)
       HIPCHK(hipMalloc(&pa, (size_t)lbk::Queue::ALT_SLOTS * lbk::MAX_BLOCKS * sizeof(double)));
+    if (m > 20 && m <= lbk::MAXM)  // the second half of a split update pass (k_update.hip)
+      HIPCHK(hipMalloc(&q.d_part_split, (size_t)lbk::SPLIT_SLOTS * lbk::MAX_BLOCKS * sizeof(double)));
     q.fin_publish = spin_on;
     // cauchy selection scratch (window mode); the full-sort buffers grow on demand
     CHK(ensure_sel(SEL_CAP));
@@ -726,7 +730,8 @@ class Solver final : public lbfgsb_hip_ctx {
         sfv.valid = false;
         const int sf_upcl = c2 - 1;
         const bool do_sfv = spec_freev_on && sfv_hot && cnstnd && store_iw && index_valid && !index && two_pass &&
-                            c2 <= two_pass_maxcol && sf_upcl > 0 && chi < 0.0 && print_level < 99 &&
+                            c2 <= two_pass_maxcol && sf_upcl > 0 && lbk::maxc_for(sf_upcl) <= 20 && chi < 0.0 &&
+                            print_level < 99 &&
                             !(flags & LBFGSB_F_PARALLEL_GCP);
         if (do_sfv) {
           const int par = fv_parity;

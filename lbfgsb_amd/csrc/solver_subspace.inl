@@ -416,9 +416,10 @@
   //      pre-walk free set, the walk corrects it for the rows it fixes, and W'Z r follows in
   //      closed form from the walk's p and WN1 (subspace_closed_form) -- no cmprlb pass ----
   bool two_pass = true;  // (option "two_pass")
-  // (col <= 20: beyond that the update pass has no registers for the 4 col + 4 extra sums;
-  //  option "two_pass_maxcol" lowers the limit, for measurements)
-  int two_pass_maxcol = 20;
+  // (every col the fused kernels take; beyond 21 stored pairs the update pass has no registers for the 4 col + 4
+  //  extra sums and runs as two launches over half of the columns each, k_update.hip "the split pass";
+  //  option "two_pass_maxcol" lowers the limit, for measurements: 20 = round 3's three passes at col > 20)
+  int two_pass_maxcol = lbk::MAXM;
   bool exact_always = false;  // (option "exact_always": every walk in the reference's heap order)
   bool defer_on = false;      // (LBFGSB_F_DEFER_LNSRCH / option "defer_lnsrch")
   bool fold_fin = true;       // (option "fold_finalize": reductions nobody waits for yet park their finalize)
@@ -440,7 +441,7 @@
       return 0;
     };
     if (k == "two_pass") return flag(two_pass);
-    if (k == "two_pass_maxcol") return in_range(0, 20, two_pass_maxcol);
+    if (k == "two_pass_maxcol") return in_range(0, lbk::MAXM, two_pass_maxcol);
     if (k == "lean") return flag(lean_on);
     if (k == "spec_capture") return flag(spec_on);
     if (k == "exact_always") return flag(exact_always);

@@ -368,6 +368,8 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     (8000, 30, 1200, 33, 80, None), (8100, 20, 1200, 33, 80, "pp"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
+    # col > 21 without the split update pass: three passes over W (the pair-shared cmprlb_wtv kernel at MC = 32)
+    (5000, 40, 3000, 21, 33, "two_pass_maxcol=20"), (5100, 30, 3000, 21, 33, "pp,two_pass_maxcol=20"),
     (7000, 40, 1500, 1, 25, "spec_capture=1"), (7100, 40, 1500, 1, 25, "two_pass=0"),
     (7200, 40, 1500, 1, 25, "lean=0")])
 def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi, switch):

@@ -53,6 +53,8 @@ def oracle_rows(po, n, m, iters, mixed):
     (4, "gloo", 10007, 5, 6, True),       # four ranks on one GPU, m = 5
     (2, "gloo", 30011, 20, 26, True),     # m = 20 until the memory is full: the pair-shared update pass,
                                           # its leftover rows, the closed form at col = 20, on 2 ranks
+    (2, "gloo", 20011, 27, 33, True),     # m = 27: the update pass split over the columns (col - 1 > 20), its two
+                                          # result sets merged before the ranks' sums are gathered
     (1, "rccl1", 50021, 5, 6, True),
     (3, "gloo", 6007, 40, 46, True),      # m > 32: the unfused tile path (solver_wide.inl) over 3 ranks
 ])
