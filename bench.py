@@ -615,7 +615,20 @@ def main():
                            "not launched inside the timed region: back-to-back launches after it"),
                 "avg_launch_ms_back_to_back": ms_iso, "rows_per_launch": n_loc, "col": col,
                 "stores": stores}
-    rec_us = pass_record("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
+    wide = m > 32   # beyond the width of the fused kernels: the iteration out of tile primitives
+    if wide:
+        # no fused pass to time: one record for the whole iteration, priced at the bytes the fused route would move
+        it_bytes = (upd_bpr + sub_bpr + 2 * rbytes) * n_loc
+        ach = it_bytes / (dt / a.steps) / 1e9
+        wide_rec = {"bound": "hbm", "kernel": "m > 32: unfused tile passes (solver_wide.inl) -- the whole iteration, "
+                    "priced at the bytes of the fused two-pass route", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": it_bytes, "avg_launch_ms": dt / a.steps * 1e3,
+                    "launches_timed": a.steps, "rows_per_launch": n_loc, "col": col}
+
+    def pass_record_or_none(*args):
+        return None if wide else pass_record(*args)
+    rec_us = pass_record_or_none("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
                          "first trial point: W'd of cauchy, S'y / S's of matupd, formk's new row%s)"
                          % (tname, mc, nts, "; col - 1 > 20: two launches of the <20> kernel over half of the columns "
                             "each + a merge, timed together, priced at the bytes of ONE pass" if mc > 20 else ""),
@@ -627,26 +640,30 @@ def main():
         st_txt = "t, r, trial x + Ws/Wy column (5 of %d streams)" % (2 * col + 9)
     else:
         st_txt = "z, d, t, r, trial x + Ws/Wy column (7 of %d streams)" % (2 * col + 11)
-    rec_su = pass_record("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (%s, pending pair committed)"
+    rec_su = pass_record_or_none("subsm_update", 3, "subsm_update_kernel<%s, %d, %s> (%s, pending pair committed)"
                          % (tname, mc, nts, entry), sub_bpr, st_txt,
                          ("subsm_update_pp" if run.pp else "subsm_update") + ubs)
-    rec_cw = pass_record("cmprlb_wtv", 2, "cmprlb_wtv_kernel<%s, %d, true, %s>" % (tname, mc, nts),
+    rec_cw = pass_record_or_none("cmprlb_wtv", 2, "cmprlb_wtv_kernel<%s, %d, true, %s>" % (tname, mc, nts),
                          (2 * col + 2) * rbytes + 1, "none", "cmprlb_wtv")
     closed_steps, three_steps, handed_windows = sol.path_counts()
-    if not rec_cw["launches_timed"]:
+    if wide:
+        roofline, others, roofline_wtv = wide_rec, [], None
+        rec_us = {"avg_launch_ms": None, "frac": None}
+    else:
+      if not rec_cw["launches_timed"]:
         rec_cw["note"] = "not part of this run's iteration (W'Z r in closed form); timed back to back"
-    # the headline roofline is the DOMINANT kernel of the iteration: the one with the largest total
-    # time inside the timed region -- the storing pass
-    recs = [rec_su, rec_us] + ([rec_cw] if rec_cw["launches_timed"] else [])
-    recs.sort(key=lambda d: -(d["avg_launch_ms"] * max(d["launches_timed"], 1)))
-    roofline = recs[0]
-    roofline["dominant"] = "largest share of the iteration: %.2f of %.2f ms per step" % (
+      # the headline roofline is the DOMINANT kernel of the iteration: the one with the largest total
+      # time inside the timed region -- the storing pass
+      recs = [rec_su, rec_us] + ([rec_cw] if rec_cw["launches_timed"] else [])
+      recs.sort(key=lambda d: -(d["avg_launch_ms"] * max(d["launches_timed"], 1)))
+      roofline = recs[0]
+      roofline["dominant"] = "largest share of the iteration: %.2f of %.2f ms per step" % (
         roofline["avg_launch_ms"] * roofline["launches_timed"] / a.steps, dt / a.steps * 1e3)
-    others = recs[1:] + ([] if rec_cw["launches_timed"] else [rec_cw])
-    ms_kernel = sol.wtv_time(run.g, col, head, a.roofline_reps)
-    alg_bytes = (2 * col + 1) * n_loc * rbytes
-    achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
-    roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s, %d, %s> (the bare WS/WY matvec W'v)" % (tname, mc, nts),
+      others = recs[1:] + ([] if rec_cw["launches_timed"] else [rec_cw])
+      ms_kernel = sol.wtv_time(run.g, col, head, a.roofline_reps)
+      alg_bytes = (2 * col + 1) * n_loc * rbytes
+      achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
+      roofline_wtv = {"bound": "hbm", "kernel": "wtv_kernel<%s, %d, %s> (the bare WS/WY matvec W'v)" % (tname, mc, nts),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": static_traffic("wtv_traffic.json", None, n_loc),
                     "traffic_source": "profiles/wtv_traffic.json (static PMC measurement, see roofline)",
