@@ -455,6 +455,8 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *   "skip_reuse" (0/1)      after a skipped BFGS update, cauchy's n-loop sums come from the pass that evaluated
  *                           the accepted point (+ a one-column scan when the memory is full) (default 1) /
  *                           from a scan over all of W
+ *   "wide_incr" (0/1)       m > 32: formk adds the new pair's row and column to WN1 while no row changes status
+ *                           (default 1) / from scratch whenever it runs
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel

@@ -57,6 +57,33 @@ void launch_masked_copy(Queue &q, int64_t n, const T *src, const iw_t *iwhere, i
   LB_LAUNCHED(q);
 }
 
+// the rows of a (sorted) changed-row list as dense records: out[k][c] = Wy(row_k, c) for c < upcl, Ws(row_k,
+// c - upcl) beyond -- what formk's patch for entering / leaving variables (:1801-1851) needs, for any number of
+// pairs (formk_patch_kernel keeps its tiles in LDS and is sized for 32)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void rows_gather_kernel(const uint32_t *__restrict__ chg, uint32_t cnt,
+                                                            const T *__restrict__ ws, const T *__restrict__ wy,
+                                                            int64_t ldw, int m, int head, int upcl,
+                                                            double *__restrict__ out) {
+  const int64_t total = (int64_t)cnt * 2 * upcl;
+  for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+    const int64_t k = e / (2 * upcl);
+    const int c = (int)(e % (2 * upcl)), jj = c < upcl ? c : c - upcl;
+    const int64_t off = (int64_t)((head - 1 + jj) % m) * ldw + (int64_t)(chg[k] & 0x7FFFFFFFu);
+    out[e] = c < upcl ? (double)wy[off] : (double)ws[off];
+  }
+}
+template <typename T>
+void launch_rows_gather(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w, int head, int upcl, double *out) {
+  const int64_t total = (int64_t)cnt * 2 * upcl;
+  int64_t gr = (total + BLOCK - 1) / BLOCK;
+  if (gr < 1) gr = 1;
+  if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
+  hipLaunchKernelGGL(rows_gather_kernel<T>, dim3((int)gr), dim3(BLOCK), 0, q.stream, chg, cnt, w.ws, w.wy, w.ld, w.m,
+                     head, upcl, out);
+  LB_LAUNCHED(q);
+}
+
 // cauchy's direction as a vector (:1270-1330): d_i = -g_i for the variables that move (tbrk >= 0, incl.
 // +inf), 0 for the others (tbrk = -1), from the breakpoint times the scan has just written
 template <typename T>
@@ -148,6 +175,7 @@ void launch_subsm_project(Queue &q, int64_t n, T *z, T *dir, const T *x, const T
 #define INSTANTIATE(T) \
   template void launch_tile_axpy<T>(Queue &, int64_t, WStore<T>, int, int, const Coef &, double, const iw_t *, int, T *); \
   template void launch_masked_copy<T>(Queue &, int64_t, const T *, const iw_t *, int, T *); \
+  template void launch_rows_gather<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int, double *); \
   template void launch_cauchy_dvec<T>(Queue &, int64_t, const T *, const T *, T *); \
   template void launch_cmprlb_init<T>(Queue &, int64_t, const T *, const T *, const T *, const iw_t *, double, int, T *); \
   template void launch_subsm_project<T>(Queue &, int64_t, T *, T *, const T *, const T *, const T *, const T *, const int32_t *, const iw_t *, double);

@@ -409,6 +409,8 @@ void launch_tile_axpy(Queue &q, int64_t n, WStore<T> w, int head, int tc, const 
 // out = src on the free (want_free) / active rows, 0 elsewhere
 template <typename T>
 void launch_masked_copy(Queue &q, int64_t n, const T *src, const iw_t *iwhere, int want_free, T *out);
+template <typename T>
+void launch_rows_gather(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w, int head, int upcl, double *out);
 // cauchy's d as a vector from tbrk (moving rows: -g, others 0)
 template <typename T>
 void launch_cauchy_dvec(Queue &q, int64_t n, const T *g, const T *tbrk, T *out);

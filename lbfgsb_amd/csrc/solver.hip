@@ -146,7 +146,7 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_part_split), F(q.d_fin_count), F(d_fcount),
+        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_part_split), F(q.d_fin_count), F(d_fcount), F(wide_rows),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all),
         F(ub_buf), F(mg_keys[0]), F(mg_keys[1]), F(mg_vals[0]), F(mg_vals[1]), F(mg_tmp), F(d_merged);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
@@ -1078,7 +1078,16 @@ class Solver final : public lbfgsb_hip_ctx {
       // every col the fused kernels take (round 3: col <= 20; beyond that formk ran from scratch in every
       // iteration -- 30 ms of the 45 at m = 32, n = 5e7)
       const bool incr = wrk && col <= lbk::MAXM && !wide();
-      if (wrk && !incr) CHK(formk(col, head, theta, info));
+      if (wrk && !incr) {
+        // (m > 32: the new pair's row alone when no row changed status, solver_wide.inl)
+        bool incr_done = false;
+        if (wide() && wide_incr_on && wide_wn1_ok) CHK(wide_formk_incr(col, head, updatd, iupdat, incr_done));
+        if (incr_done)
+          formk_factor(col, theta, info);
+        else
+          CHK(formk(col, head, theta, info));
+        wide_wn1_ok = true;  // (WN1 describes this iteration's free set and pairs from here on)
+      }
       if (info != 0) {  // :666-682
         if (ipr >= 1)
           std::fprintf(rep.out,

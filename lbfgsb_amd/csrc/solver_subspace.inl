@@ -27,14 +27,17 @@
   // WN1 kept incrementally exactly as the reference does (:1735-1851): shift, new row and
   // column from `nr` (the four sum vectors that rode along in the cmprlb_wtv pass), and
   // patches for the variables that entered / left the free set (sparse signed Gram).
-  int formk_incremental(int col, int head, bool updatd, int iupdat, const double *nr, int MCnr) {
+  int formk_incremental(int col, int head, bool updatd, int iupdat, const double *nr, int MCnr,
+                        const std::vector<double> *patch = nullptr) {
     const int m2 = 2 * m;
     lbh::Mat WN1{snd.data(), m2};
     const int upcl = updatd ? col - 1 : col;
     const int64_t nchg = nenter_g + (nglob + 1 - ileave_g);
     bool patched = false;
     std::vector<double> P;
-    if (nchg > 0 && upcl > 0 && eager.valid && eager.upcl == upcl && eager.head == head) {
+    if (patch) {  // (m > 32: the caller's own patch sums, solver_wide.inl)
+      if (nchg > 0 && upcl > 0) P = *patch, patched = true;
+    } else if (nchg > 0 && upcl > 0 && eager.valid && eager.upcl == upcl && eager.head == head) {
       P = eager.P;  // (came with freev's counts: same kernels, same sums)
       patched = true;
       eager.valid = false;
@@ -416,6 +419,8 @@
   //      pre-walk free set, the walk corrects it for the rows it fixes, and W'Z r follows in
   //      closed form from the walk's p and WN1 (subspace_closed_form) -- no cmprlb pass ----
   bool two_pass = true;  // (option "two_pass")
+  bool wide_incr_on = true;  // (option "wide_incr": m > 32 keeps WN1 incrementally)
+  bool wide_wn1_ok = false;  // ... once a formk of this run has filled it
   // (every col the fused kernels take; beyond 21 stored pairs the update pass has no registers for the 4 col + 4
   //  extra sums and runs as two launches over half of the columns each, k_update.hip "the split pass";
   //  option "two_pass_maxcol" lowers the limit, for measurements: 20 = round 3's three passes at col > 20)
@@ -455,6 +460,7 @@
     if (k == "eager_patch") return flag(eager_on);
     if (k == "spec_freev") return flag(spec_freev_on);
     if (k == "skip_reuse") return flag(skip_reuse_on);
+    if (k == "wide_incr") return flag(wide_incr_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");

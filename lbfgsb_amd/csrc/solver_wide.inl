@@ -83,6 +83,79 @@ int wide_formk(int col, int head) {
   return 0;
 }
 
+// ... and incrementally, the way the reference keeps WN1 (:1735-1851), for the usual iteration: only the new
+// pair's row and column are missing -- the free part of the new Wy column and the active part of the new Ws
+// column against all columns: two masked copies + two tiled W'v instead of 2 col of them (at m = 40, n = 2e7
+// formk from scratch was 170 of the iteration's 184 ms) -- and the rows that entered or left the free set
+// change the old entries by their own outer products (:1801-1851): their records are gathered
+// (rows_gather_kernel; the sparse patch kernel of the fused route keeps its tiles in LDS and is sized for 32
+// pairs), summed on the host in the order of the sorted list, and reduced over the ranks like every sum.
+// More changed rows than WIDE_PATCH_DOUBLES of records: from scratch.
+static constexpr int64_t WIDE_PATCH_DOUBLES = 1 << 22;
+double *wide_rows = nullptr;
+size_t wide_rows_cap = 0;
+int wide_formk_incr(int col, int head, bool updatd, int iupdat, bool &done) {
+  done = false;
+  const int upcl = updatd ? col - 1 : col;
+  const int64_t nchg = nenter_g + (nglob + 1 - ileave_g);
+  std::vector<double> P;
+  if (nchg > 0 && upcl > 0) {
+    if (nchg > (int64_t)CHG_CAP || nchg * 2 * upcl > WIDE_PATCH_DOUBLES) return 0;  // (the same on every rank)
+    CHK(commit_pending((const T *)cg, col, head));
+    const uint32_t nl = std::min<uint32_t>(chg_local, CHG_CAP);
+    const int tri = upcl * (upcl + 1) / 2, E = 2 * upcl * upcl + upcl;
+    P.assign((size_t)E, 0.0);
+    if (nl > 0) {
+      const size_t need = (size_t)nl * 2 * upcl;
+      if (need > wide_rows_cap) {
+        if (wide_rows) (void)hipFree(wide_rows);
+        wide_rows = nullptr, wide_rows_cap = 0;
+        HIPCHK(hipMalloc(&wide_rows, need * sizeof(double)));
+        wide_rows_cap = need;
+      }
+      const uint32_t *lst = lbk::launch_sort_u32(q, sort_tmp, sort_tmp_bytes, d_chg, idx[1], nl);
+      lbk::launch_rows_gather<T>(q, lst, nl, W(), head, upcl, wide_rows);
+      std::vector<double> rows(need);
+      std::vector<uint32_t> ids(nl);
+      HIPCHK(hipMemcpyAsync(rows.data(), wide_rows, need * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(ids.data(), lst, (size_t)nl * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      nsync++;
+      for (uint32_t k = 0; k < nl; ++k) {  // (+ entering, - leaving: the flag in bit 31)
+        const double sg = (ids[k] & 0x80000000u) ? -1.0 : 1.0;
+        const double *y = &rows[(size_t)k * 2 * upcl], *s_ = y + upcl;
+        for (int i = 0; i < upcl; ++i) {
+          const double yi = sg * y[i], si = sg * s_[i];
+          double *py = &P[(size_t)i * (i + 1) / 2], *ps = &P[(size_t)tri + (size_t)i * (i + 1) / 2];
+          for (int j = 0; j <= i; ++j) py[j] += yi * y[j], ps[j] += si * s_[j];
+          double *pm = &P[(size_t)2 * tri + (size_t)i * upcl];
+          for (int j = 0; j < upcl; ++j) pm[j] += si * y[j];
+        }
+      }
+    }
+    if (nranks > 1) {  // every rank's share, summed in rank order like every other sum
+      HIPCHK(hipMemcpyAsync(q.d_res, P.data(), (size_t)E * sizeof(double), hipMemcpyHostToDevice, stream));
+      CHK(fetch(E, 0, 0));
+      P.assign(h_res, h_res + E);
+    }
+  }
+  std::vector<double> nr;
+  if (updatd) {
+    CHK(commit_pending((const T *)cg, col, head));
+    nr.assign((size_t)4 * col, 0.0);
+    std::vector<double> a(col), b(col);
+    lbk::launch_masked_copy<T>(q, n, wcol(wy, head, col - 1), iwhere, 1, xp);
+    CHK(wide_wtv(xp, col, head, a.data(), b.data()));
+    for (int j = 0; j < col; ++j) nr[0 * col + j] = a[j], nr[3 * col + j] = b[j];  // Y'ZZ'Y row, R_z column
+    lbk::launch_masked_copy<T>(q, n, wcol(ws, head, col - 1), iwhere, 0, xp);
+    CHK(wide_wtv(xp, col, head, a.data(), b.data()));
+    for (int j = 0; j < col; ++j) nr[1 * col + j] = b[j], nr[2 * col + j] = a[j];  // S'AA'S row, L_a row
+  }
+  CHK(formk_incremental(col, head, updatd, iupdat, nr.data(), col, &P));
+  done = true;
+  return 0;
+}
+
 // cmprlb (:1548-1586) with r as a vector: tbrk = r on the free rows, 0 elsewhere
 int wide_cmprlb(const T *x, const T *l, const T *u, const T *g, double theta, int col, int head, bool cnstnd,
                 int &info) {

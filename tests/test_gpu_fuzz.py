@@ -366,6 +366,8 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     (0, 120, 400, 1, 13, "pp"), (5000, 40, 3000, 11, 33, "pp"), (7300, 40, 1500, 1, 25, "pp,lean=0"),
     # m > 32: the iteration out of unfused tile primitives (solver_wide.inl)
     (8000, 30, 1200, 33, 80, None), (8100, 20, 1200, 33, 80, "pp"),
+    # ... with formk from scratch whenever it runs (default: the new pair's row alone while the free set stands)
+    (8200, 15, 1200, 33, 80, "wide_incr=0"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
     # col > 21 without the split update pass: three passes over W (the pair-shared cmprlb_wtv kernel at MC = 32)

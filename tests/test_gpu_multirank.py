@@ -56,7 +56,8 @@ def oracle_rows(po, n, m, iters, mixed):
     (2, "gloo", 20011, 27, 33, True),     # m = 27: the update pass split over the columns (col - 1 > 20), its two
                                           # result sets merged before the ranks' sums are gathered
     (1, "rccl1", 50021, 5, 6, True),
-    (3, "gloo", 6007, 40, 46, True),      # m > 32: the unfused tile path (solver_wide.inl) over 3 ranks
+    (3, "gloo", 6007, 40, 46, True),      # m > 32: the unfused tile path (solver_wide.inl) over 3 ranks -- WN1 kept
+                                          # incrementally, the changed rows' patch summed per rank and reduced
 ])
 def test_sharded_trajectory_matches_oracle(oracle_built, tmp_path, world, mode, n, m, iters, mixed):
     po = oracle_built
