@@ -371,40 +371,49 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   }
   block_reduce_store<NA>(acc, X + NX, 1, 1, part, MAX_BLOCKS);
 }
-// ---- 20 < nold <= 32 with formk's new-row sums: the split pass ----
+// ---- more than 20 old pairs with formk's new-row sums: the split pass ----
 // Eight sums per column pair are 256 fp64 accumulators at MC = 32 -- no sharing between two lanes brings that
-// into the register file next to the 64 operands of a row.  The pass runs as TWO launches of the MC = 20
-// kernel over half of the columns each (a sub-range of the ring of pairs is again a ring: head' = head + j0):
-// W is still read once, the row vectors (x, g, r, d, bounds: ~10 % of the bytes) twice -- against a third
-// pass over W (cmprlb_wtv) in the iteration, which this saves.  The sums that do not depend on the columns
-// (y'y, the line search's g'd, cauchy's f1 and counts, the new pair's own dots) are taken from the first launch,
-// which also stores iwhere; the second finds iwhere already final (the n-loop's update is idempotent).
-// One finalize for both; update_split_merge_kernel puts the results into the layout of a single MC = 32 launch.
-__device__ __forceinline__ int split_src(int k, int c0, int c1, int sa, int sb, int ma, int mb) {
-  // (ma, mb: the column capacity each half ran with -- 20, or 10 for a second half of exactly 10 columns)
-  constexpr int MO = 32, XO = 4 * MO + 9, NXO = 4 * MO + 4;
-  const int xa = 4 * ma + 9, xb = 4 * mb + 9;
-  // slot `base(mi)` + j of a half's own layout, for logical column j of the whole
-  auto colmap = [&](int j, int basea, int baseb) {
-    return j < c0 ? sa + basea + j : (j < c0 + c1 ? sb + baseb + (j - c0) : -1);
+// into the register file next to the 64 operands of a row.  The pass runs as SEVERAL launches of the MC <= 20
+// kernels over <= 16 columns each (a sub-range of the ring of pairs is again a ring: head' = head + j0):
+// W is still read once, the row vectors (x, g, r, d, bounds: ~10 % of the bytes at two parts) once per part --
+// against a third pass over W (cmprlb_wtv) in the iteration, which this saves.  The sums that do not depend on
+// the columns (y'y, the line search's g'd, cauchy's f1 and counts, the new pair's own dots) are taken from the
+// first launch, which also stores iwhere; the others find iwhere already final (the n-loop's update is
+// idempotent).  update_split_merge_kernel puts the results into the layout of ONE launch with column
+// capacity MO = maxc_stride(nold) -- a stride of the result layout only, so any number of pairs is served
+// (m > 32: solver.hip runs this pass in front of the unfused subspace steps).
+struct SplitPlan {
+  int nparts, mo;
+  int src[SPLIT_MAXPARTS], j0[SPLIT_MAXPARTS], cnt[SPLIT_MAXPARTS], mc[SPLIT_MAXPARTS];
+};
+__device__ __forceinline__ int split_src(int k, const SplitPlan &P) {
+  const int MO = P.mo, XO = 4 * MO + 9, NXO = 4 * MO + 4;
+  const int sa = P.src[0], ma = P.mc[0], xa = 4 * ma + 9;
+  // section `sec` (its offset as a function of the part's capacity mi) of logical column j
+  auto colmap = [&](int j, int mul, int add, int xmul) {
+    for (int p = 0; p < P.nparts; ++p)
+      if (j >= P.j0[p] && j < P.j0[p] + P.cnt[p]) {
+        const int mi = P.mc[p];
+        return P.src[p] + (xmul >= 0 ? 4 * mi + 9 + xmul * mi : mul * mi + add) + (j - P.j0[p]);
+      }
+    return -1;
   };
-  if (k < MO) return colmap(k, 0, 0);                                          // Sy(col, .)
-  if (k < 2 * MO) return colmap(k - MO, ma, mb);                               // Ss(., col)
-  if (k == 2 * MO) return sa + 2 * ma;                                         // y'y
-  if (k < 3 * MO + 1) return colmap(k - (2 * MO + 1), 2 * ma + 1, 2 * mb + 1);  // p (Wy half)
+  if (k < MO) return colmap(k, 0, 0, -1);                            // Sy(col, .)
+  if (k < 2 * MO) return colmap(k - MO, 1, 0, -1);                   // Ss(., col)
+  if (k == 2 * MO) return sa + 2 * ma;                               // y'y
+  if (k < 3 * MO + 1) return colmap(k - (2 * MO + 1), 2, 1, -1);     // p (Wy half)
   if (k == 3 * MO + 1) return sa + 3 * ma + 1;
-  if (k < 4 * MO + 2) return colmap(k - (3 * MO + 2), 3 * ma + 2, 3 * mb + 2);  // p (Ws half)
+  if (k < 4 * MO + 2) return colmap(k - (3 * MO + 2), 3, 2, -1);     // p (Ws half)
   if (k < XO) return sa + 4 * ma + 2 + (k - (4 * MO + 2));  // new Ws column . d, f1, counts, g'd, #iwhere changed
   const int k2 = k - XO;
-  if (k2 < 4 * MO) return colmap(k2 % MO, xa + (k2 / MO) * ma, xb + (k2 / MO) * mb);  // the four new-row vectors
-  if (k2 < NXO) return sa + xa + 4 * ma + (k2 - 4 * MO);                       // their four scalars
-  return sa + xa + 4 * ma + 4 + (k2 - NXO);                                    // bkmin, |proj g|
+  if (k2 < 4 * MO) return colmap(k2 % MO, 0, 0, k2 / MO);            // the four new-row vectors
+  if (k2 < NXO) return sa + xa + 4 * ma + (k2 - 4 * MO);             // their four scalars
+  return sa + xa + 4 * ma + 4 + (k2 - NXO);                          // bkmin, |proj g|
 }
-__global__ __launch_bounds__(BLOCK) void update_split_merge_kernel(double *res, int sa, int sb, int dst, int c0,
-                                                                   int c1, int ma, int mb) {
-  constexpr int NO = 4 * 32 + 11 + 4 * 32 + 4;
+__global__ __launch_bounds__(BLOCK) void update_split_merge_kernel(double *res, SplitPlan P, int dst) {
+  const int NO = 8 * P.mo + 15;
   for (int k = threadIdx.x; k < NO; k += BLOCK) {
-    const int s = split_src(k, c0, c1, sa, sb, ma, mb);
+    const int s = split_src(k, P);
     res[dst + k] = s >= 0 ? res[s] : 0.0;
   }
 }
@@ -416,22 +425,27 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
                         uint32_t ccap, uint32_t *ccount, int ub) {
   const int nold = col - 1;
-  if (newrow && maxc_for(nold) > 20 && maxc_for(nold) <= MAXM) {  // the split pass (see above)
-    if (!q.d_part_split || q.part_sel != 0 || store_pair) {
+  if (newrow && nold > 20) {  // the split pass (see above)
+    const int nparts = split_parts(nold);
+    if (nparts > SPLIT_MAXPARTS || q.part_sel != 0 || store_pair) {
       if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "update_scan: split pass";
       return;
     }
-    const int c0 = (nold + 1) / 2, c1 = nold - c0, dst = q.res_off;
-    q.res_off = SPLIT_A;
-    q.hold_fin = true;  // (one finalize launch for both halves)
-    launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w, head, c0 + 1, itail, 0, store_iw,
-                          1, -1.0, ckeys, cidx, ccap, ccount, ub);
-    q.res_off = SPLIT_B, q.part_sel = 3;
-    launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, (T *)nullptr, w,
-                          (head - 1 + c0) % w.m + 1, c1 + 1, itail, 0, 0, 1, -1.0, ckeys, cidx, ccap, ccount, ub);
-    q.res_off = dst, q.part_sel = 0;
-    hipLaunchKernelGGL(update_split_merge_kernel, dim3(1), dim3(BLOCK), 0, q.stream, q.d_res, SPLIT_A, SPLIT_B, dst,
-                       c0, c1, maxc_for(c0), maxc_for(c1));
+    SplitPlan P{};
+    P.nparts = nparts, P.mo = maxc_stride(nold);
+    const int dst = q.res_off, base = split_base(nold, dst);
+    int j0 = 0;
+    for (int k = 0; k < nparts; ++k) {
+      const int cnt = (nold - j0 + (nparts - k) - 1) / (nparts - k);  // balanced: 21 -> 11 + 10, 40 -> 14 + 13 + 13
+      P.src[k] = base + k * SPLIT_SLOTS, P.j0[k] = j0, P.cnt[k] = cnt, P.mc[k] = maxc_for(cnt);
+      q.res_off = P.src[k];
+      launch_update_scan<T>(q, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, k == 0 ? tbrk : (T *)nullptr, w,
+                            (head - 1 + j0) % w.m + 1, cnt + 1, itail, 0, k == 0 ? store_iw : 0, 1, -1.0, ckeys,
+                            cidx, ccap, ccount, ub);
+      j0 += cnt;
+    }
+    q.res_off = dst;
+    hipLaunchKernelGGL(update_split_merge_kernel, dim3(1), dim3(BLOCK), 0, q.stream, q.d_res, P, dst);
     LB_LAUNCHED(q);
     return;
   }

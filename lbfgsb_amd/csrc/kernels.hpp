@@ -15,10 +15,10 @@ constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 workgroups, grid-stride beyond 
 constexpr int GRAM_BLOCKS = 1024;
 constexpr int MAXM = 32;          // LBFGSB_MAX_M
 constexpr int RES_MAX = 8 * MAXM + 16;  // >= 6*MC slots of cmprlb_wtv(newrow), 8*MC+15 of update_scan(newrow)
-// update pass with formk's new-row sums at 20 < col - 1 <= 32 (k_update.hip): two launches over half of the columns
-// each; their results land at d_res[SPLIT_A..), d_res[SPLIT_B..) and are merged into the one-launch layout
-constexpr int SPLIT_SLOTS = 8 * 20 + 16, SPLIT_A = RES_MAX + 16, SPLIT_B = SPLIT_A + SPLIT_SLOTS;
-constexpr int SPLIT_END = SPLIT_B + SPLIT_SLOTS;
+// update pass with formk's new-row sums at col - 1 > 20 (k_update.hip): several launches over a part of the columns
+// each; their results land behind the merged layout in d_res (split_base) and are merged into the one-launch layout
+// (any col - 1 > 20, k_update.hip "the split pass": parts of <= 16 columns)
+constexpr int SPLIT_SLOTS = 8 * 20 + 16, SPLIT_COLS = 16, SPLIT_MAXPARTS = 64;
 
 // per-context launch options (lbfgsb_hip_set_option; nothing is read from the environment)
 struct Tune {
@@ -49,8 +49,7 @@ struct Queue {
   bool hold_fin = false;
   FinJob held[2];
   int nheld = 0;
-  double *d_part_split = nullptr;  // [SPLIT_SLOTS][MAX_BLOCKS]: the second half of a split update pass (part_sel = 3)
-  double *part() const { return part_sel == 0 ? d_part : (part_sel == 3 ? d_part_split : d_part_alt[part_sel - 1]); }
+  double *part() const { return part_sel == 0 ? d_part : d_part_alt[part_sel - 1]; }
   // finalize as publisher (single-rank contexts): device views of the host mirror of d_res and of the
   // sequence word, the workgroup counter, the number of the last publishing launch
   bool fin_publish = false;
@@ -433,9 +432,16 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, con
 template <typename T>
 void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out);
 
-inline int update_scan_extra(int nold, int newrow) {
-  const int mc = maxc_for(nold);
-  return newrow && mc <= MAXM ? 4 * mc + 4 : 0;  // (mc = 32: the split pass, k_update.hip)
+// the stride of the update pass's result layout: the column capacity of the kernel that ran, or -- beyond 32
+// columns, where the pass is split into sub-launches and merged -- the next multiple of 32
+inline int maxc_stride(int col) { return col <= MAXM ? maxc_for(col) : (col + 31) / 32 * 32; }
+inline int update_scan_extra(int nold, int newrow) { return newrow ? 4 * maxc_stride(nold) + 4 : 0; }
+// where the sub-launches of a split update pass put their results in d_res: behind the merged layout at `dst`
+inline int split_base(int nold, int dst) { return std::max(RES_MAX + 16, dst + 8 * maxc_stride(nold) + 32); }
+inline int split_parts(int nold) { return (nold + SPLIT_COLS - 1) / SPLIT_COLS; }
+// d_res doubles a context with m pairs needs for a split update pass
+inline size_t split_res_len(int m) {
+  return m <= 20 ? 0 : (size_t)split_base(m, 1) + (size_t)split_parts(m) * SPLIT_SLOTS + 8;
 }
 
 // finalize: partials -> d_res (nsum sums, then nmin mins, then nmax maxes); takes parked jobs along

@@ -146,7 +146,7 @@ class Solver final : public lbfgsb_hip_ctx {
     F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
-        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_part_split), F(q.d_fin_count), F(d_fcount), F(wide_rows),
+        F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_fin_count), F(d_fcount), F(wide_rows),
         F(d_fix), F(pg_buf), F(pg_tmp), F(sp_keys), F(sp_idx), F(sp_count), F(sp_msg), F(sp_msg_all), F(d_res_all),
         F(ub_buf), F(mg_keys[0]), F(mg_keys[1]), F(mg_vals[0]), F(mg_vals[1]), F(mg_tmp), F(d_merged);
     F(hx), F(hg), F(hl), F(hu), F(hnbd);
@@ -225,7 +225,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // (the widest phase or a from-scratch Gram; behind DEFER_OFF the four deferred sums, behind SPEC_OFF the
     //  speculative freev counts + formk patch of a trial point: 4 + E + 1)
     res_len = std::max<size_t>(std::max<size_t>(lbk::RES_MAX, E) + 8, (size_t)SPEC_OFF + 4 + E + 1 + 8);
-    res_len = std::max<size_t>(res_len, (size_t)lbk::SPLIT_END + 8);  // (the two halves of a split update pass)
+    res_len = std::max<size_t>(res_len, lbk::split_res_len(m));  // (the parts of a split update pass)
     HIPCHK(hipMalloc(&q.d_part, (size_t)lbk::RES_MAX * lbk::MAX_BLOCKS * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_res, res_len * sizeof(double)));
     HIPCHK(hipMalloc(&q.d_gpart, (E + 1) * lbk::GRAM_BLOCKS * sizeof(double)));  // (+ the eager patch's flag slot)
@@ -245,8 +245,6 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMemsetAsync(q.d_fin_count, 0, 64, stream));
     for (double *&pa : q.d_part_alt)
       HIPCHK(hipMalloc(&pa, (size_t)lbk::Queue::ALT_SLOTS * lbk::MAX_BLOCKS * sizeof(double)));
-    if (m > 20 && m <= lbk::MAXM)  // the second half of a split update pass (k_update.hip)
-      HIPCHK(hipMalloc(&q.d_part_split, (size_t)lbk::SPLIT_SLOTS * lbk::MAX_BLOCKS * sizeof(double)));
     q.fin_publish = spin_on;
     // cauchy selection scratch (window mode); the full-sort buffers grow on demand
     CHK(ensure_sel(SEL_CAP));
