@@ -39,9 +39,10 @@ enum {
 };
 
 /* m: the fused passes hold all 2 m operands of a row group in registers and are unrolled for at most
- * LBFGSB_FUSED_M pairs (two passes over W per iteration for m <= 20, three for 21..32); beyond that a
- * context composes the same steps from unfused tile kernels (k_wide.hip: correct, memory-bound, not
- * fast).  LBFGSB_MAX_M only bounds the host's O(m^2) arrays. */
+ * LBFGSB_FUSED_M pairs (two passes over W per iteration; beyond 21 stored pairs the first one runs as
+ * several launches over a part of the columns each); beyond that a context runs that first pass the same
+ * way in front of unfused tile kernels for the subspace steps (k_wide.hip) -- two passes over W as well,
+ * a few more vector kernels.  LBFGSB_MAX_M only bounds the host's O(m^2) arrays. */
 #define LBFGSB_FUSED_M 32
 #define LBFGSB_MAX_M 1024
 
@@ -455,6 +456,10 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *   "skip_reuse" (0/1)      after a skipped BFGS update, cauchy's n-loop sums come from the pass that evaluated
  *                           the accepted point (+ a one-column scan when the memory is full) (default 1) /
  *                           from a scan over all of W
+ *   "wide_fused" (0/1)      m > 32: matupd's, cauchy's and formk's sums from the update pass (split over the columns,
+ *                           one pass over W) in front of the unfused subspace steps (default 1) / all unfused
+ *   "wide_closed" (0/1)     m > 32: W'Z r in closed form and cmprlb's + subsm's updates of r as one pass over W
+ *                           (default 1) / a W'r pass and two updates
  *   "wide_incr" (0/1)       m > 32: formk adds the new pair's row and column to WN1 while no row changes status
  *                           (default 1) / from scratch whenever it runs
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)

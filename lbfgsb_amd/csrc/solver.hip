@@ -698,7 +698,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // update is real (iwhere_update_kernel at the NEW_X entry).
       // Unconstrained problems (two_pass): the same pass -- every row is free, its p = W'd is
       // W'Z r itself (r = -g, c = 0), and the new pair needs no copy pass of its own.
-      if ((cnstnd || two_pass) && first_trial && !wide()) {
+      if ((cnstnd || two_pass) && first_trial && (!wide() || wide_fused())) {
         const int store_iw = (flags & LBFGSB_F_MIRROR_INDEX) ? 0 : 1;
         int c2, h2, it2;  // matupd's pointer update (:2303-2309), as if this trial is accepted
         if (iupdat + 1 <= m) {
@@ -706,7 +706,7 @@ class Solver final : public lbfgsb_hip_ctx {
         } else {
           c2 = col, it2 = itail % m + 1, h2 = head % m + 1;
         }
-        const int MCo = lbk::maxc_for(c2 - 1);
+        const int MCo = lbk::maxc_stride(c2 - 1);
         const int NX = lbk::update_scan_extra(c2 - 1, nr_flag(c2));
         clk_begin(1);
         q.res_off = fo;
@@ -765,7 +765,7 @@ class Solver final : public lbfgsb_hip_ctx {
         L.spec_iw_changed = store_iw ? R[4 * MCo + 8] : 0.0;
         gd = R[4 * MCo + 7];
         spec_sbgnrm = R[4 * MCo + 10 + NX];
-        std::memcpy(spec.res, R, sizeof(double) * (4 * MCo + 11 + NX));
+        std::memcpy(spec.res.data(), R, sizeof(double) * (4 * MCo + 11 + NX));
         spec.valid = true;  // dropped below unless dcsrch accepts this point
         spec.x = x, spec.g = g, spec.stp = stp_here, spec.head = h2, spec.col = c2, spec.itail = it2;
         tbrk_valid = false;
@@ -904,7 +904,7 @@ class Solver final : public lbfgsb_hip_ctx {
       // no walk: the update pass's p = W'd over all rows IS W'Z r (subspace_closed_form with
       // tsum = 0 and no cmprlb term), its new-row sums need no correction
       closed_ok = false;
-      std::memset(nrc, 0, sizeof nrc);
+      nrc_clear();
       if (scan.ready) {
         for (int j = 0; j < col; ++j) {
           p_fin[j] = scan.p[j];
@@ -1079,7 +1079,21 @@ class Solver final : public lbfgsb_hip_ctx {
       if (wrk && !incr) {
         // (m > 32: the new pair's row alone when no row changed status, solver_wide.inl)
         bool incr_done = false;
-        if (wide() && wide_incr_on && wide_wn1_ok) CHK(wide_formk_incr(col, head, updatd, iupdat, incr_done));
+        if (wide() && wide_incr_on && wide_wn1_ok) {
+          // (the new pair's row and column: from the update pass if it carried them -- corrected for the rows
+          //  the walk fixed, as in subspace() -- else from two masked columns)
+          std::vector<double> nrp;
+          if (updatd && nrpre.valid && nrpre.col == col) {
+            nrp.assign((size_t)4 * col, 0.0);
+            for (int j = 0; j < col; ++j) {
+              nrp[0 * col + j] = nrpre.t[0][j] - nrc[0][j];
+              nrp[1 * col + j] = nrpre.t[1][j] + nrc[1][j];
+              nrp[2 * col + j] = nrpre.t[2][j] + nrc[2][j];
+              nrp[3 * col + j] = nrpre.t[3][j] - nrc[3][j];
+            }
+          }
+          CHK(wide_formk_incr(col, head, updatd, iupdat, incr_done, nrp.empty() ? nullptr : nrp.data()));
+        }
         if (incr_done)
           formk_factor(col, theta, info);
         else
@@ -1099,9 +1113,12 @@ class Solver final : public lbfgsb_hip_ctx {
       // does not cancel)
       const bool closed = two_pass && closed_ok && col <= two_pass_maxcol && !pre_valid &&
                           (!updatd || (nrpre.valid && nrpre.col == col));
-      if (wide())
-        CHK(wide_subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info));
-      else
+      if (wide()) {
+        CHK(commit_pending(g, col, head));  // (the unfused steps read the newest pair from W)
+        const bool wclosed = wide_fused() && wide_closed_on && two_pass && closed_ok && !pre_valid &&
+                             (!updatd || (nrpre.valid && nrpre.col == col)) && closed_form_safe(col);
+        CHK(wide_subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, wclosed));
+      } else
         CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
                      pre_valid ? pre_res : nullptr, closed));
       pre_valid = false;
@@ -1329,9 +1346,9 @@ class Solver final : public lbfgsb_hip_ctx {
     const int c2 = spec.col, nold = c2 - 1;
     const bool full = c2 == col;  // (the pass ran with head + 1)
     if (!(full ? (col == m && spec.head == head % m + 1) : (c2 == col + 1 && spec.head == head))) return 0;
-    const int MCo = lbk::maxc_for(nold);
+    const int MCo = lbk::maxc_stride(nold);
     const int NX = lbk::update_scan_extra(nold, nr_flag(c2));
-    const double *R = spec.res;
+    const double *R = spec.res.data();
     const int shift = full ? 1 : 0;
     if (full) {
       const int MC1 = lbk::maxc_for(1);
@@ -1371,7 +1388,7 @@ class Solver final : public lbfgsb_hip_ctx {
       nskip++;
       updatd = false;
       if (debug_walk) std::fprintf(stderr, "[update] iter %d skipped: dr %g ddum %g\n", iter, dr, ddum);
-      if (skip_reuse_on && spec.valid && spec.x == x && spec.g == g && spec.stp == stp && !wide())
+      if (skip_reuse_on && spec.valid && spec.x == x && spec.g == g && spec.stp == stp && (!wide() || wide_fused()))
         CHK(scan_from_skipped(L));
       spec.valid = false;
       spcand.valid = false;
@@ -1392,10 +1409,11 @@ class Solver final : public lbfgsb_hip_ctx {
       itail = itail % m + 1;
       head = head % m + 1;
     }
-    const int MCo = lbk::maxc_for(col - 1);
+    const int MCo = lbk::maxc_stride(col - 1);
     double rr;
     std::vector<double> wsy, wss;  // (m > 32: Sy's new row, Ss's new column from the tile passes)
-    if (wide()) {
+    const bool unfused = wide() && !wide_fused();
+    if (unfused) {
       CHK(ensure_d(x));
       CHK(wide_matupd(g, stp, head, col, wsy, wss, rr));
       spec.valid = false, pend.on = 0, scan.ready = false;
@@ -1408,7 +1426,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (debug_walk) std::fprintf(stderr, "[update] iter %d stp %g reuse %d\n", iter, stp, (int)reuse);
       if (!reuse) sfv.valid = false;
       if (reuse) {
-        std::memcpy(h_res, spec.res, sizeof(double) * (4 * MCo + 11 + NX));
+        std::memcpy(h_res, spec.res.data(), sizeof(double) * (4 * MCo + 11 + NX));
         if ((flags & LBFGSB_F_MIRROR_INDEX) && h_res[4 * MCo + 8] > 0.0)
           lbk::launch_iwhere_update<T>(q, n, x, l, u, nbd, g, iwhere), iw_dirty += 1.0;  // the pass held it back
       } else {
@@ -1455,7 +1473,7 @@ class Solver final : public lbfgsb_hip_ctx {
       rr = h_res[2 * MCo];
     }
     theta = rr / dr;
-    matupd_small(col, iupdat, wide() ? wsy.data() : h_res, wide() ? wss.data() : h_res + MCo,
+    matupd_small(col, iupdat, unfused ? wsy.data() : h_res, unfused ? wss.data() : h_res + MCo,
                  stp == 1.0 ? dtd : stp * stp * dtd, dr);
     info = lbh::formt(m, wt.data(), sy.data(), ss.data(), col, theta);  // :849
     if (info != 0) {

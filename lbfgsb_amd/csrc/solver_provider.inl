@@ -129,7 +129,7 @@
     const void *x = nullptr, *g = nullptr;
     double stp = 0.0;
     int head = 0, col = 0, itail = 0;
-    double res[lbk::RES_MAX];
+    std::vector<double> res = std::vector<double>(8 * (size_t)LBFGSB_MAX_M + 64, 0.0);  // (the widest merged layout)
   } spec;
   int commit_pending(const T *g, int col, int head) {
     if (pend.on) {

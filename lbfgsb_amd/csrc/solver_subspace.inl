@@ -189,6 +189,10 @@
     return true;
   }
   void subspace_closed_form(int col, double theta, double *wv) {
+    subspace_closed_form(col, theta, cm_cf.a, cm_cf.a + lbk::MAXM, wv);
+  }
+  // (a1 = (M c)_j, a2 = theta (M c)_{col+j}: cmprlb's coefficients, :1576-1577)
+  void subspace_closed_form(int col, double theta, const double *a1, const double *a2, double *wv) {
     const int m2 = 2 * m;
     lbh::Mat WN1{snd.data(), m2}, SY{sy.data(), m}, SS{ss.data(), m};
     const double k1 = 1.0 - theta * gcp.tsum;
@@ -201,7 +205,6 @@
     auto SYf = [&](int is, int jy) {  // sum_free s_is y_jy
       return is <= jy ? WN1(m + is, jy) : SY(is, jy) - WN1(m + is, jy);
     };
-    const double *a1 = cm_cf.a, *a2 = cm_cf.a + lbk::MAXM;  // (M c)_j, theta (M c)_{col+j}
     for (int i = 0; i < col; ++i) {
       double ay = k1 * p_fin[i], as = k1 * (p_fin[col + i] / theta);
       for (int j = 0; j < col; ++j) {
@@ -461,6 +464,8 @@
     if (k == "spec_freev") return flag(spec_freev_on);
     if (k == "skip_reuse") return flag(skip_reuse_on);
     if (k == "wide_incr") return flag(wide_incr_on);
+    if (k == "wide_fused") return flag(wide_fused_on);
+    if (k == "wide_closed") return flag(wide_closed_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
@@ -479,13 +484,25 @@
     return fail(LBFGSB_E_ARG, "set_option: unknown option '" + k + "'");
   }
   // update_scan_kernel's NEWROW flag for the pass that forms pair number `colnew`
-  int nr_flag(int colnew) const { return two_pass && colnew <= two_pass_maxcol ? 1 : 0; }
+  // (m > 32: every col while the update pass stays fused in front of the unfused subspace steps)
+  int nr_flag(int colnew) const { return two_pass && (colnew <= two_pass_maxcol || wide_fused()) ? 1 : 0; }
+  // m > 32: matupd's, cauchy's and formk's sums from the (split) update pass -- one pass over W instead of
+  // five; the subspace steps stay the unfused ones (solver_wide.inl).  Option "wide_fused" = 0: all unfused
+  bool wide_fused_on = true, wide_closed_on = true;  // ("wide_closed": W'Z r in closed form, one axpy pass)
+  bool wide_fused() const { return wide() && wide_fused_on && two_pass; }
   struct NewRow {
     bool valid = false;
     int col = 0;
-    double t[4][lbk::MAXM];  // logical columns 0..col-1: Y'ZZ'Y row, S'AA'S row, L_a row, R_z column
+    // logical columns 0..col-1: Y'ZZ'Y row, S'AA'S row, L_a row, R_z column
+    std::vector<double> t[4] = {std::vector<double>(LBFGSB_MAX_M, 0.0), std::vector<double>(LBFGSB_MAX_M, 0.0),
+                                std::vector<double>(LBFGSB_MAX_M, 0.0), std::vector<double>(LBFGSB_MAX_M, 0.0)};
   } nrpre;
-  double nrc[4][lbk::MAXM];  // what the walk's fixed rows take from / add to them
+  // what the walk's fixed rows take from / add to them
+  std::vector<double> nrc[4] = {std::vector<double>(LBFGSB_MAX_M, 0.0), std::vector<double>(LBFGSB_MAX_M, 0.0),
+                                std::vector<double>(LBFGSB_MAX_M, 0.0), std::vector<double>(LBFGSB_MAX_M, 0.0)};
+  void nrc_clear() {
+    for (auto &v : nrc) std::fill(v.begin(), v.end(), 0.0);
+  }
   std::vector<double> p_fin = std::vector<double>(2 * (size_t)LBFGSB_MAX_M, 0.0);
   double p_ini_max = 0.0;
   bool closed_ok = false;    // this call's cauchy left everything the closed form needs

@@ -149,7 +149,7 @@
     fix_overflow = false;
     closed_ok = false;
     z_in_x = false;  // z means this call's Cauchy point from here on
-    std::memset(nrc, 0, sizeof nrc);
+    nrc_clear();
     const int ipr = quiet ? -1 : print_level;
     if (sbgnrm <= 0.0) {  // :1245-1249
       scan.ready = false;
@@ -466,7 +466,7 @@
           fixlist.push_back(rec_gi * 2 + (dibp > 0.0 ? 1 : 0));
         else
           fix_overflow = true;
-        if (col > 0 && col <= two_pass_maxcol) {
+        if (col > 0 && nr_flag(col)) {
           // this row leaves the free set: its share of formk's new row/column moves from the
           // free sums to the active ones (the update pass summed with the pre-walk split)
           const double yk = rec[4 + col - 1], sk = rec[4 + 2 * col - 1];
@@ -543,7 +543,7 @@
         last_t = -1.0, last_i = -1;
         fixlist.clear();
         fix_overflow = false;
-        std::memset(nrc, 0, sizeof nrc);
+        nrc_clear();
         continue;
       }
     }

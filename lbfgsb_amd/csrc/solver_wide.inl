@@ -1,12 +1,13 @@
 // solver_wide.inl -- member functions of Solver<T> (included inside the class body in solver.hip):
 // the iteration for m > 32.  The reference puts no upper limit on m (src/lbfgsb.f90:93-97); the fused
-// passes are unrolled for at most MAXM = 32 pairs.  A context with more pairs composes every
-// n-dimensional step from the unfused pieces of k_wide.hip, in tiles of <= 32 logical columns (the
-// circular column addressing makes a tile just another (head, col) pair): matupd's dot products,
-// cauchy's p = W'd, formk's inner products (from scratch, one masked column at a time), cmprlb's r,
-// subsm's W'r and Newton direction, the projected step.  No pending pair, no speculative pass, no closed
-// form: the reference's own sequence of steps, each a memory-bound kernel -- the completeness path, not
-// the fast one.  Element-wise arithmetic in the reference's operation order, as everywhere.
+// passes are unrolled for at most MAXM = 32 pairs.  A context with more pairs has every n-dimensional step
+// as an unfused piece of k_wide.hip, in tiles of <= 32 logical columns (the circular column addressing makes a
+// tile just another (head, col) pair): matupd's dot products, cauchy's p = W'd, formk's inner products, cmprlb's
+// r, subsm's W'r and Newton direction, the projected step -- the reference's own sequence of steps, element-wise
+// arithmetic in its operation order.  By default three pieces of the fused route run in front of them (DESIGN.md
+// 4f): the update pass, split over the columns (matupd's, cauchy's and formk's sums in one pass over W:
+// wide_fused()), WN1 kept incrementally (wide_formk_incr), and W'Z r in closed form with cmprlb's and subsm's
+// updates of r as one axpy pass (wide_subspace, closed) -- two passes over W per iteration here too.
 bool wide() const { return m > lbk::MAXM; }
 
 // outY[j] = Wy_j' v, outS[j] = Ws_j' v for the col logical columns, tile by tile (one fetch per tile)
@@ -94,7 +95,7 @@ int wide_formk(int col, int head) {
 static constexpr int64_t WIDE_PATCH_DOUBLES = 1 << 22;
 double *wide_rows = nullptr;
 size_t wide_rows_cap = 0;
-int wide_formk_incr(int col, int head, bool updatd, int iupdat, bool &done) {
+int wide_formk_incr(int col, int head, bool updatd, int iupdat, bool &done, const double *nr_pass = nullptr) {
   done = false;
   const int upcl = updatd ? col - 1 : col;
   const int64_t nchg = nenter_g + (nglob + 1 - ileave_g);
@@ -140,7 +141,9 @@ int wide_formk_incr(int col, int head, bool updatd, int iupdat, bool &done) {
     }
   }
   std::vector<double> nr;
-  if (updatd) {
+  if (updatd && nr_pass) {
+    nr.assign(nr_pass, nr_pass + (size_t)4 * col);
+  } else if (updatd) {
     CHK(commit_pending((const T *)cg, col, head));
     nr.assign((size_t)4 * col, 0.0);
     std::vector<double> a(col), b(col);
@@ -198,6 +201,12 @@ int wide_subsm(const T *x, const T *l, const T *u, const int32_t *nbd, const T *
   info = lbh::dtrsl(WN, col2, wv, 1);
   if (info != 0) return 0;
   CHK(wide_axpy(tbrk, wv, wv + col, col, head, theta, 1));  // :2770-2778
+  return wide_subsm_tail(x, l, u, nbd, g, theta, xp_first, iword);
+}
+// ... from the Newton direction in tbrk on: the projected step, iword, the backtracking branch (:2780-2885)
+int wide_subsm_tail(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta, bool xp_first,
+                    int &iword) {
+  const int ipr = quiet ? -1 : print_level;
   if (xp_first) HIPCHK(hipMemcpyAsync(xp, z, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));  // :2787
   lbk::launch_subsm_project<T>(q, n, z, tbrk, x, g, l, u, nbd, iwhere, 1.0 / theta);  // :2780-2827
   z_valid = true;
@@ -228,8 +237,40 @@ int wide_subsm(const T *x, const T *l, const T *u, const int32_t *nbd, const T *
   return 0;
 }
 
+// closed: W'Z r in closed form from the walk's p and WN1 (subspace_closed_form: no W'r pass), and -- with wv known
+// before any row of r exists -- cmprlb's and subsm's two updates of r as ONE pass over W:
+//   r = r0 + Wy (a1 + wv_y / theta) + Ws (a2 + wv_s)      (the reference adds W (M c) first, then divides the
+// Wy product by theta: the same sums in another association; the caller has checked closed_form_safe)
 int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, double theta, int col,
-                  int head, bool cnstnd, int &iword, int &info) {
+                  int head, bool cnstnd, int &iword, int &info, bool closed = false) {
+  if (closed) {
+    const bool plain = !cnstnd && col > 0;
+    std::vector<double> a1(col, 0.0), a2(col, 0.0), ca(col), cb(col);
+    if (!plain) {
+      if (lbh::bmv(m, sy.data(), wt.data(), col, &wa8m[2 * m], &wa8m[0]) != 0) {
+        info = -8;
+        return 0;
+      }
+      for (int j = 0; j < col; ++j) a1[j] = wa8m[j], a2[j] = theta * wa8m[col + j];  // :1576-1577
+    }
+    double *wv = &wa8m[0];
+    subspace_closed_form(col, theta, a1.data(), a2.data(), wv);
+    nclosed++;
+    if (print_level >= 99 && !quiet) std::fprintf(rep.out, "\n----------------SUBSM entered-----------------\n\n");
+    lbh::Mat WN{wn.data(), 2 * m};
+    const int col2 = 2 * col;
+    info = lbh::dtrsl(WN, col2, wv, 11);
+    if (info != 0) return 0;
+    for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+    info = lbh::dtrsl(WN, col2, wv, 1);
+    if (info != 0) return 0;
+    for (int j = 0; j < col; ++j) ca[j] = a1[j] + wv[j] / theta, cb[j] = a2[j] + wv[col + j];
+    CHK(ensure_z(x, l, u, g));
+    lbk::launch_cmprlb_init<T>(q, n, x, g, z, iwhere, theta, plain ? 1 : 0, tbrk);
+    tbrk_valid = false;
+    CHK(wide_axpy(tbrk, ca.data(), cb.data(), col, head, 1.0, 1));
+    return wide_subsm_tail(x, l, u, nbd, g, theta, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword);
+  }
   CHK(wide_cmprlb(x, l, u, g, theta, col, head, cnstnd, info));
   if (info != 0) return 0;
   return wide_subsm(x, l, u, nbd, g, theta, col, head, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword, info);

@@ -368,6 +368,9 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     (8000, 30, 1200, 33, 80, None), (8100, 20, 1200, 33, 80, "pp"),
     # ... with formk from scratch whenever it runs (default: the new pair's row alone while the free set stands)
     (8200, 15, 1200, 33, 80, "wide_incr=0"),
+    # ... all unfused (matupd, cauchy's p and formk's new row as separate W'v passes), and with the fused update pass
+    # but W'Z r from a pass over W instead of the closed form
+    (8300, 12, 1200, 33, 80, "wide_fused=0"), (8400, 12, 1200, 33, 80, "pp,wide_closed=0"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
     # col > 21 without the split update pass: three passes over W (the pair-shared cmprlb_wtv kernel at MC = 32)
