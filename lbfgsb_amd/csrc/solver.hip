@@ -1079,7 +1079,9 @@ class Solver final : public lbfgsb_hip_ctx {
       if (wrk && !incr) {
         // (m > 32: the new pair's row alone when no row changed status, solver_wide.inl)
         bool incr_done = false;
-        if (wide() && wide_incr_on && wide_wn1_ok) {
+        // (from the FIRST formk of a run on, as the reference: a formk it skipped -- no free variable -- leaves
+        //  that pair's row unwritten there too, its K fails and the memory is refreshed: fuzz 80740)
+        if (wide() && wide_incr_on) {
           // (the new pair's row and column: from the update pass if it carried them -- corrected for the rows
           //  the walk fixed, as in subspace() -- else from two masked columns)
           std::vector<double> nrp;
@@ -1098,7 +1100,6 @@ class Solver final : public lbfgsb_hip_ctx {
           formk_factor(col, theta, info);
         else
           CHK(formk(col, head, theta, info));
-        wide_wn1_ok = true;  // (WN1 describes this iteration's free set and pairs from here on)
       }
       if (info != 0) {  // :666-682
         if (ipr >= 1)

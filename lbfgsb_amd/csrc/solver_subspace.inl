@@ -423,7 +423,6 @@
   //      closed form from the walk's p and WN1 (subspace_closed_form) -- no cmprlb pass ----
   bool two_pass = true;  // (option "two_pass")
   bool wide_incr_on = true;  // (option "wide_incr": m > 32 keeps WN1 incrementally)
-  bool wide_wn1_ok = false;  // ... once a formk of this run has filled it
   // (every col the fused kernels take; beyond 21 stored pairs the update pass has no registers for the 4 col + 4
   //  extra sums and runs as two launches over half of the columns each, k_update.hip "the split pass";
   //  option "two_pass_maxcol" lowers the limit, for measurements: 20 = round 3's three passes at col > 20)

@@ -1,0 +1,37 @@
+"""Sweep of the randomised differential test (tests/test_gpu_fuzz.py) over m = 33 ... 90 only -- the route of
+DESIGN.md 4f -- in its settings: default (split update pass + incremental WN1 + closed form), both entries, and
+each piece switched off.
+
+    python profiles/scripts/fuzz_wide.py [first] [count] > gpurun_out/fuzz_wide.txt
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fuzz as tf  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+po.build(ref=False)
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+# (not swept: wide_incr = 0.  A from-scratch WN1 is not the reference's WN1 where the reference skipped a formk for
+#  want of a free variable -- there its K fails later and the memory is refreshed, fuzz 80740 -- so that diagnostic
+#  setting is held to the bar on the committed seeds only)
+MODES = [(False, {}), (True, {}), (True, {"wide_closed": 0}), (False, {"wide_fused": 0}), (False, {"two_pass": 0})]
+bad, total, splits, t0 = 0, 0, 0, time.time()
+for seed in range(first, first + count):
+    pp, opts = MODES[seed % len(MODES)]
+    p = tf.make(po, seed, 1500, 33, 90)
+    try:
+        split, _ = tf.drive_with_replay(po, p, 100, pp=pp, options=opts)
+        total += 1
+        splits += split is not None
+    except AssertionError as e:
+        bad += 1
+        print("FAIL seed %d mode %s: %s" % (seed, MODES[seed % len(MODES)], str(e)[:600]), flush=True)
+print("m = 33...90: problems %d  splits reproduced %d  (line-search branch flips %d)  failures %d  (%.0f s)"
+      % (total, splits, len(tf.FLIPS), bad, time.time() - t0))
+sys.exit(1 if bad else 0)
