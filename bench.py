@@ -786,6 +786,9 @@ def main():
              dict(n=12_500_000, m=10, real32=False, kind=0, rccl_self=True, steps=60, warm_min=12, defer=False)),
             ("m = 32 (two passes over W per iteration; the update pass split over the columns: col > 21), n = 5e7, fp64", dict(n=50_000_000, m=32,
              real32=False, kind=0, rccl_self=False, steps=10, warm_min=33)),
+            ("m = 48 (> 32 pairs: the update pass split over the columns in front of the unfused subspace steps, W'Z r in "
+             "closed form, one axpy pass -- DESIGN.md 4f), n = 2e7, fp64", dict(n=20_000_000, m=48, real32=False, kind=0,
+             rccl_self=False, steps=10, warm_min=49)),
         ]
         out["other_configs"] = []
         for name, kw in legs:
