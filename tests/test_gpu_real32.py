@@ -141,7 +141,8 @@ def _tightest(err):
 R32_CASES = [
     ("quadmix20000_m20", dict(n=20000, m=20, mixed=True), 64),     # MC = 20: configs[4]'s kernels
     ("quad6007_m17", dict(n=6007, m=17, mixed=False), 52),         # MC = 20, col < MC slots unused
-    ("quadmix3001_m25", dict(n=3001, m=25, mixed=True), 70),       # MC = 32, from-scratch formk
+    ("quadmix3001_m25", dict(n=3001, m=25, mixed=True), 70),       # col 21...25: the update pass in two parts
+    ("quadmix2003_m36", dict(n=2003, m=36, mixed=True), 90),       # m > 32 in REAL32
 ]
 
 
