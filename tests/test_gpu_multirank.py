@@ -237,6 +237,8 @@ def _fake_rccl():
     (2, 20011, 7, 8, True),
     (3, 300000, 10, 3, False),     # long first walk: all-gathered record chunks, merged on every rank
     (4, 10007, 5, 6, "rosen"),     # halo exchange of the sharded objective through ncclAllGather
+    (2, 10007, 27, 33, True),      # the split update pass: several launches, one merged result set gathered
+    (2, 6007, 40, 46, True),       # m > 32: results wider than the fused layout, the changed-row patch reduced
 ])
 def test_communicator_code_path_with_several_ranks(oracle_built, tmp_path, monkeypatch, world, n, m,
                                                    iters, mixed):
