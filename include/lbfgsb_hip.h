@@ -469,6 +469,8 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule (m = 20, fp32 m = 10) / off /
  *                           the default rule again (the other shapes are not compiled with it)
  *   "pair" (0/1/2)          MC = 20 update pass: lane pairs share accumulators (off / 1 trip / 2 trips)
+ *   "split" (10/20)         update pass with formk's new-row sums: split over the columns beyond 20 old pairs into
+ *                           parts of <= 16 (default) / beyond 10 into parts of <= 10 (measurement: slower at m = 20)
  *   "gram_rows" (0/1)       formk from scratch with the LDS-slab kernel instead of the quad kernel
  * Returns LBFGSB_E_ARG for an unknown name or a value out of range. */
 int lbfgsb_hip_set_option(lbfgsb_hip_ctx *ctx, const char *name, double value);

@@ -425,8 +425,8 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
                         int store_iw, int newrow, double cand_hi, uint64_t *ckeys, uint32_t *cidx,
                         uint32_t ccap, uint32_t *ccount, int ub) {
   const int nold = col - 1;
-  if (newrow && nold > 20) {  // the split pass (see above)
-    const int nparts = split_parts(nold);
+  if (newrow && nold > q.tune.split_from) {  // the split pass (see above)
+    const int nparts = split_parts(nold, q.tune.split_cols);
     if (nparts > SPLIT_MAXPARTS || q.part_sel != 0 || store_pair) {
       if (q.launch_err == hipSuccess) q.launch_err = hipErrorInvalidValue, q.launch_err_where = "update_scan: split pass";
       return;

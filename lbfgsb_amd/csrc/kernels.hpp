@@ -27,6 +27,8 @@ struct Tune {
   int pipe = -1;    // two trips in flight per wave: -1 / 1 default rule (pipe_on), 0 off
   int pair = 2;     // MC = 20 update pass with new-row sums: lane pairs share the per-column
                     // accumulators; 0 off, 1 one trip in flight, 2 two trips
+  int split_from = 20;  // update pass with the new-row sums: split over the columns beyond this many old pairs ...
+  int split_cols = 16;  // ... into parts of at most this many (experiment: 10 / 10 = two MC = 10 launches at m = 20)
   int gram_rows = 0;  // formk from scratch: 1 = the LDS-slab kernel instead of the quad kernel
 };
 
@@ -438,10 +440,10 @@ inline int maxc_stride(int col) { return col <= MAXM ? maxc_for(col) : (col + 31
 inline int update_scan_extra(int nold, int newrow) { return newrow ? 4 * maxc_stride(nold) + 4 : 0; }
 // where the sub-launches of a split update pass put their results in d_res: behind the merged layout at `dst`
 inline int split_base(int nold, int dst) { return std::max(RES_MAX + 16, dst + 8 * maxc_stride(nold) + 32); }
-inline int split_parts(int nold) { return (nold + SPLIT_COLS - 1) / SPLIT_COLS; }
-// d_res doubles a context with m pairs needs for a split update pass
+inline int split_parts(int nold, int cols = SPLIT_COLS) { return (nold + cols - 1) / cols; }
+// d_res doubles a context with m pairs needs for a split update pass (parts of >= 5 columns)
 inline size_t split_res_len(int m) {
-  return m <= 20 ? 0 : (size_t)split_base(m, 1) + (size_t)split_parts(m) * SPLIT_SLOTS + 8;
+  return m <= 5 ? 0 : (size_t)split_base(m, 1) + (size_t)split_parts(m, 5) * SPLIT_SLOTS + 8;
 }
 
 // finalize: partials -> d_res (nsum sums, then nmin mins, then nmax maxes); takes parked jobs along

@@ -480,6 +480,11 @@
     if (k == "pipe") return in_range(-1, 1, q.tune.pipe);
     if (k == "pair") return in_range(0, 2, q.tune.pair);
     if (k == "gram_rows") return in_range(0, 1, q.tune.gram_rows);
+    if (k == "split") {  // 20 (default: parts of <= 16 columns beyond 20 old pairs) or 10 (parts of <= 10 beyond 10)
+      if (v != 10.0 && v != 20.0) return fail(LBFGSB_E_ARG, "set_option: split takes 10 or 20");
+      q.tune.split_from = (int)v, q.tune.split_cols = v == 10.0 ? 10 : 16;
+      return 0;
+    }
     return fail(LBFGSB_E_ARG, "set_option: unknown option '" + k + "'");
   }
   // update_scan_kernel's NEWROW flag for the pass that forms pair number `colnew`
