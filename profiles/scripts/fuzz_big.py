@@ -2,7 +2,7 @@
 breakpoint provider works in windows, refills, merges and keeps the rows a walk fixes as a cursor instead of a
 list -- from the general generator and from the families with long walks (linear) and huge tie groups (lattice).
 
-    python profiles/scripts/fuzz_big.py [first] [count per kind] > gpurun_out/fuzz_big.txt
+    python profiles/scripts/fuzz_big.py [first] [count per kind] [kind substring] > gpurun_out/fuzz_big.txt
 """
 import os
 import sys
@@ -24,7 +24,13 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 KINDS = [("make x300", lambda po_, s: tf.scaled_up(lambda q, t: tf.make(q, t, 2000, 1, 9), 300)(po_, s)),
          ("linear x300", tf.scaled_up(tf.FAMILIES["linear"], 300)),
          ("lattice x400", tf.scaled_up(tf.FAMILIES["lattice"], 400)),
-         ("rosenchain x500", tf.scaled_up(tf.FAMILIES["rosenchain"], 500))]
+         ("rosenchain x500", tf.scaled_up(tf.FAMILIES["rosenchain"], 500)),
+         # 21 ... 32 pairs (the update pass split over the columns), more than 32, skipped updates
+         ("make m21-32 x150", lambda po_, s: tf.scaled_up(lambda q, t: tf.make(q, t, 2000, 21, 33), 150)(po_, s)),
+         ("make m33-60 x100", lambda po_, s: tf.scaled_up(lambda q, t: tf.make(q, t, 1500, 33, 61), 100)(po_, s)),
+         ("cubic x300", tf.scaled_up(tf.FAMILIES["cubic"], 300))]
+if len(sys.argv) > 3:   # a substring selects kinds
+    KINDS = [k for k in KINDS if sys.argv[3] in k[0]]
 t0 = time.time()
 worst = 0
 for name, gen in KINDS:
@@ -34,7 +40,8 @@ for name, gen in KINDS:
         p = gen(po, seed)
         ns.append(p.n)
         try:
-            s, _ = tf.drive_with_replay(po, p, 25, pp=bool(seed & 1), final_check=False)
+            # (long enough for the memory to fill where m is large)
+            s, _ = tf.drive_with_replay(po, p, 25 if p.m < 20 else p.m + 25, pp=bool(seed & 1), final_check=False)
             tot += 1
             spl += s is not None
         except AssertionError as e:
