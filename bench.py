@@ -280,21 +280,75 @@ def cpu_baseline(m, n_full, n_sample):
                 "peak_rss_gb": d["peak_rss_gb"], "host_cpu_model": d["host"]["model"],
             }
             out["extrapolated_over_measured_full_size"] = out["value"] / d["iters_per_sec_col_eq_m"]
-            # `value` is the MEASURED full-size figure whenever the file's run is this host's CPU (VERDICT r3
-            # item 7: the linear extrapolation of the sample overstates the CPU by 1.4-1.5 x); the live sample
-            # of this run stays beside it
-            if d["host"]["model"] == cpu["model"]:
-                out["value_from_live_sample_scaled_to_full_size"] = out["value"]
-                out["value"] = d["iters_per_sec_col_eq_m"]
-                out["value_source"] = ("measured at FULL size (n = 1e8, m = 10) on one core of this CPU model: "
-                                       "profiles/r3a_cpu_ref_full_n1e8_m10.json; the live bounded sample of this "
-                                       "run (n_sample rows, scaled linearly in n) is "
-                                       "value_from_live_sample_scaled_to_full_size")
-            else:
-                out["value_source"] = "live bounded sample of this run, scaled linearly in n (the full-size run on "\
-                                      "file was measured on another CPU model)"
+            # `value` is ALWAYS this run's live bounded sample scaled linearly in n (never a number from a file);
+            # the one full-size measurement on file stands beside it under its own name.  At n = 1e8 the
+            # reference is slower than the linear scaling says (caches, TLB): the ratio above says by how much.
+            out["value_source"] = "live bounded sample of this run, scaled linearly in n"
+            out["value_full_size_on_file"] = d["iters_per_sec_col_eq_m"]
         except Exception:   # noqa: BLE001
             pass
+    return out
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` given bare (no launcher around it): start
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a CHILD process -- before this
+    process has made any GPU call, so nothing that has initialised the GPU is ever replaced -- forward rank 0's
+    JSON line and exit with the child's code.  Under a launcher (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    printed = 0
+    for line in pr.stdout:            # (stderr goes straight through)
+        if line.startswith("{") and not printed:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            printed += 1
+        else:
+            sys.stderr.write(line)
+    rc = pr.wait()
+    if rc == 0 and not printed:
+        sys.stderr.write("bench.py: the launched ranks exited 0 without a JSON line\n")
+        rc = 1
+    return rc
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+# (n, m, objective kind) -> rows the REAL reference printed for that workload at full size, and the tolerance on f
+# the GPU parity tests use for the same fixture (tests/test_gpu_parity.py)
+GOLDEN_ROWS = {(100_000_000, 10, 0): ("quad_n1e8_m10_ref_rows.json", 1e-9),
+               (10_000_000, 10, 1): ("rosenbrock_n1e7_anchors.json", 1e-7)}
+
+
+def parity_in_run(rows, n, m, real32, kind):
+    """The timed path checks itself: the (iter, nfg, nseg, nfree, f) of every NEW_X return of a leg -- the very
+    entry, flags and buffers that are timed -- against the rows the REAL reference (oracle/_ref) printed for this
+    workload at full size (tests/golden/*.json: data; generating scripts profiles/scripts/cpu_ref_full.py,
+    tests/golden/make_anchors_n1e7.py).  Integers exactly, f within the fixture's tolerance.  Shapes without
+    such rows report rows_checked = 0."""
+    fx = None if real32 else GOLDEN_ROWS.get((n, m, kind))
+    if fx is None or not os.path.exists(os.path.join(GOLDEN, fx[0])):
+        return {"rows_checked": 0, "ok": None, "why": "no reference rows on file for this shape"}
+    by_iter = {r["iter"]: r for r in json.load(open(os.path.join(GOLDEN, fx[0])))["rows"]}
+    checked, bad = 0, []
+    for it, nfg, nseg, nfree, f in rows:
+        w = by_iter.get(it)
+        if w is None:
+            continue
+        checked += 1
+        ok = (nfg, nseg, nfree) == (w["nfg"], w["nseg"], w["nfree"]) and abs(f - w["f"]) <= fx[1] * abs(w["f"])
+        if not ok and len(bad) < 3:
+            bad.append({"got": [it, nfg, nseg, nfree, f], "want": [w["iter"], w["nfg"], w["nseg"], w["nfree"], w["f"]]})
+    out = {"rows_checked": checked, "ok": checked > 0 and not bad, "f_rel_tol": fx[1],
+           "iters": [rows[0][0], rows[-1][0]] if rows else [], "against": "tests/golden/" + fx[0]}
+    if bad:
+        out["mismatch"] = bad
     return out
 
 
@@ -369,6 +423,9 @@ class Run:
         self.gs = [torch.zeros_like(x), torch.empty_like(x)] if self.pp else [torch.zeros_like(x)]
         self.cur = 0
         self.t_setulb = 0.0
+        self.rows = []        # (iter, nfg, nseg, nfree, f) at every NEW_X return of this context
+        self.stamps = []      # host clock at those returns (time-to-solution; no sync: what the caller sees)
+        self.t_start = None   # host clock just before the START call
 
     @property
     def x(self):
@@ -389,6 +446,8 @@ class Run:
         done = 0
         while done < iters:
             t0 = time.perf_counter()
+            if self.t_start is None:
+                self.t_start = t0
             if self.pp:
                 task, self.cur = sol.setulb_pp(self.xs, self.l, self.u, self.nbd, self.gs, 0.0, 0.0)
             else:
@@ -398,6 +457,9 @@ class Run:
                 sol.objective(self.kind, self.x, self.g, deferred=True)   # f rides back with the next call's sums
             elif task.startswith("NEW_X"):
                 done += 1
+                isv = sol.isave
+                self.rows.append((int(isv[29]), int(isv[33]), int(isv[32]), int(isv[37]), float(sol.f[0])))
+                self.stamps.append(time.perf_counter())
             else:
                 raise RuntimeError("solver stopped: " + task)
 
@@ -504,13 +566,17 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "lnsrch_setups_deferred_reissued": list(run.sol.defer_stats()),
                 "host_algebra_us_between_passes": r["st1"]["host_gap_us"],
                 "host_segments_us": r["st1"]["host_segments_us"],
-                "uniform_bounds_mask": ub, "options": opts}
+                "uniform_bounds_mask": ub, "options": opts,
+                "parity_in_run": parity_in_run(run.rows, n, m, real32, kind)}
     finally:
         run.close()
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: be our own launcher (a child process; nothing here has touched the GPU)
+        raise SystemExit(self_launch(a))
     import torch
     import torch.distributed as dist
     import lbfgsb_amd
@@ -519,8 +585,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        raise SystemExit("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (a.gpus, world))
     # LBFGSB_BENCH_SHARE_GPU=1 (tests): every rank on cuda:0 with a gloo group, so that this
     # file's multi-rank flow can be rehearsed on a one-GPU box (with LBFGSB_RCCL_LIBRARY pointing
     # the library at the shared-memory stand-in of tests/fake_rccl.cpp)
@@ -558,6 +623,21 @@ def main():
         print(json.dumps({"pmc_child": True, "steps": a.steps, "ms_per_step": dt / a.steps * 1e3}))
         return
     stats, st0 = r["st1"], r["st0"]
+    # ---- the timed path checks itself (every NEW_X row of this leg, warm-up and timed region) ----
+    parity = parity_in_run(run.rows, n, m, a.real32, 1 if a.rosenbrock else 0)
+    parity_fail = parity["ok"] is False
+    # time to solution as the caller sees it: host clock from just before START to the NEW_X return of
+    # iteration 30 (the two barriers of the timing protocol are inside; each costs a stream sync)
+    tts30 = None
+    for (it, *_), ts in zip(run.rows, run.stamps):
+        if it == 30:
+            tts30 = ts - run.t_start
+    first_per_rank = [r["first_iter_s"]]
+    if world > 1:
+        ft = torch.tensor([r["first_iter_s"]], dtype=torch.float64, device=run.dev)
+        fl = [torch.zeros_like(ft) for _ in range(world)]
+        dist.all_gather(fl, ft)
+        first_per_rank = [float(v[0]) for v in fl]
     f_final = float(sol.f[0])
     col = int(sol.isave[27])
     nfree = int(sol.isave[37])
@@ -702,6 +782,15 @@ def main():
                                     "LBFGSB_F_DEFER_LNSRCH: the objective is the library's own kernel on the "
                                     "solver's stream, so the storing pass's sums ride with the next call's fetch "
                                     "(one host sync per iteration less; NEW_X returns bit-identical)"),
+                   # (short values: the driver's record keeps this dict, long strings are cut)
+                   "parity_in_run": parity,
+                   "rccl_nranks": (sol.comm_info()[0] if sol.comm_info()[2] == 1 else None),
+                   "first_iteration_s": r["first_iter_s"],
+                   "first_iteration_s_per_rank": first_per_rank,
+                   "refresh_count": stats["refreshes"],
+                   "time_to_30_iterations_s": tts30,
+                   "iterations_run": run.rows[-1][0] if run.rows else 0,
+                   "defer_lnsrch": not a.no_defer,
                    "uniform_bounds_mask": ub,
                    "uniform_bounds": "l, u, nbd of this workload hold one value each (detected at START, bit 0/1/2 = "
                                      "l/u/nbd): the passes over W read them as constants, not as 8+8+1 B/row "
@@ -769,7 +858,9 @@ def main():
         out["first_iteration_parallel_gcp_error"] = repr(e)
     # ---- the other BASELINE.json configs, short legs (N = 1 only; each a fresh context) ----
     if world == 1 and not a.no_other_configs and not a.real32 and n == 100_000_000 and m == 10:
-        legs = [
+        leg_tags = ["ub_off", "cfg1_n1e6", "cfg2_rosen_n1e7", "cfg4_r32_m20", "cfg3_rank_shape",
+                    "cfg3_rank_shape_nodefer", "m32_n5e7", "m48_n2e7"]
+        leg_defs = [
             ("headline workload with the uniform-bounds detection OFF (l, u, nbd streamed per row)",
              dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12,
                   opts=dict(opts, uniform_bounds=0))),
@@ -791,13 +882,28 @@ def main():
              rccl_self=False, steps=10, warm_min=49)),
         ]
         out["other_configs"] = []
-        for name, kw in legs:
+        for name, kw in leg_defs:
             try:
                 kw.setdefault("opts", opts)
                 out["other_configs"].append(other_config(torch, dist, lbfgsb_amd, a, name, local_rank=local_rank,
                                                          **kw))
             except Exception as e:   # noqa: BLE001  (a leg must never take the headline line down; Ctrl-C still ends the run)
                 out["other_configs"].append({"config": name, "error": repr(e)})
+        # <= 1 KB summary of every leg INSIDE config (the driver's record keeps config; other_configs is long)
+        legs = {}
+        for tag, oc in zip(leg_tags, out["other_configs"]):
+            if "error" in oc:
+                legs[tag] = "error " + oc["error"][:60]
+                continue
+            ps = oc["passes"]
+            fr = lambda k: ("%.2f" % ps[k]["frac"]) if k in ps else "-"     # noqa: E731
+            legs[tag] = "%.1f it/s %.3f ms upd %s sub %s syncs %.2f" % (
+                oc["value"], oc["ms_per_step"], fr("update_scan"), fr("subsm_update"), oc["host_syncs_per_iter"])
+            pr = oc.get("parity_in_run") or {}
+            if pr.get("rows_checked"):
+                legs[tag] += " parity %d rows %s" % (pr["rows_checked"], "ok" if pr["ok"] else "MISMATCH")
+                parity_fail = parity_fail or not pr["ok"]
+        out["config"]["legs"] = legs
     # ---- HBM traffic of the passes over W, counted in this run (contexts above are closed: the child
     # has the card's memory to itself) ----
     if rank == 0 and world == 1 and not a.no_live_traffic:
@@ -830,9 +936,12 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "iters/sec", "cores": 1, "kind": "reference",
                                    "sample": "failed: %r" % (e,)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity_fail:      # (the line above is on record; the run itself must not pass)
+        sys.stderr.write("bench.py: parity_in_run FAILED: %s\n" % json.dumps(parity))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

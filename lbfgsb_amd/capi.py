@@ -1,4 +1,4 @@
-"""ctypes bindings of include/lbfgsb_hip.h (one prototype per declared symbol)."""
+"""ctypes bindings of include/lbfgsb_hip.h and include/lbfgsb_hip_debug.h (one prototype per declared symbol)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -62,6 +62,7 @@ PROTOTYPES = {
     "lbfgsb_hip_uniform_bounds": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_freev_skipped": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_skip_stats": (C.c_int, [_vp, _vp]),
+    "lbfgsb_hip_refresh_count": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_vec_sub": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lbfgsb_hip_vec_scale": (C.c_int, [_vp, C.c_double, _vp]),
     "lbfgsb_hip_dot": (C.c_int, [_vp, _vp, _vp, _vp]),

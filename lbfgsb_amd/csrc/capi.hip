@@ -384,6 +384,12 @@ int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count) {
   return 0;
 }
 
+int lbfgsb_hip_refresh_count(lbfgsb_hip_ctx *ctx, int64_t *count) {
+  if (!ctx || !count) return fail(LBFGSB_E_ARG, "refresh_count: NULL argument");
+  *count = ctx->nrefresh;
+  return 0;
+}
+
 int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count) {
   if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
   if (seconds) *seconds = ctx->t_mid;

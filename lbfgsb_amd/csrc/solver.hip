@@ -545,6 +545,7 @@ class Solver final : public lbfgsb_hip_ctx {
   void refresh(Mainlb &L) {
     MAINLB_VIEW(L);
     info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
+    nrefresh++;
     pend.on = 0, pend.impl = 0;  // the memory is dropped, an uncommitted pair with it
   }
 
@@ -566,6 +567,7 @@ class Solver final : public lbfgsb_hip_ctx {
     MAINLB_VIEW(L);
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
     ls.deferred = false, defer_live = false;
+    nrefresh = 0;
     sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
     spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
     epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()

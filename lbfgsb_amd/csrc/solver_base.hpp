@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/lbfgsb_hip.h"
+#include "../../include/lbfgsb_hip_debug.h"
 #include "host_dense.hpp"
 #include "kernels.hpp"
 #include "report.hpp"
@@ -169,6 +170,7 @@ struct lbfgsb_hip_ctx {
   int rank = 0, nranks = 1;
   int64_t nsync = 0, nfullsort = 0;
   int64_t ntiesplit = 0;  // walks that ended inside a group of equal breakpoints
+  int64_t nrefresh = 0;   // memory refreshes of the current run (lbfgsb_hip_refresh_count)
   int64_t ngcp_clamped = 0;  // closed-form GCPs declined because the f2 clamp would have acted
   int64_t nspecwin = 0;   // walks served by the candidates the update pass handed over
   double t_wait = 0.0;  // seconds the host spent blocked in hipStreamSynchronize

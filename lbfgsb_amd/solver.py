@@ -64,6 +64,13 @@ class DeviceSolver:
                  exact_ties: bool = True, index_ties: bool = False, options: Optional[dict] = None,
                  defer_lnsrch: bool = False):
         self.lib = load_library()
+        # LBFGSB_F_DEFER_LNSRCH returns 'FG_LNSRCH' without waiting for the pass that writes the trial point
+        # (it implies LBFGSB_F_NO_RETURN_SYNC): only a caller whose objective runs on the solver's OWN stream
+        # may use it -- one that evaluates on torch's current stream would read x while it is being written
+        if defer_lnsrch and not same_stream_objective:
+            raise ValueError("defer_lnsrch=True needs same_stream_objective=True: the flag skips the host sync at "
+                             "every FG_LNSRCH return, so f,g must be evaluated on the solver's stream "
+                             "(DeviceSolver.objective / DeviceSolver.stream)")
         self.same_stream_objective = bool(same_stream_objective)
         self.n, self.m = int(n_local), int(m)
         self.n_global = int(n_global if n_global is not None else n_local)
@@ -97,6 +104,8 @@ class DeviceSolver:
 
     def set_option(self, name: str, value: float):
         """measurement / test switch of this context (lbfgsb_hip_set_option)"""
+        if name == "defer_lnsrch" and float(value) != 0.0 and not self.same_stream_objective:
+            raise ValueError("option defer_lnsrch needs a context created with same_stream_objective=True")
         check(self.lib.lbfgsb_hip_set_option(self.h, name.encode(), float(value)))
 
     def close(self):
@@ -178,12 +187,23 @@ class DeviceSolver:
     # context and are only ever written in place: their addresses are taken once.  (Per call the wrapper
     # then costs a few microseconds instead of ~20: at n = 1e6 an iteration is 150 us, and the NEW_X
     # return -> re-entry sits on the path during which the device waits for the host.)
+    # (The cache is keyed on the array OBJECTS themselves, compared by identity, and keeps them alive: a
+    #  replaced array -- sol.isave = saved.copy() in a checkpoint / restore flow -- is always noticed; an id()
+    #  alone can be reused by CPython for a new object at another address.)
+    _OWN_SPEC = (("f", np.float64, 1), ("task", np.uint8, 60), ("csave", np.uint8, 60), ("lsave", np.int32, 4),
+                 ("isave", np.int32, 44), ("dsave", np.float64, 29))
+
     def _own_ptrs(self):
-        key = (id(self.f), id(self.task), id(self.csave), id(self.lsave), id(self.isave), id(self.dsave))
-        if getattr(self, "_own_key", None) != key:
-            self._own_key = key
-            self._own = tuple(a.ctypes.data for a in (self.f, self.task, self.csave, self.lsave, self.isave,
-                                                      self.dsave))
+        arrs = (self.f, self.task, self.csave, self.lsave, self.isave, self.dsave)
+        held = getattr(self, "_own_arrs", None)
+        if held is None or any(a is not b for a, b in zip(arrs, held)):
+            for a, (nm, dt, ln) in zip(arrs, self._OWN_SPEC):
+                if not (isinstance(a, np.ndarray) and a.dtype == dt and a.size >= ln and a.flags["C_CONTIGUOUS"]
+                        and a.flags["WRITEABLE"]):
+                    raise TypeError("DeviceSolver.%s must be a writable contiguous %s array of >= %d elements"
+                                    % (nm, np.dtype(dt).name, ln))
+            self._own_arrs = arrs
+            self._own = tuple(a.ctypes.data for a in arrs)
         return self._own
 
     @staticmethod
@@ -471,6 +491,8 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_freev_skipped(self.h, C.byref(fs)))
         sr = C.c_int64()
         check(self.lib.lbfgsb_hip_skip_stats(self.h, C.byref(sr)))
+        rf = C.c_int64()
+        check(self.lib.lbfgsb_hip_refresh_count(self.h, C.byref(rf)))
         return dict(launches=a.value, syncs=b.value, cauchy_fullsorts=c.value, wait_seconds=w.value,
                     collectives=nc.value, collective_bytes=nb.value, freev_skipped=fs.value,
-                    skip_scans_reused=sr.value)
+                    skip_scans_reused=sr.value, refreshes=rf.value)

@@ -34,6 +34,8 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
                                      # LBFGSB_F_DEFER_LNSRCH over several ranks (the deferred sums are one more
                                      # reduced segment of every rank's fetch): tests/test_gpu_multirank.py
                                      defer_lnsrch=os.environ.get("LBFGSB_TEST_DEFER") == "1",
+                                     # (this worker evaluates f, g with sol.objective: the solver's own stream)
+                                     same_stream_objective=os.environ.get("LBFGSB_TEST_DEFER") == "1",
                                      index_ties=(variant == "sym"),
                                      options={"exact_always": 1} if variant == "symx" else None)
         if mode == "gloo":

@@ -59,12 +59,13 @@ def test_group_reducers_gloo_world2():
 
 
 def test_c_abi_exports_every_declared_symbol():
-    """include/lbfgsb_hip.h vs the shared library: every declared entry point resolves
-    (no compute call is made -- this runs without a GPU)."""
+    """include/*.h (the drop-in surface lbfgsb_hip.h + the instruments of lbfgsb_hip_debug.h) vs the shared
+    library: every declared entry point resolves (no compute call is made -- this runs without a GPU)."""
     import re
     import lbfgsb_amd
     from lbfgsb_amd import capi
-    hdr = open(os.path.join(ROOT, "include", "lbfgsb_hip.h")).read()
+    import glob
+    hdr = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     declared = set(re.findall(r"\b(lbfgsb_hip_[a-z0-9_]+)\s*\(", hdr)) - {"lbfgsb_hip_ctx"}
     assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
     lib = lbfgsb_amd.load_library()

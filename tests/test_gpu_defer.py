@@ -24,7 +24,9 @@ def _run(p, pp, defer, max_iter, **ctx):
     stream (sol.sync() first: a deferring context does not synchronise at an FG return)"""
     import torch
     import lbfgsb_amd as la
-    sol = la.DeviceSolver(p.n, p.m, defer_lnsrch=defer, **ctx)
+    # (a deferring context must declare that its objective is ordered on the solver's stream: this harness
+    #  synchronises the solver before it reads x and the device after it has written g)
+    sol = la.DeviceSolver(p.n, p.m, defer_lnsrch=defer, same_stream_objective=defer, **ctx)
     try:
         xs = [torch.from_numpy(p.x0.copy()).cuda(), torch.full((p.n,), 7.0, dtype=torch.float64, device="cuda")]
         gs = [torch.zeros_like(xs[0]), torch.full_like(xs[0], -3.0)]
@@ -120,7 +122,13 @@ def test_export_is_refused_while_deferred_and_start_resets(oracle_built):
     from test_gpu_fuzz import make
     po = oracle_built
     p = make(po, 207, 400, 4, 9)
-    sol = la.DeviceSolver(p.n, p.m, defer_lnsrch=True)
+    with pytest.raises(ValueError, match="same_stream_objective"):   # the flag skips the sync at FG_LNSRCH returns
+        la.DeviceSolver(p.n, p.m, defer_lnsrch=True)
+    plain = la.DeviceSolver(p.n, p.m)
+    with pytest.raises(ValueError, match="same_stream_objective"):
+        plain.set_option("defer_lnsrch", 1)
+    plain.close()
+    sol = la.DeviceSolver(p.n, p.m, defer_lnsrch=True, same_stream_objective=True)
     x = torch.from_numpy(p.x0.copy()).cuda()
     g = torch.zeros_like(x)
     l, u = torch.from_numpy(p.l).cuda(), torch.from_numpy(p.u).cuda()

@@ -261,16 +261,18 @@ def test_communicator_code_path_with_several_ranks(oracle_built, tmp_path, monke
 
 def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py's multi-rank flow (row partition, communicator set-up with the id broadcast,
-    barriers, MAX over ranks of the timings, rank-0 JSON line) launched exactly as the driver
-    launches it -- torch.distributed.run, 2 ranks -- on ONE GPU: LBFGSB_BENCH_SHARE_GPU puts both
-    ranks on cuda:0 with a gloo group, LBFGSB_RCCL_LIBRARY swaps librccl for the stand-in."""
+    barriers, MAX over ranks of the timings, rank-0 JSON line) on ONE GPU: LBFGSB_BENCH_SHARE_GPU puts both
+    ranks on cuda:0 with a gloo group, LBFGSB_RCCL_LIBRARY swaps librccl for the stand-in.  Launched BARE --
+    `python bench.py --gpus 2`, no launcher around it: bench.py starts torch.distributed.run itself as a child
+    process (before it touches the GPU) and forwards rank 0's line and the exit code; the launched ranks take
+    the very route the driver's own `python -m torch.distributed.run ... bench.py --gpus N` takes."""
     root = os.path.dirname(HERE)
     env = dict(os.environ, LBFGSB_BENCH_SHARE_GPU="1", LBFGSB_RCCL_LIBRARY=_fake_rccl(),
                MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "2000000", "--steps", "5", "--warmup", "12",
-           "--no-cpu-baseline"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "2000000", "--steps", "5",
+           "--warmup", "12", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -281,6 +283,8 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert out["collectives_per_iter"] == out["host_syncs_per_iter"] > 0     # one collective per host sync
     assert out["first_iteration_nseg"] > 1900000     # ~0.977 n segments, walked across both ranks
     assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["rccl_nranks"] == 2 and len(out["config"]["first_iteration_s_per_rank"]) == 2
+    assert out["config"]["parity_in_run"]["rows_checked"] == 0     # (no reference rows for this small shape)
 
 
 @pytest.mark.parametrize("world,mode,n,m,iters,mixed", [

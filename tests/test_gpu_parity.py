@@ -813,17 +813,27 @@ def test_headline_config_n1e8_fp64_anchors(env):
     if free_b < 40 * (1 << 30):
         pytest.skip("needs ~30 GB of HBM")
 
-    def run():
-        sol = la.DeviceSolver(n, m)
+    def run(timed_path=False):
+        """timed_path: exactly what bench.py times -- lbfgsb_hip_setulb_dev_pp (ping-pong iterate buffers) on a
+        context with LBFGSB_F_DEFER_LNSRCH, the objective deferred (its value rides with the next call's fetch)"""
+        sol = la.DeviceSolver(n, m, same_stream_objective=timed_path, defer_lnsrch=timed_path)
         x = torch.zeros(n, dtype=torch.float64, device="cuda")
         g = torch.zeros_like(x)
+        xs, gs = ([x, torch.empty_like(x)], [g, torch.empty_like(g)]) if timed_path else ([x], [g])
         l, u = torch.full_like(x, -1.0), torch.full_like(x, 1.0)
         nbd = torch.full((n,), 2, dtype=torch.int32, device="cuda")
         rows = []
+        cur = 0
         while True:
-            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if timed_path:
+                t, cur = sol.setulb_pp(xs, l, u, nbd, gs, 0.0, 0.0)
+            else:
+                t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
             if t.startswith("FG"):
-                sol.f[0] = sol.objective(0, x, g)
+                if timed_path:
+                    sol.objective(0, xs[cur], gs[cur], deferred=True)
+                else:
+                    sol.f[0] = sol.objective(0, x, g)
             elif t.startswith("NEW_X"):
                 rows.append((int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
                              float(sol.f[0]), float(sol.dsave[12])))
@@ -832,11 +842,12 @@ def test_headline_config_n1e8_fp64_anchors(env):
             else:
                 break
         counts = sol.path_counts()
+        deferred = sol.defer_stats()
         sol.close()
-        del x, g, l, u, nbd
+        del x, g, l, u, nbd, xs, gs
         torch.cuda.empty_cache()
-        return rows, counts
-    rows, (closed_steps, three_steps, _) = run()
+        return rows, counts, deferred
+    rows, (closed_steps, three_steps, _), _d = run()
     assert len(rows) == iters
     assert rows[0][2] == 97_671_921, rows[0]
     assert rows[1][3] == 49_999_496, rows[1]
@@ -854,8 +865,20 @@ def test_headline_config_n1e8_fp64_anchors(env):
         assert got[5] == pytest.approx(want["sbgnrm"], rel=1e-7 if want["nfg"] == want["iter"] + 1 else 1e-5), \
             (got, want)
     assert closed_steps >= 8, (closed_steps, three_steps)
-    rows2, _ = run()
+    rows2, _, _d = run()
     assert rows2 == rows       # bit for bit, f and |proj g| included
+    # THE TIMED PATH at size: ping-pong entry + LBFGSB_F_DEFER_LNSRCH + deferred f (what bench.py drives).  Its
+    # contract is "every NEW_X return bit for bit the default's": integers, |proj g| (same kernels, same order)
+    # exactly; f differs from the classic run only by WHERE the objective's partial sums are completed (the
+    # deferred value is reduced by the next pass's finalize instead of its own) -- still within 1e-12
+    rows3, (closed3, _t3, _h3), (ndef, nredo) = run(timed_path=True)
+    assert len(rows3) == iters and ndef >= iters - 2 and closed3 >= 8, (ndef, nredo, closed3)
+    for got, want in zip(rows3, rows):
+        assert got[:4] == want[:4], (got, want)
+        assert got[4] == pytest.approx(want[4], rel=1e-12) and got[5] == pytest.approx(want[5], rel=1e-9), (got, want)
+    for got, want in zip(rows3, ref["rows"]):
+        assert got[:4] == (want["iter"], want["nfg"], want["nseg"], want["nfree"]), (got, want)
+        assert got[4] == pytest.approx(want["f"], rel=1e-9), (got, want)
 
 
 def test_unconstrained_problem_takes_the_two_pass_iteration(env):
