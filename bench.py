@@ -572,6 +572,66 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
         run.close()
 
 
+def host_form_leg(la, n=10_000_000, m=10, iters=26, warm=12):
+    """The HOST-POINTER form, the reference's own argument list (what the Fortran module's setulb and
+    lbfgsb_amd.setulb bind: lbfgsb_hip_setulb_host): x, g, wa live in host memory, the objective is evaluated on
+    the host (numpy), and per iteration g travels H2D, the trial x and the previous-iterate slot of wa D2H --
+    24 n bytes over PCIe.  Timed inside setulb only (the host objective is the caller's business) over the
+    iterations warm+1 .. iters; the PCIe-inclusive rate is never the headline `value`.  Pinned by SURVEY.md 8c's
+    anchors of this problem at n = 1e7: nseg(it1) = 9767199, nfree(it2) = 4999953."""
+    i = np.arange(1, n + 1, dtype=np.int64)
+    a_ = 1.0 + 99.0 * ((7919 * i) % 10007) / 10006.0
+    c_ = -2.0 + 4.0 * ((104729 * i) % 100003) / 100002.0
+    del i
+    x, g = np.zeros(n), np.zeros(n)
+    l, u = np.full(n, -1.0), np.full(n, 1.0)
+    nbd = np.full(n, 2, np.int32)
+    wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m)
+    iwa = np.zeros(3 * n, np.int32)
+    task, csave = la.solver.pad60("START"), la.solver.pad60("")
+    lsave, isave, dsave, f = np.zeros(4, np.int32), np.zeros(44, np.int32), np.zeros(29), np.zeros(1)
+    t_in = t_obj = 0.0
+    marks, rows = {}, []
+    t_first = None
+    tmp = np.empty(n)
+    try:
+        while True:
+            t0 = time.perf_counter()
+            la.setulb(n, m, x, l, u, nbd, f, g, 0.0, 0.0, wa, iwa, task, -1, csave, lsave, isave, dsave)
+            t_in += time.perf_counter() - t0
+            ts = la.solver.task_str(task)
+            if ts.startswith("FG"):
+                t0 = time.perf_counter()
+                np.subtract(x, c_, out=tmp)
+                np.multiply(a_, tmp, out=g)
+                f[0] = 0.5 * float(np.dot(g, tmp))
+                t_obj += time.perf_counter() - t0
+            elif ts.startswith("NEW_X"):
+                it = int(isave[29])
+                rows.append((it, int(isave[33]), int(isave[32]), int(isave[37])))
+                marks[it] = (t_in, t_obj)
+                if it == 1:
+                    t_first = t_in
+                if it >= iters:
+                    break
+            else:
+                raise RuntimeError("host-form leg stopped: " + ts)
+    finally:
+        la.load_library().lbfgsb_hip_release_host(isave.ctypes.data)
+    k = iters - warm
+    dt_in, dt_obj = marks[iters][0] - marks[warm][0], marks[iters][1] - marks[warm][1]
+    nfg = rows[-1][1] - rows[warm - 1][1]
+    pcie = (nfg * 2 + k) * 8.0 * n        # g up + trial x down per evaluation, the t slot once per iteration
+    anchors_ok = (n != 10_000_000 or m != 10) or (rows[0][2] == 9767199 and rows[1][3] == 4999953)
+    return {"config": "host-pointer form (lbfgsb_hip_setulb_host: the reference's argument list, host arrays, host "
+                      "objective), separable bounded quadratic n=%d, m=%d, fp64" % (n, m), "n": n, "m": m,
+            "value": k / dt_in, "unit": "iters/sec inside setulb (PCIe transfers included, host objective excluded)",
+            "ms_per_step": dt_in / k * 1e3, "steps": k, "iters_per_sec_with_host_objective": k / (dt_in + dt_obj),
+            "host_objective_ms_per_eval": dt_obj / max(1, nfg) * 1e3, "pcie_bytes_per_iter": pcie / k,
+            "pcie_GBs_inside_setulb": pcie / dt_in / 1e9, "first_iteration_s_inside_setulb": t_first,
+            "anchors_ok": bool(anchors_ok), "rows_first2": rows[:2]}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -792,10 +852,9 @@ def main():
                    "iterations_run": run.rows[-1][0] if run.rows else 0,
                    "defer_lnsrch": not a.no_defer,
                    "uniform_bounds_mask": ub,
-                   "uniform_bounds": "l, u, nbd of this workload hold one value each (detected at START, bit 0/1/2 = "
-                                     "l/u/nbd): the passes over W read them as constants, not as 8+8+1 B/row "
-                                     "streams; other_configs has the same workload with the detection off"
-                                     if ub else "not detected / off: l, u, nbd are streamed"},
+                   "uniform_bounds": ("l, u few-valued: dictionary-coded in the nbd byte (bit 3)" if ub & 8 else
+                                      "l, u, nbd hold one value each: read as constants (bits 0-2); leg ub_off streams them"
+                                      if ub else "not detected / off: l, u, nbd are streamed")},
         "iters_per_sec_setulb_only": a.steps / dt_setulb,
         "first_iteration_s": r["first_iter_s"],
         "first_iteration_nseg": r["nseg_first"],
@@ -889,6 +948,12 @@ def main():
                                                          **kw))
             except Exception as e:   # noqa: BLE001  (a leg must never take the headline line down; Ctrl-C still ends the run)
                 out["other_configs"].append({"config": name, "error": repr(e)})
+        # the host-pointer form (reference argument list, host arrays): PCIe-inclusive, never the headline
+        try:
+            out["host_form"] = host_form_leg(lbfgsb_amd)
+            parity_fail = parity_fail or not out["host_form"]["anchors_ok"]
+        except Exception as e:   # noqa: BLE001
+            out["host_form"] = {"error": repr(e)}
         # <= 1 KB summary of every leg INSIDE config (the driver's record keeps config; other_configs is long)
         legs = {}
         for tag, oc in zip(leg_tags, out["other_configs"]):
@@ -903,6 +968,10 @@ def main():
             if pr.get("rows_checked"):
                 legs[tag] += " parity %d rows %s" % (pr["rows_checked"], "ok" if pr["ok"] else "MISMATCH")
                 parity_fail = parity_fail or not pr["ok"]
+        hf = out["host_form"]
+        legs["host_form_n1e7"] = ("error " + hf["error"][:60]) if "error" in hf else (
+            "%.1f it/s %.3f ms in setulb, PCIe %.1f GB/s, anchors %s" % (
+                hf["value"], hf["ms_per_step"], hf["pcie_GBs_inside_setulb"], "ok" if hf["anchors_ok"] else "MISMATCH"))
         out["config"]["legs"] = legs
     # ---- HBM traffic of the passes over W, counted in this run (contexts above are closed: the child
     # has the card's memory to itself) ----

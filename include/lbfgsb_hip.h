@@ -175,16 +175,16 @@ int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar,
  *   - lsave[4] are int32 0/1, isave[44] int32, dsave[29] double, with the
  *     reference's meaning slot for slot (src/lbfgsb.f90:188-242).
  * The caller evaluates f,g on the device whenever task(1:2)=='FG'.
- * l, u and nbd MUST NOT CHANGE between task='START' and the end of the run -- neither
- * the pointers' contents nor (without cost) the pointers.  The reference re-reads the
- * three arrays on every call; this library does not: the context keeps a packed
- * one-byte copy of nbd for its passes over W (refreshed on START, after import_state
- * and when the nbd POINTER changes), and bound arrays found to hold ONE value each at
- * START are read as that constant by the passes over W for the rest of the run
- * (lbfgsb_hip_uniform_bounds below; a different POINTER switches that off, an edit in
- * place is NOT noticed and gives an inconsistent iteration).  A caller that has to edit
- * bounds in place starts a new run (task='START'), or disables the constant-folding with
- * lbfgsb_hip_set_option(ctx, "uniform_bounds", 0) before START.
+ * l, u and nbd MUST NOT CHANGE between task='START' and the end of the run.  The reference re-reads the three
+ * arrays on every call (src/lbfgsb.f90:1270-1330, 2594-2622, 2789-2816); this library's passes over W read a
+ * snapshot: a packed one-byte copy of nbd (refreshed on START, after import_state and when the nbd POINTER
+ * changes), and for bound arrays found at START to hold one value each, or a few values (<= 8 each), that
+ * constant / a table entry selected by the packed byte (lbfgsb_hip_uniform_bounds below).  An edit IN PLACE is
+ * detected, not ignored: after the first iteration and then every 16th (option "bounds_check") the caller's
+ * arrays are compared with the snapshot bit for bit, and a difference ends the run with
+ * task = 'ERROR: BOUNDS CHANGED DURING RUN' (isave(35), info, = -10).  Passing OTHER array pointers than at
+ * START is allowed: the constants / tables are dropped and the arrays are streamed from then on.  A caller that
+ * has to change bounds starts a new run (task='START').
  * ------------------------------------------------------------------------- */
 int lbfgsb_hip_setulb_dev(lbfgsb_hip_ctx *ctx, void *x, const void *l, const void *u,
                           const int32_t *nbd, double *f, void *g, double factr, double pgtol,
@@ -232,10 +232,14 @@ int lbfgsb_hip_wait_stream(lbfgsb_hip_ctx *ctx, void *producer_stream);
  * isave(17:18) (never touched by the reference, src/lbfgsb.f90:250-284),
  * created on task='START' and released when a terminal task is returned (or by
  * lbfgsb_hip_release_host).
- * x and g travel over PCIe on every FG return; `wa`'s t-slot
- * (wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175) and, when
- * iprint >= 0, nothing else of wa/iwa is written unless mirror != 0, in which
- * case the full reference layout of wa and iwa is exported on every return.
+ * What crosses PCIe per call, and only then: g host -> device on an 'FG...' entry; x device -> host at START
+ * (active's projection), at every 'FG_LNSRCH' return (the trial point) and when the call restored the previous
+ * iterate (src/lbfgsb.f90:568-569, 736-737: then g too); `wa`'s t-slot (wa(3n+2mn+11m^2+1 : +n), the previous
+ * iterate test/driver3.f90:171-175 reads) when a line search was set up in the call (:2235).  At 'NEW_X' and at
+ * the convergence returns the caller already holds x and g: nothing n-long moves.  The caller's x, g and that
+ * slot of wa are pinned (hipHostRegister) from START to the end of the run, so the transfers are DMA copies
+ * queued on the context's stream; the call returns when they have landed.  Nothing else of wa / iwa is written
+ * unless mirror != 0, in which case the full reference layout of wa and iwa is exported on every return.
  * iteration_file may be NULL (-> 'iterate.dat', src/lbfgsb.f90:483-489).
  * ------------------------------------------------------------------------- */
 int lbfgsb_hip_setulb_host(int32_t n, int32_t m, void *x, const void *l, const void *u,
@@ -447,6 +451,9 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           (default 1) / from scratch whenever it runs
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
+ *   "dict_bounds" (0/1)     dictionary-code bound arrays with <= 8 distinct values each (same place; default 1)
+ *   "bounds_check" (0..)    compare the caller's l, u, nbd with the context's snapshot after the first iteration and
+ *                           then every k-th (default 16; 0 = never): 'ERROR: BOUNDS CHANGED DURING RUN'
  *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel
  *                           launched, 256 ... 768)
  *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule (m = 20, fp32 m = 10) / off /
@@ -458,16 +465,21 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  * Returns LBFGSB_E_ARG for an unknown name or a value out of range. */
 int lbfgsb_hip_set_option(lbfgsb_hip_ctx *ctx, const char *name, double value);
 
-/* Uniform bounds.  Bound arrays that hold ONE value each -- the box [a, b]^n, x >= 0 -- are the common
- * case, and on a bandwidth-bound device streaming 2 x 8 + 1 constant bytes per row through each of the
- * two passes over W of an iteration is 8 % of its traffic.  At task 'START' the pass that validates
- * the bounds (errclb, src/lbfgsb.f90:1601-1643) also checks, bit for bit, whether every l_i equals l_1,
- * every u_i equals u_1, every nbd_i equals nbd_1 (among this rank's rows); the passes over W then read
- * the value from a 64-byte buffer instead of the array -- same arithmetic, same results bit for bit.
- * *mask: bit 0 = l, bit 1 = u, bit 2 = nbd is treated as uniform in the current run.  The arrays must
- * not change during a run (as for nbd above); passing OTHER array pointers than at 'START' switches the
- * corresponding bit off.  Option "uniform_bounds" = 0 (lbfgsb_hip_set_option, before START) disables
- * the detection. */
+/* Uniform and few-valued bounds.  Bound arrays that hold ONE value each -- the box [a, b]^n, x >= 0 -- are the
+ * common case, and on a bandwidth-bound device streaming 2 x 8 + 1 constant bytes per row through each of the
+ * two passes over W of an iteration is 8 % of its traffic.  At task 'START' the pass that validates the bounds
+ * (errclb, src/lbfgsb.f90:1601-1643) also checks, bit for bit, whether every l_i equals l_1, every u_i equals
+ * u_1, every nbd_i equals nbd_1 (among this rank's rows); the passes over W then read the value from a 64-byte
+ * buffer instead of the array -- same arithmetic, same results bit for bit.
+ * Arrays with a FEW distinct values -- the reference's own test box, l alternating 1 / -100 with u = 100
+ * (test/driver3.f90:102-120); a box with some variables on another box -- are dictionary-coded: if l and u hold
+ * at most 8 distinct values each (bit patterns; found by a few probing passes at START, identical on all ranks),
+ * the one-byte copy of nbd the passes stream anyway carries  nbd | l-index << 2 | u-index << 5  and the values
+ * come from two 8-entry tables held in LDS: 1 byte per row instead of 17.  Same values, same arithmetic.
+ * *mask: bit 0 = l, bit 1 = u, bit 2 = nbd is treated as uniform in the current run; bit 3 (with bits 0 and 1):
+ * l and u are dictionary-coded.  Passing OTHER array pointers than at 'START' switches the corresponding bits
+ * off (any of the three for the dictionary).  Options "uniform_bounds" = 0 / "dict_bounds" = 0
+ * (lbfgsb_hip_set_option, before START) disable the detection / the dictionary. */
 int lbfgsb_hip_uniform_bounds(lbfgsb_hip_ctx *ctx, int32_t *mask);
 
 /* Profiling clocks, counters and bare-kernel timing doors (bench.py, profiles/scripts, tests) are declared in

@@ -552,9 +552,17 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
       finish_ints();
       return 0;
     }
-    int fl = (r32 ? LBFGSB_F_REAL32 : 0) | (mirror ? LBFGSB_F_MIRROR_INDEX : 0);
+    // (NO_RETURN_SYNC: this function queues its own D2H copies behind the call and synchronises once)
+    int fl = (r32 ? LBFGSB_F_REAL32 : 0) | (mirror ? LBFGSB_F_MIRROR_INDEX : 0) | LBFGSB_F_NO_RETURN_SYNC;
     int rc = lbfgsb_hip_create(n, n, 0, (int)m, fl, 0, nullptr, &ctx);
     if (rc) return rc;
+    // the caller's x, g and the t slot of wa are pinned for the run: the per-call transfers below are then DMA
+    // copies on the context's stream (unpinned again when the context goes; arrays that cannot be pinned, or
+    // other arrays than these on a later call, travel as pageable copies)
+    ctx->host_register(0, x, (size_t)n * rb);
+    ctx->host_register(1, g, (size_t)n * rb);
+    if (wa && !mirror)
+      ctx->host_register(2, (char *)wa + (size_t)(2ll * m * n + 11ll * m * m + 3ll * n) * rb, (size_t)n * rb);
     if (iteration_file && iteration_file[0]) ctx->itfile_name = iteration_file;
     const size_t vb = ((size_t)n + 32) * rb;
     auto stage = [&]() -> int {
@@ -590,8 +598,47 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
     ctx = g_host.find(isave);
     if (!ctx || ctx->n != n || ctx->m != m)
       return fail(LBFGSB_E_STATE, "setulb called without a live context (task must be START first)");
+    // l, u, nbd were copied at START; the reference re-reads the caller's arrays on every call (:1270-1330,
+    // :2594-2622, :2789-2816).  After the first iteration and then every 16th the arrays are uploaded again and
+    // compared with the copies, bit for bit: an edit in place ends the run with an error instead of being ignored.
+    if (lbh::str60_pre(task, "NEW_X") && (isave[29] == 1 || (isave[29] > 0 && isave[29] % 16 == 0))) {
+      void *tl = nullptr, *tu = nullptr;
+      int32_t *tn = nullptr;
+      double ndiff = 0.0;
+      auto check = [&]() -> int {
+        const size_t vb = ((size_t)n + 32) * rb;
+        HIPCHK(hipMalloc(&tl, vb));
+        HIPCHK(hipMalloc(&tu, vb));
+        HIPCHK(hipMalloc(&tn, ((size_t)n + 32) * 4));
+        HIPCHK(hipMemcpy(tl, l, (size_t)n * rb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(tu, u, (size_t)n * rb, hipMemcpyHostToDevice));
+        if (i8) {
+          std::vector<int32_t> nb((size_t)n);
+          const int64_t *src = (const int64_t *)nbd_;
+          for (int64_t k = 0; k < n; ++k) nb[(size_t)k] = (src[k] < 0 || src[k] > 3) ? -1 : (int32_t)src[k];
+          HIPCHK(hipMemcpy(tn, nb.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        } else {
+          HIPCHK(hipMemcpy(tn, nbd_, (size_t)n * 4, hipMemcpyHostToDevice));
+        }
+        return ctx->bounds_same(ctx->hl, ctx->hu, ctx->hnbd, tl, tu, tn, &ndiff);
+      };
+      const int rcc = check();
+      if (tl) (void)hipFree(tl);
+      if (tu) (void)hipFree(tu);
+      if (tn) (void)hipFree(tn);
+      if (rcc) return rcc;
+      if (ndiff != 0.0) {
+        lbh::str60_set(task, "ERROR: BOUNDS CHANGED DURING RUN");
+        if (iprint >= 0) std::printf("\n l, u or nbd were modified during the run (%.0f rows differ from the arrays of task = 'START').\n", ndiff);
+        g_host.drop(isave);
+        finish_ints();
+        return 0;
+      }
+    }
+    // the caller's gradient (and f) at the point the last return asked for; x is the library's own trial point
+    // and is not read back (the reference's caller does not modify x between calls either, :104-108)
     if (lbh::str60_pre(task, "FG"))
-      HIPCHK(hipMemcpy(ctx->hg, g, (size_t)n * rb, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpyAsync(ctx->hg, g, (size_t)n * rb, hipMemcpyHostToDevice, ctx->q.stream));
   }
   // the wa offsets the reference persists in isave(4:16) (:250-265: lws, lwy, lsy, lss, lwt, lwn,
   // lsnd, lz, lr, ld, lt, lxp, lwa; isave(1:3) = m*n, m^2, 4m^2), 1-based, computed in 64 bits
@@ -609,6 +656,8 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
   double fd = r32 ? (double)*(float *)f : *(double *)f;
   double ds[29];
   for (int i = 0; i < 29; ++i) ds[i] = r32 ? (double)((float *)dsave)[i] : ((double *)dsave)[i];
+  ctx->restored_xg = false;
+  const int64_t setups0 = ctx->n_ls_setup;
   int rc = ctx->setulb_dev(ctx->hx, ctx->hl, ctx->hu, ctx->hnbd, &fd, ctx->hg, factr, pgtol, task,
                            iprint, csave, lsave, isave, ds);
   isave[16] = keep_id, isave[17] = keep_tag;
@@ -629,9 +678,19 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
     *(float *)f = (float)fd;
   else
     *(double *)f = fd;
-  HIPCHK(hipMemcpy(x, ctx->hx, (size_t)n * rb, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(g, ctx->hg, (size_t)n * rb, hipMemcpyDeviceToHost));
+  // What travels back (the reference writes these arrays only at these points):
+  //   x   at START (active's projection, :965-1040), at every 'FG_LNSRCH' return (the trial point, :2262-2268)
+  //       and when the call restored the previous iterate (:568-569, :736-737) -- at 'NEW_X' and at the
+  //       convergence returns x is the point the caller already holds;
+  //   g   only when the call restored it (the same two places); otherwise the device copy IS the caller's;
+  //   t   (wa's previous-iterate slot) only when a line search was set up in this call (:2235).
+  // Queued on the context's stream behind the call's kernels, one synchronisation for all of them.
+  hipStream_t st = ctx->q.stream;
+  const bool x_back = start || ctx->restored_xg || lbh::str60_pre(task, "FG_LN");
+  if (x_back) HIPCHK(hipMemcpyAsync(x, ctx->hx, (size_t)n * rb, hipMemcpyDeviceToHost, st));
+  if (ctx->restored_xg) HIPCHK(hipMemcpyAsync(g, ctx->hg, (size_t)n * rb, hipMemcpyDeviceToHost, st));
   if (mirror) {
+    HIPCHK(hipStreamSynchronize(st));
     if (i8) {  // the library's int32 iwa, widened into the caller's
       std::vector<int32_t> iw((size_t)3 * (size_t)n);
       rc = ctx->export_state(wa, iw.data());
@@ -642,12 +701,13 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
       rc = ctx->export_state(wa, (int32_t *)iwa_);
       if (rc) return rc;
     }
-  } else if (wa) {
+  } else if (wa && ctx->n_ls_setup != setups0) {
     // previous iterate: wa(3n+2mn+11m^2+1 : +n), read by test/driver3.f90:171-175
     const int64_t off_t = 2ll * m * n + 11ll * m * m + 3ll * n;
     const void *src = ctx->prev_iterate();
-    HIPCHK(hipMemcpy((char *)wa + (size_t)off_t * rb, src, (size_t)n * rb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync((char *)wa + (size_t)off_t * rb, src, (size_t)n * rb, hipMemcpyDeviceToHost, st));
   }
+  HIPCHK(hipStreamSynchronize(st));
   if (!lbh::str60_pre(task, "FG") && !lbh::str60_pre(task, "NEW_X"))
     g_host.drop(isave);  // terminal task: CONVERGENCE / ABNORMAL / ERROR / STOP
   finish_ints();

@@ -203,6 +203,8 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
     const iw_t *__restrict__ iwhere, double lo_t, int64_t lo_i, double hi_t, uint64_t *keys,
     uint32_t *idx, uint32_t cap, uint32_t *count, int ub) {
   const int lane = threadIdx.x & 63;
+  __shared__ T dict[16];
+  dict_fill<T>(dict, l, u, ub);
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], tv[W];
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_window_fly_kernel(
     ldx<W, true>(g + i, gv);
     ldi<W>((ub & 4) ? nbd : nbd + i, nb);
     ldi<W>(iwhere + i, iw);
+    dict_apply<T, W>(dict, ub, nb, lv, uv);
     unsigned bits = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k) {

@@ -488,6 +488,150 @@ void launch_nbd_pack(Queue &q, int64_t n, const int32_t *nbd, nb_t *out) {
   hipLaunchKernelGGL(nbd_pack_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, nbd, out);
   LB_LAUNCHED(q);
 }
+
+// ---- dictionary-coded bounds (kernels_common.hpp, UB_DICT): build, pack, verify ----
+// One probe pass: how many l_i / u_i are NOT in the tables yet (bit-for-bit membership), and the smallest such
+// value of each array.  The host adds those two values to its tables and probes again until nothing is left
+// or a table would exceed 8 entries; every quantity is reduced over the ranks, so all ranks build the SAME
+// tables with the same number of passes.  res: sum [0] #l outside, [1] #u outside | min [2] l value, [3] u value
+template <typename T>
+__device__ __forceinline__ int dict_find(const BoundTables &tb, int which, double v) {
+  const long long b = __double_as_longlong(v);
+  const int cnt = which ? tb.nu : tb.nl;
+  for (int j = 0; j < 8; ++j)
+    if (j < cnt && __double_as_longlong(which ? tb.u[j] : tb.l[j]) == b) return j;
+  return -1;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void dict_probe_kernel(int64_t n, const T *__restrict__ l,
+                                                           const T *__restrict__ u, BoundTables tb,
+                                                           double *part) {
+  double acc[4] = {0.0, 0.0, LB_INF, LB_INF};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double lv[W], uv[W];
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (dict_find<T>(tb, 0, lv[k]) < 0) acc[0] += 1.0, acc[2] = fmin(acc[2], lv[k]);
+      if (dict_find<T>(tb, 1, uv[k]) < 0) acc[1] += 1.0, acc[3] = fmin(acc[3], uv[k]);
+    }
+  });
+  block_reduce_store<4>(acc, 2, 2, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_dict_probe(Queue &q, int64_t n, const T *l, const T *u, const BoundTables &tb) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(dict_probe_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, l, u, tb, q.part());
+  LB_LAUNCHED(q);
+  launch_finalize(q, g, 2, 2, 0);
+}
+// the code byte of every row: nbd | l-index << 2 | u-index << 5 (a value the tables do not hold cannot occur:
+// the probe has just found none; such a row would get index 0 and be caught by bounds_verify_kernel)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void nbd_pack_dict_kernel(int64_t n, const int32_t *__restrict__ nbd,
+                                                              const T *__restrict__ l, const T *__restrict__ u,
+                                                              BoundTables tb, nb_t *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int jl = dict_find<T>(tb, 0, (double)l[i]), ju = dict_find<T>(tb, 1, (double)u[i]);
+    out[i] = (nb_t)(unsigned char)((unsigned)(nbd[i] & 3) | ((unsigned)(jl < 0 ? 0 : jl) << 2) |
+                                   ((unsigned)(ju < 0 ? 0 : ju) << 5));
+  }
+}
+template <typename T>
+void launch_nbd_pack_dict(Queue &q, int64_t n, const int32_t *nbd, const T *l, const T *u, const BoundTables &tb,
+                          nb_t *out) {
+  hipLaunchKernelGGL(nbd_pack_dict_kernel<T>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, nbd, l, u, tb,
+                     out);
+  LB_LAUNCHED(q);
+}
+// The reference re-reads l, u, nbd on every call (src/lbfgsb.f90:1270-1330, 2594-2622, 2789-2816); the passes
+// over W read the context's snapshot of them instead (the packed nbd byte, constants or table entries for
+// uniform / few-valued bound arrays).  This pass compares the caller's arrays with that snapshot, bit for
+// bit: a caller that edits bounds in place during a run is NOTICED (task 'ERROR: BOUNDS CHANGED DURING RUN')
+// instead of silently iterated on with stale bounds.  ub bits as in the passes; tb: the values the passes
+// use where an array is not streamed.  res: sum [0] = rows that differ
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void bounds_verify_kernel(int64_t n, const T *__restrict__ l,
+                                                              const T *__restrict__ u,
+                                                              const int32_t *__restrict__ nbd,
+                                                              const nb_t *__restrict__ code, int ub, BoundTables tb,
+                                                              double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double lv[W], uv[W];
+    int nb[W], cd[W];
+    ld<W>(l + i, lv);
+    ld<W>(u + i, uv);
+    ldi<W>(nbd + i, nb);
+    if (ub & 4) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) cd[k] = 0;
+    } else {
+      ldi<W>(code + i, cd);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const unsigned c = (unsigned)cd[k] & 0xffu;
+      bool bad;
+      if (ub & UB_DICT) {
+        bad = nb[k] != (int)(c & 3u) ||
+              __double_as_longlong(lv[k]) != __double_as_longlong(tb.l[(c >> 2) & 7u]) ||
+              __double_as_longlong(uv[k]) != __double_as_longlong(tb.u[c >> 5]);
+      } else {
+        bad = (ub & 4) ? nb[k] != tb.nb0 : nb[k] != cd[k];
+        if (ub & 1) bad = bad || __double_as_longlong(lv[k]) != __double_as_longlong(tb.l[0]);
+        if (ub & 2) bad = bad || __double_as_longlong(uv[k]) != __double_as_longlong(tb.u[0]);
+      }
+      if (bad) acc[0] += 1.0;
+    }
+  });
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_bounds_verify(Queue &q, int64_t n, const T *l, const T *u, const int32_t *nbd, const nb_t *code,
+                          int ub, const BoundTables &tb) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(bounds_verify_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, l, u, nbd, code, ub, tb,
+                     q.part());
+  LB_LAUNCHED(q);
+  launch_finalize(q, g, 1, 0, 0);
+}
+// bit-for-bit comparison of two copies of (l, u, nbd) -- the host-pointer form, whose device copies were made at
+// START: the caller's arrays are uploaded again from time to time and compared.  res: sum [0] = rows that differ
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void bounds_same_kernel(int64_t n, const T *__restrict__ l0,
+                                                            const T *__restrict__ u0,
+                                                            const int32_t *__restrict__ nb0,
+                                                            const T *__restrict__ l1, const T *__restrict__ u1,
+                                                            const int32_t *__restrict__ nb1, double *part) {
+  double acc[1] = {0.0};
+  for_rows<T>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double la[W], ua[W], lb[W], ub_[W];
+    int na[W], nb[W];
+    ld<W>(l0 + i, la), ld<W>(u0 + i, ua), ldi<W>(nb0 + i, na);
+    ld<W>(l1 + i, lb), ld<W>(u1 + i, ub_), ldi<W>(nb1 + i, nb);
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+      if (__double_as_longlong(la[k]) != __double_as_longlong(lb[k]) ||
+          __double_as_longlong(ua[k]) != __double_as_longlong(ub_[k]) || na[k] != nb[k])
+        acc[0] += 1.0;
+  });
+  block_reduce_store<1>(acc, 1, 0, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_bounds_same(Queue &q, int64_t n, const T *l0, const T *u0, const int32_t *nb0, const T *l1,
+                        const T *u1, const int32_t *nb1) {
+  const int g = grid_for(n, VecOf<T>::V);
+  hipLaunchKernelGGL(bounds_same_kernel<T>, dim3(g), dim3(BLOCK), 0, q.stream, n, l0, u0, nb0, l1, u1, nb1,
+                     q.part());
+  LB_LAUNCHED(q);
+  launch_finalize(q, g, 1, 0, 0);
+}
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const T *__restrict__ x,
                                                                const T *__restrict__ t,
@@ -853,6 +997,10 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
 #define INSTANTIATE(T) \
   template void launch_active<T>(Queue &, int64_t, T *, const T *, const T *, const int32_t *, iw_t *, int8_t *); \
   template void launch_errclb<T>(Queue &, int64_t, int64_t, const T *, const T *, const int32_t *); \
+  template void launch_dict_probe<T>(Queue &, int64_t, const T *, const T *, const BoundTables &); \
+  template void launch_nbd_pack_dict<T>(Queue &, int64_t, const int32_t *, const T *, const T *, const BoundTables &, nb_t *); \
+  template void launch_bounds_verify<T>(Queue &, int64_t, const T *, const T *, const int32_t *, const nb_t *, int, const BoundTables &); \
+  template void launch_bounds_same<T>(Queue &, int64_t, const T *, const T *, const int32_t *, const T *, const T *, const int32_t *); \
   template void launch_projgr<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *); \
   template void launch_vec_sub<T>(Queue &, int64_t, const T *, const T *, T *); \
   template void launch_vec_scale<T>(Queue &, int64_t, double, T *); \

@@ -85,6 +85,8 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
   // for a few stores too): the trial point / z (+ the committed pair in the steady-state shape)
   constexpr int NS = PSPEC ? 3 : 1;
   const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, pr, pd, nbd, iwhere, ldw, m, head, col, pe, ub};
+  __shared__ T dict[16];
+  dict_fill<T>(dict, l, u, ub);
   for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     raw_get<W>(tr.rg, (const T *)nullptr, gv);
     raw_geti<W>(tr.rnb, (const nb_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
+    dict_apply<T, W>(dict, ub, nb, lv, uv);
     get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     fix_pending<T, MC, W, PSPEC>(col, pe, gv, xv, a, b);
     if (PSPEC || pe.on) {

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   const bool hi = threadIdx.x & 1;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
   const UpdScanCtx<T> ctx{x, l, u, g, r, d, ws, wy, zero, nbd, iwhere, ldw, m, head, nold, ub};
+  __shared__ T dict[16];
+  dict_fill<T>(dict, l, u, ub);
   for_rows_raw<UpdScanTrip<T, MC, V, NT>, UpdScanTrip<T, MC, 1, NT>, V, PIPE, 0>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     raw_get<W>(tr.rd, (const T *)nullptr, dv);
     raw_geti<W>(tr.rnb, (const nb_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
+    dict_apply<T, W>(dict, ub, nb, lv, uv);
     bool iw_changed = false;
 #pragma unroll
     for (int k = 0; k < W; ++k) {

@@ -386,6 +386,8 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 // l_i is one value, bit 1: every u_i, bit 2: every nbd_i -- the corresponding pointer then is a
 // 64-byte device buffer filled with that value, which every lane reads from its start (a cache hit
 // instead of an HBM stream of 8 / 8 / 1 bytes per row).  Detected at START (errclb's pass).
+// bit 3 (UB_DICT, with bits 0 and 1 set, bit 2 clear): FEW-VALUED bounds -- the l / u buffers hold tables of
+// <= 8 values each and the nbd byte stream carries nbd | l-index << 2 | u-index << 5 (kernels_common.hpp).
 // cand_hi >= 0: rows whose breakpoint t lies in [0, cand_hi] are appended (unordered) to
 // ckeys / cidx (capacity ccap), *ccount = how many there are (zeroed by the launch)
 // newrow (col - 1 <= 10): 4 MC + 4 more sum slots in front of the min / max slots -- the new
@@ -394,6 +396,29 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
 inline int update_scan_extra(int nold, int newrow);
 // Ws/Wy slot of logical column col-1 <- the pending pair (paths without a subspace pass)
 void launch_nbd_pack(Queue &q, int64_t n, const int32_t *nbd, nb_t *out);
+// Dictionary-coded bounds (ub bit 3 = UB_DICT, kernels_common.hpp): bound arrays with <= 8 distinct values each.
+// The tables travel by value; entry j of l / u beyond nl / nu repeats entry 0.
+constexpr int UB_DICT = 8;  // the dictionary bit of `ub`
+struct BoundTables {
+  double l[8], u[8];  // values of the context's real kind, widened exactly
+  int nl, nu, nb0;    // entries in use; nb0: the value of a uniform nbd array
+};
+// res: sum [0] #l_i outside the table, [1] #u_i outside | min [2] smallest such l_i, [3] smallest such u_i
+template <typename T>
+void launch_dict_probe(Queue &q, int64_t n, const T *l, const T *u, const BoundTables &tb);
+// out[i] = nbd_i | index of l_i << 2 | index of u_i << 5
+template <typename T>
+void launch_nbd_pack_dict(Queue &q, int64_t n, const int32_t *nbd, const T *l, const T *u, const BoundTables &tb,
+                          nb_t *out);
+// the caller's l, u, nbd against the snapshot the passes over W read (packed byte / constants / tables), bit for
+// bit.  res: sum [0] = rows that differ
+template <typename T>
+void launch_bounds_verify(Queue &q, int64_t n, const T *l, const T *u, const int32_t *nbd, const nb_t *code,
+                          int ub, const BoundTables &tb);
+// two copies of (l, u, nbd) against each other, bit for bit.  res: sum [0] = rows that differ
+template <typename T>
+void launch_bounds_same(Queue &q, int64_t n, const T *l0, const T *u0, const int32_t *nb0, const T *l1,
+                        const T *u1, const int32_t *nb1);
 // d = x - t, z = x: the vectors a lean subsm_update_kernel pass left implicit (Pend::impl)
 template <typename T>
 void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z);

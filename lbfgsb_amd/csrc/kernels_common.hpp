@@ -305,6 +305,35 @@ __device__ __forceinline__ void newest_cols(int col, const double (&a)[MC][W], c
 void finalize_from(Queue &q, const double *part, int pstride, int nblocks, int nsum, int nmin,
                    int nmax);
 
+// ---- dictionary-coded bounds (ub bit 3, UB_DICT) ----
+// Bound arrays with FEW distinct values (the box [a, b]^n with some variables on another box, driver3's
+// alternating l = 1 / -100, test/driver3.f90:102-120) are not streamed by the passes over W either: the
+// packed one-byte copy of nbd the passes read anyway then carries  nbd | l-index << 2 | u-index << 5 , and
+// the values come from two tables of <= 8 entries each -- the SAME 64-byte buffers the uniform case reads
+// (l at +0, u at +64: a uniform array is the dictionary whose entries are all that one value), copied into
+// LDS once per workgroup.  The table entries are the caller's values bit for bit, so the arithmetic and
+// every result are those of the streaming kernels; 1 byte per row instead of 2 x sizeof(T) + 1.
+template <typename T>
+__device__ __forceinline__ void dict_fill(T (&tab)[16], const T *l, const T *u, int ub) {
+  if (ub & UB_DICT) {  // (uniform over the grid)
+    if (threadIdx.x < 16) tab[threadIdx.x] = threadIdx.x < 8 ? l[threadIdx.x] : u[threadIdx.x - 8];
+    __syncthreads();
+  }
+}
+template <typename T, int W>
+__device__ __forceinline__ void dict_apply(const T (&tab)[16], int ub, int (&nb)[W], double (&lv)[W],
+                                           double (&uv)[W]) {
+  if (ub & UB_DICT) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const unsigned c = (unsigned)nb[k] & 0xffu;
+      lv[k] = (double)tab[(c >> 2) & 7u];
+      uv[k] = (double)tab[8u + (c >> 5)];
+      nb[k] = (int)(c & 3u);
+    }
+  }
+}
+
 // ---- projgr (:2594-2622) of one row ----
 __device__ __forceinline__ double proj_g(double x, double l, double u, int nb, double gi) {
   if (nb != 0) {

@@ -65,8 +65,16 @@ class Solver final : public lbfgsb_hip_ctx {
   //      streamed by the passes over W: the kernels read a 64-byte constant buffer instead (8 + 8 + 1
   //      bytes per row less in each of the two passes; kernels.hpp `ub`).  Detected at START by
   //      errclb's pass, bit for bit; l, u, nbd must not change during a run anyway. ----
+  //      FEW-VALUED bound arrays (<= 8 distinct values each: driver3's alternating box, test/driver3.f90:102-120)
+  //      are dictionary-coded (bit 3, lbk::UB_DICT): the one-byte nbd copy carries nbd | l-index << 2 |
+  //      u-index << 5 and the two buffers hold the value tables (kernels_common.hpp).
+  //      The caller's arrays are compared with this snapshot every bcheck_every iterations (bounds_verify). ----
   bool ub_on = true;          // (option "uniform_bounds")
-  int ub_mask = 0;            // bit 0 l, bit 1 u, bit 2 nbd
+  bool dict_on = true;        // (option "dict_bounds")
+  int bcheck_every = 16;      // (option "bounds_check": 0 = never)
+  int64_t nbounds_checks = 0;
+  lbk::BoundTables ub_tab{};  // the values the passes use where an array is not streamed
+  int ub_mask = 0;            // bit 0 l, bit 1 u, bit 2 nbd, bit 3 dictionary (with bits 0, 1)
   char *ub_buf = nullptr;     // 3 x 64 bytes on the device
   const void *ub_l = nullptr, *ub_u = nullptr;  // the caller arrays the detection looked at
   const int32_t *ub_nbd = nullptr;
@@ -552,6 +560,7 @@ class Solver final : public lbfgsb_hip_ctx {
   // x = t, g = r (:568-569, :736-737).  Ping-pong buffers: the previous iterate still sits in its
   // own pair, which simply becomes the pair the caller is pointed at again.
   int restore_iterate(Mainlb &L) {
+    restored_xg = true;
     if (pp && (t == xb[0] || t == xb[1])) {
       pp_cur = t == xb[0] ? 0 : 1;
       L.x = xb[pp_cur], L.g = gb[pp_cur];
@@ -593,6 +602,10 @@ class Solver final : public lbfgsb_hip_ctx {
     {
       // uniform bounds (this rank's rows; every rank decides for itself: only loads are affected)
       ub_mask = 0;
+      ub_tab = lbk::BoundTables{};
+      // (errclb's answers before the probes below reuse h_res)
+      const int64_t k6_ = (int64_t)h_res[0], k7_ = (int64_t)h_res[1];
+      const bool uni_l = h_res[2] == 0.0, uni_u = h_res[3] == 0.0, uni_nb = h_res[4] == 0.0;
       if (ub_on) {
         T lu0[2];
         int32_t nb0 = 0;
@@ -601,19 +614,64 @@ class Solver final : public lbfgsb_hip_ctx {
         HIPCHK(hipMemcpy(&nb0, nbd, sizeof(int32_t), hipMemcpyDeviceToHost));
         // (h_res[2..4] are maxima over ALL ranks: a rank whose own rows are uniform but another's
         //  are not simply keeps streaming -- harmless)
+        for (int j = 0; j < 8; ++j) ub_tab.l[j] = (double)lu0[0], ub_tab.u[j] = (double)lu0[1];
+        ub_tab.nl = ub_tab.nu = 1, ub_tab.nb0 = nb0;
+        if (uni_l) ub_mask |= 1;
+        if (uni_u) ub_mask |= 2;
+        if (uni_nb && nb0 >= 0 && nb0 <= 3) ub_mask |= 4;
+        // few-valued l / u: build the tables by probing (every quantity reduced over the ranks: all ranks
+        // hold the same tables after the same number of passes).  Only for valid input (errclb found nothing).
+        if (dict_on && !(uni_l && uni_u) && k6_ == 0 && k7_ == 0) {
+          lbk::BoundTables tb{};
+          bool ok = true;
+          auto member = [](const double *tab, int cnt, double v) {
+            for (int j = 0; j < cnt; ++j)
+              if (std::memcmp(&tab[j], &v, sizeof(double)) == 0) return true;
+            return false;
+          };
+          for (int trip = 0; trip < 18 && ok; ++trip) {
+            lbk::launch_dict_probe<T>(q, n, l, u, tb);
+            CHK(fetch(2, 2, 0));
+            const double cl = h_res[0], cu = h_res[1], vl = h_res[2], vu = h_res[3];
+            if (cl == 0.0 && cu == 0.0) break;
+            if (trip == 17) ok = false;
+            if (cl > 0.0) {
+              if (tb.nl == 8 || member(tb.l, tb.nl, vl)) ok = false;  // a 9th value, or one that == cannot find (NaN)
+              else tb.l[tb.nl++] = vl;
+            }
+            if (cu > 0.0) {
+              if (tb.nu == 8 || member(tb.u, tb.nu, vu)) ok = false;
+              else tb.u[tb.nu++] = vu;
+            }
+          }
+          if (ok && tb.nl >= 1 && tb.nu >= 1) {
+            for (int j = tb.nl; j < 8; ++j) tb.l[j] = tb.l[0];
+            for (int j = tb.nu; j < 8; ++j) tb.u[j] = tb.u[0];
+            tb.nb0 = nb0;
+            ub_tab = tb;
+            ub_mask = 1 | 2 | lbk::UB_DICT;
+            lbk::launch_nbd_pack_dict<T>(q, n, nbd, l, u, ub_tab, nbd8);
+            nbd8_src = nbd;
+          }
+        }
         char host[192];
         std::memset(host, 0, sizeof host);
-        for (int k = 0; k < (int)(64 / sizeof(T)); ++k) {
-          std::memcpy(host + k * sizeof(T), &lu0[0], sizeof(T));
-          std::memcpy(host + 64 + k * sizeof(T), &lu0[1], sizeof(T));
+        for (int k = 0; k < 8; ++k) {  // (fp64: the whole 64 bytes; fp32: the first 32 -- every lane reads from the start)
+          const T lv = (T)ub_tab.l[k], uv = (T)ub_tab.u[k];
+          std::memcpy(host + k * sizeof(T), &lv, sizeof(T));
+          std::memcpy(host + 64 + k * sizeof(T), &uv, sizeof(T));
         }
+        if (sizeof(T) == 4 && !(ub_mask & lbk::UB_DICT))  // (uniform fp32: the value fills the buffer as before)
+          for (int k = 8; k < 16; ++k) {
+            const T lv = (T)ub_tab.l[0], uv = (T)ub_tab.u[0];
+            std::memcpy(host + k * sizeof(T), &lv, sizeof(T));
+            std::memcpy(host + 64 + k * sizeof(T), &uv, sizeof(T));
+          }
         std::memset(host + 128, (int)(lbk::nb_t)nb0, 64);
         HIPCHK(hipMemcpy(ub_buf, host, sizeof host, hipMemcpyHostToDevice));
-        if (h_res[2] == 0.0) ub_mask |= 1;
-        if (h_res[3] == 0.0) ub_mask |= 2;
-        if (h_res[4] == 0.0 && nb0 >= 0 && nb0 <= 3) ub_mask |= 4;
         ub_l = l, ub_u = u, ub_nbd = nbd;
       }
+      h_res[0] = (double)k6_, h_res[1] = (double)k7_;
     }
     {
       const int64_t k6 = (int64_t)h_res[0], k7 = (int64_t)h_res[1];
@@ -786,6 +844,21 @@ class Solver final : public lbfgsb_hip_ctx {
     } else if (lbh::str60_pre(task, "NEW_X")) {
       seg(1);
       compute_pg = false, prelims = false, linesearch = false;
+      // The caller's l, u, nbd against the snapshot the passes over W read -- after the first iteration, then every
+      // bcheck_every-th: the reference re-reads the arrays on every call (:1270-1330, :2594-2622, :2789-2816), so
+      // an edit in place would take effect there; here it ends the run with an error instead of being ignored.
+      // (At a NEW_X entry nothing deferred is in flight: the fetch is this call's own.)
+      if (bcheck_every > 0 && (iter == 1 || iter % bcheck_every == 0)) {
+        lbk::launch_bounds_verify<T>(q, n, l, u, nbd, nbd8, ub_mask, ub_tab);
+        CHK(fetch(1, 0, 0));
+        nbounds_checks++;
+        if (h_res[0] != 0.0) {
+          lbh::str60_set(task, "ERROR: BOUNDS CHANGED DURING RUN");
+          info = -10;
+          finish(L);
+          return done(flow);
+        }
+      }
     } else if (!lbh::str60_pre(task, "FG_ST")) {
       if (lbh::str60_pre(task, "STOP")) {
         if (std::strncmp(task + 6, "CPU", 3) == 0) {  // :566-571
@@ -1168,6 +1241,7 @@ class Solver final : public lbfgsb_hip_ctx {
       return done(flow);
     }
     if (setup_call) {
+      n_ls_setup++;
       const int do_stpmx = (cnstnd && iter != 0) ? 1 : 0;
       double stpmx_cand;
       if (ls.ready) {  // d, t, r, dtd, g'd came out of the subsm pass
@@ -1565,12 +1639,17 @@ class Solver final : public lbfgsb_hip_ctx {
         }
       }
     }
-    CHK(ensure_nbd8(nbd));
     if (ub_mask && !lbh::str60_eq(task, "START")) {  // other arrays than the ones START looked at
-      if (L.l != ub_l) ub_mask &= ~1;
-      if (L.u != ub_u) ub_mask &= ~2;
-      if (nbd != ub_nbd) ub_mask &= ~4;
+      if (ub_mask & lbk::UB_DICT) {
+        // (the code bytes were made from all three arrays: any other array ends the dictionary mode)
+        if (L.l != ub_l || L.u != ub_u || nbd != ub_nbd) ub_mask = 0, nbd8_src = nullptr;
+      } else {
+        if (L.l != ub_l) ub_mask &= ~1;
+        if (L.u != ub_u) ub_mask &= ~2;
+        if (nbd != ub_nbd) ub_mask &= ~4;
+      }
     }
+    CHK(ensure_nbd8(nbd));
     Flow flow = NEXT;
 #define PHASE(call)               \
   {                               \

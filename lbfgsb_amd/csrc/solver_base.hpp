@@ -112,7 +112,7 @@ using namespace lbs;
 
 // ===================================================================== context
 struct lbfgsb_hip_ctx {
-  virtual ~lbfgsb_hip_ctx() {}
+  virtual ~lbfgsb_hip_ctx() { host_unregister_all(); }
   virtual int setulb_dev(void *x, const void *l, const void *u, const int32_t *nbd, double *f,
                          void *g, double factr, double pgtol, char *task, int iprint, char *csave,
                          int32_t *lsave, int32_t *isave, double *dsave) = 0;
@@ -164,6 +164,29 @@ struct lbfgsb_hip_ctx {
   // host-entry staging (setulb_host)
   void *hx = nullptr, *hg = nullptr, *hl = nullptr, *hu = nullptr;
   int32_t *hnbd = nullptr;
+  // ... what a call did to the vectors the host form mirrors back: x = t, g = r restored (:568-569, :736-737);
+  // a line-search set-up ran (t = x, r = g written, :2235-2236) -- only then g / the t slot of wa travel D2H
+  bool restored_xg = false;
+  int64_t n_ls_setup = 0;
+  // caller arrays of the host form pinned for the run (hipHostRegister at START: x, g, the t slot of wa), so
+  // that the per-call copies are DMA transfers queued on the context's stream instead of staged pageable copies
+  struct HostReg {
+    void *p = nullptr;
+    size_t bytes = 0;
+  } host_reg[3];
+  void host_register(int k, void *p, size_t bytes) {
+    if (!p || bytes < ((size_t)1 << 20)) return;  // (small arrays: pinning costs more than it saves)
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess)
+      host_reg[k].p = p, host_reg[k].bytes = bytes;
+    else
+      (void)hipGetLastError();  // (already registered by the caller, stack memory, ...: pageable copies then)
+  }
+  void host_unregister_all() {
+    for (HostReg &r : host_reg) {
+      if (r.p && hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
+      r.p = nullptr, r.bytes = 0;
+    }
+  }
   std::string itfile_name = "iterate.dat";
   int64_t n = 0, nglob = 0, row0 = 0;
   int m = 0, flags = 0, device = 0;
@@ -190,6 +213,9 @@ struct lbfgsb_hip_ctx {
   }
   int64_t ncoll = 0, coll_bytes = 0;  // collectives issued / bytes THIS rank contributed to them
   virtual int uniform_mask() const = 0;  // lbfgsb_hip_uniform_bounds
+  // two device copies of (l, u, nbd) compared bit for bit -> number of rows that differ (host-pointer form)
+  virtual int bounds_same(const void *l0, const void *u0, const int32_t *nb0, const void *l1, const void *u1,
+                          const int32_t *nb1, double *ndiff) = 0;
   virtual int64_t freev_skipped() const = 0;
   virtual int64_t skip_scans_reused() const = 0;
   virtual void defer_counts(int64_t &deferred, int64_t &reissued) const = 0;

@@ -280,3 +280,11 @@
   void defer_counts(int64_t &deferred, int64_t &reissued) const override { deferred = ndeferred, reissued = nredo; }
   const void *prev_iterate() const override { return t; }
   int uniform_mask() const override { return ub_mask; }
+  int bounds_same(const void *l0, const void *u0, const int32_t *nb0, const void *l1, const void *u1,
+                  const int32_t *nb1, double *ndiff) override {
+    HIPCHK(hipSetDevice(device));
+    lbk::launch_bounds_same<T>(q, n, (const T *)l0, (const T *)u0, nb0, (const T *)l1, (const T *)u1, nb1);
+    CHK(fetch(1, 0, 0));
+    *ndiff = h_res[0];
+    return 0;
+  }

@@ -473,9 +473,14 @@
     }
     if (k == "uniform_bounds") {
       const int rc = flag(ub_on);
-      if (!ub_on) ub_mask = 0;
+      if (!ub_on) {
+        if (ub_mask & lbk::UB_DICT) nbd8_src = nullptr;  // (the plain nbd bytes again at the next call)
+        ub_mask = 0;
+      }
       return rc;
     }
+    if (k == "dict_bounds") return flag(dict_on);            // (before START)
+    if (k == "bounds_check") return in_range(0, 1 << 20, bcheck_every);
     if (k == "wgrid") return in_range(0, lbk::MAX_BLOCKS - 1, q.tune.wgrid);
     if (k == "pipe") return in_range(-1, 1, q.tune.pipe);
     if (k == "pair") return in_range(0, 2, q.tune.pair);

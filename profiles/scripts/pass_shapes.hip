@@ -147,6 +147,101 @@ __global__ __launch_bounds__(256) void k_flat(int64_t n, const double *__restric
   if (s.x + s.y == 12345.678) sink[0] = s.x;
 }
 
+
+// ---- round 5: the ONE-store-stream candidate of the storing pass, as exactly as a bare
+// kernel can state it.  Today (k_cols): 2 col W columns + x + g read, the subspace step formed per row, THREE
+// streams written (trial x, the pending pair's Ws / Wy column), four sums reduced.  Candidate (k_ring): the
+// library keeps rings of col + 1 ITERATES and col + 1 GRADIENTS instead of Ws / Wy; y_j = G_{j+1} - G_j is
+// always the stored y bit for bit, s_j = X_{j+1} - X_j is the stored s only after a unit step
+// (src/lbfgsb.f90:822, 2313-2314), so each s column reads two ADDRESS-SELECTED operands: (X_{j+1}, X_j), or
+// (materialised Ws_j, a zero buffer) for a column whose step was not 1.  One stream written (the trial x =
+// the next iterate of the ring).  Same arithmetic per row, same reductions.
+struct RingArgs {
+  const double *a[10], *b[10];   // s_j = a_j - b_j
+  int bstride[10];               // 2 (a ring operand: advances with the rows) or 0 (the zero buffer)
+  const double *g[11];           // gradient ring
+  double cs[10], cy[10];
+};
+__device__ __forceinline__ void block_sums4(double (&acc)[4], double *part) {
+  __shared__ double sm[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) sm[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
+}
+__global__ __launch_bounds__(256) void k_ring(int64_t n, RingArgs A, const signed char *__restrict__ iwhere, double *xout,
+                                              double *part) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  double acc[4] = {0, 0, 0, 0};
+  for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += stride) {
+    d2 av[10], bv[10], gv[11];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) av[j] = ldnt(A.a[j] + iv * 2);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) bv[j] = ldnt(A.b[j] + iv * A.bstride[j]);
+#pragma unroll
+    for (int j = 0; j < 11; ++j) gv[j] = ldnt(A.g[j] + iv * 2);
+    const short iw2 = *reinterpret_cast<const short *>(iwhere + iv * 2);
+    d2 dk = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const d2 sj = av[j] - bv[j], yj = gv[j + 1] - gv[j];
+      dk += sj * A.cs[j] + yj * A.cy[j];
+    }
+    if ((signed char)(iw2 & 0xff) > 0) dk.x = 0.0;
+    if ((signed char)(iw2 >> 8) > 0) dk.y = 0.0;
+    const d2 xv = av[9];   // the newest iterate is the current x
+    const d2 zv = xv + dk;
+    acc[0] += dk.x * gv[10].x + dk.y * gv[10].y;
+    acc[1] += dk.x * dk.x + dk.y * dk.y;
+    acc[2] += (zv.x == 1.0) + (zv.y == 1.0);
+    acc[3] += zv.x + zv.y;
+    stnt(xout + iv * 2, zv);
+  }
+  block_sums4(acc, part);
+}
+struct ColArgs {
+  const double *wy[10], *ws[10];
+  const double *x, *g;
+  double cs[10], cy[10];
+};
+template <int NW>
+__global__ __launch_bounds__(256) void k_cols(int64_t n, ColArgs A, const signed char *__restrict__ iwhere, double *xout,
+                                              double *cwy, double *cws, double *part) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  double acc[4] = {0, 0, 0, 0};
+  for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += stride) {
+    d2 yv[10], sv[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) yv[j] = ldnt(A.wy[j] + iv * 2);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) sv[j] = ldnt(A.ws[j] + iv * 2);
+    const d2 xv = ldnt(A.x + iv * 2), gv = ldnt(A.g + iv * 2);
+    const short iw2 = *reinterpret_cast<const short *>(iwhere + iv * 2);
+    d2 dk = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 10; ++j) dk += sv[j] * A.cs[j] + yv[j] * A.cy[j];
+    if ((signed char)(iw2 & 0xff) > 0) dk.x = 0.0;
+    if ((signed char)(iw2 >> 8) > 0) dk.y = 0.0;
+    const d2 zv = xv + dk;
+    acc[0] += dk.x * gv.x + dk.y * gv.y;
+    acc[1] += dk.x * dk.x + dk.y * dk.y;
+    acc[2] += (zv.x == 1.0) + (zv.y == 1.0);
+    acc[3] += zv.x + zv.y;
+    stnt(xout + iv * 2, zv);
+    if (NW >= 3) {
+      stnt(cwy + iv * 2, yv[9] + gv);
+      stnt(cws + iv * 2, sv[9] + xv);
+    }
+  }
+  block_sums4(acc, part);
+}
+
 static hipEvent_t e0, e1;
 template <typename F>
 float timeit(F &&launch, int reps = 8) {
@@ -186,11 +281,52 @@ int main(int argc, char **argv) {
   const int64_t n = 100000000;   // multiple of 512
   double *w, *out, *sink;
   CK(hipMalloc(&w, (size_t)n * 24 * 8));
-  CK(hipMalloc(&out, (size_t)n * 8 * 8));
+  CK(hipMalloc(&out, (size_t)n * 14 * 8));   // (mode c: up to 10 materialised columns behind 3 store targets)
   CK(hipMalloc(&sink, 64));
   CK(hipMemset(w, 0, (size_t)n * 24 * 8));
-  CK(hipMemset(out, 0, (size_t)n * 8 * 8));
+  CK(hipMemset(out, 0, (size_t)n * 14 * 8));
   const double *vec = w + (size_t)n * 20;   // the 4 separate n-vectors of the tiled form
+  if (argc > 1 && argv[1][0] == 'c') {
+    // round 5: today's storing pass against the one-store-stream candidate, both with their reductions
+    signed char *iw;
+    double *part, *zero;
+    CK(hipMalloc(&iw, (size_t)n));
+    CK(hipMemset(iw, 0, (size_t)n));
+    CK(hipMalloc(&part, 4 * 4096 * 8));
+    CK(hipMalloc(&zero, 256));
+    CK(hipMemset(zero, 0, 256));
+    ColArgs C{};
+    for (int j = 0; j < 10; ++j) C.wy[j] = w + (size_t)n * j, C.ws[j] = w + (size_t)n * (10 + j), C.cs[j] = 0.5 + j, C.cy[j] = 0.25 * j;
+    C.x = w + (size_t)n * 20, C.g = w + (size_t)n * 21;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int grid : {512, 768, 1024}) {
+        float ms = timeit([&] { hipLaunchKernelGGL((k_cols<3>), dim3(grid), dim3(256), 0, 0, n, C, iw, out, out + n, out + 2 * n, part); });
+        printf("today     22 read streams, 3 written, 4 sums            grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_cols<1>), dim3(grid), dim3(256), 0, 0, n, C, iw, out, out + n, out + 2 * n, part); });
+        printf("(bound)   22 read streams, 1 written, 4 sums            grid %5d  %7.3f ms\n", grid, ms);
+        for (int nmat : {0, 1, 3, 10}) {
+          // iterates X_0 .. X_10 = streams 0..10, gradients = streams 11..21, materialised Ws_j = out + (3 + k) n
+          RingArgs R{};
+          int k = 0;
+          for (int j = 0; j < 10; ++j) {
+            const bool mat = j < nmat;
+            R.a[j] = mat ? out + (size_t)n * (3 + k++) : w + (size_t)n * (j + 1);
+            R.b[j] = mat ? zero : w + (size_t)n * j;
+            R.bstride[j] = mat ? 0 : 2;
+            R.cs[j] = 0.5 + j, R.cy[j] = 0.25 * j;
+          }
+          if (nmat == 10) R.a[9] = w + (size_t)n * 10;   // (the current x is always a ring operand)
+          for (int j = 0; j < 11; ++j) R.g[j] = w + (size_t)n * (11 + j);
+          ms = timeit([&] { hipLaunchKernelGGL(k_ring, dim3(grid), dim3(256), 0, 0, n, R, iw, out, part); });
+          printf("candidate %2d + 11 ring streams, %2d materialised s columns, 1 written, 4 sums  grid %5d  %7.3f ms\n",
+                 11, nmat, grid, ms);
+        }
+      }
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 's') {
     // round 4: what would the storing pass gain with ONE store stream instead of three
     // (s_j, y_j formed in registers from a ring of iterates / gradients instead of stored)?  The bare mixes:

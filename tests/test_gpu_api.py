@@ -296,7 +296,9 @@ def test_host_entry_with_eight_byte_integers_matches_the_four_byte_one():
 
 def test_uniform_bounds_are_detected_and_change_nothing():
     """Bound arrays that hold one value each are read as constants by the passes over W
-    (lbfgsb_hip_uniform_bounds): detection per array (l, u, nbd independently), and the trajectory --
+    (lbfgsb_hip_uniform_bounds): detection per array (l, u, nbd independently); arrays with FEW distinct values
+    (<= 8 each: driver3's alternating box, test/driver3.f90:102-120) are dictionary-coded (bit 3: the packed nbd
+    byte carries the table indices, mask = 1 | 2 | 8); a 9th value falls back to streaming.  The trajectory --
     every isave / dsave slot, f, x, the exported state -- is bit for bit the one of a context with the
     detection switched off."""
     import numpy as np
@@ -307,15 +309,25 @@ def test_uniform_bounds_are_detected_and_change_nothing():
     cases = []
     cases.append((po.problem_quadratic(5003, 7), 7))                      # l, u, nbd all uniform
     cases.append((po.problem_quadratic(4099, 6, mixed_nbd=True), 3))      # nbd varies
-    cases.append((po.problem_rosenbrock(1000, 10, 0.0, 0.0), 6))          # l alternates, u and nbd uniform
+    cases.append((po.problem_rosenbrock(1000, 10, 0.0, 0.0), 11))         # l alternates (2 values): dictionary
     q = po.problem_quadratic(3001, 12)
     q.u[17] = np.nextafter(1.0, 2.0)                                      # one entry differs in the last bit
-    cases.append((q, 5))
+    cases.append((q, 11))                                                 # ... a 2-entry table for u
     q = po.problem_quadratic(2000, 5)
     q.l[:] = -0.0
     q.l[3] = 0.0                                                          # -0.0 vs 0.0 count as different
     q.u[:] = 2.0
-    cases.append((q, 6))
+    cases.append((q, 11))
+    rng = np.random.default_rng(5)
+    for nl, nu, mixed, want in ((3, 1, False, 11), (8, 8, True, 11), (9, 1, False, 6), (2, 9, True, 0),
+                                (9, 9, False, 4)):
+        q = po.problem_quadratic(6007, 8, mixed_nbd=mixed)
+        lv = -1.0 - 0.125 * np.arange(nl)                                 # nl distinct lower, nu distinct upper bounds
+        uv = 1.0 + 0.25 * np.arange(nu)
+        q.l[:] = lv[rng.integers(0, nl, q.n)]
+        q.u[:] = uv[rng.integers(0, nu, q.n)]
+        q.l[:nl], q.u[:nu] = lv, uv                                       # (every value occurs)
+        cases.append((q, want))
     for p, want_mask in cases:
         def run(on):
             sol = la.DeviceSolver(p.n, p.m, options={"uniform_bounds": 1 if on else 0})
@@ -539,3 +551,125 @@ def test_null_arguments_are_refused_not_dereferenced():
         assert sol.setulb(x, l, u, nbd, g, 0.0, 0.0).startswith("FG_START")
     finally:
         sol.close()
+
+
+def test_bounds_edited_in_place_end_the_run_with_an_error(env):
+    """The reference re-reads l, u, nbd on every call (src/lbfgsb.f90:1270-1330, 2594-2622, 2789-2816); the
+    passes over W read a snapshot (packed nbd byte; constants or table entries for uniform / few-valued bounds).
+    The caller's arrays are compared with the snapshot after the first iteration and then every `bounds_check`
+    iterations (default 16): an edit in place is reported -- task 'ERROR: BOUNDS CHANGED DURING RUN' -- instead of
+    silently iterated on with stale bounds.  Uniform, dictionary-coded and plain (streamed) bounds; device and
+    host form.  (l, u that ARE streamed live take effect as in the reference: only nbd is a snapshot there.)"""
+    po, torch, la = env["po"], env["torch"], env["la"]
+
+    def drive(p, edit, every, want_mask, max_iter=40):
+        sol = la.DeviceSolver(p.n, p.m, options={"bounds_check": every})
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l.copy()).cuda(), torch.from_numpy(p.u.copy()).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        t, edited_at = "", None
+        for _ in range(10000):
+            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+                torch.cuda.synchronize()
+            elif t.startswith("NEW_X"):
+                if sol.isave[29] == 3 and edited_at is None:
+                    assert sol.uniform_bounds() == want_mask
+                    edit(l, u, nbd)
+                    torch.cuda.synchronize()
+                    edited_at = 3
+                if sol.isave[29] >= max_iter:
+                    break
+            else:
+                break
+        it = int(sol.isave[29])
+        sol.close()
+        return t, it
+    quad = po.problem_quadratic(5003, 6)                       # uniform l, u, nbd: mask 7
+    rosen = po.problem_rosenbrock(1000, 8, 0.0, 0.0)           # l alternates: dictionary, mask 11
+    mixed = po.problem_quadratic(4099, 6, mixed_nbd=True)      # l, u uniform, nbd streamed: mask 3
+    many = po.problem_quadratic(4099, 6)
+    many.l[:] = -1.0 - np.arange(many.n) / many.n              # n distinct lower bounds: l streamed live, mask 2 | 4
+    def set_u(l, u, nbd): u[7] = 0.5                           # noqa: E306
+    def set_l(l, u, nbd): l[11] = -0.25                        # noqa: E306
+    def set_nbd(l, u, nbd): nbd[5] = 0                         # noqa: E306
+    def nothing(l, u, nbd): pass                               # noqa: E306
+    # checked at every NEW_X entry: noticed by the call that follows the edit
+    for p, edit, mask in ((quad, set_u, 7), (quad, set_nbd, 7), (rosen, set_l, 11), (rosen, set_nbd, 11),
+                          (mixed, set_nbd, 3), (mixed, set_u, 3), (many, set_nbd, 6)):
+        t, it = drive(p, edit, 1, mask)
+        assert t.startswith("ERROR: BOUNDS CHANGED DURING RUN") and it == 3, (p.name, t, it)
+    # default cadence: noticed at the first multiple of 16
+    t, it = drive(quad, set_u, 16, 7)
+    assert t.startswith("ERROR: BOUNDS CHANGED DURING RUN") and it == 16, (t, it)
+    # no edit, or an edit of an array that is streamed live: the run goes on
+    t, it = drive(rosen, nothing, 1, 11)
+    assert t.startswith("NEW_X") and it == 40
+    t, it = drive(many, set_l, 1, 6)
+    assert t.startswith("NEW_X") and it == 40
+    # switched off: never looked at
+    t, it = drive(quad, set_u, 0, 7)
+    assert t.startswith("NEW_X") and it == 40
+    # the host-pointer form (copies made at START): the caller's arrays are uploaded again and compared
+    p = po.problem_quadratic(3001, 5)
+    s = po.State.fresh(p)
+    nbd = p.nbd.astype(np.int32)
+    lo = p.l.copy()
+    for _ in range(10000):
+        la.setulb(p.n, p.m, s.x, lo, p.u, nbd, s.f, s.g, 0.0, 0.0, s.wa, s.iwa, s.task, -1, s.csave, s.lsave,
+                  s.isave, s.dsave)
+        if s.task_s.startswith("FG"):
+            s.f[0] = p.fg(s.x, s.g)
+        elif s.task_s.startswith("NEW_X"):
+            if s.isave[29] == 2:
+                lo[17] = -0.5
+            if s.isave[29] >= 40:
+                break
+        else:
+            break
+    assert s.task_s.startswith("ERROR: BOUNDS CHANGED DURING RUN") and s.isave[29] == 16, (s.task_s, s.isave[29])
+    assert s.isave[16] == 0 and s.isave[17] == 0         # the context was released with the terminal task
+
+
+def test_other_bound_arrays_during_a_run_end_the_dictionary_mode_not_the_run(env):
+    """Dictionary-coded bounds are a property of the ARRAYS task 'START' looked at: a caller that passes other
+    arrays (same contents) on a later call gets the streaming kernels from then on -- same results bit for bit."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    p = po.problem_rosenbrock(2000, 7, 0.0, 0.0)
+
+    def run(swap_at):
+        sol = la.DeviceSolver(p.n, p.m)
+        x = torch.from_numpy(p.x0.copy()).cuda()
+        g = torch.zeros_like(x)
+        l, u = torch.from_numpy(p.l.copy()).cuda(), torch.from_numpy(p.u.copy()).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        l2 = l.clone()
+        rows, masks = [], []
+        for _ in range(10000):
+            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            masks.append(sol.uniform_bounds())
+            if t.startswith("FG"):
+                xh = x.cpu().numpy()
+                gh = np.empty_like(xh)
+                sol.f[0] = p.fg(xh, gh)
+                g.copy_(torch.from_numpy(gh))
+                torch.cuda.synchronize()
+            elif t.startswith("NEW_X"):
+                rows.append((tuple(int(v) for v in sol.isave[21:44]), sol.f.tobytes(), x.cpu().numpy().tobytes()))
+                if sol.isave[29] == swap_at:
+                    l = l2
+                if sol.isave[29] >= 25:
+                    break
+            else:
+                break
+        sol.close()
+        return rows, masks
+    a, ma = run(None)
+    b, mb = run(6)
+    assert a == b
+    assert set(ma) == {11} and mb[0] == 11 and mb[-1] == 0

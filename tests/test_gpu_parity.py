@@ -1163,6 +1163,54 @@ def test_minimize_wrapper_matches_reverse_communication(env):
     sol.close()
 
 
+def test_run_to_convergence_with_the_drivers_tolerances_n1e6(env):
+    """Time to SOLUTION, not just iterations: the bounded quadratic at n = 1e6, m = 10 with driver1's own
+    stopping tolerances (test/driver1.f90:212-213: factr = 1e7, pgtol = 1e-5) run to its CONVERGENCE message
+    (src/lbfgsb.f90:795-810) -- through lbfgsb_hip_minimize with the built-in objective, and through the timed
+    path's entry (ping-pong + deferred set-up) -- against the LIVE reference (oracle/_ref; the C oracle if it is
+    not built) on the same problem: same message, same iteration and evaluation counts (a stop by relative
+    reduction at factr = 1e7 is decided four decades above rounding noise: an exact anchor), f to 1e-10."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m = 1_000_000, 10
+    base = po.problem_quadratic(n, m)
+    p = po.Problem("quadratic_conv", n, m, base.x0, base.l, base.u, base.nbd, 1.0e7, 1.0e-5, base.fg, np.float64)
+    eng = po.Engine("ref") if po.Engine.available("ref") else po.Engine("oracle")
+    ref = po.run(eng, p)
+    assert ref.task_s.startswith("CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"), ref.task_s
+    it_ref, nfg_ref, f_ref = int(ref.isave[29]), int(ref.isave[33]), float(ref.f[0])
+    assert 10 <= it_ref <= 200
+
+    def tensors():
+        x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        return (x, torch.full_like(x, -1.0), torch.full_like(x, 1.0),
+                torch.full((n,), 2, dtype=torch.int32, device="cuda"), torch.zeros_like(x))
+    sol = la.DeviceSolver(n, m)
+    x, l, u, nbd, g = tensors()
+    t = sol.minimize(x, l, u, nbd, g, builtin=0, factr=p.factr, pgtol=p.pgtol)
+    assert t == ref.task_s
+    assert (int(sol.isave[29]), int(sol.isave[33])) == (it_ref, nfg_ref)
+    assert float(sol.f[0]) == pytest.approx(f_ref, rel=1e-10)
+    assert np.max(np.abs(x.cpu().numpy() - ref.x)) <= 1e-7
+    sol.close()
+    # the timed path's entry and flags, by hand
+    sol = la.DeviceSolver(n, m, same_stream_objective=True, defer_lnsrch=True)
+    x, l, u, nbd, g = tensors()
+    xs, gs = [x, torch.empty_like(x)], [g, torch.empty_like(g)]
+    cur = 0
+    while True:
+        t, cur = sol.setulb_pp(xs, l, u, nbd, gs, p.factr, p.pgtol)
+        if t.startswith("FG"):
+            sol.objective(0, xs[cur], gs[cur], deferred=True)
+        elif not t.startswith("NEW_X"):
+            break
+    sol.sync()
+    assert t == ref.task_s
+    assert (int(sol.isave[29]), int(sol.isave[33])) == (it_ref, nfg_ref)
+    assert float(sol.f[0]) == pytest.approx(f_ref, rel=1e-10)
+    assert np.max(np.abs(xs[cur].cpu().numpy() - ref.x)) <= 1e-7
+    sol.close()
+
+
 @pytest.mark.parametrize("kind", ["quadratic", "quadmix", "rosenbrock"])
 def test_parallel_gcp_opt_in(env, kind):
     """LBFGSB_F_PARALLEL_GCP (col = 0 case): the closed-form GCP
