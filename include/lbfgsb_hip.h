@@ -154,7 +154,10 @@ const char *lbfgsb_hip_last_error(void);
 int lbfgsb_hip_rccl_unique_id(void *id128);
 int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, int nranks);
 /* (ncclCommInitRank waits for every rank; the entry gives it LBFGSB_COMM_INIT_TIMEOUT_S seconds -- an
- *  environment variable, default 120 -- and returns LBFGSB_E_COMM after that instead of hanging.)
+ *  environment variable, default 120; anything but a positive number is LBFGSB_E_ARG -- and returns
+ *  LBFGSB_E_COMM after that instead of hanging.  A helper thread is then still inside the call: the process
+ *  MUST EXIT after this error (non-zero; do not re-launch in place, do not destroy the context and carry on).
+ *  Should the peers arrive later after all, the helper destroys the late communicator itself.)
  * What the context's communicator is: *kind = 0 none (one rank), 1 RCCL, 2 host callbacks; for RCCL
  * *nranks / *rank are the communicator's OWN answers (ncclCommCount, ncclCommUserRank), so a scaling
  * run can show that N ranks really took part. */

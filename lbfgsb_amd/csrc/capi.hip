@@ -47,13 +47,17 @@ int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, 
   // helper is left behind, the caller is expected to exit (bench.py does, non-zero)
   double limit = 120.0;
   if (const char *e = std::getenv("LBFGSB_COMM_INIT_TIMEOUT_S")) {
-    const double v = std::atof(e);
-    if (v > 0.0) limit = v;
+    char *end = nullptr;
+    const double v = std::strtod(e, &end);
+    if (end == e || *end != '\0' || !(v > 0.0))
+      return fail(LBFGSB_E_ARG, std::string("LBFGSB_COMM_INIT_TIMEOUT_S is not a positive number of seconds: '") + e + "'");
+    limit = v;
   }
   struct Init {
     std::mutex mu;
     std::condition_variable cv;
     bool done = false;
+    bool abandoned = false;  // the caller gave up waiting: a late communicator is destroyed by the helper
     ncclResult_t res = ncclSuccess;
     ncclComm_t comm = nullptr;
   };
@@ -63,15 +67,25 @@ int lbfgsb_hip_comm_init_rccl(lbfgsb_hip_ctx *ctx, const void *id128, int rank, 
     (void)hipSetDevice(device);
     ncclComm_t c = nullptr;
     const ncclResult_t r = g_rccl.CommInitRank(&c, nranks, id, rank);
-    std::lock_guard<std::mutex> lk(st->mu);
-    st->res = r, st->comm = c, st->done = true;
-    st->cv.notify_all();
+    bool orphan = false;
+    {
+      std::lock_guard<std::mutex> lk(st->mu);
+      st->res = r, st->comm = c, st->done = true;
+      orphan = st->abandoned;
+      st->cv.notify_all();
+    }
+    // nobody will ever use (or destroy) a communicator that arrives after the timeout: give it back here, so
+    // that it is not leaked and no peer is left with a member that never joins a collective unnoticed
+    if (orphan && r == ncclSuccess && c) g_rccl.CommDestroy(c);
   }).detach();
   {
     std::unique_lock<std::mutex> lk(st->mu);
-    if (!st->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return st->done; }))
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return st->done; })) {
+      st->abandoned = true;
       return fail(LBFGSB_E_COMM, "ncclCommInitRank did not return within " + std::to_string((int)limit) +
-                                     " s (a rank is missing?)");
+                                     " s (a rank is missing?); the process should exit (non-zero): the helper "
+                                     "thread is still inside the call");
+    }
   }
   if (st->res != ncclSuccess) return fail(LBFGSB_E_COMM, "ncclCommInitRank failed");
   ncclComm_t comm = st->comm;

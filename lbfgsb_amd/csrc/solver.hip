@@ -788,7 +788,11 @@ class Solver final : public lbfgsb_hip_ctx {
         sfv.valid = false;
         const int sf_upcl = c2 - 1;
         const bool do_sfv = spec_freev_on && sfv_hot && cnstnd && store_iw && index_valid && !index && two_pass &&
-                            c2 <= two_pass_maxcol && sf_upcl > 0 && lbk::maxc_for(sf_upcl) <= 20 && chi < 0.0 &&
+                            c2 <= two_pass_maxcol && sf_upcl > 0 && lbk::maxc_for(sf_upcl) <= 20 &&
+                            !(nr_flag(c2) && sf_upcl > q.tune.split_from) &&  // (never behind a SPLIT update pass: its
+                            // merge kernel writes d_res directly, the chain's finalize would become the tail of the
+                            // stream and the fetch would take stale update-pass sums from the host mirror)
+                            chi < 0.0 &&
                             print_level < 99 &&
                             !(flags & LBFGSB_F_PARALLEL_GCP);
         if (do_sfv) {

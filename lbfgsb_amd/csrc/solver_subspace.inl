@@ -487,6 +487,8 @@
     if (k == "gram_rows") return in_range(0, 1, q.tune.gram_rows);
     if (k == "split") {  // 20 (default: parts of <= 16 columns beyond 20 old pairs) or 10 (parts of <= 10 beyond 10)
       if (v != 10.0 && v != 20.0) return fail(LBFGSB_E_ARG, "set_option: split takes 10 or 20");
+      if (v == 10.0 && lbk::split_parts(m - 1, 10) > lbk::SPLIT_MAXPARTS)
+        return fail(LBFGSB_E_ARG, "set_option: split = 10 needs more parts than the split pass has (m too large)");
       q.tune.split_from = (int)v, q.tune.split_cols = v == 10.0 ? 10 : 16;
       return 0;
     }
