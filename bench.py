@@ -352,14 +352,22 @@ def parity_in_run(rows, n, m, real32, kind):
     return out
 
 
-def problem_tensors(torch, dev, kind, n_loc, row0, real32):
+def problem_tensors(torch, dev, kind, n_loc, row0, real32, arbitrary_box=False):
     """x0, l, u, nbd of this rank's rows: kind 0 = separable bounded quadratic,
-    kind 1 = extended Rosenbrock with the drivers' box (test/driver1.f90:233-251)."""
+    kind 1 = extended Rosenbrock with the drivers' box (test/driver1.f90:233-251).
+    arbitrary_box (kind 0): every l_i, u_i its own value (the box [-1, 1] widened by up to 1e-3 per side, a
+    closed-form function of the row number) -- neither the uniform-bounds constants nor the dictionary apply,
+    the passes stream l, u and nbd: what a caller with per-variable bounds gets."""
     rdt = torch.float32 if real32 else torch.float64
     if kind == 0:
         x = torch.zeros(n_loc, dtype=rdt, device=dev)
         l = torch.full_like(x, -1.0)
         u = torch.full_like(x, 1.0)
+        if arbitrary_box:
+            i = torch.arange(row0 + 1, row0 + n_loc + 1, dtype=torch.int64, device=dev)
+            l -= ((7919 * i) % 1000003).to(rdt) * 1.0e-9
+            u += ((104729 * i) % 1000033).to(rdt) * 1.0e-9
+            del i
     else:
         x = torch.full((n_loc,), 3.0, dtype=rdt, device=dev)
         u = torch.full_like(x, 100.0)
@@ -373,7 +381,7 @@ class Run:
     """one solver context + its problem, advanced iteration by iteration"""
 
     def __init__(self, torch, dist, la, a, *, n, m, real32, kind, world, rank, local_rank, rccl_self, opts,
-                 parallel_gcp=False, defer=None):
+                 parallel_gcp=False, defer=None, classic=None, arbitrary_box=False):
         self.torch, self.dist, self.world = torch, dist, world
         self.kind, self.n, self.m = kind, n, m
         dev = torch.device("cuda", local_rank)
@@ -416,8 +424,8 @@ class Run:
             with stdout_to_stderr():
                 la.attach_rccl(self.sol, 0, 1, dev)
             self.collective = "RCCL all-gather on a 1-rank communicator (--rccl-self: latency floor)"
-        x, self.l, self.u, self.nbd = problem_tensors(torch, dev, kind, n_loc, row0, real32)
-        self.pp = not a.classic
+        x, self.l, self.u, self.nbd = problem_tensors(torch, dev, kind, n_loc, row0, real32, arbitrary_box)
+        self.pp = not (a.classic if classic is None else classic)
         # ping-pong entry: two pairs of iterate / gradient buffers, the library tells which one is live
         self.xs = [x, torch.empty_like(x)] if self.pp else [x]
         self.gs = [torch.zeros_like(x), torch.empty_like(x)] if self.pp else [torch.zeros_like(x)]
@@ -535,10 +543,10 @@ def pass_bytes(col, rbytes, pp, lean=True, ub=0):
 
 
 def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, steps, warm_min, local_rank, opts,
-                 defer=None):
+                 defer=None, classic=None, arbitrary_box=False):
     """a short leg for one of the other BASELINE.json configs: it/s and the two pass fractions"""
     run = Run(torch, dist, la, a, n=n, m=m, real32=real32, kind=kind, world=1, rank=0, local_rank=local_rank,
-              rccl_self=rccl_self, opts=opts, defer=defer)
+              rccl_self=rccl_self, opts=opts, defer=defer, classic=classic, arbitrary_box=arbitrary_box)
     try:
         r = timed_leg(run, steps, warm_min, need_full_memory=(kind == 0))
         col = int(run.sol.isave[27])
@@ -567,7 +575,9 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "host_algebra_us_between_passes": r["st1"]["host_gap_us"],
                 "host_segments_us": r["st1"]["host_segments_us"],
                 "uniform_bounds_mask": ub, "options": opts,
-                "parity_in_run": parity_in_run(run.rows, n, m, real32, kind)}
+                # (the arbitrary-box leg is another problem than the one the reference's rows belong to)
+                "parity_in_run": ({"rows_checked": 0, "ok": None, "why": "per-variable bounds: not the fixture's problem"}
+                                  if arbitrary_box else parity_in_run(run.rows, n, m, real32, kind))}
     finally:
         run.close()
 
@@ -917,9 +927,14 @@ def main():
         out["first_iteration_parallel_gcp_error"] = repr(e)
     # ---- the other BASELINE.json configs, short legs (N = 1 only; each a fresh context) ----
     if world == 1 and not a.no_other_configs and not a.real32 and n == 100_000_000 and m == 10:
-        leg_tags = ["ub_off", "cfg1_n1e6", "cfg2_rosen_n1e7", "cfg4_r32_m20", "cfg3_rank_shape",
+        leg_tags = ["ordinary_caller", "ub_off", "cfg1_n1e6", "cfg2_rosen_n1e7", "cfg4_r32_m20", "cfg3_rank_shape",
                     "cfg3_rank_shape_nodefer", "m32_n5e7", "m48_n2e7"]
         leg_defs = [
+            ("ORDINARY CALLER, ARBITRARY BOX: the headline problem size with per-variable bounds (every l_i, u_i its own "
+             "value: l, u, nbd streamed by the passes, no constants, no dictionary), the classic in-place entry "
+             "lbfgsb_hip_setulb_dev (t = x, r = g as copies) and no LBFGSB_F_DEFER_LNSRCH -- nothing the headline leans on",
+             dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12, defer=False, classic=True,
+                  arbitrary_box=True)),
             ("headline workload with the uniform-bounds detection OFF (l, u, nbd streamed per row)",
              dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12,
                   opts=dict(opts, uniform_bounds=0))),
@@ -968,6 +983,9 @@ def main():
             if pr.get("rows_checked"):
                 legs[tag] += " parity %d rows %s" % (pr["rows_checked"], "ok" if pr["ok"] else "MISMATCH")
                 parity_fail = parity_fail or not pr["ok"]
+        oc0 = out["other_configs"][0]
+        out["iters_per_sec_ordinary_caller_arbitrary_box"] = oc0.get("value")
+        out["config"]["ordinary_caller_arbitrary_box_its"] = oc0.get("value")
         hf = out["host_form"]
         legs["host_form_n1e7"] = ("error " + hf["error"][:60]) if "error" in hf else (
             "%.1f it/s %.3f ms in setulb, PCIe %.1f GB/s, anchors %s" % (
