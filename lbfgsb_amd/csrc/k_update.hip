@@ -73,6 +73,18 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // The same pass serves as the line search's evaluation at a trial point (g'd, |proj g|): run
 // speculatively there (store_pair = 0; it writes nothing but -- with store_iw -- the few iwhere
 // entries that changed), its sums ARE the matupd + cauchy-scan results if the trial is accepted.
+// One term of a running dot product.  fp64 kinds: product and sum rounded separately, as the reference's ddot
+// rounds them (src/lbfgsb_blas_module.F90:187-202) -- only the ORDER of the sum differs from the reference.  REAL32:
+// the operands are fp32 values (after a unit step; s = stp d is a double otherwise), their product is exact in
+// fp64, so the fused form is the SAME number with one instruction less -- and the fp32 m = 20 instantiation of
+// this pass is issue-bound, not HBM-bound.
+template <typename T>
+__device__ __forceinline__ double dot_term(double acc, double a, double b) {
+  if constexpr (sizeof(T) == 4)
+    return __builtin_fma(a, b, acc);
+  else
+    return acc + a * b;
+}
 template <typename T>
 struct UpdScanCtx {
   const T *x, *l, *u, *g, *r, *d, *ws, *wy, *zero;
@@ -269,10 +281,10 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         raw_get_col<W, false>(tb_, (const T *)nullptr, pbj);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-          accp[0][jj] += dv[k] * aj[k];
-          accp[1][jj] += bj[k] * dv[k];
-          accp[2][jj] += aj[k] * ng[k];
-          accp[3][jj] += bj[k] * ng[k];
+          accp[0][jj] = dot_term<T>(accp[0][jj], dv[k], aj[k]);
+          accp[1][jj] = dot_term<T>(accp[1][jj], bj[k], dv[k]);
+          accp[2][jj] = dot_term<T>(accp[2][jj], aj[k], ng[k]);
+          accp[3][jj] = dot_term<T>(accp[3][jj], bj[k], ng[k]);
           accp[4][jj] = __builtin_fma(yf[k], aj[k], accp[4][jj]);
           accp[5][jj] = __builtin_fma(sa[k], bj[k], accp[5][jj]);
           accp[6][jj] = __builtin_fma(sa[k], aj[k], accp[6][jj]);
@@ -280,10 +292,10 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-          accp[0][jj] += pdv[k] * paj[k];
-          accp[1][jj] += pbj[k] * pdv[k];
-          accp[2][jj] += paj[k] * png[k];
-          accp[3][jj] += pbj[k] * png[k];
+          accp[0][jj] = dot_term<T>(accp[0][jj], pdv[k], paj[k]);
+          accp[1][jj] = dot_term<T>(accp[1][jj], pbj[k], pdv[k]);
+          accp[2][jj] = dot_term<T>(accp[2][jj], paj[k], png[k]);
+          accp[3][jj] = dot_term<T>(accp[3][jj], pbj[k], png[k]);
           accp[4][jj] = __builtin_fma(pyf[k], paj[k], accp[4][jj]);
           accp[5][jj] = __builtin_fma(psa[k], pbj[k], accp[5][jj]);
           accp[6][jj] = __builtin_fma(psa[k], paj[k], accp[6][jj]);

@@ -21,11 +21,23 @@ MODES = [  # (nmax, mlo, mhi, pp, options)
     (600, 1, 13, False, {}), (600, 1, 13, True, {}), (2500, 11, 33, True, {}), (2500, 11, 33, False, {}),
     (1200, 1, 25, True, {"two_pass": 0}), (1200, 1, 25, False, {"lean": 0}), (1200, 1, 25, True, {"uniform_bounds": 0}),
     (1200, 1, 25, True, {"spec_capture": 1}), (1000, 33, 90, True, {}), (1500, 1, 25, True, {"exact_always": 1}),
+    # round 5: FEW-VALUED bounds (l, u drawn from <= 8 values each: dictionary-coded in the nbd byte), both entries,
+    # and the same with the caller's arrays compared with the snapshot at every iteration
+    (1500, 1, 25, True, {"_few_valued": 1}), (1500, 1, 25, False, {"_few_valued": 1, "bounds_check": 1}),
 ]
 bad, total, splits, t0 = 0, 0, 0, time.time()
 for seed in range(first, first + count):
     nmax, mlo, mhi, pp, opts = MODES[seed % len(MODES)]
     p = tf.make(po, seed, nmax, mlo, mhi)
+    opts = dict(opts)
+    if opts.pop("_few_valued", 0):
+        import numpy as np
+        rng = np.random.default_rng(seed)
+        kl, ku = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        lv = np.sort(rng.normal(-1.5, 1.0, kl))
+        uv = lv.max() + np.abs(rng.normal(1.0, 1.0, ku)) + 0.05
+        p.l[:] = lv[rng.integers(0, kl, p.n)]
+        p.u[:] = uv[rng.integers(0, ku, p.n)]
     try:
         split, _ = tf.drive_with_replay(po, p, 80, pp=pp, options=opts)
         total += 1
