@@ -26,6 +26,7 @@
 
 #include <atomic>
 #include <random>
+#include <set>
 #include <thread>
 
 extern "C" {
@@ -415,6 +416,78 @@ void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T 
   }
   q.launches++;
 }
+
+// ---- task 'START': errclb (+ the uniformity flags), the bound dictionary's probe and pack, active ----
+template <typename T>
+void launch_errclb(Queue &q, int64_t n, int64_t row0, const T *l, const T *u, const int32_t *nbd) {
+  double *res = q.d_res + q.res_off;
+  for (int k = 0; k < 5; ++k) res[k] = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double gi = (double)(row0 + i + 1);
+    if (nbd[i] < 0 || nbd[i] > 3) res[0] = std::fmax(res[0], gi);
+    if (nbd[i] == 2 && (double)l[i] > (double)u[i]) res[1] = std::fmax(res[1], gi);
+    if (std::memcmp(&l[i], &l[0], sizeof(T)) != 0) res[2] = 1.0;
+    if (std::memcmp(&u[i], &u[0], sizeof(T)) != 0) res[3] = 1.0;
+    if (nbd[i] != nbd[0]) res[4] = 1.0;
+  }
+  q.launches++;
+}
+static int dict_find_h(const BoundTables &tb, int which, double v) {
+  const int cnt = which ? tb.nu : tb.nl;
+  for (int j = 0; j < cnt && j < 8; ++j)
+    if (std::memcmp(which ? &tb.u[j] : &tb.l[j], &v, 8) == 0) return j;
+  return -1;
+}
+template <typename T>
+void launch_dict_probe(Queue &q, int64_t n, const T *l, const T *u, const BoundTables &tb) {
+  double *res = q.d_res + q.res_off;
+  res[0] = res[1] = 0.0, res[2] = res[3] = INF;
+  for (int64_t i = 0; i < n; ++i) {
+    if (dict_find_h(tb, 0, (double)l[i]) < 0) res[0] += 1.0, res[2] = std::fmin(res[2], (double)l[i]);
+    if (dict_find_h(tb, 1, (double)u[i]) < 0) res[1] += 1.0, res[3] = std::fmin(res[3], (double)u[i]);
+  }
+  q.launches++;
+}
+template <typename T>
+void launch_nbd_pack_dict(Queue &q, int64_t n, const int32_t *nbd, const T *l, const T *u, const BoundTables &tb,
+                          nb_t *out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const int jl = dict_find_h(tb, 0, (double)l[i]), ju = dict_find_h(tb, 1, (double)u[i]);
+    out[i] = (nb_t)(unsigned char)((unsigned)(nbd[i] & 3) | ((unsigned)(jl < 0 ? 0 : jl) << 2) |
+                                   ((unsigned)(ju < 0 ? 0 : ju) << 5));
+  }
+  q.launches++;
+}
+template <typename T>
+void launch_active(Queue &q, int64_t n, T *x, const T *l, const T *u, const int32_t *nbd, iw_t *iwhere,
+                   int8_t *wasfree) {
+  double *res = q.d_res + q.res_off;
+  for (int k = 0; k < 4; ++k) res[k] = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int nb = nbd[i];
+    double xv = (double)x[i];
+    const double lv = (double)l[i], uv = (double)u[i];
+    if (nb > 0) {
+      if (nb <= 2 && xv <= lv) {
+        if (xv < lv) res[0] += 1.0, xv = lv;
+        res[3] += 1.0;
+      } else if (nb >= 2 && xv >= uv) {
+        if (xv > uv) res[0] += 1.0, xv = uv;
+        res[3] += 1.0;
+      }
+    }
+    if (nb != 2) res[2] += 1.0;
+    if (nb == 0) {
+      iwhere[i] = -1;
+    } else {
+      res[1] += 1.0;
+      iwhere[i] = (nb == 2 && uv - lv <= 0.0) ? 3 : 0;
+    }
+    wasfree[i] = 1;
+    x[i] = (T)xv;
+  }
+  q.launches++;
+}
 #define INST(T)                                                                                                          \
   template void launch_cauchy_scan<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *,    \
                                       iw_t *, T *, WStore<T>, int, int);                                                \
@@ -436,7 +509,12 @@ void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T 
                                         const T *, iw_t *, T *, double, double, int64_t, int);                          \
   template void launch_xcp_fill<T>(Queue &, int64_t, const T *, const T *, const T *, const T *, const iw_t *, double,  \
                                    T *);                                                                                \
-  template void launch_dz_materialise<T>(Queue &, int64_t, const T *, const T *, T *, T *);
+  template void launch_dz_materialise<T>(Queue &, int64_t, const T *, const T *, T *, T *);                            \
+  template void launch_errclb<T>(Queue &, int64_t, int64_t, const T *, const T *, const int32_t *);                    \
+  template void launch_dict_probe<T>(Queue &, int64_t, const T *, const T *, const BoundTables &);                     \
+  template void launch_nbd_pack_dict<T>(Queue &, int64_t, const int32_t *, const T *, const T *, const BoundTables &,  \
+                                        nb_t *);                                                                        \
+  template void launch_active<T>(Queue &, int64_t, T *, const T *, const T *, const int32_t *, iw_t *, int8_t *);
 INST(double)
 INST(float)
 #undef INST
@@ -723,6 +801,97 @@ static std::string check_case(const Case &c, const Opts &op) {
   return "";
 }
 
+// ============================================================ task 'START' over several ranks
+// The bound dictionary is built by probing passes whose results are reduced over the ranks: every rank must end
+// with the SAME tables after the same number of collectives whatever its own rows hold (a rank may see one value
+// only, or none of the values another rank sees), the codes must decode to the row's own l, u, nbd, and a ninth
+// value anywhere must make every rank fall back.  Also: the uniform flags, active's projection and counts.
+static std::string check_start(std::mt19937_64 &rng, int n, int nranks, int kl, int ku, bool nbd_uniform) {
+  using S = Solver<double>;
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  std::vector<double> lv(kl), uv(ku), l(n), u(n), x(n);
+  for (int j = 0; j < kl; ++j) lv[j] = -1.0 - 0.25 * j;
+  for (int j = 0; j < ku; ++j) uv[j] = 1.0 + 0.5 * j;
+  std::vector<int32_t> nbd(n);
+  for (int i = 0; i < n; ++i) {
+    // (blocks of rows share values, so that ranks see different subsets)
+    const int blk = (int)((int64_t)i * 5 / n);
+    l[i] = lv[(blk + (int)(U(rng) * 2)) % kl], u[i] = uv[(blk * 3 + (int)(U(rng) * 2)) % ku];
+    nbd[i] = nbd_uniform ? 2 : (int)(U(rng) * 4.0) & 3;
+    x[i] = 4.0 * (U(rng) - 0.5);
+  }
+  for (int j = 0; j < kl; ++j) l[(size_t)(rng() % n)] = lv[j];
+  for (int j = 0; j < ku; ++j) u[(size_t)(rng() % n)] = uv[j];
+  std::set<double> sl(l.begin(), l.end()), su(u.begin(), u.end());
+  const bool want_dict = sl.size() <= 8 && su.size() <= 8 && !(sl.size() == 1 && su.size() == 1);
+  World w;
+  w.nranks = nranks, w.bar.n = nranks, w.src.assign(nranks, nullptr);
+  std::vector<std::string> errs(nranks);
+  std::vector<int> masks(nranks, -1);
+  std::vector<lbk::BoundTables> tabs(nranks);
+  std::vector<int64_t> colls(nranks, 0);
+  auto body = [&](int rank) {
+    const int64_t lo = (int64_t)n * rank / nranks, hi = (int64_t)n * (rank + 1) / nranks, nl = hi - lo;
+    S *s = new S();
+    int rc = s->init(nl, n, lo, 3, 0, 0, nullptr);
+    RankComm rcomm{&w, rank};
+    if (!rc && nranks > 1) rc = s->attach_host(cb_allreduce, cb_allgather, &rcomm, rank, nranks);
+    if (!rc) rc = s->set_option("spin", 0.0);
+    // (every rank's rows in buffers of their own: the entry asks for 16-byte aligned vectors)
+    std::vector<double> xr(x.begin() + lo, x.begin() + hi), lr(l.begin() + lo, l.begin() + hi),
+        ur(u.begin() + lo, u.begin() + hi), g(nl, 0.0), dsave(29, 0.0);
+    std::vector<int32_t> nbr(nbd.begin() + lo, nbd.begin() + hi), lsave(4, 0), isave(44, 0);
+    char task[60], csave[60];
+    std::memset(task, ' ', 60), std::memset(csave, ' ', 60);
+    std::memcpy(task, "START", 5);
+    double f = 0.0;
+    if (!rc)
+      rc = s->setulb_dev(xr.data(), lr.data(), ur.data(), nbr.data(), &f, g.data(), 0.0, 0.0, task, -1, csave,
+                         lsave.data(), isave.data(), dsave.data());
+    if (rc) {
+      errs[rank] = g_err;
+    } else if (std::strncmp(task, "FG_START", 8) != 0) {
+      errs[rank] = std::string("task ") + std::string(task, 20);
+    } else {
+      masks[rank] = s->ub_mask, tabs[rank] = s->ub_tab, colls[rank] = s->ncoll;
+      for (int64_t i = 0; i < nl && errs[rank].empty(); ++i) {
+        const double xi = std::min(std::max(x[lo + i], nbd[lo + i] != 0 && nbd[lo + i] <= 2 ? l[lo + i] : -1e300),
+                                   nbd[lo + i] >= 2 ? u[lo + i] : 1e300);
+        if (xr[i] != xi) errs[rank] = "active: x not projected as the reference projects it";
+        if (s->ub_mask & lbk::UB_DICT) {
+          const unsigned c = (unsigned)(unsigned char)s->nbd8[i];
+          if ((int)(c & 3u) != nbd[lo + i] || s->ub_tab.l[(c >> 2) & 7u] != l[lo + i] || s->ub_tab.u[c >> 5] != u[lo + i])
+            errs[rank] = "code byte of row " + std::to_string(lo + i) + " does not decode to its l, u, nbd";
+        } else if (!(s->ub_mask & 4) && (int)s->nbd8[i] != nbd[lo + i]) {
+          errs[rank] = "packed nbd";
+        }
+      }
+    }
+    delete s;
+  };
+  if (nranks == 1) {
+    body(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < nranks; ++r) th.emplace_back(body, r);
+    for (auto &t : th) t.join();
+  }
+  for (int r = 0; r < nranks; ++r)
+    if (!errs[r].empty()) return "rank " + std::to_string(r) + ": " + errs[r];
+  for (int r = 0; r < nranks; ++r) {
+    if (((masks[r] & lbk::UB_DICT) != 0) != want_dict)
+      return "rank " + std::to_string(r) + ": mask " + std::to_string(masks[r]) + ", dictionary expected: " + std::to_string(want_dict);
+    if (colls[r] != colls[0]) return "the ranks issued different numbers of collectives";
+    // (nb0, the value of a uniform nbd array, is each rank's own)
+    if (want_dict && (tabs[r].nl != tabs[0].nl || tabs[r].nu != tabs[0].nu ||
+                      std::memcmp(tabs[r].l, tabs[0].l, sizeof tabs[0].l) != 0 ||
+                      std::memcmp(tabs[r].u, tabs[0].u, sizeof tabs[0].u) != 0))
+      return "the ranks hold different tables";
+  }
+  if (want_dict && (tabs[0].nl != (int)sl.size() || tabs[0].nu != (int)su.size())) return "table sizes";
+  return "";
+}
+
 // a random bounded problem, driven by the ORACLE; every NEW_X state (and the start) becomes a case
 struct Problem {
   int n, m;
@@ -875,6 +1044,21 @@ int main(int argc, char **argv) {
     }
     run_problem(rng, p, iters, modes, tl, k);
   }
+  // ---- START over 1 - 5 ranks: uniform, few-valued (2 ... 8 values, one side possibly uniform) and 9-valued arrays ----
+  long starts = 0, starts_failed = 0;
+  if (only < 0)
+    for (int rep = 0; rep < 60; ++rep) {
+      const int nr = 1 + rep % 5, kl = 1 + (int)(rng() % 9), ku = 1 + (int)(rng() % 9);
+      if (std::getenv("WALK_CHECK_VERBOSE")) std::fprintf(stderr, "start %d: ranks %d, %d / %d values\n", rep, nr, kl, ku);
+      const std::string why = check_start(rng, 200 + (int)(rng() % 3000), nr, kl, ku, rep % 3 == 0);
+      starts++;
+      if (!why.empty()) {
+        starts_failed++;
+        std::fprintf(stderr, "FAIL start %d (ranks %d, %d / %d values): %s\n", rep, nr, kl, ku, why.c_str());
+      }
+    }
+  tl.failed += starts_failed;
+  std::printf("walk_check: %ld START cases over 1-5 ranks, %ld failed\n", starts, starts_failed);
   std::printf("walk_check: %ld cases, %ld failed, %ld stationary-point-on-a-breakpoint, %ld multi-rank, %ld in heap order, "
               "%ld walks of more than 256 segments, %ld segments in all; rank 0: %ld full sorts, %ld tie splits replayed, "
               "%ld host syncs, %ld collectives\n", tl.cases, tl.failed, tl.on_breakpoint, tl.multi_rank, tl.exact_order,

@@ -5,8 +5,9 @@ product's own solver.hip, over a host stand-in for the HIP runtime and CPU twins
 (tests/cpu_walk/walk_check.cpp), and run under AddressSanitizer + UndefinedBehaviorSanitizer against the oracle's
 lbo_cauchy (reference src/lbfgsb.f90:1157-1532, hpsolb :2079-2157) on several hundred states of random bounded
 problems: one rank through the routine door, 2 - 5 ranks as host threads (host merge and device merge of the rank
-chunks), every walk in index order and in the reference's heap order, row numbers across 2^31 and 2^32.  GPU
-sanitizers do not exist on the pool; this is the buffer-heavy host code they would have been wanted for."""
+chunks), every walk in index order and in the reference's heap order, row numbers across 2^31 and 2^32; and task
+'START' (errclb, the bound dictionary built by reduced probing passes, active) over 1 - 5 ranks.  GPU sanitizers do
+not exist on the pool; this is the buffer-heavy host code they would have been wanted for."""
 import os
 import re
 import subprocess
@@ -45,6 +46,11 @@ def test_walk_and_provider_under_sanitizers_against_the_oracle():
     assert mm, r.stdout[-1500:]
     cases, failed, degenerate, multi, heap, long_walks, _segs, fullsorts, tiesplits = (int(v) for v in mm.groups())
     assert cases >= 200 and failed == 0
+    # task 'START' over 1 - 5 rank threads: the bound dictionary's probing loop ends with the same tables after the
+    # same number of collectives on every rank, the code bytes decode to each row's own l, u, nbd, a ninth value
+    # makes every rank fall back; active's projection
+    ms = re.search(r"walk_check: (\d+) START cases over 1-5 ranks, (\d+) failed", r.stdout)
+    assert ms and int(ms.group(1)) >= 60 and int(ms.group(2)) == 0, r.stdout[-1500:]
     assert multi >= 100 and heap >= 80 and long_walks >= 10 and fullsorts >= 1 and tiesplits >= 1
     # the one tolerated class (a stationary point that coincides with a breakpoint to the last bit: the decision
     # rests on the rounding of an n-term sum, walk_check.cpp / DESIGN.md section 7) stays rare
