@@ -58,9 +58,9 @@ def oracle_rows(po, n, m, iters, mixed):
     (1, "rccl1", 50021, 5, 6, True),
     (3, "gloo", 6007, 40, 46, True),      # m > 32: the unfused tile path (solver_wide.inl) over 3 ranks -- WN1 kept
                                           # incrementally, the changed rows' patch summed per rank and reduced
-    (6, "fakerccl", 600011, 10, 14, False),  # SIX rank PROCESSES (the most a GPU box admits on its card) through the
-                                          # communicator code path with the ASYNCHRONOUS stand-in for librccl: the
-                                          # headline problem's shape at 1e5 rows per rank -- a first walk of ~586 k
+    (5, "fakerccl", 500009, 10, 14, False),  # FIVE rank PROCESSES (+ this one: the six a GPU box admits on its card) through
+                                          # the communicator code path with the ASYNCHRONOUS stand-in for librccl: the
+                                          # headline problem's shape at 1e5 rows per rank -- a first walk of ~488 k
                                           # breakpoints all-gathered in chunks and merged on the device of every rank,
                                           # the filling memory, one all-gather per host sync (the 8-rank full-size run of
                                           # test_gpu_config4.py has to use rank threads and the synchronous stand-in)
