@@ -17,26 +17,66 @@ namespace lbk {
 // out_i (+)= sum_j (Wy(i,j) * a_j) / div + Ws(i,j) * b_j over the tc <= 32 logical columns of one tile,
 // j ascending as cmprlb :1576-1581 and subsm :2770-2778 run; rows with mask (iwhere > 0: not free) are
 // left alone when masked != 0.  div = theta for subsm's first term (the reference divides the PRODUCT).
-template <typename T>
+// 16 bytes per lane and column (2 rows in fp64, 4 in fp32), the columns in groups of 8 whose 16 loads are issued
+// together (slots beyond tc read the zero buffer: no branch between the loads); the sum of a row runs over j in
+// the same order as before, term by term.  (Round 4's form -- one row per lane, a run-time loop over the columns
+// -- moved 5.6 TB/s at m = 48; this is the second pass over W of every m > 32 iteration.)
+template <typename T, bool NT>
 __global__ __launch_bounds__(BLOCK) void tile_axpy_kernel(int64_t n, const T *__restrict__ ws,
-                                                          const T *__restrict__ wy, int64_t ldw, int m,
-                                                          int head, int tc, Coef cf, double div,
+                                                          const T *__restrict__ wy, const T *__restrict__ zero,
+                                                          int64_t ldw, int m, int head, int tc, Coef cf, double div,
                                                           const iw_t *__restrict__ iwhere, int masked, T *out) {
-  for_rows<T, 1>(n, [&](int64_t i, auto) {
-    if (masked && iwhere[i] > 0) return;
-    double acc = (double)out[i];
-    for (int j = 0; j < tc; ++j) {
-      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
-      acc = acc + ((double)wy[off] * cf.a[j]) / div + (double)ws[off] * cf.a[MAXM + j];
+  constexpr int G = 8;
+  for_rows<T, VecOf<T>::V>(n, [&](int64_t i, auto wt) {
+    constexpr int W = decltype(wt)::value;
+    double acc[W], old[W];
+    int iw[W];
+    ld<W>(out + i, acc);
+#pragma unroll
+    for (int k = 0; k < W; ++k) old[k] = acc[k];
+    if (masked) {
+      ldi<W>(iwhere + i, iw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) iw[k] = 0;
     }
-    out[i] = (T)acc;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < W; ++k) any = any || iw[k] <= 0;
+    if (__ballot(any) == 0ull) return;  // (a wave whose rows are all masked reads nothing)
+    for (int j0 = 0; j0 < tc; j0 += G) {
+      double a[G][W], b[G][W];
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = j0 + jj;
+        const int64_t off = (int64_t)((head - 1 + (j < tc ? j : 0)) % m) * ldw + i;
+        ld_col<T, W, NT>(j < tc, wy + off, zero, a[jj]);
+        ld_col<T, W, NT>(j < tc, ws + off, zero, b[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        if (j0 + jj < tc) {  // (uniform)
+          const double ca = cf.a[j0 + jj], cb = cf.a[MAXM + j0 + jj];
+#pragma unroll
+          for (int k = 0; k < W; ++k) acc[k] = acc[k] + (a[jj][k] * ca) / div + b[jj][k] * cb;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] = iw[k] > 0 ? old[k] : acc[k];  // (rows that are not free keep their value)
+    st<W>(out + i, acc);
   });
 }
 template <typename T>
 void launch_tile_axpy(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, double div,
                       const iw_t *iwhere, int masked, T *out) {
-  hipLaunchKernelGGL(tile_axpy_kernel<T>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy, w.ld,
-                     w.m, head, tc, cf, div, iwhere, masked, out);
+  const int gr = grid_for(n, VecOf<T>::V);
+  if (q.nt)
+    hipLaunchKernelGGL((tile_axpy_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy, w.zero, w.ld,
+                       w.m, head, tc, cf, div, iwhere, masked, out);
+  else
+    hipLaunchKernelGGL((tile_axpy_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy, w.zero, w.ld,
+                       w.m, head, tc, cf, div, iwhere, masked, out);
   LB_LAUNCHED(q);
 }
 
