@@ -450,6 +450,8 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           one pass over W) in front of the unfused subspace steps (default 1) / all unfused
  *   "wide_closed" (0/1)     m > 32: W'Z r in closed form and cmprlb's + subsm's updates of r as one pass over W
  *                           (default 1) / a W'r pass and two updates
+ *   "wide_tail" (0/1)       m > 32: cmprlb's start and subsm's projected step + the line-search set-up folded into the first /
+ *                           last tile of that pass (default 1) / as kernels of their own
  *   "wide_incr" (0/1)       m > 32: formk adds the new pair's row and column to WN1 while no row changes status
  *                           (default 1) / from scratch whenever it runs
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)

@@ -80,6 +80,133 @@ void launch_tile_axpy(Queue &q, int64_t n, WStore<T> w, int head, int tc, const 
   LB_LAUNCHED(q);
 }
 
+// The r pass with cmprlb's start and subsm's tail folded into its first / last tile (kernels.hpp, WideTail).  Per
+// row the arithmetic -- and, in REAL32, every rounding to T the unfused kernels put between their steps -- is
+// that of cmprlb_init_kernel, tile_axpy_kernel, subsm_project_kernel and lnsrlb_begin_kernel run one after the
+// other.
+template <typename T, bool NT, bool FIRST, bool LAST>
+__global__ __launch_bounds__(BLOCK) void tile_axpy_fused_kernel(int64_t n, const T *__restrict__ ws,
+                                                                const T *__restrict__ wy, const T *__restrict__ zero,
+                                                                int64_t ldw, int m, int head, int tc, Coef cf,
+                                                                const iw_t *__restrict__ iwhere, T *out, WideTail<T> wt,
+                                                                double *part) {
+  constexpr int G = 8;
+  double red[4] = {0.0, 0.0, 0.0, 1.0e10};
+  const double rtheta = 1.0 / wt.theta;
+  for_rows<T, VecOf<T>::V>(n, [&](int64_t i, auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    double acc[W], xv[W], gv[W], lv[W], uv[W], zc[W];
+    int iw[W];
+    ldi<W>(iwhere + i, iw);
+    if constexpr (FIRST || LAST) {
+      ld<W>(wt.x + i, xv);
+      ld<W>(wt.g + i, gv);
+      ld<W>(wt.l + i, lv);
+      ld<W>(wt.u + i, uv);
+#pragma unroll
+      for (int k = 0; k < W; ++k) zc[k] = (double)(T)xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], wt.tsum);
+    }
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int k = 0; k < W; ++k)  // cmprlb_init_kernel
+        acc[k] = iw[k] > 0 ? 0.0 : (double)(T)(wt.plain ? -gv[k] : -wt.theta * (zc[k] - xv[k]) - gv[k]);
+    } else {
+      ld<W>(out + i, acc);
+    }
+    for (int j0 = 0; j0 < tc; j0 += G) {
+      double a[G][W], b[G][W];
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = j0 + jj;
+        const int64_t off = (int64_t)((head - 1 + (j < tc ? j : 0)) % m) * ldw + i;
+        ld_col<T, W, NT>(j < tc, wy + off, zero, a[jj]);
+        ld_col<T, W, NT>(j < tc, ws + off, zero, b[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        if (j0 + jj < tc) {  // (uniform)
+          const double ca = cf.a[j0 + jj], cb = cf.a[MAXM + j0 + jj];
+#pragma unroll
+          for (int k = 0; k < W; ++k)
+            if (iw[k] <= 0) acc[k] = acc[k] + a[jj][k] * ca + b[jj][k] * cb;  // (tile_axpy_kernel with div = 1)
+        }
+      }
+    }
+    if constexpr (!LAST) {
+      st<W>(out + i, acc);
+    } else {
+      double zv[W], dv[W];
+      int nbk[W];
+      ldi<W>(wt.nbd + i, nbk);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        zv[k] = zc[k];
+        if (iw[k] <= 0) {  // subsm_project_kernel
+          const double dk = rtheta * (double)(T)acc[k];
+          const double xk = zc[k];
+          if (nbk[k] != 0) {
+            if (nbk[k] == 1) {
+              zv[k] = fmax(lv[k], xk + dk);
+              if (zv[k] == lv[k]) red[0] += 1.0;
+            } else if (nbk[k] == 2) {
+              const double t1 = fmax(lv[k], xk + dk);
+              zv[k] = fmin(uv[k], t1);
+              if (zv[k] == lv[k] || zv[k] == uv[k]) red[0] += 1.0;
+            } else if (nbk[k] == 3) {
+              zv[k] = fmin(uv[k], xk + dk);
+              if (zv[k] == uv[k]) red[0] += 1.0;
+            }
+          } else {
+            zv[k] = xk + dk;
+          }
+          zv[k] = (double)(T)zv[k];
+        }
+        dv[k] = zv[k] - xv[k];              // mainlb :720-722 (lnsrlb_begin_kernel)
+        red[1] = red[1] + dv[k] * gv[k];    // dd_p (:2824-2827) == g'd (:2244)
+        red[2] = red[2] + dv[k] * dv[k];    // dtd (:2196)
+        if (wt.do_stpmx && nbk[k] != 0) {   // :2206-2225
+          const double a1 = dv[k];
+          if (a1 < 0.0 && nbk[k] <= 2) {
+            const double a2 = lv[k] - xv[k];
+            red[3] = fmin(red[3], a2 >= 0.0 ? 0.0 : a2 / a1);
+          } else if (a1 > 0.0 && nbk[k] >= 2) {
+            const double a2 = uv[k] - xv[k];
+            red[3] = fmin(red[3], a2 <= 0.0 ? 0.0 : a2 / a1);
+          }
+        }
+      }
+      if (wt.zout) st<W>(wt.zout + i, zv);
+      if (wt.dvec) st<W>(wt.dvec + i, dv);
+      if (wt.tvec) st<W>(wt.tvec + i, xv);  // t = x (:2235)
+      if (wt.rout) st<W>(wt.rout + i, gv);  // r = g (:2236)
+      if (wt.xout) st<W>(wt.xout + i, zv);  // the first trial point x = z (:2265); may alias wt.x (row read above)
+    }
+  });
+  if constexpr (LAST) block_reduce_store<4>(red, 3, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_tile_axpy_fused(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, const iw_t *iwhere,
+                            T *out, int first, int last, const WideTail<T> &wt) {
+  const int gr = grid_for(n, VecOf<T>::V);
+#define LB_TAF(NTV, FV, LV)                                                                                         \
+  hipLaunchKernelGGL((tile_axpy_fused_kernel<T, NTV, FV, LV>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy,   \
+                     w.zero, w.ld, w.m, head, tc, cf, iwhere, out, wt, q.part())
+  if (q.nt) {
+    if (first && last) LB_TAF(true, true, true);
+    else if (first) LB_TAF(true, true, false);
+    else if (last) LB_TAF(true, false, true);
+    else LB_TAF(true, false, false);
+  } else {
+    if (first && last) LB_TAF(false, true, true);
+    else if (first) LB_TAF(false, true, false);
+    else if (last) LB_TAF(false, false, true);
+    else LB_TAF(false, false, false);
+  }
+#undef LB_TAF
+  LB_LAUNCHED(q);
+  if (last) launch_finalize(q, gr, 3, 1, 0);
+}
+
 // out_i = src_i on the rows selected (want_free: iwhere <= 0, else iwhere > 0), 0 elsewhere
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void masked_copy_kernel(int64_t n, const T *__restrict__ src,
@@ -214,6 +341,7 @@ void launch_subsm_project(Queue &q, int64_t n, T *z, T *dir, const T *x, const T
 
 #define INSTANTIATE(T) \
   template void launch_tile_axpy<T>(Queue &, int64_t, WStore<T>, int, int, const Coef &, double, const iw_t *, int, T *); \
+  template void launch_tile_axpy_fused<T>(Queue &, int64_t, WStore<T>, int, int, const Coef &, const iw_t *, T *, int, int, const WideTail<T> &); \
   template void launch_masked_copy<T>(Queue &, int64_t, const T *, const iw_t *, int, T *); \
   template void launch_rows_gather<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int, double *); \
   template void launch_cauchy_dvec<T>(Queue &, int64_t, const T *, const T *, T *); \

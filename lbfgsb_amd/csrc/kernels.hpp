@@ -432,6 +432,24 @@ void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d,
 template <typename T>
 void launch_tile_axpy(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, double div,
                       const iw_t *iwhere, int masked, T *out);
+// The r pass of an m > 32 iteration (solver_wide.inl, wide_subspace): the same tiles, with what cmprlb and subsm do
+// around them folded into the first and the last one.  first: the sum of a row starts from r0 = -theta (xcp - x) - g
+// (cmprlb :1565-1574; plain: -g) on the free rows instead of from `out` -- the Cauchy point evaluated per row
+// (xcp_row), neither xcp nor r0 exists as a vector.  last: the finished sum is the Newton direction; the projected
+// step (:2780-2816), dd_p (:2824-2827), d = z - x, dtd, the stpmx ratios (:2196-2225) and the stores of
+// subsm_update_kernel (trial x / z, d, t, r: any of them may be nullptr) follow in the same kernel.
+// res (last only): sum [0] = #bound hits, [1] = dd_p = g'd, [2] = dtd ; min [3] = stpmx
+template <typename T>
+struct WideTail {
+  const T *x, *g, *l, *u;
+  const int32_t *nbd;
+  double tsum, theta;
+  int plain, do_stpmx;
+  T *zout, *dvec, *tvec, *rout, *xout;
+};
+template <typename T>
+void launch_tile_axpy_fused(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, const iw_t *iwhere,
+                            T *out, int first, int last, const WideTail<T> &wt);
 // out = src on the free (want_free) / active rows, 0 elsewhere
 template <typename T>
 void launch_masked_copy(Queue &q, int64_t n, const T *src, const iw_t *iwhere, int want_free, T *out);

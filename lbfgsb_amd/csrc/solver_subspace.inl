@@ -465,6 +465,7 @@
     if (k == "wide_incr") return flag(wide_incr_on);
     if (k == "wide_fused") return flag(wide_fused_on);
     if (k == "wide_closed") return flag(wide_closed_on);
+    if (k == "wide_tail") return flag(wide_tail_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
@@ -500,6 +501,7 @@
   // m > 32: matupd's, cauchy's and formk's sums from the (split) update pass -- one pass over W instead of
   // five; the subspace steps stay the unfused ones (solver_wide.inl).  Option "wide_fused" = 0: all unfused
   bool wide_fused_on = true, wide_closed_on = true;  // ("wide_closed": W'Z r in closed form, one axpy pass)
+  bool wide_tail_on = true;  // ("wide_tail": cmprlb's start and subsm's tail folded into that pass's first / last tile)
   bool wide_fused() const { return wide() && wide_fused_on && two_pass; }
   struct NewRow {
     bool valid = false;

@@ -371,6 +371,8 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     # ... all unfused (matupd, cauchy's p and formk's new row as separate W'v passes), and with the fused update pass
     # but W'Z r from a pass over W instead of the closed form
     (8300, 12, 1200, 33, 80, "wide_fused=0"), (8400, 12, 1200, 33, 80, "pp,wide_closed=0"),
+    # ... and with cmprlb's start / subsm's tail as kernels of their own instead of folded into the r pass's tiles
+    (8500, 12, 1200, 33, 80, "wide_tail=0"), (8600, 12, 1200, 33, 80, "pp,lean=0"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
     # col > 21 without the split update pass: three passes over W (the pair-shared cmprlb_wtv kernel at MC = 32)
