@@ -99,3 +99,28 @@ def test_header_and_c_example_are_plain_c():
     assert cc, "no C compiler"
     subprocess.check_call([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "driver1.c")])
+
+
+def test_bench_parity_in_run_flags_what_it_should():
+    """bench.py's in-run check (the timed leg's NEW_X rows against the rows the real reference printed at full
+    size): the fixture's own rows pass, a changed integer or an f off by 1e-8 fails, other shapes are not compared."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "quad_n1e8_m10_ref_rows.json")))["rows"]
+    rows = [(r["iter"], r["nfg"], r["nseg"], r["nfree"], r["f"]) for r in ref]
+    more = rows + [(17, 19, 1, 49999496, 1.0), (18, 20, 1, 49999496, 0.9)]      # (iterations beyond the fixture)
+    ok = bench.parity_in_run(more, 100_000_000, 10, False, 0)
+    assert ok["ok"] is True and ok["rows_checked"] == len(ref)
+    bad = list(rows)
+    bad[3] = (bad[3][0], bad[3][1], bad[3][2] + 1, bad[3][3], bad[3][4])
+    r = bench.parity_in_run(bad, 100_000_000, 10, False, 0)
+    assert r["ok"] is False and r["mismatch"][0]["got"][0] == 4
+    bad = list(rows)
+    bad[7] = bad[7][:4] + (bad[7][4] * (1 + 1e-8),)
+    assert bench.parity_in_run(bad, 100_000_000, 10, False, 0)["ok"] is False
+    assert bench.parity_in_run(rows, 1_000_000, 10, False, 0)["ok"] is None          # no rows on file for this shape
+    assert bench.parity_in_run(rows, 100_000_000, 10, True, 0)["ok"] is None          # REAL32: not the fixture's kind
+    assert bench.parity_in_run([], 100_000_000, 10, False, 0)["ok"] is False         # nothing ran: not a pass

@@ -753,6 +753,51 @@ def test_wide_memory_one_step_parity(env, name, spec, ncalls, stride):
     assert tested >= 20, tested
 
 
+@pytest.mark.parametrize("real32", [False, True], ids=["fp64", "real32"])
+@pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
+def test_wide_tail_folded_into_the_r_pass_changes_no_row(env, pp, real32):
+    """m > 32: cmprlb's start (r0 = -theta (xcp - x) - g) and subsm's tail (projected step, d = z - x, the line-search
+    set-up, the first trial point) run inside the first / last tile of the r pass (tile_axpy_fused_kernel, option
+    wide_tail) instead of as six vector kernels.  Per row that is the same arithmetic with the same roundings to the
+    storage kind in between -- so the iterates must be the unfused route's BIT FOR BIT, in fp64 and in REAL32 (where
+    every intermediate vector the unfused kernels store is rounded to fp32), through both entries, while the memory
+    grows from 1 to 40 pairs and beyond (one tile, two tiles, the shift of a full memory)."""
+    po, torch, la = env["po"], env["torch"], env["la"]
+    n, m, iters = 7001, 40, 55
+    rdt = torch.float32 if real32 else torch.float64
+    p = po.problem_quadratic(n, m, mixed_nbd=True)
+
+    def run(tail):
+        sol = la.DeviceSolver(n, m, real32=real32, options={"wide_tail": tail})
+        xs = [torch.from_numpy(p.x0.copy()).to(rdt).cuda(), torch.zeros(n, dtype=rdt, device="cuda")]
+        gs = [torch.zeros_like(xs[0]), torch.zeros_like(xs[0])]
+        l, u = torch.from_numpy(p.l).to(rdt).cuda(), torch.from_numpy(p.u).to(rdt).cuda()
+        nbd = torch.from_numpy(p.nbd.astype(np.int32)).cuda()
+        rows, cur = [], 0
+        for _ in range(100000):
+            if pp:
+                t, cur = sol.setulb_pp(xs, l, u, nbd, gs, 0.0, 0.0)
+            else:
+                t = sol.setulb(xs[0], l, u, nbd, gs[0], 0.0, 0.0)
+            if t.startswith("FG"):
+                sol.f[0] = sol.objective(0, xs[cur], gs[cur])
+                rows.append(("FG", int(sol.isave[35]), xs[cur].cpu().numpy().tobytes()))   # (ifun, the trial point)
+            elif t.startswith("NEW_X"):
+                rows.append(("NEW_X", int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]), int(sol.isave[37]),
+                             int(sol.isave[27]), float(sol.f[0]), xs[cur].cpu().numpy().tobytes()))
+                if sol.isave[29] >= iters:
+                    break
+            else:
+                break
+        sol.close()
+        return rows
+    a, b = run(1), run(0)
+    assert len(a) == len(b) and len(a) > iters
+    assert max(r[5] for r in a if r[0] == "NEW_X") == m
+    for k, (ra, rb) in enumerate(zip(a, b)):
+        assert ra == rb, (k, ra[:6], rb[:6])
+
+
 @pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
 def test_wide_memory_trajectory_to_convergence(env, pp):
     """m = 48 on the production path (default context, both device-pointer entries), bounded quadratic with all
