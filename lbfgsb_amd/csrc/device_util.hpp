@@ -316,7 +316,10 @@ template <typename E, int W>
 using RawOf = RawReg<(int)sizeof(E) * W>;
 
 // ---- lane pairs (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS traffic ----
-__device__ __forceinline__ int pair_xchg(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+// (bound_ctrl = 1 with full row / bank masks: every lane is written and no source lane is out of range, so the
+//  result is the same -- but the compiler then knows the destination's old value is dead and does not
+//  initialise it: one v_mov_b32 less per moved register)
+__device__ __forceinline__ int pair_xchg(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ double pair_xchg(double v) {
   const long long b = __builtin_bit_cast(long long, v);
   const unsigned lo = (unsigned)pair_xchg((int)b), hi = (unsigned)pair_xchg((int)(b >> 32));
@@ -466,8 +469,8 @@ __device__ __forceinline__ void for_rows_raw(int64_t n, const Ctx &c, F &&f) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {  // every lane: the value of its DPP source lane
   const long long b = __builtin_bit_cast(long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]

@@ -315,7 +315,7 @@ struct GramQuad {
 };
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);  // (quad_perm only: see pair_xchg)
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {

@@ -96,6 +96,8 @@ struct UpdScanCtx {
   // array pointer then is a 64-byte buffer holding that value and every lane reads ITS start -- a
   // cache hit instead of an HBM stream, selected by ADDRESS like the zero columns (no new code path)
   int ub;
+  // PAIR: column pointers per lane parity, in LDS (see UpdScanPairTrip)
+  const unsigned long long *ptab;
 };
 template <typename T, int MC, int W, bool NT>
 struct UpdScanTrip {
@@ -128,6 +130,71 @@ struct UpdScanTrip {
     land_cols<T, MC, W>(ra, rb);
   }
 };
+// PAIR (see update_scan_kernel): the lanes 2p, 2p + 1 of a wave work on the 2 W rows [i0, i0 + 2 W) together.
+// Each lane owns W of the rows for everything a row needs once (x, g, bounds, the n-loop of cauchy), and HALF of
+// the columns over all 2 W rows: the even lane logical columns [0, MC/2), the odd lane [MC/2, MC) -- so a lane
+// loads 16 bytes of each of ITS columns (the rows of both lanes) and no column value ever crosses lanes; a wave's
+// load instruction reads two columns, 512 contiguous bytes of each.  Only the row scalars (s, -g, the masked
+// y and s of formk's new row) are exchanged, by DPP.
+// The per-lane column pointers (2 x MC of them; unroll slots beyond the stored pairs point at the zero buffer)
+// live in LDS, read 16 bytes per column pair and trip: as 2 MC uniform 64-bit offsets they do not fit the scalar
+// registers next to everything else -- the compiler kept them in VGPR lanes and fetched them back with ~90
+// v_readlane per trip (profiles/round5_u_pair_isa.md).
+template <typename T, int MC, int W, bool NT>
+struct UpdScanPairTrip {
+  static constexpr int H = MC / 2;
+  static constexpr int NL = 8 + 2 * H;
+  RawOf<T, W> rx, rl, ru, rg, rr, rd;
+  RawOf<T, 2 * W> ra[H], rb[H];
+  RawOf<nb_t, W> rnb;
+  RawOf<iw_t, W> riw;
+  __device__ __forceinline__ void issue(const UpdScanCtx<T> &c, int64_t i) {
+    constexpr int B = (int)sizeof(T) * W;
+    const bool hi = threadIdx.x & 1;
+    const int64_t i0 = i - (hi ? W : 0);  // first row of the lane pair (a multiple of 2 W: 16-byte aligned)
+    // (the table is the same in every trip: an opaque index keeps its 2 MC pointers from being hoisted out of
+    //  the row loop into registers that are not there.  Read FIRST: the row vectors' address arithmetic and
+    //  loads then cover the LDS latency, which a wave that runs alone on its SIMD would otherwise sit out)
+    int tb = hi ? 2 * H : 0;
+    asm volatile("" : "+v"(tb));
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 p[H];
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) p[jj] = *reinterpret_cast<const u64x2 *>(c.ptab + tb + 2 * jj);
+    __builtin_amdgcn_sched_barrier(0);
+    raw_issue<B, NT>(rx, c.x + i);
+    raw_issue<B, NT>(rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(ru, (c.ub & 2) ? c.u : c.u + i);
+    raw_issue<B, NT>(rg, c.g + i);
+    raw_issue<B, NT>(rr, c.r + i);
+    raw_issue<B, NT>(rd, c.d + i);
+    raw_issue<W, false>(rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
+    raw_issue<W, false>(riw, c.iwhere + i);
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      const int64_t o = (hi && H + jj >= c.nold) ? 0 : i0;  // the zero buffer is 256 bytes, not a column
+      // (pointers that come out of LDS: say that they point to global memory, or the loads are flat ones)
+      typedef const __attribute__((address_space(1))) T *gptr;
+      raw_issue<2 * B, NT>(ra[jj], (const T *)((gptr)p[jj].x + o));
+      raw_issue<2 * B, NT>(rb[jj], (const T *)((gptr)p[jj].y + o));
+    }
+  }
+  __device__ __forceinline__ void land() {
+    raw_land(rx);
+    raw_land(rl);
+    raw_land(ru);
+    raw_land(rg);
+    raw_land(rr);
+    raw_land(rd);
+    raw_land(rnb);
+    raw_land(riw);
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      raw_land(ra[jj]);
+      raw_land(rb[jj]);
+    }
+  }
+};
 // NEWROW: the pass also yields the new row/column of formk's WN1 (:1756-1793) for the pair being
 // formed here -- with the free/active split of the rows as cauchy's n-loop leaves it, i.e.
 // BEFORE the breakpoint walk (the host corrects the sums for the few rows the walk fixes, from
@@ -139,11 +206,11 @@ struct UpdScanTrip {
 // PAIR (MC = 20 with the new-row sums): the 8 sums per column are what fills the register
 // file (175 fp64 accumulators per lane), and a kernel that large runs one wave per SIMD with a
 // single trip in flight.  Neighbouring lanes therefore SHARE the per-column accumulators: the even
-// lane sums columns [0, 10), the odd lane columns [10, 20), each over the rows of BOTH lanes -- the
-// operands of the other lane's rows come over by DPP (its row scalars once per trip, its column
-// values as register images) -- which leaves room for the second trip in flight.  The caller
-// passes a row count that is a multiple of 2 V (pairs are always complete) and runs the plain
-// instantiation on the few rows that remain.
+// lane sums columns [0, 10), the odd lane columns [10, 20), each over the rows of BOTH lanes, in
+// row order -- each lane loads its own columns for both lanes' rows (UpdScanPairTrip) and the row
+// scalars of the other lane come over by DPP -- which leaves room for the second trip in flight.
+// The caller passes a row count that is a multiple of 2 V (pairs are always complete) and runs the
+// plain instantiation on the few rows that remain.
 template <typename T, int MC, bool NT, bool PIPE, bool NEWROW, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
@@ -172,10 +239,21 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     for (int b = 0; b < (PAIR ? H : 1); ++b) accp[a][b] = 0.0;
   const bool hi = threadIdx.x & 1;
   const int64_t offn = (int64_t)(itail - 1) * ldw;
-  const UpdScanCtx<T> ctx{x, l, u, g, r, d, ws, wy, zero, nbd, iwhere, ldw, m, head, nold, ub};
+  __shared__ unsigned long long ptab[PAIR ? 2 * MC : 1];  // [lane parity][column of the half][Wy, Ws]
+  if constexpr (PAIR) {
+    if (threadIdx.x < 2 * MC) {
+      const int j = (int)threadIdx.x >> 1;  // logical column: the odd lanes' half follows the even lanes'
+      const T *base = (threadIdx.x & 1) ? ws : wy;
+      ptab[threadIdx.x] = (unsigned long long)(uintptr_t)(j < nold ? base + col_off(j, nold, head, m, ldw) : zero);
+    }
+    __syncthreads();
+  }
+  const UpdScanCtx<T> ctx{x, l, u, g, r, d, ws, wy, zero, nbd, iwhere, ldw, m, head, nold, ub, ptab};
   __shared__ T dict[16];
   dict_fill<T>(dict, l, u, ub);
-  for_rows_raw<UpdScanTrip<T, MC, V, NT>, UpdScanTrip<T, MC, 1, NT>, V, PIPE, 0>(
+  using TripV = std::conditional_t<PAIR, UpdScanPairTrip<T, MC, V, NT>, UpdScanTrip<T, MC, V, NT>>;
+  using Trip1 = std::conditional_t<PAIR, UpdScanPairTrip<T, MC, 1, NT>, UpdScanTrip<T, MC, 1, NT>>;
+  for_rows_raw<TripV, Trip1, V, PIPE, 0>(
       n, ctx, [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W];
@@ -260,46 +338,47 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         acc[X + 4 * MC + 3] = __builtin_fma(fr ? sst : 0.0, yst, acc[X + 4 * MC + 3]);
       }
     }
+    auto row_stores = [&]() {
+      if (store_pair) {  // else the pair stays pending (see Pend)
+        st<W>(ws + offn + i, dv);
+        st<W>(wy + offn + i, rv);
+      }
+      // iwhere settles after the first iterations: store only from waves that changed a row
+      if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
+      if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
+    };
+    // PAIR: in front of the column sums, so that nothing of the row part stays live across them (404 bytes
+    // of scratch otherwise); the other instantiations hand breakpoints over below and keep them at the end
+    if constexpr (PAIR) row_stores();
     if constexpr (PAIR) {
-      double pdv[W], png[W], pyf[W], psa[W];  // the neighbour's rows
+      // the row scalars of the pair's 2 W rows in row order: [0, W) are the even lane's, [W, 2 W) the odd lane's
+      // (-g, y and s as stored are values of T and travel as such: one register each for fp32)
+      double qd[2 * W], qn[2 * W], qy[2 * W], qs[2 * W];
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        pdv[k] = pair_xchg(dv[k]);
-        png[k] = pair_xchg_as<T>(ng[k]);  // (-g, y and s as stored: values of T)
-        pyf[k] = pair_xchg_as<T>(yf[k]), psa[k] = pair_xchg_as<T>(sa[k]);
+        const double od = pair_xchg(dv[k]);
+        qd[k] = hi ? od : dv[k], qd[W + k] = hi ? dv[k] : od;
+        const T n_ = (T)ng[k], y_ = (T)yf[k], s_ = (T)sa[k];
+        const T on = pair_xchg(n_), oy = pair_xchg(y_), os = pair_xchg(s_);
+        qn[k] = (double)(hi ? on : n_), qn[W + k] = (double)(hi ? n_ : on);
+        qy[k] = (double)(hi ? oy : y_), qy[W + k] = (double)(hi ? y_ : oy);
+        qs[k] = (double)(hi ? os : s_), qs[W + k] = (double)(hi ? s_ : os);
       }
 #pragma unroll
       for (int jj = 0; jj < H; ++jj) {
-        // own rows: this lane's half of the columns; the half it does not sum goes to the neighbour
-        const RawOf<T, W> ma = raw_sel(hi, tr.ra[H + jj], tr.ra[jj]), mb = raw_sel(hi, tr.rb[H + jj], tr.rb[jj]);
-        const RawOf<T, W> ta = raw_xchg(raw_sel(hi, tr.ra[jj], tr.ra[H + jj]));
-        const RawOf<T, W> tb_ = raw_xchg(raw_sel(hi, tr.rb[jj], tr.rb[H + jj]));
-        double aj[W], bj[W], paj[W], pbj[W];
-        raw_get_col<W, false>(ma, (const T *)nullptr, aj);
-        raw_get_col<W, false>(mb, (const T *)nullptr, bj);
-        raw_get_col<W, false>(ta, (const T *)nullptr, paj);
-        raw_get_col<W, false>(tb_, (const T *)nullptr, pbj);
+        double aj[2 * W], bj[2 * W];  // this lane's column pair jj (+ H on the odd lane), the pair's rows
+        raw_get_col<2 * W, false>(tr.ra[jj], (const T *)nullptr, aj);
+        raw_get_col<2 * W, false>(tr.rb[jj], (const T *)nullptr, bj);
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-          accp[0][jj] = dot_term<T>(accp[0][jj], dv[k], aj[k]);
-          accp[1][jj] = dot_term<T>(accp[1][jj], bj[k], dv[k]);
-          accp[2][jj] = dot_term<T>(accp[2][jj], aj[k], ng[k]);
-          accp[3][jj] = dot_term<T>(accp[3][jj], bj[k], ng[k]);
-          accp[4][jj] = __builtin_fma(yf[k], aj[k], accp[4][jj]);
-          accp[5][jj] = __builtin_fma(sa[k], bj[k], accp[5][jj]);
-          accp[6][jj] = __builtin_fma(sa[k], aj[k], accp[6][jj]);
-          accp[7][jj] = __builtin_fma(bj[k], yf[k], accp[7][jj]);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-          accp[0][jj] = dot_term<T>(accp[0][jj], pdv[k], paj[k]);
-          accp[1][jj] = dot_term<T>(accp[1][jj], pbj[k], pdv[k]);
-          accp[2][jj] = dot_term<T>(accp[2][jj], paj[k], png[k]);
-          accp[3][jj] = dot_term<T>(accp[3][jj], pbj[k], png[k]);
-          accp[4][jj] = __builtin_fma(pyf[k], paj[k], accp[4][jj]);
-          accp[5][jj] = __builtin_fma(psa[k], pbj[k], accp[5][jj]);
-          accp[6][jj] = __builtin_fma(psa[k], paj[k], accp[6][jj]);
-          accp[7][jj] = __builtin_fma(pbj[k], pyf[k], accp[7][jj]);
+        for (int k = 0; k < 2 * W; ++k) {
+          accp[0][jj] = dot_term<T>(accp[0][jj], qd[k], aj[k]);
+          accp[1][jj] = dot_term<T>(accp[1][jj], bj[k], qd[k]);
+          accp[2][jj] = dot_term<T>(accp[2][jj], aj[k], qn[k]);
+          accp[3][jj] = dot_term<T>(accp[3][jj], bj[k], qn[k]);
+          accp[4][jj] = __builtin_fma(qy[k], aj[k], accp[4][jj]);
+          accp[5][jj] = __builtin_fma(qs[k], bj[k], accp[5][jj]);
+          accp[6][jj] = __builtin_fma(qs[k], aj[k], accp[6][jj]);
+          accp[7][jj] = __builtin_fma(bj[k], qy[k], accp[7][jj]);
         }
       }
     } else
@@ -324,10 +403,6 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
           acc[X + 3 * MC + j] = __builtin_fma(bj[k], yf[k], acc[X + 3 * MC + j]);
         }
       }
-    }
-    if (store_pair) {  // else the pair stays pending (see Pend)
-      st<W>(ws + offn + i, dv);
-      st<W>(wy + offn + i, rv);
     }
     // Breakpoints up to cand_hi -- where the NEXT walk is expected to end, the caller's guess from
     // the previous one -- are handed over with this pass (appended, unordered, like the window
@@ -364,9 +439,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         }
       }
     }
-    // iwhere settles after the first iterations: store only from waves that changed a row
-    if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
-    if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
+    if constexpr (!PAIR) row_stores();
   });
   if constexpr (PAIR) {
     // each lane holds the sums of its half of the columns: zeros for the other half, then the
