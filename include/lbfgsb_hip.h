@@ -452,6 +452,8 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           (default 1) / a W'r pass and two updates
  *   "wide_tail" (0/1)       m > 32: cmprlb's start and subsm's projected step + the line-search set-up folded into the first /
  *                           last tile of that pass (default 1) / as kernels of their own
+ *   "wide_one" (0/1)        m > 32, col <= 96: that pass as ONE launch over all columns, the pending pair committed by
+ *                           it (default 1) / one launch per tile of 32 columns behind pair_commit
  *   "wide_incr" (0/1)       m > 32: formk adds the new pair's row and column to WN1 while no row changes status
  *                           (default 1) / from scratch whenever it runs
  *   "nt" (0/1)              nontemporal loads in the passes over W (default: by the size of W)

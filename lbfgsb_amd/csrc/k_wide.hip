@@ -207,6 +207,135 @@ void launch_tile_axpy_fused(Queue &q, int64_t n, WStore<T> w, int head, int tc, 
   if (last) launch_finalize(q, gr, 3, 1, 0);
 }
 
+// The r pass in one launch (kernels.hpp, launch_wide_r_pass): tile_axpy_fused_kernel<FIRST, LAST> over all col
+// columns.  Per row the arithmetic is that of the tiled launches -- in REAL32 including the rounding to T their
+// partial sum takes when it goes through memory after every MAXM columns -- with the newest pair taken from
+// (r, d) in its stored form (pend_y / pend_sx) and committed.
+template <typename T, bool NT>
+__global__ __launch_bounds__(BLOCK) void wide_r_pass_kernel(int64_t n, const T *__restrict__ ws,
+                                                            const T *__restrict__ wy, const T *__restrict__ zero,
+                                                            int64_t ldw, int m, int head, int col, CoefWide cf,
+                                                            const iw_t *__restrict__ iwhere,
+                                                            const nb_t *__restrict__ nbd8, int ub, WideTail<T> wt,
+                                                            Pend pe, const T *pr, const T *pd, T *cwy, T *cws,
+                                                            double *part) {
+  constexpr int G = 8;
+  double red[4] = {0.0, 0.0, 0.0, 1.0e10};
+  const double rtheta = 1.0 / wt.theta;
+  const int jp = pe.on ? col - 1 : -1;  // the pending column
+  __shared__ T dict[16];
+  dict_fill<T>(dict, wt.l, wt.u, ub);
+  for_rows<T, VecOf<T>::V>(n, [&](int64_t i, auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    double acc[W], xv[W], gv[W], lv[W], uv[W], zc[W];
+    int iw[W], nbk[W];
+    ldi<W>(iwhere + i, iw);
+    ld<W>(wt.x + i, xv);
+    ld<W>(wt.g + i, gv);
+    ld<W>((ub & 1) ? wt.l : wt.l + i, lv);
+    ld<W>((ub & 2) ? wt.u : wt.u + i, uv);
+    ldi<W>((ub & 4) ? nbd8 : nbd8 + i, nbk);
+    dict_apply<T, W>(dict, ub, nbk, lv, uv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      zc[k] = (double)(T)xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], wt.tsum);
+      acc[k] = iw[k] > 0 ? 0.0 : (double)(T)(wt.plain ? -gv[k] : -wt.theta * (zc[k] - xv[k]) - gv[k]);  // cmprlb_init_kernel
+    }
+    for (int j0 = 0; j0 < col; j0 += G) {
+      double a[G][W], b[G][W];
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = j0 + jj;
+        const int64_t off = (int64_t)((head - 1 + (j < col ? j : 0)) % m) * ldw + i;
+        const T *py = j == jp ? pr + i : wy + off, *ps = j == jp ? pd + i : ws + off;
+        ld_col<T, W, NT>(j < col, py, zero, a[jj]);
+        ld_col<T, W, NT>(j < col, ps, zero, b[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = j0 + jj;
+        if (j < col) {  // (uniform)
+          if (j == jp) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+              a[jj][k] = pend_y<T>(gv[k], a[jj][k]);
+              b[jj][k] = pend_sx<T>(b[jj][k], xv[k], pe);
+            }
+            st<W>(cwy + i, a[jj]);
+            st<W>(cws + i, b[jj]);
+          }
+          const double ca = cf.a[j], cb = cf.a[WIDE_MAXC + j];
+#pragma unroll
+          for (int k = 0; k < W; ++k)
+            if (iw[k] <= 0) acc[k] = acc[k] + a[jj][k] * ca + b[jj][k] * cb;  // (tile_axpy_kernel with div = 1)
+        }
+      }
+      if ((j0 + G) % MAXM == 0 && j0 + G < col) {  // where the tiled launches store r and load it again
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[k] = (double)(T)acc[k];
+      }
+    }
+    double zv[W], dv[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      zv[k] = zc[k];
+      if (iw[k] <= 0) {  // subsm_project_kernel
+        const double dk = rtheta * (double)(T)acc[k];
+        const double xk = zc[k];
+        if (nbk[k] != 0) {
+          if (nbk[k] == 1) {
+            zv[k] = fmax(lv[k], xk + dk);
+            if (zv[k] == lv[k]) red[0] += 1.0;
+          } else if (nbk[k] == 2) {
+            const double t1 = fmax(lv[k], xk + dk);
+            zv[k] = fmin(uv[k], t1);
+            if (zv[k] == lv[k] || zv[k] == uv[k]) red[0] += 1.0;
+          } else if (nbk[k] == 3) {
+            zv[k] = fmin(uv[k], xk + dk);
+            if (zv[k] == uv[k]) red[0] += 1.0;
+          }
+        } else {
+          zv[k] = xk + dk;
+        }
+        zv[k] = (double)(T)zv[k];
+      }
+      dv[k] = zv[k] - xv[k];              // mainlb :720-722 (lnsrlb_begin_kernel)
+      red[1] = red[1] + dv[k] * gv[k];    // dd_p (:2824-2827) == g'd (:2244)
+      red[2] = red[2] + dv[k] * dv[k];    // dtd (:2196)
+      if (wt.do_stpmx && nbk[k] != 0) {   // :2206-2225
+        const double a1 = dv[k];
+        if (a1 < 0.0 && nbk[k] <= 2) {
+          const double a2 = lv[k] - xv[k];
+          red[3] = fmin(red[3], a2 >= 0.0 ? 0.0 : a2 / a1);
+        } else if (a1 > 0.0 && nbk[k] >= 2) {
+          const double a2 = uv[k] - xv[k];
+          red[3] = fmin(red[3], a2 <= 0.0 ? 0.0 : a2 / a1);
+        }
+      }
+    }
+    if (wt.zout) st<W>(wt.zout + i, zv);
+    if (wt.dvec) st<W>(wt.dvec + i, dv);
+    if (wt.tvec) st<W>(wt.tvec + i, xv);  // t = x (:2235)
+    if (wt.rout) st<W>(wt.rout + i, gv);  // r = g (:2236)
+    if (wt.xout) st<W>(wt.xout + i, zv);  // the first trial point x = z (:2265); may alias wt.x and pd (rows read above)
+  });
+  block_reduce_store<4>(red, 3, 1, 0, part, MAX_BLOCKS);
+}
+template <typename T>
+void launch_wide_r_pass(Queue &q, int64_t n, WStore<T> w, int head, int col, const CoefWide &cf, const iw_t *iwhere,
+                        const nb_t *nbd8, int ub, const WideTail<T> &wt, Pend pe, const T *pr, const T *pd) {
+  const int gr = grid_for(n, VecOf<T>::V);
+  const int64_t slot = (int64_t)((head - 1 + col - 1) % w.m) * w.ld;  // physical column of col - 1
+  if (q.nt)
+    hipLaunchKernelGGL((wide_r_pass_kernel<T, true>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy, w.zero, w.ld,
+                       w.m, head, col, cf, iwhere, nbd8, ub, wt, pe, pr, pd, w.wy + slot, w.ws + slot, q.part());
+  else
+    hipLaunchKernelGGL((wide_r_pass_kernel<T, false>), dim3(gr), dim3(BLOCK), 0, q.stream, n, w.ws, w.wy, w.zero, w.ld,
+                       w.m, head, col, cf, iwhere, nbd8, ub, wt, pe, pr, pd, w.wy + slot, w.ws + slot, q.part());
+  LB_LAUNCHED(q);
+  launch_finalize(q, gr, 3, 1, 0);
+}
+
 // out_i = src_i on the rows selected (want_free: iwhere <= 0, else iwhere > 0), 0 elsewhere
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void masked_copy_kernel(int64_t n, const T *__restrict__ src,
@@ -342,6 +471,7 @@ void launch_subsm_project(Queue &q, int64_t n, T *z, T *dir, const T *x, const T
 #define INSTANTIATE(T) \
   template void launch_tile_axpy<T>(Queue &, int64_t, WStore<T>, int, int, const Coef &, double, const iw_t *, int, T *); \
   template void launch_tile_axpy_fused<T>(Queue &, int64_t, WStore<T>, int, int, const Coef &, const iw_t *, T *, int, int, const WideTail<T> &); \
+  template void launch_wide_r_pass<T>(Queue &, int64_t, WStore<T>, int, int, const CoefWide &, const iw_t *, const nb_t *, int, const WideTail<T> &, Pend, const T *, const T *); \
   template void launch_masked_copy<T>(Queue &, int64_t, const T *, const iw_t *, int, T *); \
   template void launch_rows_gather<T>(Queue &, const uint32_t *, uint32_t, WStore<T>, int, int, double *); \
   template void launch_cauchy_dvec<T>(Queue &, int64_t, const T *, const T *, T *); \

@@ -450,6 +450,17 @@ struct WideTail {
 template <typename T>
 void launch_tile_axpy_fused(Queue &q, int64_t n, WStore<T> w, int head, int tc, const Coef &cf, const iw_t *iwhere,
                             T *out, int first, int last, const WideTail<T> &wt);
+// The same pass as ONE launch over all col <= WIDE_MAXC columns (the coefficients are a kernel argument): no partial
+// sum of r goes through memory between tiles, and the pair matupd left pending is read from the vectors it was
+// formed from and stored into its W slot here, as subsm_update_kernel does for m <= 32 (cwy / cws = that slot;
+// pe.on == 0: every column is in W).  wt.l / wt.u / nbd8 with the uniform / dictionary-coded bounds of `ub`.
+constexpr int WIDE_MAXC = 96;
+struct CoefWide {
+  double a[2 * WIDE_MAXC];  // a = [0, WIDE_MAXC), b = [WIDE_MAXC, ...)
+};
+template <typename T>
+void launch_wide_r_pass(Queue &q, int64_t n, WStore<T> w, int head, int col, const CoefWide &cf, const iw_t *iwhere,
+                        const nb_t *nbd8, int ub, const WideTail<T> &wt, Pend pe, const T *pr, const T *pd);
 // out = src on the free (want_free) / active rows, 0 elsewhere
 template <typename T>
 void launch_masked_copy(Queue &q, int64_t n, const T *src, const iw_t *iwhere, int want_free, T *out);

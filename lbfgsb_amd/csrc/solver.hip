@@ -1194,7 +1194,7 @@ class Solver final : public lbfgsb_hip_ctx {
       const bool closed = two_pass && closed_ok && col <= two_pass_maxcol && !pre_valid &&
                           (!updatd || (nrpre.valid && nrpre.col == col));
       if (wide()) {
-        CHK(commit_pending(g, col, head));  // (the unfused steps read the newest pair from W)
+        // (wide_subspace commits the pending pair: in its one-launch r pass, or in front of the unfused steps)
         const bool wclosed = wide_fused() && wide_closed_on && two_pass && closed_ok && !pre_valid &&
                              (!updatd || (nrpre.valid && nrpre.col == col)) && closed_form_safe(col);
         CHK(wide_subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, wclosed));

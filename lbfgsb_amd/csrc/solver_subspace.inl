@@ -466,6 +466,7 @@
     if (k == "wide_fused") return flag(wide_fused_on);
     if (k == "wide_closed") return flag(wide_closed_on);
     if (k == "wide_tail") return flag(wide_tail_on);
+    if (k == "wide_one") return flag(wide_one_on);
     if (k == "nt") return flag(q.nt);
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
@@ -502,6 +503,7 @@
   // five; the subspace steps stay the unfused ones (solver_wide.inl).  Option "wide_fused" = 0: all unfused
   bool wide_fused_on = true, wide_closed_on = true;  // ("wide_closed": W'Z r in closed form, one axpy pass)
   bool wide_tail_on = true;  // ("wide_tail": cmprlb's start and subsm's tail folded into that pass's first / last tile)
+  bool wide_one_on = true;   // ("wide_one": that pass as ONE launch for col <= 96, the pending pair committed by it)
   bool wide_fused() const { return wide() && wide_fused_on && two_pass; }
   struct NewRow {
     bool valid = false;

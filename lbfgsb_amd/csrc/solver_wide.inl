@@ -276,6 +276,17 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
                           lean ? (T *)nullptr : z, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t,
                           pp ? (T *)nullptr : r, ls_unit_step ? xmut : (T *)nullptr};
       if (gcp.copy_x) wt.tsum = 0.0;  // (xcp = x: no walk behind this Cauchy point)
+      if (wide_one_on && col <= lbk::WIDE_MAXC) {
+        // all tiles in one launch, the pending pair committed by it (m = 48, n = 2e7: dz_materialise, pair_commit
+        // and two tile launches, 3.3 ms, become one of 2.x ms)
+        lbk::CoefWide cw;
+        std::memset(&cw, 0, sizeof cw);
+        for (int j = 0; j < col; ++j) cw.a[j] = ca[j], cw.a[lbk::WIDE_MAXC + j] = cb[j];
+        wt.l = lk(l), wt.u = uk(u);
+        lbk::launch_wide_r_pass<T>(q, n, W(), head, col, cw, iwhere, nbk(), ub_mask, wt, pend, r, d_src());
+        pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
+      } else {
+        CHK(commit_pending(g, col, head));
       for (int j0 = 0; j0 < col; j0 += lbk::MAXM) {
         const int tc = std::min(lbk::MAXM, col - j0);
         lbk::Coef cf;
@@ -283,6 +294,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
         for (int j = 0; j < tc; ++j) cf.a[j] = ca[j0 + j], cf.a[lbk::MAXM + j] = cb[j0 + j];
         lbk::launch_tile_axpy_fused<T>(q, n, W(), (head - 1 + j0) % m + 1, tc, cf, iwhere, tbrk, j0 == 0 ? 1 : 0,
                                        j0 + lbk::MAXM >= col ? 1 : 0, wt);
+      }
       }
       tbrk_valid = false;
       d_impl = z_in_x = lean;
@@ -299,12 +311,14 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
       if (ls.x_is_z && !pp) HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
       ls.x_is_z = false;
     }
+    CHK(commit_pending(g, col, head));  // (the unfused steps read the newest pair from W)
     CHK(ensure_z(x, l, u, g));
     lbk::launch_cmprlb_init<T>(q, n, x, g, z, iwhere, theta, plain ? 1 : 0, tbrk);
     tbrk_valid = false;
     CHK(wide_axpy(tbrk, ca.data(), cb.data(), col, head, 1.0, 1));
     return wide_subsm_tail(x, l, u, nbd, g, theta, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword);
   }
+  CHK(commit_pending(g, col, head));  // (the unfused steps read the newest pair from W)
   CHK(wide_cmprlb(x, l, u, g, theta, col, head, cnstnd, info));
   if (info != 0) return 0;
   return wide_subsm(x, l, u, nbd, g, theta, col, head, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword, info);

@@ -21,7 +21,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 #  want of a free variable -- there its K fails later and the memory is refreshed, fuzz 80740 -- so that diagnostic
 #  setting is held to the bar on the committed seeds only)
 MODES = [(False, {}), (True, {}), (True, {"wide_closed": 0}), (False, {"wide_fused": 0}), (False, {"two_pass": 0}),
-         (True, {"wide_tail": 0}), (False, {"lean": 0})]
+         (True, {"wide_tail": 0}), (False, {"lean": 0}), (True, {"wide_one": 0}), (False, {"wide_one": 0})]
 bad, total, splits, t0 = 0, 0, 0, time.time()
 for seed in range(first, first + count):
     pp, opts = MODES[seed % len(MODES)]
