@@ -183,7 +183,7 @@ int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar,
  * snapshot: a packed one-byte copy of nbd (refreshed on START, after import_state and when the nbd POINTER
  * changes), and for bound arrays found at START to hold one value each, or a few values (<= 8 each), that
  * constant / a table entry selected by the packed byte (lbfgsb_hip_uniform_bounds below).  An edit IN PLACE is
- * detected, not ignored: after the first iteration and then every 16th (option "bounds_check") the caller's
+ * detected, not ignored: after the first iteration and then every 32nd (option "bounds_check") the caller's
  * arrays are compared with the snapshot bit for bit, and a difference ends the run with
  * task = 'ERROR: BOUNDS CHANGED DURING RUN' (isave(35), info, = -10).  Passing OTHER array pointers than at
  * START is allowed: the constants / tables are dropped and the arrays are streamed from then on.  A caller that
@@ -452,6 +452,9 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           (default 1) / a W'r pass and two updates
  *   "wide_tail" (0/1)       m > 32: cmprlb's start and subsm's projected step + the line-search set-up folded into the first /
  *                           last tile of that pass (default 1) / as kernels of their own
+ *   "spec_trial2" (0/1)     the SECOND trial point of a line search (an interpolated step after a rejected first one) is
+ *                           evaluated by the update pass too, whose sums serve the NEW_X entry if it is accepted
+ *                           (default 1) / by the two-sum evaluation kernel, the update pass follows at NEW_X
  *   "wide_one" (0/1)        m > 32, col <= 96: that pass as ONE launch over all columns, the pending pair committed by
  *                           it (default 1) / one launch per tile of 32 columns behind pair_commit
  *   "wide_incr" (0/1)       m > 32: formk adds the new pair's row and column to WN1 while no row changes status
@@ -460,7 +463,7 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *   "uniform_bounds" (0/1)  detect bound arrays that hold one value each (lbfgsb_hip_uniform_bounds)
  *   "dict_bounds" (0/1)     dictionary-code bound arrays with <= 8 distinct values each (same place; default 1)
  *   "bounds_check" (0..)    compare the caller's l, u, nbd with the context's snapshot after the first iteration and
- *                           then every k-th (default 16; 0 = never): 'ERROR: BOUNDS CHANGED DURING RUN'
+ *                           then every k-th (default 32; 0 = never): 'ERROR: BOUNDS CHANGED DURING RUN'
  *   "wgrid" (0..2047)       workgroups of the passes over W (default 0: what is resident for the kernel
  *                           launched, 256 ... 768)
  *   "pipe" (-1/0/1)         two trips of loads in flight per wave: default rule (m = 20, fp32 m = 10) / off /

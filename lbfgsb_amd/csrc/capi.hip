@@ -613,9 +613,9 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
     if (!ctx || ctx->n != n || ctx->m != m)
       return fail(LBFGSB_E_STATE, "setulb called without a live context (task must be START first)");
     // l, u, nbd were copied at START; the reference re-reads the caller's arrays on every call (:1270-1330,
-    // :2594-2622, :2789-2816).  After the first iteration and then every 16th the arrays are uploaded again and
+    // :2594-2622, :2789-2816).  After the first iteration and then every 32nd the arrays are uploaded again and
     // compared with the copies, bit for bit: an edit in place ends the run with an error instead of being ignored.
-    if (lbh::str60_pre(task, "NEW_X") && (isave[29] == 1 || (isave[29] > 0 && isave[29] % 16 == 0))) {
+    if (lbh::str60_pre(task, "NEW_X") && (isave[29] == 1 || (isave[29] > 0 && isave[29] % 32 == 0))) {
       void *tl = nullptr, *tu = nullptr;
       int32_t *tn = nullptr;
       double ndiff = 0.0;

@@ -632,10 +632,11 @@ void launch_bounds_same(Queue &q, int64_t n, const T *l0, const T *u0, const int
   LB_LAUNCHED(q);
   launch_finalize(q, g, 1, 0, 0);
 }
+// xnew != nullptr: the next trial point x = stp d + t (lnsrlb_step_kernel's expression, :2262-2263, on d as it is
+// stored) goes out in the same pass -- xnew may be x itself (each row is read before it is written)
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const T *__restrict__ x,
-                                                               const T *__restrict__ t,
-                                                               T *__restrict__ d, T *z) {
+__global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const T *x, const T *__restrict__ t,
+                                                               T *__restrict__ d, T *z, T *xnew, double stp) {
   for_rows<T>(n, [&](int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], tv[W], dv[W];
@@ -645,12 +646,18 @@ __global__ __launch_bounds__(BLOCK) void dz_materialise_kernel(int64_t n, const 
     for (int k = 0; k < W; ++k) dv[k] = xv[k] - tv[k];  // exactly subsm_update_kernel's d = z - x
     st<W>(d + i, dv);
     if (z) st<W>(z + i, xv);
+    if (xnew) {
+      double o[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) o[k] = stp * (double)(T)dv[k] + tv[k];
+      st<W>(xnew + i, o);
+    }
   });
 }
 template <typename T>
-void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z) {
+void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z, T *xnew, double stp) {
   hipLaunchKernelGGL(dz_materialise_kernel<T>, dim3(grid_for(n, VecOf<T>::V)), dim3(BLOCK), 0, q.stream,
-                     n, x, t, d, z);
+                     n, x, t, d, z, xnew, stp);
   LB_LAUNCHED(q);
 }
 template <typename T>
@@ -1029,7 +1036,7 @@ void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out) {
   template void launch_lnsrlb_step<T>(Queue &, int64_t, T *, const T *, const T *, const T *, double); \
   template void launch_lnsrlb_eval<T>(Queue &, int64_t, const T *, const T *, const T *, const int32_t *, const T *, const T *); \
   template void launch_pair_commit<T>(Queue &, int64_t, const T *, const T *, const T *, Pend, WStore<T>, int, int); \
-  template void launch_dz_materialise<T>(Queue &, int64_t, const T *, const T *, T *, T *); \
+  template void launch_dz_materialise<T>(Queue &, int64_t, const T *, const T *, T *, T *, T *, double); \
   template void launch_obj_quadratic<T>(Queue &, int64_t, int64_t, const T *, T *); \
   template void launch_obj_rosenbrock<T>(Queue &, int64_t, int64_t, int64_t, const T *, T *, double, double); \
   template void launch_halo_pack<T>(Queue &, int64_t, const T *, double *);

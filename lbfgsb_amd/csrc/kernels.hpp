@@ -421,7 +421,8 @@ void launch_bounds_same(Queue &q, int64_t n, const T *l0, const T *u0, const int
                         const T *u1, const int32_t *nb1);
 // d = x - t, z = x: the vectors a lean subsm_update_kernel pass left implicit (Pend::impl)
 template <typename T>
-void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z);
+void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T *z, T *xnew = nullptr,
+                           double stp = 1.0);
 template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
                         WStore<T> w, int head, int col);

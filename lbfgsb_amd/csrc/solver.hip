@@ -71,7 +71,7 @@ class Solver final : public lbfgsb_hip_ctx {
   //      The caller's arrays are compared with this snapshot every bcheck_every iterations (bounds_verify). ----
   bool ub_on = true;          // (option "uniform_bounds")
   bool dict_on = true;        // (option "dict_bounds")
-  int bcheck_every = 16;      // (option "bounds_check": 0 = never)
+  int bcheck_every = 32;      // (option "bounds_check": 0 = never)
   int64_t nbounds_checks = 0;
   lbk::BoundTables ub_tab{};  // the values the passes use where an array is not streamed
   int ub_mask = 0;            // bit 0 l, bit 1 u, bit 2 nbd, bit 3 dictionary (with bits 0, 1)
@@ -750,7 +750,11 @@ class Solver final : public lbfgsb_hip_ctx {
       spcand.valid = false;
       // (landing: the set-up has not run; its step is the unit step, this is its first trial)
       const double stp_here = landing ? 1.0 : stp;
-      const bool first_trial = landing || ifun == 1;
+      // ... and the SECOND trial (an interpolated step after a rejected first one) is accepted nearly always: run
+      // as lnsrlb_eval it costs 0.8 ms at n = 1e8 and the NEW_X entry that follows needs the full pass anyway
+      // (2.6 ms + a host sync: profiles/round5_i_iter_timeline.txt, iterations 14 / 15); a third trial is a
+      // backtracking search, evaluated the cheap way
+      const bool first_trial = landing || ifun == 1 || (spec_trial2_on && ifun == 2);
       // First trial of a line search on a bounded problem: it is accepted far more often than
       // not, so evaluate it with the pass that matupd + the next cauchy scan would run anyway
       // (read-only with the pair pending); g'd and |proj g| are two of its sums.  Contexts
@@ -1287,10 +1291,12 @@ class Solver final : public lbfgsb_hip_ctx {
         iback = ifun - 1;
         const bool in_place = ls.x_is_z && ifun == 1 && stp == 1.0;  // x = z is already in place
         if (!in_place) {
-          CHK(ensure_d(setup_call ? xmut : x));  // (it still holds the rejected first trial point z)
           // (the set-up call writes this iteration's first trial point: xmut -- the caller's x, or the
           //  other buffer of a ping-pong pair; later calls are entered with x = the trial buffer)
-          lbk::launch_lnsrlb_step<T>(q, n, setup_call ? xmut : x, z, d, t, stp);
+          T *xt = setup_call ? xmut : x;
+          bool stepped = false;
+          CHK(ensure_d(xt, xt, stp, &stepped));  // (it still holds the rejected first trial point z)
+          if (!stepped) lbk::launch_lnsrlb_step<T>(q, n, xt, z, d, t, stp);
         }
         ls.x_is_z = false;
         // (a landing set-up that asks for the point in place: that point HAS been evaluated, by the pass

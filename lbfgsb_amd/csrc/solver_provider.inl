@@ -114,9 +114,14 @@
   bool z_in_x = false;  // ... and z too: until the next cauchy gives z a new meaning
   bool lean_on = true;  // (option "lean")
   const T *d_src() const { return d_impl ? t : d; }  // what the kernels read the direction from
-  int ensure_d(const T *x) {
+  // (xnew: the line search's next trial point x = stp d + t written by the same pass, see dz_materialise_kernel;
+  //  returns with *stepped = true if it was)
+  int ensure_d(const T *x, T *xnew = nullptr, double stp_new = 1.0, bool *stepped = nullptr) {
+    if (stepped) *stepped = false;
     if (!d_impl) return 0;
-    lbk::launch_dz_materialise<T>(q, n, x, t, d, z_in_x ? z : (T *)nullptr);
+    if (xnew && stp_new == 1.0) xnew = nullptr;  // (a unit step copies z bit for bit: lnsrlb_step_kernel)
+    lbk::launch_dz_materialise<T>(q, n, x, t, d, z_in_x ? z : (T *)nullptr, xnew, stp_new);
+    if (stepped) *stepped = xnew != nullptr;
     if (z_in_x) z_valid = true;
     d_impl = false, z_in_x = false;
     if (pend.on) pend.impl = 0;

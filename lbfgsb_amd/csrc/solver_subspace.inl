@@ -461,6 +461,7 @@
     if (k == "fold_finalize") return flag(fold_fin);
     if (k == "eager_patch") return flag(eager_on);
     if (k == "spec_freev") return flag(spec_freev_on);
+    if (k == "spec_trial2") return flag(spec_trial2_on);
     if (k == "skip_reuse") return flag(skip_reuse_on);
     if (k == "wide_incr") return flag(wide_incr_on);
     if (k == "wide_fused") return flag(wide_fused_on);
@@ -503,6 +504,7 @@
   // five; the subspace steps stay the unfused ones (solver_wide.inl).  Option "wide_fused" = 0: all unfused
   bool wide_fused_on = true, wide_closed_on = true;  // ("wide_closed": W'Z r in closed form, one axpy pass)
   bool wide_tail_on = true;  // ("wide_tail": cmprlb's start and subsm's tail folded into that pass's first / last tile)
+  bool spec_trial2_on = true;  // ("spec_trial2": the second trial of a line search is evaluated by the update pass too)
   bool wide_one_on = true;   // ("wide_one": that pass as ONE launch for col <= 96, the pending pair committed by it)
   bool wide_fused() const { return wide() && wide_fused_on && two_pass; }
   struct NewRow {

@@ -557,7 +557,7 @@ def test_bounds_edited_in_place_end_the_run_with_an_error(env):
     """The reference re-reads l, u, nbd on every call (src/lbfgsb.f90:1270-1330, 2594-2622, 2789-2816); the
     passes over W read a snapshot (packed nbd byte; constants or table entries for uniform / few-valued bounds).
     The caller's arrays are compared with the snapshot after the first iteration and then every `bounds_check`
-    iterations (default 16): an edit in place is reported -- task 'ERROR: BOUNDS CHANGED DURING RUN' -- instead of
+    iterations (default 32): an edit in place is reported -- task 'ERROR: BOUNDS CHANGED DURING RUN' -- instead of
     silently iterated on with stale bounds.  Uniform, dictionary-coded and plain (streamed) bounds; device and
     host form.  (l, u that ARE streamed live take effect as in the reference: only nbd is a snapshot there.)"""
     po, torch, la = env["po"], env["torch"], env["la"]
@@ -604,7 +604,7 @@ def test_bounds_edited_in_place_end_the_run_with_an_error(env):
                           (mixed, set_nbd, 3), (mixed, set_u, 3), (many, set_nbd, 6)):
         t, it = drive(p, edit, 1, mask)
         assert t.startswith("ERROR: BOUNDS CHANGED DURING RUN") and it == 3, (p.name, t, it)
-    # default cadence: noticed at the first multiple of 16
+    # a cadence of 16: noticed at the first multiple of 16
     t, it = drive(quad, set_u, 16, 7)
     assert t.startswith("ERROR: BOUNDS CHANGED DURING RUN") and it == 16, (t, it)
     # no edit, or an edit of an array that is streamed live: the run goes on
@@ -632,7 +632,7 @@ def test_bounds_edited_in_place_end_the_run_with_an_error(env):
                 break
         else:
             break
-    assert s.task_s.startswith("ERROR: BOUNDS CHANGED DURING RUN") and s.isave[29] == 16, (s.task_s, s.isave[29])
+    assert s.task_s.startswith("ERROR: BOUNDS CHANGED DURING RUN") and s.isave[29] == 32, (s.task_s, s.isave[29])
     assert s.isave[16] == 0 and s.isave[17] == 0         # the context was released with the terminal task
 
 
