@@ -452,6 +452,8 @@ int lbfgsb_hip_objective(lbfgsb_hip_ctx *ctx, int kind, const void *x, void *g, 
  *                           (default 1) / a W'r pass and two updates
  *   "wide_tail" (0/1)       m > 32: cmprlb's start and subsm's projected step + the line-search set-up folded into the first /
  *                           last tile of that pass (default 1) / as kernels of their own
+ *   "win_slack" (>= 0)      the first window of a breakpoint walk asks (1 + win_slack) x as far ahead as the walk needs
+ *                           when it starts (default 0.25; 0: exactly as far -- a second window pass usually follows)
  *   "spec_trial2" (0/1)     the SECOND trial point of a line search (an interpolated step after a rejected first one) is
  *                           evaluated by the update pass too, whose sums serve the NEW_X entry if it is accepted
  *                           (default 1) / by the two-sum evaluation kernel, the update pass follows at NEW_X

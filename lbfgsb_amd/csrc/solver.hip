@@ -578,7 +578,7 @@ class Solver final : public lbfgsb_hip_ctx {
     ls.deferred = false, defer_live = false;
     nrefresh = 0;
     sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
-    spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0;
+    spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0, last_walk_nseg = 0;
     epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
                             : std::numeric_limits<double>::epsilon();
     time1 = now_s();

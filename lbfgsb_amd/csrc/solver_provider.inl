@@ -175,6 +175,12 @@
   double last_tsum = 0.0, last_dtm0 = 0.0;  // where the previous walk ended / first aimed
   size_t sp_len() const { return 2 + (size_t)SPEC_CAP * (2 * m + 4); }
   double spec_factor = 2.0;
+  // The first window of a walk reaches (1 + win_slack) x as far beyond the cursor as the walk needs right now: while
+  // it crosses breakpoints its stationary point moves (tj0 + dtm grows by a few per cent as f'' shrinks), and a
+  // window that ends exactly at the first estimate is followed by a second pass over x, g for the last one or two
+  // breakpoints -- or for none (n = 1e8: 0.3 ms + a host sync each, profiles/round5_D_kernel_trace_*).
+  double win_slack = 0.25;
+  int64_t last_walk_nseg = 0;  // segments of the previous walk
   // Off unless option "spec_capture" = 1: measured at n = 1e8 / 1.25e7 (profiles/README.md, r02q) a walk
   // either crosses no breakpoint at all or hundreds to thousands -- SPEC_CAP records serve 0-3 of 31.
   bool spec_on = false;

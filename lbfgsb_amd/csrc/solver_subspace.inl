@@ -469,6 +469,11 @@
     if (k == "wide_tail") return flag(wide_tail_on);
     if (k == "wide_one") return flag(wide_one_on);
     if (k == "nt") return flag(q.nt);
+    if (k == "win_slack") {  // the walk's first window asks (1 + win_slack) x as far ahead as it needs
+      if (!(v >= 0.0 && v <= 8.0)) return fail(LBFGSB_E_ARG, "set_option: win_slack must be in [0, 8]");
+      win_slack = v;
+      return 0;
+    }
     if (k == "pg_min") {
       if (!(v >= 0.0)) return fail(LBFGSB_E_ARG, "set_option: pg_min must be >= 0");
       PG_MIN = v;

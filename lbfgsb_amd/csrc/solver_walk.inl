@@ -412,9 +412,11 @@
           if (pv.have && (pv.full || pv.win_hi >= hi_need)) break;  // nothing left in reach
           // (re)fetch: ask further ahead each time so long walks need few round trips
           double hi = hi_need;
-          if (pv.grow > 0 && std::isfinite(hi_need)) {
+          if (std::isfinite(hi_need)) {
             const double base = last_t > 0 ? last_t : 0.0;
-            hi = base + (hi_need - base) * std::ldexp(1.0, std::min(pv.grow, 40));
+            // (no slack behind a long walk: a quarter more of 10^4 ... 10^5 records to sort, gather and carry over)
+            const double first = last_walk_nseg <= 4096 ? 1.0 + win_slack : 1.0;
+            hi = base + (hi_need - base) * (pv.grow > 0 ? std::ldexp(1.0, std::min(pv.grow, 40)) : first);
           }
           pv.grow++;
           double in_window = 0.0;
@@ -562,6 +564,7 @@
     if (col > 0 && dtm != 0.0)
       for (int j = 0; j < col2; ++j) c[j] = c[j] + dtm * p[j];  // :1526
     last_tsum = tsum;
+    last_walk_nseg = nseg;
     iter_seen++;
     if (col > 0) {
       // p = W'd over the variables that still move = the free variables: with it W'Z r needs no
