@@ -275,6 +275,50 @@ void suite(int64_t n, const double *w, const double *vec, double *out, double *s
   fflush(stdout);
 }
 
+
+// round 5 (mode i): would an INTERLEAVED pair layout -- (y, s) of a row side by side, 16 bytes per row and column:
+// col fat read streams instead of 2 col thin ones, ONE fat store stream for the committed pair instead of two --
+// change the storing pass?  Same bytes either way.  NT thin read streams (8 B/row: lane = 16 B for 2 rows), NF fat ones
+// (16 B/row: lane = 32 B), WT thin / WF fat write streams; pipelined like k_pipe.
+template <int NT_, int NF, int WT, int WF>
+__global__ __launch_bounds__(256) void k_inter(int64_t n, const double *__restrict__ w, double *out, double *sink) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  d2 acc = {0.0, 0.0};
+  int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  d2 v[NT_ + 2 * NF];
+  auto issue = [&](int64_t i) {
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) v[j] = ldnt(w + (int64_t)j * n + i * 2);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const double *b = w + (int64_t)NT_ * n + (int64_t)j * 2 * n + i * 4;
+      v[NT_ + 2 * j] = ldnt(b), v[NT_ + 2 * j + 1] = ldnt(b + 2);
+    }
+  };
+  if (iv < nv) issue(iv);
+  while (iv < nv) {
+    d2 s = {1.0, 2.0};
+#pragma unroll
+    for (int j = 0; j < NT_ + 2 * NF; ++j) s += v[j];
+    acc += s;
+    const int64_t nx = iv + stride;
+    const int64_t nxc = nx < nv ? nx : iv;
+    __builtin_amdgcn_sched_barrier(0);
+    issue(nxc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WT; ++j) stnt(out + (int64_t)j * n + iv * 2, s + (double)j);
+#pragma unroll
+    for (int j = 0; j < WF; ++j) {
+      double *b = out + (int64_t)WT * n + (int64_t)j * 2 * n + iv * 4;
+      stnt(b, s), stnt(b + 2, s + 1.0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    iv = nx;
+  }
+  if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
+}
+
 int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -321,6 +365,23 @@ int main(int argc, char **argv) {
           printf("candidate %2d + 11 ring streams, %2d materialised s columns, 1 written, 4 sums  grid %5d  %7.3f ms\n",
                  11, nmat, grid, ms);
         }
+      }
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'i') {
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int grid : {512, 768, 1024}) {
+        float ms = timeit([&] { hipLaunchKernelGGL((k_inter<22, 0, 3, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("storing pass, today:       22 thin reads,           3 thin writes            grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter<2, 10, 1, 1>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("storing pass, interleaved:  2 thin + 10 fat reads,  1 thin + 1 fat write     grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter<22, 0, 0, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("read-only pass, today:     22 thin reads                                     grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter<2, 10, 0, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("read-only pass, interleaved: 2 thin + 10 fat reads                           grid %5d  %7.3f ms\n", grid, ms);
       }
       printf("\n");
       fflush(stdout);
