@@ -328,34 +328,6 @@ __device__ __forceinline__ double pair_xchg(double v) {
 __device__ __forceinline__ float pair_xchg(float v) {
   return __builtin_bit_cast(float, pair_xchg(__builtin_bit_cast(int, v)));
 }
-// a double that is known to hold a value of T exactly travels as a T (one register for fp32)
-template <typename T>
-__device__ __forceinline__ double pair_xchg_as(double v) {
-  return (double)pair_xchg((T)v);
-}
-template <int BYTES>
-__device__ __forceinline__ RawReg<BYTES> raw_xchg(const RawReg<BYTES> &a) {  // the neighbour's image
-  RawReg<BYTES> o;
-  if constexpr (BYTES == 16)
-    o.v = i32x4_t{pair_xchg(a.v.x), pair_xchg(a.v.y), pair_xchg(a.v.z), pair_xchg(a.v.w)};
-  else if constexpr (BYTES == 8)
-    o.v = i32x2_t{pair_xchg(a.v.x), pair_xchg(a.v.y)};
-  else
-    o.v = pair_xchg(a.v);
-  return o;
-}
-template <int BYTES>
-__device__ __forceinline__ RawReg<BYTES> raw_sel(bool c, const RawReg<BYTES> &a, const RawReg<BYTES> &b) {
-  RawReg<BYTES> o;  // c ? a : b, word by word (static register indices on both sides)
-  if constexpr (BYTES == 16)
-    o.v = i32x4_t{c ? a.v.x : b.v.x, c ? a.v.y : b.v.y, c ? a.v.z : b.v.z, c ? a.v.w : b.v.w};
-  else if constexpr (BYTES == 8)
-    o.v = i32x2_t{c ? a.v.x : b.v.x, c ? a.v.y : b.v.y};
-  else
-    o.v = c ? a.v : b.v;
-  return o;
-}
-
 // rows per lane for kernels unrolled to MC column pairs: 16 B per lane per array, halved
 // for MC >= 20 so that the 2*MC operand values of a row group still fit the register file
 template <typename T, int MC>
