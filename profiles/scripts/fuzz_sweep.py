@@ -24,6 +24,8 @@ MODES = [  # (nmax, mlo, mhi, pp, options)
     # round 5: FEW-VALUED bounds (l, u drawn from <= 8 values each: dictionary-coded in the nbd byte), both entries,
     # and the same with the caller's arrays compared with the snapshot at every iteration
     (1500, 1, 25, True, {"_few_valued": 1}), (1500, 1, 25, False, {"_few_valued": 1, "bounds_check": 1}),
+    # later in round 5: the previous forms of the second trial's evaluation and of the walk's first window
+    (1500, 1, 25, True, {"spec_trial2": 0}), (1500, 1, 25, False, {"win_slack": 0}),
 ]
 bad, total, splits, t0 = 0, 0, 0, time.time()
 for seed in range(first, first + count):

@@ -195,3 +195,25 @@ def test_launch_plumbing_options_change_nothing(oracle_built, pp, defer):
         a = _run(p, pp, defer, 80, options=old)
         b = _run(p, pp, defer, 80, options=new)
         assert a["rows"] == b["rows"] and a["wa"] == b["wa"], (p.name, p.n, p.m)
+
+
+@pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
+def test_the_reach_of_the_first_window_changes_nothing(oracle_built, pp):
+    """The first window of a breakpoint walk asks further ahead than the walk needs when it starts (option
+    `win_slack`, default 0.25), so that the stationary point's drift while breakpoints are crossed does not cost a
+    second pass over x, g.  More candidates ride back, the walk consumes the same ones in the same order: every return
+    of a run equals the run with windows that end exactly at the first estimate, and the run whose windows reach
+    three times as far (lists beyond the fast path's 256 candidates: the sorted route)."""
+    from test_gpu_fuzz import make, fam_rosenchain
+    po = oracle_built
+    for seed in list(range(900, 916)) + list(range(5400, 5404)):
+        p = make(po, seed, 600, 1, 13) if seed < 5000 else make(po, seed, 3000, 11, 33)
+        a = _run(p, pp, True, 60, options={"win_slack": 0})
+        for slack in (0.25, 2.0):
+            b = _run(p, pp, True, 60, options={"win_slack": slack})
+            assert a["rows"] == b["rows"] and a["wa"] == b["wa"] and a["iwa"] == b["iwa"], (p.name, p.n, p.m, slack)
+    for seed in range(62100, 62104):
+        p = fam_rosenchain(po, seed)
+        a = _run(p, pp, True, 80, options={"win_slack": 0})
+        b = _run(p, pp, True, 80, options={"win_slack": 0.25})
+        assert a["rows"] == b["rows"] and a["wa"] == b["wa"], (p.name, p.n, p.m)

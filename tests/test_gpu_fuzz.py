@@ -373,6 +373,11 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     (8300, 12, 1200, 33, 80, "wide_fused=0"), (8400, 12, 1200, 33, 80, "pp,wide_closed=0"),
     # ... and with cmprlb's start / subsm's tail as kernels of their own instead of folded into the r pass's tiles
     (8500, 12, 1200, 33, 80, "wide_tail=0"), (8600, 12, 1200, 33, 80, "pp,lean=0"),
+    # ... and with one launch per tile of 32 columns behind pair_commit instead of the one-launch r pass
+    (8700, 12, 1200, 33, 80, "pp,wide_one=0"),
+    # the second trial point of a line search evaluated the cheap way (the update pass follows at NEW_X); windows of the
+    # breakpoint walk that end exactly where the walk needs them when it starts
+    (7400, 40, 1500, 1, 25, "pp,spec_trial2=0"), (7500, 30, 1500, 1, 25, "win_slack=0"),
     # the measurement switches select fallback paths that must stay correct: the candidate
     # hand-over of the update pass, and the three-pass iteration (no closed form, stored z and d)
     # col > 21 without the split update pass: three passes over W (the pair-shared cmprlb_wtv kernel at MC = 32)

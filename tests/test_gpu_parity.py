@@ -753,22 +753,25 @@ def test_wide_memory_one_step_parity(env, name, spec, ncalls, stride):
     assert tested >= 20, tested
 
 
+@pytest.mark.parametrize("m", [40, 70], ids=["m40", "m70"])
 @pytest.mark.parametrize("real32", [False, True], ids=["fp64", "real32"])
 @pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
-def test_wide_tail_folded_into_the_r_pass_changes_no_row(env, pp, real32):
+def test_wide_tail_folded_into_the_r_pass_changes_no_row(env, pp, real32, m):
     """m > 32: cmprlb's start (r0 = -theta (xcp - x) - g) and subsm's tail (projected step, d = z - x, the line-search
     set-up, the first trial point) run inside the first / last tile of the r pass (tile_axpy_fused_kernel, option
     wide_tail) instead of as six vector kernels.  Per row that is the same arithmetic with the same roundings to the
     storage kind in between -- so the iterates must be the unfused route's BIT FOR BIT, in fp64 and in REAL32 (where
     every intermediate vector the unfused kernels store is rounded to fp32), through both entries, while the memory
-    grows from 1 to 40 pairs and beyond (one tile, two tiles, the shift of a full memory)."""
+    grows from 1 to m pairs and beyond (one tile, two, three; the shift of a full memory).  The same for the r pass
+    as ONE launch over all columns with the pending pair committed by it (wide_r_pass_kernel, option wide_one, the
+    default) against one launch per tile behind pair_commit_kernel: three routes, one set of bits."""
     po, torch, la = env["po"], env["torch"], env["la"]
-    n, m, iters = 7001, 40, 55
+    n, iters = 7001, m + 15
     rdt = torch.float32 if real32 else torch.float64
     p = po.problem_quadratic(n, m, mixed_nbd=True)
 
-    def run(tail):
-        sol = la.DeviceSolver(n, m, real32=real32, options={"wide_tail": tail})
+    def run(tail, one=1):
+        sol = la.DeviceSolver(n, m, real32=real32, options={"wide_tail": tail, "wide_one": one})
         xs = [torch.from_numpy(p.x0.copy()).to(rdt).cuda(), torch.zeros(n, dtype=rdt, device="cuda")]
         gs = [torch.zeros_like(xs[0]), torch.zeros_like(xs[0])]
         l, u = torch.from_numpy(p.l).to(rdt).cuda(), torch.from_numpy(p.u).to(rdt).cuda()
@@ -791,11 +794,12 @@ def test_wide_tail_folded_into_the_r_pass_changes_no_row(env, pp, real32):
                 break
         sol.close()
         return rows
-    a, b = run(1), run(0)
-    assert len(a) == len(b) and len(a) > iters
+    a, b, c = run(1), run(0), run(1, 0)
+    assert len(a) == len(b) == len(c) and len(a) > iters
     assert max(r[5] for r in a if r[0] == "NEW_X") == m
-    for k, (ra, rb) in enumerate(zip(a, b)):
+    for k, (ra, rb, rc) in enumerate(zip(a, b, c)):
         assert ra == rb, (k, ra[:6], rb[:6])
+        assert ra == rc, (k, ra[:6], rc[:6])
 
 
 @pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
