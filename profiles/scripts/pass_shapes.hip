@@ -319,6 +319,50 @@ __global__ __launch_bounds__(256) void k_inter(int64_t n, const double *__restri
   if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
 }
 
+
+// round 5 (mode j): the interleaved pair layout with ONE row per lane -- a thin stream is an 8-byte load per lane
+// (what the headline's read-only pass does today: V = 1), a fat stream ((y, s) of a row side by side) a DENSE 16-byte
+// load per lane.  PIPE: two trips in flight as in for_rows_raw.
+__device__ __forceinline__ double ldnt1(const double *p) { return __builtin_nontemporal_load(p); }
+template <int NT_, int NF, int WT, int WF>
+__global__ __launch_bounds__(256) void k_inter1(int64_t n, const double *__restrict__ w, double *out, double *sink) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  double acc = 0.0;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double v[NT_];
+  d2 f[NF > 0 ? NF : 1];
+  auto issue = [&](int64_t r) {
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) v[j] = ldnt1(w + (int64_t)j * n + r);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) f[j] = ldnt(w + (int64_t)NT_ * n + (int64_t)j * 2 * n + r * 2);
+  };
+  if (i < n) issue(i);
+  while (i < n) {
+    double s = 1.0;
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) s += v[j];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) s += f[j].x * 0.5 + f[j].y;
+    acc += s;
+    const int64_t nx = i + stride;
+    const int64_t nxc = nx < n ? nx : i;
+    __builtin_amdgcn_sched_barrier(0);
+    issue(nxc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WT; ++j) __builtin_nontemporal_store(s + (double)j, out + (int64_t)j * n + i);
+#pragma unroll
+    for (int j = 0; j < WF; ++j) {
+      d2 o = {s, s + 1.0};
+      stnt(out + (int64_t)WT * n + (int64_t)j * 2 * n + i * 2, o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    i = nx;
+  }
+  if (acc == 12345.678) sink[0] = acc;
+}
+
 int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -365,6 +409,25 @@ int main(int argc, char **argv) {
           printf("candidate %2d + 11 ring streams, %2d materialised s columns, 1 written, 4 sums  grid %5d  %7.3f ms\n",
                  11, nmat, grid, ms);
         }
+      }
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'j') {
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int grid : {512, 768, 1024, 2048}) {
+        float ms = timeit([&] { hipLaunchKernelGGL((k_inter1<22, 0, 0, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("read-only pass, one row per lane, today:       22 thin (8 B) loads                     grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter1<4, 9, 0, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("read-only pass, one row per lane, interleaved:  4 thin + 9 fat (16 B) loads            grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter1<22, 0, 3, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("storing pass,   one row per lane, columns:     22 thin loads, 3 thin stores            grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter1<4, 9, 1, 1>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("storing pass,   one row per lane, interleaved:  4 thin + 9 fat loads, 1 thin + 1 fat store grid %5d  %7.3f ms\n", grid, ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_inter<22, 0, 3, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("storing pass,   two rows per lane, today:      22 x 16 B loads, 3 x 16 B stores        grid %5d  %7.3f ms\n", grid, ms);
       }
       printf("\n");
       fflush(stdout);
