@@ -363,6 +363,58 @@ __global__ __launch_bounds__(256) void k_inter1(int64_t n, const double *__restr
   if (acc == 12345.678) sink[0] = acc;
 }
 
+
+// round 5 (mode p): would separating reads and writes in TIME help?  Persistent grid (every workgroup resident),
+// T trips of loads with the results kept in registers, a grid barrier, T trips of stores, a grid barrier.  BAR = false:
+// the same loop without the barriers (each workgroup alternates on its own) -- the cost of the restructuring alone.
+__device__ __forceinline__ void grid_barrier(unsigned int *ctr, unsigned int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // (bounded: a grid that is not fully resident must not hang the card -- the timing is then meaningless, and
+    //  the host checks residency before it launches)
+    for (int spins = 0; spins < 4000000 && __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins)
+      __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+template <int NR, int NW, int T, bool BAR>
+__global__ __launch_bounds__(256) void k_phase(int64_t n, const double *__restrict__ w, double *out, double *sink,
+                                               unsigned int *ctr) {
+  const int64_t nv = n / 2, stride = (int64_t)gridDim.x * 256;
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  d2 acc = {0.0, 0.0};
+  unsigned int phase = 0;
+  for (int64_t base = 0; base < nv; base += stride * T) {   // (uniform trip count: every workgroup reaches every barrier)
+    d2 r[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t iv = base + t * stride + t0;
+      d2 sum = {1.0, 2.0};
+      if (iv < nv) {
+        d2 v[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = ldnt(w + (int64_t)j * n + iv * 2);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) sum += v[j];
+      }
+      r[t] = sum;
+      acc += sum;
+    }
+    if (BAR) grid_barrier(ctr, ++phase * gridDim.x);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t iv = base + t * stride + t0;
+      if (iv < nv) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) stnt(out + (int64_t)j * n + iv * 2, r[t] + (double)j);
+      }
+    }
+    if (BAR) grid_barrier(ctr, ++phase * gridDim.x);
+  }
+  if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
+}
+
 int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -409,6 +461,26 @@ int main(int argc, char **argv) {
           printf("candidate %2d + 11 ring streams, %2d materialised s columns, 1 written, 4 sums  grid %5d  %7.3f ms\n",
                  11, nmat, grid, ms);
         }
+      }
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'p') {
+    unsigned int *ctr;
+    CK(hipMalloc(&ctr, 64));
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int grid : {512, 768}) {
+        float ms = timeit([&] { hipLaunchKernelGGL((k_inter<22, 0, 3, 0>), dim3(grid), dim3(256), 0, 0, n, w, out, sink); });
+        printf("storing pass today (pipelined loop)                        grid %5d  %7.3f ms\n", grid, ms);
+#define PH(T, BAR) \
+        { int per_cu = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)&k_phase<22, 3, T, BAR>, 256, 0)); \
+          if (per_cu * 256 < grid) { printf("phases of %2d trips: only %d workgroups per CU resident, grid %d skipped\n", T, per_cu, grid); } else { \
+        ms = timeit([&] { CK(hipMemsetAsync(ctr, 0, 64, 0)); hipLaunchKernelGGL((k_phase<22, 3, T, BAR>), dim3(grid), dim3(256), 0, 0, n, w, out, sink, ctr); }); \
+        printf("phases of %2d trips, %s                  grid %5d  %7.3f ms\n", T, BAR ? "grid barriers between reads and writes" : "no barrier (restructuring only)      ", grid, ms); } }
+        PH(4, false) PH(4, true) PH(8, false) PH(8, true) PH(16, false) PH(16, true)
+#undef PH
       }
       printf("\n");
       fflush(stdout);
