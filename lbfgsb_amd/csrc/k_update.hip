@@ -557,9 +557,10 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   // leaves room for the second trip in flight.  Pairs must be complete: the pair kernel takes the
   // largest multiple of 2 V rows, the plain instantiation the few rows that remain (as one more
   // workgroup: its partials go to column `gr` of the partial-sum matrix)
-  // Measured (n = 5e7 / 1e8, m = 20), two trips in flight: fp64 3.04 -> 2.78 ms, fp32 3.55 -> 3.17 ms
-  // (the fp32 instantiation sits at 509 registers: with a single spilled register its scratch
-  // reloads, which return in order behind the loads in flight, undo the pipelining -- 4.68 ms).
+  // Measured (n = 5e7 / 1e8, m = 20), two trips in flight: fp64 3.04 -> 2.78 ms, fp32 3.55 -> 3.17 ms with round 3's
+  // form of the kernel (every lane loaded all columns, halves exchanged by DPP: 509 registers in fp32, where one
+  // spilled register's scratch reloads, returning in order behind the loads in flight, undid the pipelining: 4.68
+  // ms); with the column halves loaded per lane (UpdScanPairTrip: 450 registers) fp64 2.51 - 2.53, fp32 2.56 ms
   // Tune::pair = 0: off; 1: on, one trip in flight; 2: two trips
   const int pair_mode = q.tune.pair;
   int nblocks = 0;

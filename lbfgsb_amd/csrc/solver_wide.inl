@@ -270,7 +270,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
       // tile_axpy_fused_kernel): neither xcp nor r0 is written, the Newton direction never leaves the last tile,
       // and the projected step, d = z - x, the line-search set-up sums and the first trial point come out of that
       // tile as they come out of subsm_update_kernel for m <= 32 -- six vector kernels and two host syncs less per
-      // iteration (m = 48, n = 2e7: 6.8 -> 5.9 ms).  Uphill projected steps (:2828) redo the unfused sequence below.
+      // iteration (m = 48, n = 2e7: 6.86 -> 6.25 ms).  Uphill projected steps (:2828) redo the unfused sequence below.
       const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass);
       lbk::WideTail<T> wt{x, g, l, u, nbd, gcp.tsum, theta, plain ? 1 : 0, ls_do_stpmx ? 1 : 0,
                           lean ? (T *)nullptr : z, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t,
@@ -278,7 +278,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
       if (gcp.copy_x) wt.tsum = 0.0;  // (xcp = x: no walk behind this Cauchy point)
       if (wide_one_on && col <= lbk::WIDE_MAXC) {
         // all tiles in one launch, the pending pair committed by it (m = 48, n = 2e7: dz_materialise, pair_commit
-        // and two tile launches, 3.3 ms, become one of 2.x ms)
+        // and two tile launches, 3.3 ms, become one launch of 2.7 ms: 6.25 -> 5.76 ms per iteration)
         lbk::CoefWide cw;
         std::memset(&cw, 0, sizeof cw);
         for (int j = 0; j < col; ++j) cw.a[j] = ca[j], cw.a[lbk::WIDE_MAXC + j] = cb[j];
