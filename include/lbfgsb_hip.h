@@ -116,8 +116,9 @@ enum {
                                    counted in nfgv) and the call returns 'FG_LNSRCH' once more, with
                                    the point the reference would have asked for (lbfgsb_hip_defer_stats
                                    counts these).
-                                Not with LBFGSB_F_MIRROR_INDEX, LBFGSB_F_PARALLEL_GCP, iprint >= 99 or
-                                m > LBFGSB_FUSED_M: such contexts wait as before. */
+                                Not with LBFGSB_F_MIRROR_INDEX, LBFGSB_F_PARALLEL_GCP or iprint >= 99: such
+                                contexts wait as before (m > LBFGSB_FUSED_M: deferred while col <= 96 and the
+                                options "wide_tail" / "wide_one" are on, the defaults). */
 };
 
 /* -------------------------------------------------------------------------

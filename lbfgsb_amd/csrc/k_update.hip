@@ -521,7 +521,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
     }
     SplitPlan P{};
     P.nparts = nparts, P.mo = maxc_stride(nold);
-    const int dst = q.res_off, base = split_base(nold, dst);
+    const int dst = q.res_off, base = std::max(split_base(nold, dst), q.split_base_min);
     int j0 = 0;
     for (int k = 0; k < nparts; ++k) {
       const int cnt = (nold - j0 + (nparts - k) - 1) / (nparts - k);  // balanced: 21 -> 11 + 10, 40 -> 14 + 13 + 13

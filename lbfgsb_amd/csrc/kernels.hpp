@@ -64,6 +64,9 @@ struct Queue {
   double *d_gpart;  // gram partials [E][GRAM_BLOCKS]
   int64_t launches;
   int res_off = 0;  // finalize writes d_res[res_off + slot] (lets two phases share one fetch)
+  // m > 32: the parts of a split update pass never start below this offset of d_res (behind the LONGEST merged
+  // layout the context can have + the deferred line-search sums, whatever the current number of pairs)
+  int split_base_min = 0;
   bool nt = false;  // nontemporal loads in the W-pass kernels (W much larger than the Infinity Cache)
   Tune tune{};
   // first kernel launch that failed since the last check (hipGetLastError right behind the launch,

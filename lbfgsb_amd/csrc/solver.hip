@@ -230,6 +230,10 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     // reduction scratch
     const size_t E = (size_t)2 * m * m + m;
+    if (m > lbk::MAXM) {
+      DEFER_OFF = 8 * lbk::maxc_stride(m - 1) + 24, SPEC_OFF = DEFER_OFF + 8;
+      q.split_base_min = DEFER_OFF + 8;  // (<= split_base(m, 1), which split_res_len sizes d_res for)
+    }
     // (the widest phase or a from-scratch Gram; behind DEFER_OFF the four deferred sums, behind SPEC_OFF the
     //  speculative freev counts + formk patch of a trial point: 4 + E + 1)
     res_len = std::max<size_t>(std::max<size_t>(lbk::RES_MAX, E) + 8, (size_t)SPEC_OFF + 4 + E + 1 + 8);
@@ -348,10 +352,12 @@ class Solver final : public lbfgsb_hip_ctx {
   // DEFER_OFF: four more slots (3 sums + 1 minimum) behind the widest phase -- the line-search sums of a
   // storing pass that did not wait for them (LBFGSB_F_DEFER_LNSRCH); while defer_live they travel with
   // every fetch and are reduced like the rest.
-  static constexpr int DEFER_OFF = lbk::RES_MAX;
+  // (m > 32: the merged layout of the split update pass is 8 maxc_stride(m - 1) + 15 doubles long, its parts start 32
+  //  doubles behind it (split_base): the deferred sums sit in between)
+  int DEFER_OFF = lbk::RES_MAX;
   // SPEC_OFF: the sums of a SPECULATIVE freev + formk-patch chain queued behind the evaluation of a trial point
   // (phase_entry): spec_live_len slots, all sums, fetched and reduced with that evaluation's fetch
-  static constexpr int SPEC_OFF = DEFER_OFF + 8;
+  int SPEC_OFF = lbk::RES_MAX + 8;
   int spec_live_len = 0;
   static constexpr double SPIN_LIMIT_S = 0.05;
   bool defer_live = false;
@@ -575,7 +581,7 @@ class Solver final : public lbfgsb_hip_ctx {
   int phase_start(Mainlb &L, Flow &flow) {
     MAINLB_VIEW(L);
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
-    ls.deferred = false, defer_live = false;
+    ls.deferred = false, defer_live = false, wl.pending = false;
     nrefresh = 0;
     sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
     spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0, last_walk_nseg = 0;
@@ -743,7 +749,7 @@ class Solver final : public lbfgsb_hip_ctx {
     // a deferred line-search set-up lands with this call's first fetch -- if this IS the evaluation it
     // asked for; any other task drops it (the sums stay unread)
     const bool landing = ls.deferred && lbh::str60_pre(task, "FG_LN");
-    if (!landing) ls.deferred = false, defer_live = false;
+    if (!landing) ls.deferred = false, defer_live = false, wl.pending = false;
     if (lbh::str60_pre(task, "FG_LN")) {
       compute_pg = false, prelims = false;
       spec.valid = false;
@@ -914,7 +920,10 @@ class Solver final : public lbfgsb_hip_ctx {
         CHK(apply_walk_fixes());
       }
     }
-    CHK(subspace_land(L.x, L.l, L.u, L.nbd, L.g, D, iword, info_sub));
+    if (wl.pending)
+      CHK(wide_land(L.x, L.l, L.u, L.nbd, L.g, D, iword));
+    else
+      CHK(subspace_land(L.x, L.l, L.u, L.nbd, L.g, D, iword, info_sub));
     return 0;  // (phase_linesearch counts the evaluation as wasted if its set-up asks for another point)
   }
 

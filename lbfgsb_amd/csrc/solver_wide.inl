@@ -237,6 +237,35 @@ int wide_subsm_tail(const T *x, const T *l, const T *u, const int32_t *nbd, cons
   return 0;
 }
 
+// what follows the fused r pass's four sums (in the same call, or -- deferred -- in the next one): the line-search
+// set-up values, and for an uphill projected step (:2828) the iteration's r pass again through the unfused steps
+struct WideLand {
+  bool pending = false;
+  std::vector<double> ca, cb;
+  double theta = 1.0;
+  int col = 0, head = 1;
+  bool plain = false;
+} wl;
+int wide_unfused_r(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, int &iword) {
+  CHK(ensure_z(x, l, u, g));
+  lbk::launch_cmprlb_init<T>(q, n, x, g, z, iwhere, wl.theta, wl.plain ? 1 : 0, tbrk);
+  tbrk_valid = false;
+  CHK(wide_axpy(tbrk, wl.ca.data(), wl.cb.data(), wl.col, wl.head, 1.0, 1));
+  return wide_subsm_tail(x, l, u, nbd, g, wl.theta, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword);
+}
+int wide_land(const T *x, const T *l, const T *u, const int32_t *nbd, const T *g, const double *R, int &iword) {
+  wl.pending = false;
+  iword = R[0] > 0.0 ? 1 : 0;
+  const double dd_p = R[1];
+  ls.ready = true, ls.x_is_z = ls_unit_step, ls.gd = dd_p, ls.dtd = R[2], ls.stpmx = R[3];
+  if (iword == 0 || dd_p <= 0.0) return 0;  // :2820, :2828
+  // the backtracking branch (:2830-2879): from the iterate again, through the unfused steps
+  ls.ready = false, d_impl = z_in_x = false, z_valid = false;
+  if (ls.x_is_z && !pp) HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+  ls.x_is_z = false;
+  return wide_unfused_r(x, l, u, nbd, g, iword);
+}
+
 // closed: W'Z r in closed form from the walk's p and WN1 (subspace_closed_form: no W'r pass), and -- with wv known
 // before any row of r exists -- cmprlb's and subsm's two updates of r as ONE pass over W:
 //   r = r0 + Wy (a1 + wv_y / theta) + Ws (a2 + wv_s)      (the reference adds W (M c) first, then divides the
@@ -272,6 +301,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
       // tile as they come out of subsm_update_kernel for m <= 32 -- six vector kernels and two host syncs less per
       // iteration (m = 48, n = 2e7: 6.86 -> 6.25 ms).  Uphill projected steps (:2828) redo the unfused sequence below.
       const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass);
+      bool deferred = false;
       lbk::WideTail<T> wt{x, g, l, u, nbd, gcp.tsum, theta, plain ? 1 : 0, ls_do_stpmx ? 1 : 0,
                           lean ? (T *)nullptr : z, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t,
                           pp ? (T *)nullptr : r, ls_unit_step ? xmut : (T *)nullptr};
@@ -283,7 +313,13 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
         std::memset(&cw, 0, sizeof cw);
         for (int j = 0; j < col; ++j) cw.a[j] = ca[j], cw.a[lbk::WIDE_MAXC + j] = cb[j];
         wt.l = lk(l), wt.u = uk(u);
+        // LBFGSB_F_DEFER_LNSRCH as for m <= 32 (subspace()): the four sums are not waited for, they come over with
+        // the fetch of the next call's first pass and wide_land runs there
+        deferred = defer_on && ls_unit_step && !(flags & LBFGSB_F_PARALLEL_GCP);
+        q.res_off = deferred ? DEFER_OFF : 0;
+        if (deferred && fold_fin) q.part_sel = 2, q.hold_fin = true;
         lbk::launch_wide_r_pass<T>(q, n, W(), head, col, cw, iwhere, nbk(), ub_mask, wt, pend, r, d_src());
+        q.res_off = 0, q.part_sel = 0;
         pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
       } else {
         CHK(commit_pending(g, col, head));
@@ -301,22 +337,18 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
       z_valid = !lean;
       if (lean) x_lean = xmut;
       if (pp) t = const_cast<T *>(x), r = const_cast<T *>(g);  // t = x, r = g (:2235-2236) as a change of roles
+      wl.pending = true, wl.ca = ca, wl.cb = cb, wl.theta = theta, wl.col = col, wl.head = head, wl.plain = plain;
+      if (deferred) {
+        defer_live = true, ls.deferred = true;
+        ndeferred++;
+        return 0;
+      }
       CHK(fetch(3, 1, 0));
-      iword = h_res[0] > 0.0 ? 1 : 0;
-      const double dd_p = h_res[1];
-      ls.ready = true, ls.x_is_z = ls_unit_step, ls.gd = dd_p, ls.dtd = h_res[2], ls.stpmx = h_res[3];
-      if (iword == 0 || dd_p <= 0.0) return 0;  // :2820, :2828
-      // the backtracking branch (:2830-2879): from the iterate again, through the unfused steps
-      ls.ready = false, d_impl = z_in_x = false, z_valid = false;
-      if (ls.x_is_z && !pp) HIPCHK(hipMemcpyAsync(xmut, t, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-      ls.x_is_z = false;
+      return wide_land(x, l, u, nbd, g, h_res, iword);
     }
     CHK(commit_pending(g, col, head));  // (the unfused steps read the newest pair from W)
-    CHK(ensure_z(x, l, u, g));
-    lbk::launch_cmprlb_init<T>(q, n, x, g, z, iwhere, theta, plain ? 1 : 0, tbrk);
-    tbrk_valid = false;
-    CHK(wide_axpy(tbrk, ca.data(), cb.data(), col, head, 1.0, 1));
-    return wide_subsm_tail(x, l, u, nbd, g, theta, (flags & LBFGSB_F_MIRROR_INDEX) != 0, iword);
+    wl.ca = ca, wl.cb = cb, wl.theta = theta, wl.col = col, wl.head = head, wl.plain = plain;
+    return wide_unfused_r(x, l, u, nbd, g, iword);
   }
   CHK(commit_pending(g, col, head));  // (the unfused steps read the newest pair from W)
   CHK(wide_cmprlb(x, l, u, g, theta, col, head, cnstnd, info));

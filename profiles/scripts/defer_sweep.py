@@ -24,8 +24,10 @@ GENS = [
     lambda s: tf.fam_linear(po, s), lambda s: tf.fam_lattice(po, s), lambda s: tf.fam_rosenchain(po, s),
     lambda s: tf.fam_scaled(po, s), lambda s: tf.fam_sqrt(po, s), lambda s: tf.fam_tiny(po, s),
     lambda s: tf.make(po, s, 1200, 1, 25),
+    # m > 32: the one-launch r pass defers its sums too; and the tiled launches (which wait for theirs) beside it
+    lambda s: tf.make(po, s, 1200, 33, 90), lambda s: tf.make(po, s, 1200, 33, 90),
 ]
-OPTS = [{}, {}, {}, {}, {}, {}, {}, {}, {}, {"two_pass": 0}]
+OPTS = [{}, {}, {}, {}, {}, {}, {}, {}, {}, {"two_pass": 0}, {}, {"wide_one": 0}]
 bad, total, deferred, reissued, t0 = 0, 0, 0, 0, time.time()
 for seed in range(first, first + count):
     k = seed % len(GENS)

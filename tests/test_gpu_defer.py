@@ -92,6 +92,22 @@ def test_random_problems_bit_identical(oracle_built, pp):
 
 
 @pytest.mark.parametrize("pp", [True, False])
+def test_wide_memories_bit_identical(oracle_built, pp):
+    """m > 32: the r pass as one launch over all columns defers its four sums like subsm_update_kernel does for
+    m <= 32 (they ride with the fetch of the split update pass one call later); an uphill projected step lands in
+    the unfused steps.  Every return equals the run that waits for them in the same call."""
+    from test_gpu_fuzz import make
+    po = oracle_built
+    tot = [0, 0]
+    for seed in range(8800, 8830):
+        p = make(po, seed, 1200, 33, 80)
+        d, r = _same(p, pp, max_iter=100)
+        tot[0] += d
+        tot[1] += r
+    assert tot[0] > 800, tot     # (deferred also while col > 32)
+
+
+@pytest.mark.parametrize("pp", [True, False])
 def test_backtracking_and_restarts_bit_identical(oracle_built, pp):
     """problems that reach subsm's backtracking branch (:2830-2879) and the 'refresh the memory' branches:
     the deferred set-up has to go back to the iterate, put iwhere back as the walk left it, run the
