@@ -1024,7 +1024,8 @@ class Solver final : public lbfgsb_hip_ctx {
                                (!updatd || (nrpre.valid && nrpre.col == col));
       const bool track = iter > 0 && cnstnd;  // freev looks for entering/leaving rows (:2012)
       pre_valid = false;
-      if (track && closed_cand && index_valid && !index && iw_dirty == 0.0) {
+      // (m > 32: the same -- nothing downstream of freev rides on its fetch there, closed form or not)
+      if (track && (closed_cand || wide()) && index_valid && !index && iw_dirty == 0.0) {
         // no iwhere entry has changed since the last freev: nobody enters, nobody leaves, nfree stands
         // -- neither the counting pass nor a host sync (iw_dirty is a sum over all ranks)
         nfreev_skipped++;
