@@ -548,6 +548,7 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
     run = Run(torch, dist, la, a, n=n, m=m, real32=real32, kind=kind, world=1, rank=0, local_rank=local_rank,
               rccl_self=rccl_self, opts=opts, defer=defer, classic=classic, arbitrary_box=arbitrary_box)
     try:
+        coll_us = run.sol.collective_time(1000) if rccl_self else None
         r = timed_leg(run, steps, warm_min, need_full_memory=(kind == 0))
         col = int(run.sol.isave[27])
         rb = 4 if real32 else 8
@@ -571,6 +572,7 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "freev_passes_skipped_per_iter": (r["st1"]["freev_skipped"] - r["st0"]["freev_skipped"]) / steps,
                 "passes": passes, "subspace_steps_closed_form": closed, "subspace_steps_three_pass": three,
                 "tie_splits": run.sol.tie_splits(), "collective": run.collective, "f_final": float(run.sol.f[0]),
+                "collective_us": coll_us[0] if coll_us else None, "collective_us_min": coll_us[1] if coll_us else None,
                 "lnsrch_setups_deferred_reissued": list(run.sol.defer_stats()),
                 "host_algebra_us_between_passes": r["st1"]["host_gap_us"],
                 "host_segments_us": r["st1"]["host_segments_us"],
@@ -642,6 +644,84 @@ def host_form_leg(la, n=10_000_000, m=10, iters=26, warm=12):
             "anchors_ok": bool(anchors_ok), "rows_first2": rows[:2]}
 
 
+LINE_CAP = 4096      # bytes: the driver keeps an 8 KB tail of stdout; the LAST stdout line must fit well inside
+
+
+def _r(v, nd=6):
+    """floats rounded to nd significant digits (the line is a record, not a data file)"""
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v))
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, hard-capped at
+    LINE_CAP bytes.  Everything else of `out` (other_configs, host_form, roofline_other_w_passes, the raw counters,
+    prose) goes to bench_detail.json beside this file and to stderr."""
+    c, rf, rw, cb = out["config"], out.get("roofline") or {}, out.get("roofline_wtv") or {}, out.get("cpu_baseline")
+    par = c.get("parity_in_run") or {}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {
+        "workload": c["workload"][:160], "n": c["n"], "m": c["m"], "rows_per_gpu": c["rows_per_gpu"],
+        "entry": c["entry"][:60], "defer_lnsrch": c["defer_lnsrch"], "uniform_bounds_mask": c["uniform_bounds_mask"],
+        "compact_w": c.get("compact_w"),
+        "parity_in_run": {k: par.get(k) for k in ("rows_checked", "ok", "iters", "f_rel_tol")},
+        "rccl_nranks": c["rccl_nranks"], "first_iteration_s": c["first_iteration_s"],
+        "time_to_30_iterations_s": c.get("time_to_30_iterations_s"),
+    }
+    if out["n_gpus"] > 1:   # what a scaling run needs to explain itself (SURVEY.md 8e)
+        line["config"].update({
+            "first_iteration_s_per_rank": c["first_iteration_s_per_rank"],
+            "collective_us": out.get("collective_us"), "comm_kind": out.get("comm_kind"),
+            "ms_per_step_rank_min": out["ms_per_step_rank_min"], "ms_per_step_rank_max": out["ms_per_step_rank_max"]})
+    line["config"]["host_syncs_per_iter"] = out["host_syncs_per_iter"]
+    line["config"]["collectives_per_iter"] = out["collectives_per_iter"]
+    legs = c.get("legs")
+    if legs:
+        line["config"]["legs"] = legs
+    line["roofline"] = {"bound": "hbm", "kernel": (rf.get("kernel") or "")[:100]}
+    for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
+              "algorithmic_bytes_per_row", "avg_launch_ms", "launches_timed", "rows_per_launch"):
+        line["roofline"][k] = rf.get(k)
+    line["roofline_wtv"] = ({k: rw.get(k) for k in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")}
+                            if rw else None)
+    line["update_scan"] = {"frac": out.get("update_scan_frac_of_hbm_peak"), "avg_launch_ms": out.get("update_scan_ms_in_run")}
+    if cb is not None:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "value_full_size_on_file",
+                                                       "host_cpu_model", "n_sample", "s_per_iter_at_sample")}
+        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:200]
+    line["detail"] = "bench_detail.json"
+    line = _r(line)
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > LINE_CAP and "legs" in line["config"]:      # (never expected: the legs are <= 1 KB)
+        line["config"]["legs"] = {k: v[:40] for k, v in line["config"]["legs"].items()}
+        txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > LINE_CAP:
+        line["config"].pop("legs", None)
+        line["cpu_baseline"].pop("sample", None) if "cpu_baseline" in line else None
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) <= LINE_CAP, len(txt)
+    return txt
+
+
+def emit(out):
+    """detail -> bench_detail.json (+ stderr), then the compact line as the LAST line of stdout"""
+    detail = json.dumps(out)
+    try:
+        with open(os.path.join(ROOT, "bench_detail.json"), "w") as fh:
+            fh.write(detail + "\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: bench_detail.json not written (%r)\n" % (e,))
+    sys.stderr.write("bench.py detail: " + detail + "\n")
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -682,6 +762,9 @@ def main():
     run = Run(torch, dist, lbfgsb_amd, a, n=n, m=m, real32=a.real32, kind=1 if a.rosenbrock else 0, world=world,
               rank=rank, local_rank=local_rank, rccl_self=a.rccl_self, opts=opts)
     sol, n_loc = run.sol, run.n_loc
+    # one host sync of the iteration by itself, before the run starts (every rank: it is a collective): what each of
+    # the host_syncs_per_iter below costs on this communicator (all-gather + copy to mapped host memory + poll)
+    coll_us = sol.collective_time(1000) if (world > 1 or a.rccl_self) else None
     # Untimed until the memory is full (col == m): whatever --warmup says, at least m + 1
     # iterations run first, so that every timed launch streams all 2m columns of W and the
     # roofline bytes below (computed for col = m) are the bytes each timed launch really moved.
@@ -875,6 +958,9 @@ def main():
         "nfree": nfree,
         "host_syncs_per_iter": (stats["syncs"] - st0["syncs"]) / a.steps,
         "collectives_per_iter": (stats["collectives"] - st0["collectives"]) / a.steps,
+        # median / minimum of 1000 host syncs by themselves on this communicator, measured before START
+        "collective_us": coll_us[0] if coll_us else None,
+        "collective_us_min": coll_us[1] if coll_us else None,
         # what the communicator itself says (ncclCommCount / ncclCommUserRank): N ranks took part
         "rccl_nranks": (sol.comm_info()[0] if sol.comm_info()[2] == 1 else None),
         "comm_kind": {0: "none", 1: "rccl", 2: "host callbacks"}[sol.comm_info()[2]],
@@ -981,6 +1067,8 @@ def main():
             fr = lambda k: ("%.2f" % ps[k]["frac"]) if k in ps else "-"     # noqa: E731
             legs[tag] = "%.1f it/s %.3f ms upd %s sub %s syncs %.2f" % (
                 oc["value"], oc["ms_per_step"], fr("update_scan"), fr("subsm_update"), oc["host_syncs_per_iter"])
+            if oc.get("collective_us") is not None:
+                legs[tag] += " coll %.0f us" % oc["collective_us"]
             pr = oc.get("parity_in_run") or {}
             if pr.get("rows_checked"):
                 legs[tag] += " parity %d rows %s" % (pr["rows_checked"], "ok" if pr["ok"] else "MISMATCH")
@@ -1025,7 +1113,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "iters/sec", "cores": 1, "kind": "reference",
                                    "sample": "failed: %r" % (e,)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
     if parity_fail:      # (the line above is on record; the run itself must not pass)

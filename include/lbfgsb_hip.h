@@ -275,6 +275,14 @@ int lbfgsb_hip_release_host_ik(void *isave, int32_t int_bytes);
  * call is made from a static destructor).  isave(1:16)
  * receive the reference's wa offsets (:250-265), saturated at INT32_MAX instead of wrapped. */
 int lbfgsb_hip_release_host(int32_t *isave);
+/* Pinning of the caller's arrays by the host-pointer form, for the whole process: mode 1 (default) = START
+ * registers x, g and wa's t slot with hipHostRegister (3 n real_bytes: 2.4 GB at n = 1e8) until the run's
+ * context goes; mode 0 = never, every transfer is a pageable copy (slower per call, nothing to undo).  Use 0 for
+ * short runs of large problems, and for callers that may free x / g / wa of a run they abandoned without
+ * lbfgsb_hip_release_host: an array must not be freed while it is registered.  What the library does by itself:
+ * a call that arrives with another x, g or wa than START's releases that registration; a START whose arrays
+ * overlap the registrations of a run still on the registry drops that (abandoned) run first. */
+int lbfgsb_hip_host_pinning(int mode);
 
 /* -------------------------------------------------------------------------
  * Convenience driver around lbfgsb_hip_setulb_dev -- the "high-level wrapper so the user

@@ -65,6 +65,13 @@ int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count);
  * assembly and factorisations, W'Z r in closed form: the part of an iteration during which the device waits
  * for the host (window / freev syncs inside the stretch included) */
 int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count);
+/* ONE host sync of the iteration timed by itself, `reps` times (microseconds: median and minimum): the
+ * 8 min(m, 32) + 15 fp64 partials of the widest phase through the library's own fetch -- with a communicator the
+ * all-gather over the ranks on the solver's stream (the sums of src/lbfgsb.f90:813-816, 2196-2244
+ * completed over the row blocks), the copy into mapped host memory and the poll; without one the publish + poll.
+ * A collective: every rank calls it, between runs (not while sums of a run are deferred).  What a --gpus N bench
+ * line reports as collective_us. */
+int lbfgsb_hip_collective_time(lbfgsb_hip_ctx *ctx, int reps, double *median_us, double *min_us);
 /* the same stretches cut at their milestones, accumulated seconds: [0] line search + return to the caller,
  * [1] the caller between the NEW_X return and the re-entry, [2] termination tests + matupd + formt,
  * [3] cauchy (host walk, window syncs if any) + freev, [4] formk's assembly / factorisations, W'Z r, the

@@ -36,9 +36,11 @@ PROTOTYPES = {
     "lbfgsb_hip_get_stream": (C.c_void_p, [_vp]),
     "lbfgsb_hip_wait_stream": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_release_host": (C.c_int, [_vp]),
+    "lbfgsb_hip_host_pinning": (C.c_int, [C.c_int]),
     "lbfgsb_hip_tie_splits": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_defer_stats": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_host_gap": (C.c_int, [_vp, _vp, _vp]),
+    "lbfgsb_hip_collective_time": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "lbfgsb_hip_host_segments": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_comm_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lbfgsb_hip_path_counts": (C.c_int, [_vp, _vp, _vp, _vp]),

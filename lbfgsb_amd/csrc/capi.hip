@@ -398,6 +398,11 @@ int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count) {
   return 0;
 }
 
+int lbfgsb_hip_collective_time(lbfgsb_hip_ctx *ctx, int reps, double *median_us, double *min_us) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  return ctx->collective_time(reps, median_us, min_us);
+}
+
 int lbfgsb_hip_refresh_count(lbfgsb_hip_ctx *ctx, int64_t *count) {
   if (!ctx || !count) return fail(LBFGSB_E_ARG, "refresh_count: NULL argument");
   *count = ctx->nrefresh;
@@ -490,7 +495,39 @@ struct HostRegistry {
   }
 };
 HostRegistry g_host;
+std::atomic<int> g_host_pinning{1};  // lbfgsb_hip_host_pinning
+
+// Runs the caller abandoned (the reference's driver2 / driver3 set task = 'STOP' and never re-enter setulb) keep
+// their context and the registrations of the arrays they pinned.  A START whose arrays overlap such a registration
+// can only mean that run is over (the same arrays started again, or the memory was freed and handed out again):
+// it is dropped here, its registrations with it, before the new run pins anything.
+void drop_runs_overlapping(const void *const *ptr, const size_t *bytes, int cnt) {
+  std::vector<lbfgsb_hip_ctx *> dead;
+  {
+    std::lock_guard<std::mutex> lk(g_host.mu);
+    for (auto it = g_host.live.begin(); it != g_host.live.end();) {
+      bool hit = false;
+      for (const auto &r : it->second->host_reg)
+        for (int k = 0; k < cnt && !hit; ++k)
+          hit = r.p && ptr[k] && (const char *)ptr[k] < (const char *)r.p + r.bytes &&
+                (const char *)r.p < (const char *)ptr[k] + bytes[k];
+      if (hit) {
+        dead.push_back(it->second);
+        it = g_host.live.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  for (lbfgsb_hip_ctx *c : dead) delete c;
+}
 }  // namespace
+
+int lbfgsb_hip_host_pinning(int mode) {
+  if (mode != 0 && mode != 1) return fail(LBFGSB_E_ARG, "host_pinning: mode must be 0 or 1");
+  g_host_pinning.store(mode);
+  return 0;
+}
 
 int lbfgsb_hip_release_host(int32_t *isave) {
   if (!isave) return fail(LBFGSB_E_ARG, "isave == NULL");
@@ -573,10 +610,16 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
     // the caller's x, g and the t slot of wa are pinned for the run: the per-call transfers below are then DMA
     // copies on the context's stream (unpinned again when the context goes; arrays that cannot be pinned, or
     // other arrays than these on a later call, travel as pageable copies)
-    ctx->host_register(0, x, (size_t)n * rb);
-    ctx->host_register(1, g, (size_t)n * rb);
-    if (wa && !mirror)
-      ctx->host_register(2, (char *)wa + (size_t)(2ll * m * n + 11ll * m * m + 3ll * n) * rb, (size_t)n * rb);
+    // lbfgsb_hip_host_pinning(0) switches this off for the process (include/lbfgsb_hip.h: when to).
+    if (g_host_pinning.load()) {
+      void *tslot = (wa && !mirror) ? (char *)wa + (size_t)(2ll * m * n + 11ll * m * m + 3ll * n) * rb : nullptr;
+      const void *pv[3] = {x, g, tslot};
+      const size_t pb[3] = {(size_t)n * rb, (size_t)n * rb, (size_t)n * rb};
+      drop_runs_overlapping(pv, pb, 3);
+      ctx->host_register(0, x, pb[0]);
+      ctx->host_register(1, g, pb[1]);
+      if (tslot) ctx->host_register(2, tslot, pb[2]);
+    }
     if (iteration_file && iteration_file[0]) ctx->itfile_name = iteration_file;
     const size_t vb = ((size_t)n + 32) * rb;
     auto stage = [&]() -> int {
@@ -612,6 +655,12 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
     ctx = g_host.find(isave);
     if (!ctx || ctx->n != n || ctx->m != m)
       return fail(LBFGSB_E_STATE, "setulb called without a live context (task must be START first)");
+    // a caller that hands over OTHER arrays than START's (a fresh g per call, say): the START-time array may be
+    // gone already -- its registration is released now, this call's array travels as a pageable copy
+    ctx->host_unregister_if_not(0, x);
+    ctx->host_unregister_if_not(1, g);
+    if (wa && !mirror)
+      ctx->host_unregister_if_not(2, (char *)wa + (size_t)(2ll * m * n + 11ll * m * m + 3ll * n) * rb);
     // l, u, nbd were copied at START; the reference re-reads the caller's arrays on every call (:1270-1330,
     // :2594-2622, :2789-2816).  After the first iteration and then every 32nd the arrays are uploaded again and
     // compared with the copies, bit for bit: an edit in place ends the run with an error instead of being ignored.
@@ -636,10 +685,15 @@ static int setulb_host_impl(int64_t n, int64_t m, void *x, const void *l, const 
         }
         return ctx->bounds_same(ctx->hl, ctx->hu, ctx->hnbd, tl, tu, tn, &ndiff);
       };
-      const int rcc = check();
+      int rcc = check();
       if (tl) (void)hipFree(tl);
       if (tu) (void)hipFree(tu);
       if (tn) (void)hipFree(tn);
+      if (rcc && (!tl || !tu || !tn)) {
+        // no room for the three temporary copies (a run that fits must not fail for a CHECK): skipped this time
+        (void)hipGetLastError();
+        rcc = 0, ndiff = 0.0;
+      }
       if (rcc) return rcc;
       if (ndiff != 0.0) {
         lbh::str60_set(task, "ERROR: BOUNDS CHANGED DURING RUN");

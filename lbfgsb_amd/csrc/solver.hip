@@ -748,6 +748,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     // a deferred line-search set-up lands with this call's first fetch -- if this IS the evaluation it
     // asked for; any other task drops it (the sums stay unread)
+    const bool was_deferred = ls.deferred;
     const bool landing = ls.deferred && lbh::str60_pre(task, "FG_LN");
     if (!landing) ls.deferred = false, defer_live = false, wl.pending = false;
     if (lbh::str60_pre(task, "FG_LN")) {
@@ -878,6 +879,8 @@ class Solver final : public lbfgsb_hip_ctx {
         if (std::strncmp(task + 6, "CPU", 3) == 0) {  // :566-571
           CHK(restore_iterate(L));
           HIPCHK(hipStreamSynchronize(stream));
+          // (a line search whose set-up was still deferred has not stored fold = f yet, :2237)
+          if (was_deferred) fold = defer_f0;
           *f = fold;
         }
         finish(L);

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <chrono>
 #include <condition_variable>
@@ -181,6 +182,13 @@ struct lbfgsb_hip_ctx {
     else
       (void)hipGetLastError();  // (already registered by the caller, stack memory, ...: pageable copies then)
   }
+  void host_unregister_if_not(int k, const void *p) {
+    HostReg &r = host_reg[k];
+    if (r.p && r.p != p) {
+      if (hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
+      r.p = nullptr, r.bytes = 0;
+    }
+  }
   void host_unregister_all() {
     for (HostReg &r : host_reg) {
       if (r.p && hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
@@ -217,6 +225,7 @@ struct lbfgsb_hip_ctx {
   virtual int bounds_same(const void *l0, const void *u0, const int32_t *nb0, const void *l1, const void *u1,
                           const int32_t *nb1, double *ndiff) = 0;
   virtual int64_t freev_skipped() const = 0;
+  virtual int collective_time(int reps, double *median_us, double *min_us) = 0;  // lbfgsb_hip_collective_time
   virtual int64_t skip_scans_reused() const = 0;
   virtual void defer_counts(int64_t &deferred, int64_t &reissued) const = 0;
   // a built-in objective whose value is still on the device (d_res[0], to be scaled by f_scale):

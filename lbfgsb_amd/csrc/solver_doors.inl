@@ -19,7 +19,10 @@
     ls.ready = false, ls.x_is_z = false;
     t = t_own, r = r_own;
     if (nbd) {
+      // (plain nbd bytes, streamed bounds: a run that ended in dictionary / uniform mode must not have its codes or
+      //  constants applied to the arrays a door is handed, as import_state does)
       nbd8_src = nullptr;
+      ub_mask = 0;
       CHK(ensure_nbd8(nbd));
     }
     return 0;

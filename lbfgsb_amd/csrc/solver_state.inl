@@ -276,6 +276,30 @@
     closed_form = nclosed, three_pass = nthreepass;
   }
   int64_t freev_skipped() const override { return nfreev_skipped; }
+  // one host sync of the iteration, timed by itself: the 8 min(m, 32) + 15 partials of the widest phase through
+  // fetch() -- with a communicator the all-gather over the ranks on the solver's stream, the copy into mapped host
+  // memory and the poll for it; without one the publish + poll alone.  Every rank must call this (it IS a
+  // collective).  Not inside a run (between the returns of one: nothing may be deferred / pending).
+  int collective_time(int reps, double *median_us, double *min_us) override {
+    if (reps < 1 || reps > 100000) return fail(LBFGSB_E_ARG, "collective_time: reps out of range");
+    if (defer_live || spec_live_len) return fail(LBFGSB_E_STATE, "collective_time: sums of a run are in flight");
+    HIPCHK(hipSetDevice(device));
+    const int k = std::min<int>(8 * std::min(m, lbk::MAXM) + 15, lbk::RES_MAX);
+    const int64_t ns0 = nsync, nc0 = ncoll, cb0 = coll_bytes;
+    const double tw0 = t_wait;
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<double> t((size_t)reps);
+    for (int it = 0; it < reps; ++it) {
+      const double t0 = now_s();
+      CHK(fetch(k, 0, 0));
+      t[(size_t)it] = (now_s() - t0) * 1e6;
+    }
+    nsync = ns0, ncoll = nc0, coll_bytes = cb0, t_wait = tw0;  // (a measurement, not part of any run's counts)
+    std::sort(t.begin(), t.end());
+    if (median_us) *median_us = t[t.size() / 2];
+    if (min_us) *min_us = t.front();
+    return 0;
+  }
   int64_t skip_scans_reused() const override { return nskip_reused; }
   void defer_counts(int64_t &deferred, int64_t &reissued) const override { deferred = ndeferred, reissued = nredo; }
   const void *prev_iterate() const override { return t; }

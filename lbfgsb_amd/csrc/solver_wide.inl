@@ -302,23 +302,23 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
       // iteration (m = 48, n = 2e7: 6.86 -> 6.25 ms).  Uphill projected steps (:2828) redo the unfused sequence below.
       const bool lean = lean_on && ls_unit_step && (cnstnd || two_pass);
       bool deferred = false;
-      lbk::WideTail<T> wt{x, g, l, u, nbd, gcp.tsum, theta, plain ? 1 : 0, ls_do_stpmx ? 1 : 0,
+      lbk::WideTail<T> tail{x, g, l, u, nbd, gcp.tsum, theta, plain ? 1 : 0, ls_do_stpmx ? 1 : 0,
                           lean ? (T *)nullptr : z, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t,
                           pp ? (T *)nullptr : r, ls_unit_step ? xmut : (T *)nullptr};
-      if (gcp.copy_x) wt.tsum = 0.0;  // (xcp = x: no walk behind this Cauchy point)
+      if (gcp.copy_x) tail.tsum = 0.0;  // (xcp = x: no walk behind this Cauchy point)
       if (wide_one_on && col <= lbk::WIDE_MAXC) {
         // all tiles in one launch, the pending pair committed by it (m = 48, n = 2e7: dz_materialise, pair_commit
         // and two tile launches, 3.3 ms, become one launch of 2.7 ms: 6.25 -> 5.76 ms per iteration)
         lbk::CoefWide cw;
         std::memset(&cw, 0, sizeof cw);
         for (int j = 0; j < col; ++j) cw.a[j] = ca[j], cw.a[lbk::WIDE_MAXC + j] = cb[j];
-        wt.l = lk(l), wt.u = uk(u);
+        tail.l = lk(l), tail.u = uk(u);
         // LBFGSB_F_DEFER_LNSRCH as for m <= 32 (subspace()): the four sums are not waited for, they come over with
         // the fetch of the next call's first pass and wide_land runs there
         deferred = defer_on && ls_unit_step && !(flags & LBFGSB_F_PARALLEL_GCP);
         q.res_off = deferred ? DEFER_OFF : 0;
         if (deferred && fold_fin) q.part_sel = 2, q.hold_fin = true;
-        lbk::launch_wide_r_pass<T>(q, n, W(), head, col, cw, iwhere, nbk(), ub_mask, wt, pend, r, d_src());
+        lbk::launch_wide_r_pass<T>(q, n, W(), head, col, cw, iwhere, nbk(), ub_mask, tail, pend, r, d_src());
         q.res_off = 0, q.part_sel = 0;
         pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
       } else {
@@ -329,7 +329,7 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
         std::memset(&cf, 0, sizeof cf);
         for (int j = 0; j < tc; ++j) cf.a[j] = ca[j0 + j], cf.a[lbk::MAXM + j] = cb[j0 + j];
         lbk::launch_tile_axpy_fused<T>(q, n, W(), (head - 1 + j0) % m + 1, tc, cf, iwhere, tbrk, j0 == 0 ? 1 : 0,
-                                       j0 + lbk::MAXM >= col ? 1 : 0, wt);
+                                       j0 + lbk::MAXM >= col ? 1 : 0, tail);
       }
       }
       tbrk_valid = false;

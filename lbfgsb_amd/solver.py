@@ -458,6 +458,13 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_comm_info(self.h, C.byref(a), C.byref(b), C.byref(k)))
         return int(a.value), int(b.value), int(k.value)
 
+    def collective_time(self, reps: int = 1000):
+        """(median_us, min_us) of one host sync of the iteration by itself (lbfgsb_hip_collective_time); a
+        collective: every rank calls it"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(self.lib.lbfgsb_hip_collective_time(self.h, int(reps), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def host_gap(self):
         """(seconds, stretches) the device waited for the host's 2m x 2m algebra between the two passes"""
         a, b = C.c_double(), C.c_int64()

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--iters", type=int, default=13)
     ap.add_argument("--engine", default="ref_i8")
     ap.add_argument("--budget-s", type=float, default=900.0)
+    ap.add_argument("--mem-factor", type=float, default=1.5,
+                    help="refuse to start unless MemAvailable >= this x the arrays' size (m = 20 at n = 1e8 needs "
+                         "42 GB: 1.3 on a 62 GB host)")
     a = ap.parse_args()
     from bench import host_cpu
     from oracle import pyoracle as po
@@ -44,7 +47,7 @@ def main():
     real_bytes = 4 if a.engine.endswith("r32") or "r32" in a.engine else 8
     need_gb = ((2 * a.m + 5 + 4) * a.n * real_bytes + 4 * a.n * 8) / 2**30
     avail = mem_available_gb()
-    if avail is not None and avail < 1.5 * need_gb:
+    if avail is not None and avail < a.mem_factor * need_gb:
         print(json.dumps({"error": "not enough host memory", "need_gb": need_gb, "available_gb": avail}))
         return 1
     eng = po.Engine(a.engine)

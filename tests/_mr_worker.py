@@ -69,8 +69,22 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     u = torch.from_numpy(p.u[sl].copy()).to(dev)
     nbd = torch.from_numpy(p.nbd[sl].astype(np.int32)).to(dev)
     rows = []
+    stopcpu = None
     for _ in range(100000):
         t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+        if variant == "stopcpu" and t.startswith("FG_LN") and sol.isave[29] == iters:
+            # 'STOP: CPU' (src/lbfgsb.f90:565-573) at the first trial point after iteration `iters`: every rank gets
+            # ITS rows of the iterate back, bit for bit, and the global f
+            sol.sync()
+            sol.set_task("STOP: CPU EXCEEDING THE TIME LIMIT.")
+            t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+            sol.sync()
+            ok = (t.startswith("STOP: CPU") and bool(torch.equal(x, stopcpu[0])) and bool(torch.equal(g, stopcpu[1]))
+                  and float(sol.f[0]) == stopcpu[2] and float(sol.dsave[1]) == stopcpu[2])
+            oks = [None] * world
+            dist.all_gather_object(oks, ok)
+            stopcpu = all(oks)
+            break
         if t.startswith("FG") and two_scale is not None:
             # host objective on this rank's rows, f summed over the ranks
             xh = x.cpu().numpy()
@@ -84,6 +98,10 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
         elif t.startswith("NEW_X"):
             rows.append([int(sol.isave[29]), int(sol.isave[33]), int(sol.isave[32]),
                          int(sol.isave[37]), float(sol.f[0]), float(sol.dsave[12])])
+            if variant == "stopcpu" and sol.isave[29] == iters:
+                sol.sync()
+                stopcpu = (x.clone(), g.clone(), float(sol.f[0]))
+                continue
             if sol.isave[29] >= iters:
                 break
             if variant == "ckpt" and sol.isave[29] == iters // 2:
@@ -107,7 +125,8 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump({"rows": rows, "task": sol.task_s, "x": np.concatenate(xs).tolist(),
-                       "stats": sol.stats(), "tie_splits": sol.tie_splits(), "defer": list(sol.defer_stats())}, fh)
+                       "stats": sol.stats(), "tie_splits": sol.tie_splits(), "defer": list(sol.defer_stats()),
+                       "stopcpu": stopcpu if isinstance(stopcpu, bool) else None}, fh)
     sol.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -322,3 +322,27 @@ def test_deferred_line_search_sums_over_several_ranks(oracle_built, tmp_path, mo
         assert a[4] == pytest.approx(b[4], rel=1e-9)
     # one collective per host sync still holds, and there is one sync per iteration less
     assert res["stats"]["syncs"] < base["stats"]["syncs"]
+
+
+@pytest.mark.parametrize("world,mode,defer", [(2, "gloo", False), (2, "fakerccl", True), (3, "fakerccl", False)])
+def test_stop_cpu_sharded(oracle_built, tmp_path, monkeypatch, world, mode, defer):
+    """task = 'STOP: CPU' (src/lbfgsb.f90:565-573, test/driver3.f90:151-182) on a sharded run, sent at the first trial
+    point after iteration 9 (with LBFGSB_F_DEFER_LNSRCH: while that line search's set-up is still deferred): every rank
+    gets its rows of the iterate and its gradient back bit for bit, f = dsave(2) = the iterate's value, and the rows
+    up to there are the oracle's."""
+    po = oracle_built
+    n, m, iters = 20011, 7, 9
+    if mode == "fakerccl":
+        monkeypatch.setenv("LBFGSB_RCCL_LIBRARY", _fake_rccl())
+    if defer:
+        monkeypatch.setenv("LBFGSB_TEST_DEFER", "1")
+    res = launch(world, mode, n, m, iters, "stopcpu", str(tmp_path / "out.json"))
+    assert res["stopcpu"] is True
+    assert res["task"].startswith("STOP: CPU")
+    rows, x = oracle_rows(po, n, m, iters, False)
+    assert len(res["rows"]) == len(rows) == iters
+    for a, b in zip(res["rows"], rows):
+        assert a[:4] == b[:4], (a, b)
+    assert np.max(np.abs(np.array(res["x"]) - x)) <= 1e-9 * max(1.0, np.max(np.abs(x)))
+    if defer:
+        assert res["defer"][0] >= iters - 2
