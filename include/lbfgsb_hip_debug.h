@@ -65,6 +65,12 @@ int lbfgsb_hip_tie_splits(lbfgsb_hip_ctx *ctx, int64_t *count);
  * assembly and factorisations, W'Z r in closed form: the part of an iteration during which the device waits
  * for the host (window / freev syncs inside the stretch included) */
 int lbfgsb_hip_host_gap(lbfgsb_hip_ctx *ctx, double *seconds, int64_t *count);
+/* Option "compact_w" (lbfgsb_hip_set_option): how often the tiles of W were re-sorted to the free-rows-first layout
+ * (packs) and back to natural row order because a kernel that does not know the layout had to run (unpacks);
+ * packed = the columns are not in natural order right now; eligible = this context runs its two passes over W on
+ * the layout (fp64, m <= 10, no LBFGSB_F_MIRROR_INDEX, option set). */
+int lbfgsb_hip_compact_stats(lbfgsb_hip_ctx *ctx, int64_t *packs, int64_t *unpacks, int32_t *packed,
+                             int32_t *eligible);
 /* ONE host sync of the iteration timed by itself, `reps` times (microseconds: median and minimum): the
  * 8 min(m, 32) + 15 fp64 partials of the widest phase through the library's own fetch -- with a communicator the
  * all-gather over the ranks on the solver's stream (the sums of src/lbfgsb.f90:813-816, 2196-2244

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "lbfgsb_hip_defer_stats": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_host_gap": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_collective_time": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "lbfgsb_hip_compact_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "lbfgsb_hip_host_segments": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_comm_info": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lbfgsb_hip_path_counts": (C.c_int, [_vp, _vp, _vp, _vp]),

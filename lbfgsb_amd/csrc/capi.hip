@@ -403,6 +403,19 @@ int lbfgsb_hip_collective_time(lbfgsb_hip_ctx *ctx, int reps, double *median_us,
   return ctx->collective_time(reps, median_us, min_us);
 }
 
+int lbfgsb_hip_compact_stats(lbfgsb_hip_ctx *ctx, int64_t *packs, int64_t *unpacks, int32_t *packed,
+                              int32_t *eligible) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  int64_t a = 0, b = 0;
+  int c = 0, d = 0;
+  ctx->compact_stats(a, b, c, d);
+  if (packs) *packs = a;
+  if (unpacks) *unpacks = b;
+  if (packed) *packed = c;
+  if (eligible) *eligible = d;
+  return 0;
+}
+
 int lbfgsb_hip_refresh_count(lbfgsb_hip_ctx *ctx, int64_t *count) {
   if (!ctx || !count) return fail(LBFGSB_E_ARG, "refresh_count: NULL argument");
   *count = ctx->nrefresh;

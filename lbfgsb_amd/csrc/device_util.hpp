@@ -422,6 +422,60 @@ __device__ __forceinline__ void for_rows_raw(int64_t n, const Ctx &c, F &&f) {
   }
 }
 
+// ---- the passes over W under the tile-local free-row layout (WStore::lmask, "compact W") ----
+// A wave takes one aligned tile of 128 rows per trip; lane l owns rows l and l + 64 of it (NOT 2l, 2l + 1: the rows
+// whose layout bit is set sit at the front of the tile in ascending order, so the lanes that own such a row read ONE
+// contiguous run of the column with each instruction -- measured against the lane-pair form, which reads every other
+// element of the run twice: store pass 3.50 -> 2.80 ms, update pass 2.23 -> 1.95 ms at half of the rows free,
+// n = 1e8; profiles/round6_a_compact_shapes_ab.txt).  The slots of the tile's rows follow from its two mask words,
+// which are wave-uniform and fetched one trip ahead; a row's n-vector operands (x, g, ...) stay in natural order
+// (8-byte loads, 512 contiguous bytes per wave instruction).
+// TripCW (a one-row trip) provides
+//   void issue_cw(const Ctx &, int64_t i, int64_t slot, bool lf)   start every load of row i: its n-vector operands,
+//                                                    and its W entries from `slot` if lf (else the zero buffer)
+//   void land()
+// f(trip, i, WTag<1>) consumes one landed row; it is called for the tile's rows in the order l, l + 64.  Rows that
+// need their W entries although their layout bit is clear (the status changed since the layout was made) fetch
+// them inside f (TripCW::reload_cols): the layout decides how many bytes move, never a result.
+template <typename TripCW, typename Ctx, typename F>
+__device__ __forceinline__ void for_tiles_cw(int64_t n, const Ctx &c, const uint64_t *__restrict__ lmask, F &&f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ntile = (n + 127) >> 7;
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  int64_t tr = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // (wave-uniform, which the compiler cannot see: scalar registers for the tile arithmetic and the mask words)
+  tr = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tr >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)tr));
+  if (tr >= ntile) return;
+  uint64_t m0 = lmask[2 * tr], m1 = lmask[2 * tr + 1];
+  for (;;) {
+    const int64_t nx = tr + stride;
+    const bool more = nx < ntile;
+    const int64_t nxc = more ? nx : tr;
+    const uint64_t m0n = lmask[2 * nxc], m1n = lmask[2 * nxc + 1];  // the next trip's words
+    const int c0 = __popcll(m0), tf = c0 + __popcll(m1);
+    // layout-free rows of the tile in front of this lane's two rows
+    const int b0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+    const int b1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+    const bool f0 = (m0 >> lane) & 1ull, f1 = (m1 >> lane) & 1ull;
+    const int64_t tb = tr << 7;
+    const int64_t s0 = tb + (f0 ? b0 : tf + (lane - b0));
+    const int64_t s1 = tb + (f1 ? b1 : tf + (64 + lane - b1));
+    const int64_t i0 = tb + lane, i1 = i0 + 64;
+    const bool v0 = i0 < n, v1 = i1 < n;  // (false only in the last tile; such rows have no layout bit)
+    TripCW A, B;
+    A.issue_cw(c, v0 ? i0 : n - 1, s0, f0);
+    B.issue_cw(c, v1 ? i1 : n - 1, s1, f1);
+    raw_wait<0>();
+    A.land();
+    B.land();
+    if (v0) f(A, i0, WTag<1>{});
+    if (v1) f(B, i1, WTag<1>{});
+    if (!more) break;
+    tr = nx, m0 = m0n, m1 = m1n;
+  }
+}
+
 // ---- reductions: DPP inside the 16-lane rows of a wave, LDS across rows and waves ----
 // Round 3 reduced every slot with six dependent __shfl_down steps: each step is two ds_bpermute_b32,
 // an s_waitcnt lgkmcnt(0) and an add, and the compiler kept the slots' chains one behind the other --

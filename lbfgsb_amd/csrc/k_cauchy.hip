@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
     const uint32_t *__restrict__ idx, const uint64_t *__restrict__ keys, uint32_t cnt,
     int64_t row0, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const T *__restrict__ g, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
-    int m, int head, int col, const T *pr, const T *pd, Pend pe, double *rec) {
+    int m, int head, int col, const T *pr, const T *pd, Pend pe, double *rec, const uint64_t *__restrict__ lmask) {
   const int rl = 2 * col + 4;
   const int64_t total = (int64_t)cnt * rl;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
@@ -408,11 +408,11 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_kernel(
       v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
     } else if (f < 4 + col) {
       v = (pe.on && f - 4 == col - 1) ? pend_y<T>((double)g[i], (double)pr[i])
-                                      : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
+                                      : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + wrow(lmask, i)];
     } else {
       v = (pe.on && f - 4 - col == col - 1)
               ? pend_sx<T>((double)pd[i], (double)x[i], pe)
-              : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
+              : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + wrow(lmask, i)];
     }
     rec[q] = v;
   }
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
     const uint32_t *__restrict__ d_count, uint32_t cap, int64_t row0, const T *__restrict__ x,
     const T *__restrict__ l, const T *__restrict__ u, const T *__restrict__ g,
     const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw, int m, int head, int col,
-    const T *pr, const T *pd, Pend pe, double *msg) {
+    const T *pr, const T *pd, Pend pe, double *msg, const uint64_t *__restrict__ lmask) {
   const uint32_t total_cnt = *d_count;
   const uint32_t cnt = total_cnt < cap ? total_cnt : cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -454,11 +454,11 @@ __global__ __launch_bounds__(BLOCK) void cauchy_gather_dyn_kernel(
       v = d > 0.0 ? (double)u[i] - (double)x[i] : (double)l[i] - (double)x[i];
     } else if (f < 4 + col) {
       v = (pe.on && f - 4 == col - 1) ? pend_y<T>((double)g[i], (double)pr[i])
-                                      : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + i];
+                                      : (double)wy[(int64_t)((head - 1 + (f - 4)) % m) * ldw + wrow(lmask, i)];
     } else {
       v = (pe.on && f - 4 - col == col - 1)
               ? pend_sx<T>((double)pd[i], (double)x[i], pe)
-              : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + i];
+              : (double)ws[(int64_t)((head - 1 + (f - 4 - col)) % m) * ldw + wrow(lmask, i)];
     }
     rec[q] = v;
   }
@@ -472,7 +472,7 @@ void launch_cauchy_gather_dyn(Queue &q, const uint32_t *idx, const uint64_t *key
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > 64) gr = 64;
   hipLaunchKernelGGL(cauchy_gather_dyn_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys,
-                     d_count, cap, row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, msg);
+                     d_count, cap, row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, msg, w.lmask);
   LB_LAUNCHED(q);
 }
 
@@ -485,7 +485,7 @@ void launch_cauchy_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, u
   int gr = (int)((total + BLOCK - 1) / BLOCK);
   if (gr > MAX_BLOCKS) gr = MAX_BLOCKS;
   hipLaunchKernelGGL(cauchy_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, cnt,
-                     row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, rec);
+                     row0, x, l, u, g, w.ws, w.wy, w.ld, w.m, head, col, pr, pd, pe, rec, w.lmask);
   LB_LAUNCHED(q);
 }
 

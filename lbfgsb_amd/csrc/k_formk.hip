@@ -504,7 +504,8 @@ __global__ __launch_bounds__(BLOCK) void formk_patch_kernel(const uint32_t *__re
                                                             const T *__restrict__ ws,
                                                             const T *__restrict__ wy, int64_t ldw,
                                                             int m, int head, int upcl,
-                                                            double *gpart) {
+                                                            double *gpart,
+                                                            const uint64_t *__restrict__ lmask) {
   constexpr int R = 64, RS = 2 * MAXM + 1;
   __shared__ double tile[R * RS];
   __shared__ double sgn[R];
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void formk_patch_kernel(const uint32_t *__re
       if (k < cnt) {
         const int64_t row = chg[k] & 0x7FFFFFFFu;
         const int jj = c < upcl ? c : c - upcl;
-        const int64_t off = (int64_t)((head - 1 + jj) % m) * ldw + row;
+        const int64_t off = (int64_t)((head - 1 + jj) % m) * ldw + wrow(lmask, row);
         v = c < upcl ? (double)wy[off] : (double)ws[off];
       }
       tile[rr * RS + c] = v;
@@ -578,7 +579,7 @@ void launch_formk_patch(Queue &q, const uint32_t *chg, uint32_t cnt, WStore<T> w
   if (gr < 1) gr = 1;
   if (gr > 256) gr = 256;
   hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cnt,
-                     (const uint32_t *)nullptr, w.ws, w.wy, w.ld, w.m, head, upcl, q.d_gpart);
+                     (const uint32_t *)nullptr, w.ws, w.wy, w.ld, w.m, head, upcl, q.d_gpart, w.lmask);
   LB_LAUNCHED(q);
   finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * upcl * upcl + upcl, 0, 0);
 }
@@ -590,7 +591,7 @@ void launch_formk_patch_dev(Queue &q, const uint32_t *chg, const uint32_t *cnt_p
                             int head, int upcl) {
   const int gr = (int)((cap + 63) / 64);
   hipLaunchKernelGGL(formk_patch_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, chg, cap, cnt_ptr, w.ws, w.wy,
-                     w.ld, w.m, head, upcl, q.d_gpart);
+                     w.ld, w.m, head, upcl, q.d_gpart, w.lmask);
   LB_LAUNCHED(q);
   finalize_from(q, q.d_gpart, GRAM_BLOCKS, gr, 2 * upcl * upcl + upcl + 1, 0, 0);
 }

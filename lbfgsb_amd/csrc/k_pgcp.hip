@@ -23,7 +23,8 @@ __global__ __launch_bounds__(BLOCK) void pgcp_gather_kernel(
     const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const T *__restrict__ g, const T *__restrict__ ws, const T *__restrict__ wy, int64_t ldw,
     int m, int head, int col, double theta, const T *pr, const T *pd, Pend pe, double *tt,
-    double *dd, double *a0, double *wb, double *uu, double *gi, int64_t row0) {
+    double *dd, double *a0, double *wb, double *uu, double *gi, int64_t row0,
+    const uint64_t *__restrict__ lmask) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += stride) {
     const int64_t i = idx[k];
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(BLOCK) void pgcp_gather_kernel(
     dd[k] = d;
     a0[k] = d * d - theta * d * z;
     for (int j = 0; j < col; ++j) {
-      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + i;
+      const int64_t off = (int64_t)((head - 1 + j) % m) * ldw + wrow(lmask, i);
       const bool pj = pe.on && j == col - 1;
       const double yv = pj ? pend_y<T>((double)g[i], (double)pr[i]) : (double)wy[off];
       const double sv = theta * (pj ? pend_sx<T>((double)pd[i], (double)x[i], pe) : (double)ws[off]);
@@ -292,7 +293,7 @@ void launch_pgcp_gather(Queue &q, const uint32_t *idx, const uint64_t *keys, int
   const int gr = grid_for(nb, 1);
   hipLaunchKernelGGL(pgcp_gather_kernel<T>, dim3(gr), dim3(BLOCK), 0, q.stream, idx, keys, nb, nbp, x,
                      l, u, g, w.ws, w.wy, w.ld, w.m, head, col, theta, pr, pd, pe, tt, dd, a0, wb, uu,
-                     gi, row0);
+                     gi, row0, w.lmask);
   LB_LAUNCHED(q);
 }
 void launch_pgcp_last(Queue &q, int64_t nb, int64_t nbp, int col2, const double *uu, double *uu_last) {

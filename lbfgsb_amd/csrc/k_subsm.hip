@@ -44,6 +44,8 @@ struct SubsmCtx {
 template <typename T, int MC, int W, bool NT, bool PSPEC>
 struct SubsmTrip {
   static constexpr int NL = 6 + 2 * MC;
+  static constexpr bool CW = false;
+  __device__ __forceinline__ int64_t wrow(int64_t i) const { return i; }  // where row i sits in a W column
   RawOf<T, W> rl, ru, rx, rg, ra[MC], rb[MC];
   RawOf<nb_t, W> rnb;
   RawOf<iw_t, W> riw;
@@ -70,14 +72,65 @@ struct SubsmTrip {
     land_cols<T, MC, W>(ra, rb);
   }
 };
-template <typename T, int MC, bool NT, bool PSPEC, bool PIPE>
+// One row under the tile-local free-row layout of W (for_tiles_cw): x, g, the bounds, iwhere and a pending
+// pair's vectors from row i, the stored columns from the row's slot if its layout bit is set -- only free rows
+// (iwhere <= 0) use them (cmprlb :1565-1583 and subsm :2770-2778 run over Index(1:nfree)); a free row whose bit is
+// clear fetches them in the kernel body (reload_cols).
+template <typename T, int MC, bool NT, bool PSPEC>
+struct SubsmTripCW : SubsmTrip<T, MC, 1, NT, PSPEC> {
+  static constexpr bool CW = true;
+  int64_t ws_;
+  bool lf_;
+  __device__ __forceinline__ int64_t wrow(int64_t) const { return ws_; }
+  template <bool NTL>
+  __device__ __forceinline__ void cols(const SubsmCtx<T> &c, int64_t i, bool lf) {
+    constexpr int B = (int)sizeof(T);
+    if constexpr (PSPEC) {
+#pragma unroll
+      for (int j = 0; j < MC - 1; ++j) {
+        const int64_t off = (int64_t)((c.head - 1 + j) % c.m) * c.ldw + ws_;
+        raw_issue<B, NTL>(this->ra[j], lf ? c.wy + off : c.zero);
+        raw_issue<B, NTL>(this->rb[j], lf ? c.ws + off : c.zero);
+      }
+      raw_issue<B, NTL>(this->ra[MC - 1], c.r + i);
+      raw_issue<B, NTL>(this->rb[MC - 1], c.pd + i);
+    } else {
+#pragma unroll
+      for (int j = 0; j < MC; ++j) {
+        const int64_t off = col_off(j, c.col, c.head, c.m, c.ldw) + ws_;
+        const bool live = j < c.col, pj = c.pe.on && j == c.col - 1;
+        const T *py = pj ? c.r + i : c.wy + off, *ps = pj ? c.pd + i : c.ws + off;
+        raw_issue<B, NTL>(this->ra[j], live && (lf || pj) ? py : c.zero);
+        raw_issue<B, NTL>(this->rb[j], live && (lf || pj) ? ps : c.zero);
+      }
+    }
+  }
+  __device__ __forceinline__ void issue_cw(const SubsmCtx<T> &c, int64_t i, int64_t slot, bool lf) {
+    constexpr int B = (int)sizeof(T);
+    ws_ = slot, lf_ = lf;
+    ri_ = i;
+    raw_issue<B, NT>(this->rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(this->ru, (c.ub & 2) ? c.u : c.u + i);
+    raw_issue<B, NT>(this->rx, c.xx + i);
+    raw_issue<B, NT>(this->rg, c.gg + i);
+    raw_issue<1, false>(this->rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
+    raw_issue<1, false>(this->riw, c.iwhere + i);
+    cols<NT>(c, i, lf);
+  }
+  int64_t ri_;
+  __device__ __forceinline__ void reload_cols(const SubsmCtx<T> &c) { cols<false>(c, ri_, true); }
+};
+// CW: W in the tile-local free-row layout `lmask` (fp64, MC <= 10; for_tiles_cw)
+template <typename T, int MC, bool NT, bool PSPEC, bool PIPE, bool CW = false>
 __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int64_t n, double tsum, T *__restrict__ zout, const T *pr, T *rout,
     const T *__restrict__ l, const T *__restrict__ u, const nb_t *__restrict__ nbd,
     const iw_t *__restrict__ iwhere, const T *xx, const T *__restrict__ gg,
     const T *__restrict__ ws, const T *__restrict__ wy, const T *__restrict__ zero, int64_t ldw,
     int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
-    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part, int pstride) {
+    T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part, int pstride,
+    const uint64_t *__restrict__ lmask = nullptr) {
+  static_assert(!CW || (!PIPE && sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10, one trip in flight");
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
@@ -87,8 +140,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
   const SubsmCtx<T> ctx{l, u, xx, gg, ws, wy, zero, pr, pd, nbd, iwhere, ldw, m, head, col, pe, ub};
   __shared__ T dict[16];
   dict_fill<T>(dict, l, u, ub);
-  for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(
-      n, ctx, [&](auto &tr, int64_t i, auto wt) {
+  auto body = [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double zv[W], lv[W], uv[W], xv[W], gv[W], a[MC][W], b[MC][W];
     int nb[W], iw[W];
@@ -99,17 +151,25 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     raw_geti<W>(tr.rnb, (const nb_t *)nullptr, nb);
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
     dict_apply<T, W>(dict, ub, nb, lv, uv);
+    if constexpr (std::remove_reference_t<decltype(tr)>::CW) {
+      // a free row whose layout bit is clear (it became free after the layout was made)
+      const bool miss = !tr.lf_ && iw[0] <= 0;
+      if (__ballot(miss) != 0ull) {
+        if (miss) tr.reload_cols(ctx);
+      }
+    }
     get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     fix_pending<T, MC, W, PSPEC>(col, pe, gv, xv, a, b);
     if (PSPEC || pe.on) {
       double yn[W], sn[W];
       newest_cols<MC, W, PSPEC>(col, a, b, yn, sn);
+      const int64_t iw_ = tr.wrow(i);  // (the committed pair goes to the row's slot of the layout)
       if (NT) {
-        stnt<W>(cwy + i, yn);
-        stnt<W>(cws + i, sn);
+        stnt<W>(cwy + iw_, yn);
+        stnt<W>(cws + iw_, sn);
       } else {
-        st<W>(cwy + i, yn);
-        st<W>(cws + i, sn);
+        st<W>(cwy + iw_, yn);
+        st<W>(cws + iw_, sn);
       }
     }
 #pragma unroll
@@ -177,7 +237,11 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
       // xout may alias xx (each row is read above before it is written here)
       if (xout) st<W>(xout + i, zv);
     }
-  });
+  };
+  if constexpr (CW)
+    for_tiles_cw<SubsmTripCW<T, MC, NT, PSPEC>>(n, ctx, lmask, body);
+  else
+    for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(n, ctx, body);
   block_reduce_store<4>(acc, 3, 1, 0, part, pstride);
 }
 template <typename T>
@@ -191,6 +255,35 @@ void launch_subsm_update(Queue &q, int64_t n, double tsum, T *zout, const T *pr,
   const bool spec = pe.on && col == maxc_for(col);
   double *part = q.part();
   const int pstride = MAX_BLOCKS;
+  if (w.lmask) {  // W in the tile-local free-row layout
+    bool done = false;
+    if constexpr (sizeof(T) == 8) {
+      if (col <= 10) {
+#define LB_SUBSM_CW(MCV, NTV, PSPECV)                                                                           \
+  {                                                                                                             \
+    gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&subsm_update_kernel<T, MCV, NTV, PSPECV, false, true>);   \
+    hipLaunchKernelGGL((subsm_update_kernel<T, MCV, NTV, PSPECV, false, true>), dim3(gr), dim3(BLOCK), 0,       \
+                       q.stream, n, tsum, zout, pr, rout, l, u, nbd, iwhere, xx, gg, w.ws, w.wy, w.zero, w.ld,   \
+                       w.m, head, col, theta, cf, wv, dvec, tvec, xout, do_stpmx, pe, pd, w.wy + slot,          \
+                       w.ws + slot, ub, part, pstride, w.lmask);                                                \
+  }
+        if (col <= 5) {
+          if (q.nt) { if (spec) LB_SUBSM_CW(5, true, true) else LB_SUBSM_CW(5, true, false) }
+          else { if (spec) LB_SUBSM_CW(5, false, true) else LB_SUBSM_CW(5, false, false) }
+        } else {
+          if (q.nt) { if (spec) LB_SUBSM_CW(10, true, true) else LB_SUBSM_CW(10, true, false) }
+          else { if (spec) LB_SUBSM_CW(10, false, true) else LB_SUBSM_CW(10, false, false) }
+        }
+#undef LB_SUBSM_CW
+        LB_LAUNCHED(q);
+        finalize_from(q, part, pstride, gr, 3, 1, 0);
+        done = true;
+      }
+    }
+    if (!done && q.launch_err == hipSuccess)
+      q.launch_err = hipErrorInvalidValue, q.launch_err_where = "subsm_update: compact W needs fp64, col <= 10";
+    return;
+  }
 #define LB_SUBSM(PSPECV)                                                                            \
   DISPATCH_MAXC_NT(col, q.nt, DISPATCH_PIPE(MC, {                                                   \
                      gr = grid_for_w(q, n, VecOf<T>::V,                                             \

@@ -102,6 +102,8 @@ struct UpdScanCtx {
 template <typename T, int MC, int W, bool NT>
 struct UpdScanTrip {
   static constexpr int NL = 8 + 2 * MC;
+  static constexpr bool CW = false;
+  __device__ __forceinline__ int64_t wrow(int64_t i) const { return i; }  // where row i sits in a W column
   RawOf<T, W> rx, rl, ru, rg, rr, rd, ra[MC], rb[MC];
   RawOf<nb_t, W> rnb;
   RawOf<iw_t, W> riw;
@@ -130,6 +132,46 @@ struct UpdScanTrip {
     land_cols<T, MC, W>(ra, rb);
   }
 };
+// One row under the tile-local free-row layout of W (for_tiles_cw, device_util.hpp): the n-vector operands from
+// row i, the W entries from the row's slot -- if its layout bit is set; the rows behind the layout-free ones are
+// multiplied by exact zeros in nearly every case (s = 0: they sat at a bound, -g masked: they stay there) and
+// read the zero buffer instead; the few that changed status since the layout was made fetch their entries in
+// the kernel body (reload_cols), so the sums never depend on the layout.
+template <typename T, int MC, bool NT>
+struct UpdScanTripCW : UpdScanTrip<T, MC, 1, NT> {
+  static constexpr bool CW = true;
+  int64_t ws_;
+  bool lf_;
+  __device__ __forceinline__ int64_t wrow(int64_t) const { return ws_; }
+  __device__ __forceinline__ void issue_cw(const UpdScanCtx<T> &c, int64_t i, int64_t slot, bool lf) {
+    constexpr int B = (int)sizeof(T);
+    ws_ = slot, lf_ = lf;
+    raw_issue<B, NT>(this->rx, c.x + i);
+    raw_issue<B, NT>(this->rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(this->ru, (c.ub & 2) ? c.u : c.u + i);
+    raw_issue<B, NT>(this->rg, c.g + i);
+    raw_issue<B, NT>(this->rr, c.r + i);
+    raw_issue<B, NT>(this->rd, c.d + i);
+    raw_issue<1, false>(this->rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
+    raw_issue<1, false>(this->riw, c.iwhere + i);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + slot;
+      const bool live = lf && j < c.nold;
+      raw_issue<B, NT>(this->ra[j], live ? c.wy + off : c.zero);
+      raw_issue<B, NT>(this->rb[j], live ? c.ws + off : c.zero);
+    }
+  }
+  __device__ __forceinline__ void reload_cols(const UpdScanCtx<T> &c) {
+    constexpr int B = (int)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + ws_;
+      raw_issue<B, false>(this->ra[j], j < c.nold ? c.wy + off : c.zero);
+      raw_issue<B, false>(this->rb[j], j < c.nold ? c.ws + off : c.zero);
+    }
+  }
+};
 // PAIR (see update_scan_kernel): the lanes 2p, 2p + 1 of a wave work on the 2 W rows [i0, i0 + 2 W) together.
 // Each lane owns W of the rows for everything a row needs once (x, g, bounds, the n-loop of cauchy), and HALF of
 // the columns over all 2 W rows: the even lane logical columns [0, MC/2), the odd lane [MC/2, MC) -- so a lane
@@ -144,6 +186,8 @@ template <typename T, int MC, int W, bool NT>
 struct UpdScanPairTrip {
   static constexpr int H = MC / 2;
   static constexpr int NL = 8 + 2 * H;
+  static constexpr bool CW = false;
+  __device__ __forceinline__ int64_t wrow(int64_t i) const { return i; }
   RawOf<T, W> rx, rl, ru, rg, rr, rd;
   RawOf<T, 2 * W> ra[H], rb[H];
   RawOf<nb_t, W> rnb;
@@ -211,14 +255,16 @@ struct UpdScanPairTrip {
 // scalars of the other lane come over by DPP -- which leaves room for the second trip in flight.
 // The caller passes a row count that is a multiple of 2 V (pairs are always complete) and runs the
 // plain instantiation on the few rows that remain.
-template <typename T, int MC, bool NT, bool PIPE, bool NEWROW, bool PAIR = false>
+// CW: W in the tile-local free-row layout `lmask` (fp64, MC <= 10; for_tiles_cw)
+template <typename T, int MC, bool NT, bool PIPE, bool NEWROW, bool PAIR = false, bool CW = false>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const nb_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
     const T *__restrict__ d, int dimpl, double stp, iw_t *iwhere, T *tbrk, T *ws, T *wy,
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
     int store_iw, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap, uint32_t *ccount,
-    int ub, double *part) {
+    int ub, double *part, const uint64_t *__restrict__ lmask = nullptr) {
+  static_assert(!CW || (!PAIR && !PIPE && sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10, one trip in flight");
   constexpr int NX = NEWROW ? 4 * MC + 4 : 0;  // extra sums
   constexpr int X = 4 * MC + 9;                // first extra slot
   constexpr int NA = 4 * MC + 11 + NX;
@@ -253,8 +299,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   dict_fill<T>(dict, l, u, ub);
   using TripV = std::conditional_t<PAIR, UpdScanPairTrip<T, MC, V, NT>, UpdScanTrip<T, MC, V, NT>>;
   using Trip1 = std::conditional_t<PAIR, UpdScanPairTrip<T, MC, 1, NT>, UpdScanTrip<T, MC, 1, NT>>;
-  for_rows_raw<TripV, Trip1, V, PIPE, 0>(
-      n, ctx, [&](auto &tr, int64_t i, auto wt) {
+  auto body = [&](auto &tr, int64_t i, auto wt) {
     constexpr int W = decltype(wt)::value;
     double xv[W], lv[W], uv[W], gv[W], rv[W], dv[W], tb[W], ng[W];
     int nb[W], iw[W];
@@ -338,10 +383,17 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         acc[X + 4 * MC + 3] = __builtin_fma(fr ? sst : 0.0, yst, acc[X + 4 * MC + 3]);
       }
     }
+    if constexpr (std::remove_reference_t<decltype(tr)>::CW) {
+      // a row whose W entries are needed (it moved, or it is free at this point) although its layout bit is clear
+      const bool miss = !tr.lf_ && (dv[0] != 0.0 || iw[0] <= 0);
+      if (__ballot(miss) != 0ull) {
+        if (miss) tr.reload_cols(ctx);
+      }
+    }
     auto row_stores = [&]() {
       if (store_pair) {  // else the pair stays pending (see Pend)
-        st<W>(ws + offn + i, dv);
-        st<W>(wy + offn + i, rv);
+        st<W>(ws + offn + tr.wrow(i), dv);
+        st<W>(wy + offn + tr.wrow(i), rv);
       }
       // iwhere settles after the first iterations: store only from waves that changed a row
       if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
@@ -440,7 +492,11 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
       }
     }
     if constexpr (!PAIR) row_stores();
-  });
+  };
+  if constexpr (CW)
+    for_tiles_cw<UpdScanTripCW<T, MC, NT>>(n, ctx, lmask, body);
+  else
+    for_rows_raw<TripV, Trip1, V, PIPE, 0>(n, ctx, body);
   if constexpr (PAIR) {
     // each lane holds the sums of its half of the columns: zeros for the other half, then the
     // ordinary fixed-order reduction over all lanes
@@ -539,6 +595,36 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
   }
   if (cand_hi >= 0.0) (void)hipMemsetAsync(ccount, 0, sizeof(uint32_t), q.stream);
   int gr = 0;
+  if (w.lmask) {  // W in the tile-local free-row layout
+    bool done = false;
+    if constexpr (sizeof(T) == 8) {
+      if (nold <= 10) {
+        const bool nrw = update_scan_extra(nold, newrow) != 0;
+#define LB_UPDSCAN_CW(MCV, NTV, NRV)                                                                   \
+  {                                                                                                    \
+    gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, false, NRV, false, true>); \
+    hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, false, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,     \
+                       q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
+                       w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
+                       q.part(), w.lmask);                                                                       \
+  }
+        if (nold <= 5) {
+          if (q.nt) { if (nrw) LB_UPDSCAN_CW(5, true, true) else LB_UPDSCAN_CW(5, true, false) }
+          else { if (nrw) LB_UPDSCAN_CW(5, false, true) else LB_UPDSCAN_CW(5, false, false) }
+        } else {
+          if (q.nt) { if (nrw) LB_UPDSCAN_CW(10, true, true) else LB_UPDSCAN_CW(10, true, false) }
+          else { if (nrw) LB_UPDSCAN_CW(10, false, true) else LB_UPDSCAN_CW(10, false, false) }
+        }
+#undef LB_UPDSCAN_CW
+        LB_LAUNCHED(q);
+        launch_finalize(q, gr, 4 * maxc_for(nold) + 9 + update_scan_extra(nold, newrow), 1, 1);
+        done = true;
+      }
+    }
+    if (!done && q.launch_err == hipSuccess)
+      q.launch_err = hipErrorInvalidValue, q.launch_err_where = "update_scan: compact W needs fp64, col - 1 <= 10";
+    return;
+  }
 #define LB_UPDSCAN(NEWROWV)                                                                          \
   DISPATCH_MAXC_NT(nold, q.nt, DISPATCH_PIPE(MC, {                                                   \
                      constexpr bool NRV = NEWROWV && MC <= 20;                                       \

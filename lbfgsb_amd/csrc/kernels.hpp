@@ -90,7 +90,14 @@ struct WStore {
   int64_t ld;
   int m;
   const T *zero;  // >= 64 bytes of zeros: what the unroll slots beyond the stored pairs read
+  // Tile-local free-row layout ("compact W"): nullptr = every column holds its rows in
+  // natural order.  Else one bit per row: inside each aligned tile of CW_TILE rows a column stores the rows whose
+  // bit is set first (ascending: the order of the reference's Index(1:nfree), src/lbfgsb.f90:2044-2054), the others
+  // behind them.  Only the kernels that take the layout into account may be handed a WStore with lmask set
+  // (update_scan, subsm_update, the record gathers and formk's patch); the solver's W() hands out natural order.
+  const uint64_t *lmask = nullptr;
 };
+constexpr int CW_TILE = 128;  // rows per layout tile = what one wave64 covers per trip with two rows per lane
 
 // iwhere (cauchy's per-variable status, -3..3) is kept as one byte per row on the device; the
 // reference's int32 layout exists only in export_state / import_state
@@ -429,6 +436,15 @@ void launch_dz_materialise(Queue &q, int64_t n, const T *x, const T *t, T *d, T 
 template <typename T>
 void launch_pair_commit(Queue &q, int64_t n, const T *g, const T *r, const T *d, Pend pe,
                         WStore<T> w, int head, int col);
+
+// ---- tile-local free-row layout of W (k_layout.hip) ----
+// Re-sort every live column (logical 0 .. col-1 from head) of Ws and Wy, tile by tile, from the layout `lmask`
+// describes to the one where the rows with iwhere <= 0 come first (iwhere == nullptr: natural order, every bit
+// set), and write the new bits.  Tiles whose bits do not change are skipped.  fp64 contexts only use it.
+template <typename T>
+void launch_w_relayout(Queue &q, int64_t n, const iw_t *iwhere, uint64_t *lmask, WStore<T> w, int head, int col);
+// every bit of rows [0, n) set, the rest clear (natural order)
+void launch_lmask_ones(Queue &q, int64_t n, uint64_t *lmask);
 
 // ---- m > 32: unfused tile primitives (k_wide.hip) -------------------------------------------------
 // out_i (+)= sum_j (Wy(i,j) a_j) / div + Ws(i,j) b_j over the tc <= 32 logical columns from `head`

@@ -105,6 +105,25 @@ __device__ __forceinline__ void ld_col(bool live, const T *p, const T *zero, dou
   ldx<W, NT>(live ? p : zero, o);
 }
 
+// ---- tile-local free-row layout of W (WStore::lmask) ----
+// where row `row` of a column sits: inside its aligned tile of CW_TILE = 128 rows the rows whose layout bit is set
+// come first, in ascending order, the others follow in ascending order (lmask == nullptr: natural order).
+// For the kernels that touch single rows (record gathers, formk's patch); the two passes over W derive the slots of
+// a whole tile from its two mask words (for_tiles_cw).
+__device__ __forceinline__ int64_t wrow(const uint64_t *__restrict__ lmask, int64_t row) {
+  if (!lmask) return row;
+  const int64_t tile = row >> 7;
+  const int r = (int)(row & 127);
+  const uint64_t m0 = lmask[2 * tile], m1 = lmask[2 * tile + 1];
+  const int c0 = __popcll(m0), tf = c0 + __popcll(m1);
+  const bool hi = r >= 64;
+  const uint64_t mw = hi ? m1 : m0;
+  const int b = r & 63;
+  const int before = (hi ? c0 : 0) + __popcll(mw & ((1ull << b) - 1ull));
+  const bool fr = (mw >> b) & 1ull;
+  return (tile << 7) + (fr ? before : tf + (r - before));
+}
+
 // ---- pending pair ----
 // Between matupd and the subspace pass of the same setulb call the newest pair (logical column
 // col-1) is not in W yet: update_scan_kernel only reduces, so that it stays a read-only pass

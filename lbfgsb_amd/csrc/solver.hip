@@ -151,7 +151,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (p) (void)hipFree(p);
       p = nullptr;
     };
-    F(ws), F(wy), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
+    F(ws), F(wy), F(lmask), F(zero_buf), F(z), F(r_own), F(d), F(t_own), F(xp), F(tbrk), F(iwhere), F(nbd8), F(index), F(indx2),
         F(scan_tmp), F(wasfree), F(prevfree), F(keys[0]), F(keys[1]), F(idx[0]), F(idx[1]),
         F(sort_tmp), F(d_count), F(d_chg), F(d_msg), F(d_msg2), F(d_msg_all), F(q.d_part), F(q.d_res), F(q.d_gpart),
         F(q.d_part_alt[0]), F(q.d_part_alt[1]), F(q.d_fin_count), F(d_fcount), F(wide_rows),
@@ -196,7 +196,7 @@ class Solver final : public lbfgsb_hip_ctx {
     }
     q.stream = stream;
     defer_on = (flags & LBFGSB_F_DEFER_LNSRCH) != 0;
-    ld = ((n + 31) / 32) * 32;
+    ld = ((n + lbk::CW_TILE - 1) / lbk::CW_TILE) * lbk::CW_TILE;  // (whole layout tiles)
     // streamed-once data: nontemporal loads unless W fits the 256 MiB Infinity Cache
     q.nt = (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
     const size_t wbytes = (size_t)ld * m * sizeof(T);
@@ -204,6 +204,12 @@ class Solver final : public lbfgsb_hip_ctx {
     HIPCHK(hipMalloc(&wy, wbytes));
     HIPCHK(hipMemsetAsync(ws, 0, wbytes, stream));
     HIPCHK(hipMemsetAsync(wy, 0, wbytes, stream));
+    {
+      const size_t nw = (size_t)((n + lbk::CW_TILE - 1) / lbk::CW_TILE) * (lbk::CW_TILE / 64) + 4;
+      HIPCHK(hipMalloc(&lmask, nw * sizeof(uint64_t)));
+      HIPCHK(hipMemsetAsync(lmask, 0, nw * sizeof(uint64_t), stream));
+      lbk::launch_lmask_ones(q, n, lmask);
+    }
     HIPCHK(hipMalloc(&ub_buf, 192));
     HIPCHK(hipMalloc(&zero_buf, 256));  // read by the unroll slots beyond the stored pairs
     HIPCHK(hipMemsetAsync(zero_buf, 0, 256, stream));
@@ -458,7 +464,59 @@ class Solver final : public lbfgsb_hip_ctx {
     return 0;
   }
 
-  lbk::WStore<T> W() const { return lbk::WStore<T>{ws, wy, ld, m, zero_buf}; }
+  // ---- tile-local free-row layout of W ("compact W": k_layout.hip; option "compact_w") ----
+  uint64_t *lmask = nullptr;   // one bit per row (ceil128(n) bits): set = the row sits in the front run of its tile
+  bool cw_on = false;          // option: the two passes over W run on the layout (fp64, m <= 10, no mirroring)
+  bool cw_packed = false;      // some bit is clear: the columns are NOT in natural order
+  int cw_policy = 1;           // option "compact_policy": 0 never pack, 1 automatic, 2 re-pack in every iteration
+  int64_t cw_stale = 0;        // rows (all ranks) that changed status since the layout was made
+  int64_t ncw_pack = 0, ncw_unpack = 0;
+  int cw_hold = 0;             // iterations the automatic policy waits after something asked for natural order
+  int live_head = 1, live_col = 0;  // the columns of W that hold pairs (what a re-sort has to move)
+  bool cw_eligible() const {
+    return cw_on && sizeof(T) == 8 && m <= 10 && !(flags & LBFGSB_F_MIRROR_INDEX);
+  }
+  lbk::WStore<T> Wraw() const { return lbk::WStore<T>{ws, wy, ld, m, zero_buf}; }
+  // natural row order -- for every kernel that does not know the layout (fallback passes, Gram, doors, export)
+  lbk::WStore<T> W() {
+    if (cw_packed) {
+      lbk::launch_w_relayout<T>(q, n, nullptr, lmask, Wraw(), live_head, live_col);
+      cw_packed = false, cw_stale = 0, ncw_unpack++;
+      cw_hold = std::min(64, std::max(4, 2 * cw_hold));  // (a path that keeps asking: back off)
+    }
+    return Wraw();
+  }
+  // the layout as it is, for the kernels that take it into account
+  lbk::WStore<T> Wc() {
+    lbk::WStore<T> w = Wraw();
+    if (cw_eligible()) w.lmask = lmask;
+    return w;
+  }
+  // Re-sort the tiles so that the rows that are free NOW (iwhere <= 0, after the walk) come first.  Called in front
+  // of the storing pass, where iwhere is final for the iteration.  Automatic policy: pack once a tenth of the rows
+  // is not free and the free set has settled (this iteration changed < 2 % of the rows), re-pack when 3 % of the
+  // rows have changed status since (each costs one read + write of the live columns; a stale layout costs only
+  // the bytes of the stale rows).  The sums do not depend on any of this (for_tiles_cw).
+  void cw_maybe_pack(int head, int col, int64_t changed_now) {
+    live_head = head, live_col = col;
+    if (!cw_eligible() || cw_policy == 0) return;
+    cw_stale += changed_now;
+    bool go = cw_policy == 2;
+    if (cw_policy == 1) {
+      if (cw_hold > 0) {
+        cw_hold--;
+        return;
+      }
+      const double nn = (double)nglob;
+      if (!cw_packed)
+        go = (double)(nglob - nfree_g) >= 0.10 * nn && (double)changed_now <= 0.02 * nn;
+      else
+        go = (double)cw_stale >= 0.03 * nn;
+    }
+    if (!go) return;
+    lbk::launch_w_relayout<T>(q, n, iwhere, lmask, Wraw(), head, col);
+    cw_packed = true, cw_stale = 0, ncw_pack++;
+  }
 
 #include "solver_provider.inl"  // the Cauchy point: breakpoint provider (windows, sorts, gathers, merges)
 #include "solver_walk.inl"      // ... its functional form, the exact host walk: cauchy()
@@ -560,6 +618,7 @@ class Solver final : public lbfgsb_hip_ctx {
     MAINLB_VIEW(L);
     info = 0, col = 0, head = 1, theta = 1.0, iupdat = 0, updatd = false;
     nrefresh++;
+    live_col = 0;
     pend.on = 0, pend.impl = 0;  // the memory is dropped, an uncommitted pair with it
   }
 
@@ -583,6 +642,7 @@ class Solver final : public lbfgsb_hip_ctx {
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
     ls.deferred = false, defer_live = false, wl.pending = false;
     nrefresh = 0;
+    live_head = 1, live_col = 0, cw_stale = 0, cw_hold = 0;  // (no pair is stored: any layout bits may stay)
     sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
     spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0, last_walk_nseg = 0;
     epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
@@ -784,7 +844,7 @@ class Solver final : public lbfgsb_hip_ctx {
         // (the MC = 20 instantiation with the new-row sums has no registers for the hand-over)
         const double chi = (nr_flag(c2) && lbk::maxc_for(c2 - 1) > 10) ? -1.0 : spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, lk(l), uk(u), nbk(), g, r, d_src(), d_impl ? 1 : 0, stp_here, iwhere,
-                                   (T *)nullptr, W(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
+                                   (T *)nullptr, Wc(), h2, c2, it2, 0, store_iw, nr_flag(c2), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count, ub_mask);
         q.res_off = 0;
         clk_end(1);
@@ -815,7 +875,7 @@ class Solver final : public lbfgsb_hip_ctx {
           fv_parity ^= 1;
           lbk::launch_sort_u32_small_dev(q, d_chg, d_fcount + (par & 1));
           q.res_off = SPEC_OFF + 4;
-          lbk::launch_formk_patch_dev<T>(q, d_chg, d_fcount + (par & 1), (uint32_t)lbk::small_sort_cap(), W(), h2,
+          lbk::launch_formk_patch_dev<T>(q, d_chg, d_fcount + (par & 1), (uint32_t)lbk::small_sort_cap(), Wc(), h2,
                                          sf_upcl);
           q.res_off = 0;
           spec_live_len = 4 + 2 * sf_upcl * sf_upcl + sf_upcl + 1;
@@ -1082,7 +1142,7 @@ class Solver final : public lbfgsb_hip_ctx {
           const uint32_t *cnt_ptr = d_fcount + ((fv_parity ^ 1) & 1);  // the counter freev_launch just used
           lbk::launch_sort_u32_small_dev(q, d_chg, cnt_ptr);
           q.res_off = 4;
-          lbk::launch_formk_patch_dev<T>(q, d_chg, cnt_ptr, (uint32_t)lbk::small_sort_cap(), W(), head, upcl);
+          lbk::launch_formk_patch_dev<T>(q, d_chg, cnt_ptr, (uint32_t)lbk::small_sort_cap(), Wc(), head, upcl);
           q.res_off = 0;
           neager = 2 * upcl * upcl + upcl + 1;
           eager.upcl = upcl, eager.head = head;
@@ -1215,9 +1275,12 @@ class Solver final : public lbfgsb_hip_ctx {
         const bool wclosed = wide_fused() && wide_closed_on && two_pass && closed_ok && !pre_valid &&
                              (!updatd || (nrpre.valid && nrpre.col == col)) && closed_form_safe(col);
         CHK(wide_subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, wclosed));
-      } else
+      } else {
+        // (iwhere is final for this iteration: the moment to re-sort the tiles of W, if the policy wants it)
+        cw_maybe_pack(head, col, nenter_g + (nglob + 1 - ileave_g));
         CHK(subspace(x, l, u, nbd, g, theta, col, head, cnstnd, iword, info, incr, updatd, iupdat,
                      pre_valid ? pre_res : nullptr, closed));
+      }
       pre_valid = false;
       if (info == -1 || info == -2) {  // formk failed inside the fused pass (:666-682)
         if (ipr >= 1)
@@ -1533,7 +1596,7 @@ class Solver final : public lbfgsb_hip_ctx {
         clk_begin(1);
         const double chi = (nr_flag(col) && lbk::maxc_for(col - 1) > 10) ? -1.0 : spec_hi(cnstnd);
         lbk::launch_update_scan<T>(q, n, x, lk(l), uk(u), nbk(), g, r, d_src(), d_impl ? 1 : 0, stp, iwhere,
-                                   (T *)nullptr, W(), head, col, itail, 0, 1, nr_flag(col), chi,
+                                   (T *)nullptr, Wc(), head, col, itail, 0, 1, nr_flag(col), chi,
                                    sp_keys, sp_idx, SPEC_CAP, sp_count, ub_mask);
         clk_end(1);
         spcand.valid = false;

@@ -122,7 +122,7 @@
     }
     HIPCHK(hipStreamSynchronize(stream));  // (M, p0, counts, map are host temporaries)
     if (!multi) {
-      lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], nb, nbp, x, l, u, g, W(), head, col, theta, r,
+      lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], nb, nbp, x, l, u, g, Wc(), head, col, theta, r,
                                  d_src(), pend, tt, dd, a0, wb, pp, (double *)nullptr, row0);
     } else {
       // own records in local order -> all ranks -> merged by (t, global index): the merge sort is
@@ -131,7 +131,7 @@
              *Lu = Lw + (size_t)col2 * lbp;
       HIPCHK(hipMemsetAsync(L, 0, (size_t)narr_l * lbp * sizeof(double), stream));
       if (cnt)
-        lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], (int64_t)cnt, lbp, x, l, u, g, W(), head, col, theta,
+        lbk::launch_pgcp_gather<T>(q, idx[1], keys[1], (int64_t)cnt, lbp, x, l, u, g, Wc(), head, col, theta,
                                    r, d_src(), pend, Lt, Ld, La, Lw, Lu, Lg, row0);
       CHK(allgather_big(L, G, (size_t)narr_l * lbp));
       const size_t slots = (size_t)nranks * lbp;

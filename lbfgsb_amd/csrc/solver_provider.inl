@@ -192,7 +192,7 @@
   // queue the gather of the candidates' records and their way to the host (all ranks') behind the
   // update pass; spec_land() completes it after the phase's one host sync
   int spec_queue(const T *x, const T *l, const T *u, const T *g, int head, int col, double stp) {
-    lbk::launch_cauchy_gather_dyn<T>(q, sp_idx, sp_keys, sp_count, SPEC_CAP, row0, x, l, u, g, W(), head,
+    lbk::launch_cauchy_gather_dyn<T>(q, sp_idx, sp_keys, sp_count, SPEC_CAP, row0, x, l, u, g, Wc(), head,
                                      col, r, d_src(), lbk::Pend{1, stp, d_impl ? 1 : 0}, sp_msg);
     const size_t cnt = 2 + (size_t)SPEC_CAP * (2 * col + 4);
     tail_copy_queued = true;  // (the fetch that follows must wait for THIS copy, not for the finalize in front of it)
@@ -296,7 +296,7 @@
     else
       lbk::launch_cauchy_window_fly<T>(q, n, row0, x, lk(l), uk(u), nbk(), g, iwhere, lo_t, lo_i, hi, keys[0],
                                        idx[0], SEL_CAP, d_count, ub_mask);
-    lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, W(),
+    lbk::launch_cauchy_gather_dyn<T>(q, idx[0], keys[0], d_count, FAST_CAP, row0, x, l, u, g, Wc(),
                                      head, col, r, d_src(), pend, d_msg);
     const size_t fcount = 2 + (size_t)FAST_CAP * recl;
     CHK(exchange(fcount));
@@ -507,7 +507,7 @@
     if (own) {
       HIPCHK(hipMemcpyAsync(keys[0], hk.data(), (size_t)own * 8, hipMemcpyHostToDevice, stream));
       HIPCHK(hipMemcpyAsync(idx[0], hi.data(), (size_t)own * 4, hipMemcpyHostToDevice, stream));
-      lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], own, row0, x, l, u, g, W(), head, col, r, d_src(), pend,
+      lbk::launch_cauchy_gather<T>(q, idx[0], keys[0], own, row0, x, l, u, g, Wc(), head, col, r, d_src(), pend,
                                    d_msg + 2);
     }
     CHK(put_header((double)own, (double)pv.hleft));
@@ -636,7 +636,7 @@
       h_msg_all[0] = (double)pf_len, h_msg_all[1] = (double)pf_rem;
     } else {
       lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + pv.pl, keys[pv.cur] + pv.pl, len, row0, x, l, u, g,
-                                   W(), head, col, r, d_src(), pend, d_msg + 2);
+                                   Wc(), head, col, r, d_src(), pend, d_msg + 2);
       CHK(put_header((double)len, (double)(pv.Cl - pv.pl - len)));
       if (comm && nranks > 1 && nranks <= 255 && !debug_walk) {
         bool merged = false;
@@ -652,7 +652,7 @@
     if (single && pv.Cl - pv.pl > len) {  // prefetch the chunk after this one
       const uint32_t npl = pv.pl + len;
       const uint32_t nlen = std::min<uint32_t>(pv.next_chunk, pv.Cl - npl);
-      lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + npl, keys[pv.cur] + npl, nlen, row0, x, l, u, g, W(),
+      lbk::launch_cauchy_gather<T>(q, idx[pv.cur] + npl, keys[pv.cur] + npl, nlen, row0, x, l, u, g, Wc(),
                                    head, col, r, d_src(), pend, d_msg2 + 2);
       HIPCHK(hipMemcpyAsync(h_msg_loc, d_msg2, (2 + (size_t)nlen * recl) * sizeof(double),
                             hipMemcpyDeviceToHost, stream));

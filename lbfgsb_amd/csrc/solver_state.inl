@@ -12,6 +12,7 @@
       return fail(LBFGSB_E_STATE, "export_state: the line-search set-up of this 'FG_LNSRCH' return is still "
                                   "deferred (LBFGSB_F_DEFER_LNSRCH): export at a NEW_X return");
     HIPCHK(hipSetDevice(device));
+    (void)W();  // (the reference's wa holds the columns in natural row order; the layout is re-made by the policy)
     T *wa = (T *)wa_;
     const int64_t mn = (int64_t)m * n, mm = (int64_t)m * m;
     HIPCHK(hipMemcpy2DAsync(wa, (size_t)n * sizeof(T), ws, (size_t)ld * sizeof(T),
@@ -91,6 +92,10 @@
     }
     const T *wa = (const T *)wa_;
     const int64_t mn = (int64_t)m * n;
+    // (the imported columns are in natural row order)
+    lbk::launch_lmask_ones(q, n, lmask);
+    cw_packed = false, cw_stale = 0, cw_hold = 0;
+    live_head = std::min(std::max(isave_user[26], 1), m), live_col = std::min(std::max(isave_user[27], 0), m);
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
                             (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), wa + mn, (size_t)n * sizeof(T),
@@ -181,13 +186,13 @@
       const bool lean = lean_on && !(flags & LBFGSB_F_MIRROR_INDEX);
       if (which == 3)  // with a pending pair: the variant every iteration after an update runs
         lbk::launch_subsm_update<T>(q, n, 0.5, lean ? (T *)nullptr : z, r_own, pp ? (T *)nullptr : r_own, lk(l),
-                                    uk(u), nbk(), iwhere, (const T *)x, (const T *)g, W(), head, col, 1.0, cf,
+                                    uk(u), nbk(), iwhere, (const T *)x, (const T *)g, Wc(), head, col, 1.0, cf,
                                     cf, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own,
                                     lean ? z : (T *)nullptr, 1, lbk::Pend{1, 0.5, lean ? 1 : 0},
                                     lean ? t_own : d, ub_mask);
       else             // as the evaluation of a trial point: reduces only
         lbk::launch_update_scan<T>(q, n, (const T *)x, lk(l), uk(u), nbk(), (const T *)g, r_own,
-                                   lean ? t_own : d, lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, W(), head, col,
+                                   lean ? t_own : d, lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, Wc(), head, col,
                                    (head + col - 2) % m + 1, 0, 0, nr_flag(col), -1.0, nullptr, nullptr, 0,
                                    nullptr, ub_mask);
     } else
@@ -196,6 +201,8 @@
   }
   int k_set_w(const void *hws, const void *hwy) override {
     HIPCHK(hipSetDevice(device));
+    lbk::launch_lmask_ones(q, n, lmask);  // (natural row order)
+    cw_packed = false, cw_stale = 0, live_head = 1, live_col = m;
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), hws, (size_t)n * sizeof(T),
                             (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpy2DAsync(wy, (size_t)ld * sizeof(T), hwy, (size_t)n * sizeof(T),
@@ -276,6 +283,9 @@
     closed_form = nclosed, three_pass = nthreepass;
   }
   int64_t freev_skipped() const override { return nfreev_skipped; }
+  void compact_stats(int64_t &packs, int64_t &unpacks, int &packed, int &eligible) const override {
+    packs = ncw_pack, unpacks = ncw_unpack, packed = cw_packed ? 1 : 0, eligible = cw_eligible() ? 1 : 0;
+  }
   // one host sync of the iteration, timed by itself: the 8 min(m, 32) + 15 partials of the widest phase through
   // fetch() -- with a communicator the all-gather over the ranks on the solver's stream, the copy into mapped host
   // memory and the poll for it; without one the publish + poll alone.  Every rank must call this (it IS a

@@ -49,7 +49,7 @@
       //  reproducible bit for bit; idx[1] is free here: the walk is over)
       const uint32_t nl = std::min<uint32_t>(chg_local, CHG_CAP);
       const uint32_t *lst = lbk::launch_sort_u32(q, sort_tmp, sort_tmp_bytes, d_chg, idx[1], nl);
-      lbk::launch_formk_patch<T>(q, lst, nl, W(), head, upcl);
+      lbk::launch_formk_patch<T>(q, lst, nl, Wc(), head, upcl);
       const int E = 2 * upcl * upcl + upcl;
       CHK(fetch(E, 0, 0));
       P.assign(h_res, h_res + E);
@@ -332,7 +332,7 @@
     seg(4);
     if (t_mid0 > 0.0) t_mid += now_s() - t_mid0, n_mid++, t_mid0 = 0.0;
     lbk::launch_subsm_update<T>(q, n, gcp.tsum, lean ? (T *)nullptr : z, r, pp ? (T *)nullptr : r, lk(l), uk(u),
-                                nbk(), iwhere, x, g, W(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
+                                nbk(), iwhere, x, g, Wc(), head, col, theta, cm_cf, cw, lean ? (T *)nullptr : d,
                                 pp ? (T *)nullptr : t, ls_unit_step ? xmut : nullptr, ls_do_stpmx ? 1 : 0,
                                 pend, d_src(), ub_mask);
     q.res_off = 0, q.part_sel = 0;
@@ -447,6 +447,13 @@
       dst = (int)v;
       return 0;
     };
+    if (k == "compact_w") {  // the two passes over W on the tile-local free-row layout (fp64, m <= 10)
+      const bool was = cw_on;
+      const int rc = flag(cw_on);
+      if (rc == 0 && was && !cw_on) (void)W();  // (back to natural order for the kernels that will run now)
+      return rc;
+    }
+    if (k == "compact_policy") return in_range(0, 2, cw_policy);
     if (k == "two_pass") return flag(two_pass);
     if (k == "two_pass_maxcol") return in_range(0, lbk::MAXM, two_pass_maxcol);
     if (k == "lean") return flag(lean_on);

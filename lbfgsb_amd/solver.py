@@ -458,6 +458,13 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_comm_info(self.h, C.byref(a), C.byref(b), C.byref(k)))
         return int(a.value), int(b.value), int(k.value)
 
+    def compact_stats(self):
+        """option compact_w: (packs, unpacks, packed now, eligible) -- lbfgsb_hip_compact_stats"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        c, d = C.c_int32(0), C.c_int32(0)
+        check(self.lib.lbfgsb_hip_compact_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
     def collective_time(self, reps: int = 1000):
         """(median_us, min_us) of one host sync of the iteration by itself (lbfgsb_hip_collective_time); a
         collective: every rank calls it"""
