@@ -383,7 +383,11 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     # col > 21 without the split update pass: three passes over W (the pair-shared cmprlb_wtv kernel at MC = 32)
     (5000, 40, 3000, 21, 33, "two_pass_maxcol=20"), (5100, 30, 3000, 21, 33, "pp,two_pass_maxcol=20"),
     (7000, 40, 1500, 1, 25, "spec_capture=1"), (7100, 40, 1500, 1, 25, "two_pass=0"),
-    (7200, 40, 1500, 1, 25, "lean=0")])
+    (7200, 40, 1500, 1, 25, "lean=0"),
+    # the two passes over W on the tile-local free-row layout (m <= 10), the tiles re-sorted in every iteration and
+    # un-sorted by every export of the replay harness; and packed by the automatic rule
+    (9200, 60, 400, 1, 11, "compact_w=1,compact_policy=2"), (9300, 40, 3000, 1, 11, "pp,compact_w=1,compact_policy=2"),
+    (9400, 40, 3000, 3, 11, "pp,compact_w=1")])
 def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi, switch):
     po = oracle_built
     words = switch.split(",") if switch else []

@@ -346,3 +346,21 @@ def test_stop_cpu_sharded(oracle_built, tmp_path, monkeypatch, world, mode, defe
     assert np.max(np.abs(np.array(res["x"]) - x)) <= 1e-9 * max(1.0, np.max(np.abs(x)))
     if defer:
         assert res["defer"][0] >= iters - 2
+
+
+@pytest.mark.parametrize("world,mode,variant", [(2, "gloo", True), (3, "fakerccl", "ckpt")])
+def test_sharded_runs_on_the_compact_layout(oracle_built, tmp_path, monkeypatch, world, mode, variant):
+    """option compact_w on every rank (each re-sorts the tiles of ITS rows in every iteration; the layout is local
+    and never changes a sum): the oracle's trajectory, also across a sharded checkpoint / resume"""
+    po = oracle_built
+    n, m, iters = 20011, 7, 12
+    if mode == "fakerccl":
+        monkeypatch.setenv("LBFGSB_RCCL_LIBRARY", _fake_rccl())
+    monkeypatch.setenv("LBFGSB_TEST_COMPACT", "1")
+    res = launch(world, mode, n, m, iters, variant, str(tmp_path / "out.json"))
+    rows, x = oracle_rows(po, n, m, iters, variant is True)
+    assert len(res["rows"]) == len(rows) == iters
+    for a, b in zip(res["rows"], rows):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-9)
+    assert np.max(np.abs(np.array(res["x"]) - x)) <= 1e-8 * max(1.0, np.max(np.abs(x)))
