@@ -71,6 +71,10 @@ def parse():
                          "pass's sums (one more host sync per iteration; what an ordinary caller gets)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="lbfgsb_hip_set_option on every context of the run (A/B measurements)")
+    ap.add_argument("--no-compact", action="store_true",
+                    help="contexts WITHOUT the option compact_w: the two passes over W stream every row of every "
+                         "column under the iwhere mask (what every round before 6 measured) instead of running on the "
+                         "tile-local free-row layout (fp64, m <= 10: DESIGN.md 4g)")
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs that count the HBM bytes of the passes over W "
@@ -146,6 +150,7 @@ def live_traffic(a, n_loc, timeout_s=240):
              "--no-live-traffic"]
     child += ["--real32"] if a.real32 else []
     child += ["--classic"] if a.classic else []
+    child += ["--no-compact"] if a.no_compact else []
     for kv in a.opt:
         child += ["--opt", kv]
     counted = {}
@@ -532,13 +537,18 @@ def timed_leg(run, steps, warm_min, need_full_memory=True):
                 step_ms_median=float(np.median(step_ms)), step_ms_max=float(np.max(step_ms)))
 
 
-def pass_bytes(col, rbytes, pp, lean=True, ub=0):
-    """algorithmic bytes per row of the two passes over W of an iteration (DESIGN.md section 4a);
-    ub = lbfgsb_hip_uniform_bounds mask: bound arrays that hold one value are not streamed"""
+def pass_bytes(col, rbytes, pp, lean=True, ub=0, wfrac=1.0):
+    """algorithmic bytes per row of the two passes over W of an iteration (DESIGN.md section 4a / 4g);
+    ub = lbfgsb_hip_uniform_bounds mask: bound arrays that hold one value are not streamed;
+    wfrac = the fraction of the rows whose W entries a pass needs: 1 for the kernels that stream every row under
+    a mask, nfree / n on the tile-local free-row layout (option compact_w) -- SURVEY.md 8(d)'s R = nf for the
+    stored columns (src/lbfgsb.f90:1565-1583, :2743-2778, :1756-1793 run over Index(1:nfree)); the n-vectors, the
+    pending pair's two vectors and the stores are per row either way"""
     bounds = (0 if ub & 1 else rbytes) + (0 if ub & 2 else rbytes) + (0 if ub & 4 else 1)   # l, u, nbd
-    upd = (2 * (col - 1) + 4) * rbytes + 1 + bounds   # 2(col-1) W columns + x, g, r, t + iwhere (1 B) + bounds
+    upd = 2 * (col - 1) * rbytes * wfrac + 4 * rbytes + 1 + bounds   # 2(col-1) W columns + x, g, r, t + iwhere + bounds
     n_st = (3 if pp else 5) if lean else (5 if pp else 7)
-    sub = (2 * col + 2 + n_st) * rbytes + 1 + bounds  # 2 col W (the pending pair from r, t) + x, g + bounds + stores
+    # 2 (col - 1) stored W columns + the pending pair from r, t + x, g + iwhere + bounds + stores
+    sub = 2 * (col - 1) * rbytes * wfrac + (4 + n_st) * rbytes + 1 + bounds
     return upd, sub, n_st
 
 
@@ -553,7 +563,9 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
         col = int(run.sol.isave[27])
         rb = 4 if real32 else 8
         ub = run.sol.uniform_bounds()
-        upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0, ub)
+        cst = run.sol.compact_stats()
+        wfrac = (int(run.sol.isave[37]) / float(n)) if cst[3] else 1.0   # rows whose W entries the passes need
+        upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0, ub, wfrac)
         passes = {}
         cw_b = (2 * max(col, 1) + 2) * rb + 1     # the third pass of col > 20: 2 col W columns + x, g + iwhere
         for key, bpr in (("update_scan", upd_b), ("subsm_update", sub_b), ("cmprlb_wtv", cw_b)):
@@ -577,6 +589,8 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
                 "host_algebra_us_between_passes": r["st1"]["host_gap_us"],
                 "host_segments_us": r["st1"]["host_segments_us"],
                 "uniform_bounds_mask": ub, "options": opts,
+                "compact_w": {"eligible": cst[3], "packs": cst[0], "unpacks": cst[1], "packed": cst[2],
+                              "w_rows_fraction": wfrac},
                 # (the arbitrary-box leg is another problem than the one the reference's rows belong to)
                 "parity_in_run": ({"rows_checked": 0, "ok": None, "why": "per-variable bounds: not the fixture's problem"}
                                   if arbitrary_box else parity_in_run(run.rows, n, m, real32, kind))}
@@ -754,6 +768,9 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=", 1)
         opts[k] = float(v)
+    if not a.no_compact:
+        # (contexts that cannot use it -- REAL32, m > 10 -- ignore the option: lbfgsb_hip_compact_stats says so)
+        opts.setdefault("compact_w", 1.0)
 
     n, m = a.n, a.m
     rbytes = 4 if a.real32 else 8
@@ -809,7 +826,10 @@ def main():
     tname = "float" if a.real32 else "double"
     lean = opts.get("lean", 1) != 0
     ub = sol.uniform_bounds()
-    upd_bpr, sub_bpr, n_st = pass_bytes(col, rbytes, run.pp, lean, ub)
+    cst = sol.compact_stats()          # (packs, unpacks, packed now, eligible)
+    wfrac = (nfree / float(n)) if cst[3] else 1.0
+    upd_bpr, sub_bpr, n_st = pass_bytes(col, rbytes, run.pp, lean, ub, wfrac)
+    upd_masked, sub_masked, _ = pass_bytes(col, rbytes, run.pp, lean, ub, 1.0)
     ubs = "_ub%d" % ub if ub else ""
 
     def static_traffic(fname, key, rows):
@@ -840,7 +860,8 @@ def main():
         ach = alg_bytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": static_traffic("w_pass_traffic.json", traffic_key, n_loc),
+                # (the counts on file are of the kernels that stream every row: not those of the compact layout)
+                "traffic": None if cst[3] else static_traffic("w_pass_traffic.json", traffic_key, n_loc),
                 "traffic_source": "profiles/w_pass_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "over this bench at n=1e8, in-iteration launches of this kernel: bytes per "
                                   "row x rows; not re-measured in this run)",
@@ -866,9 +887,12 @@ def main():
     rec_us = pass_record_or_none("update_scan", 4, "update_scan_kernel<%s, %d, %s> (run as the evaluation of the "
                          "first trial point: W'd of cauchy, S'y / S's of matupd, formk's new row%s)"
                          % (tname, mc, nts, "; col - 1 > 20: two launches of the <20> kernel over half of the columns "
-                            "each + a merge, timed together, priced at the bytes of ONE pass" if mc > 20 else ""),
+                            "each + a merge, timed together, priced at the bytes of ONE pass" if mc > 20 else
+                            ("; compact_w: lane pairs share the column sums, W entries of the free rows only"
+                             if cst[3] else "")),
                          upd_bpr, "none", "update_scan" + ubs)
-    entry = "ping-pong entry" if run.pp else "classic entry"
+    entry = ("ping-pong entry" if run.pp else "classic entry") + (
+        ", W in the tile-local free-row layout: option compact_w" if cst[3] else "")
     if run.pp:
         st_txt = "trial x + Ws/Wy column (3 of %d streams; t = x, r = g are a change of roles)" % (2 * col + 7)
     elif lean:
@@ -946,6 +970,10 @@ def main():
                    "time_to_30_iterations_s": tts30,
                    "iterations_run": run.rows[-1][0] if run.rows else 0,
                    "defer_lnsrch": not a.no_defer,
+                   # option compact_w: the passes over W on the tile-local free-row layout -- [on, tile re-sorts,
+                   # un-sorts, packed at the end, fraction of the rows whose W entries a pass needs (nfree / n)]
+                   "compact_w": [cst[3], cst[0], cst[1], cst[2], round(wfrac, 4)],
+                   "bytes_per_row_masked_design": [upd_masked, sub_masked],
                    "uniform_bounds_mask": ub,
                    "uniform_bounds": ("l, u few-valued: dictionary-coded in the nbd byte (bit 3)" if ub & 8 else
                                       "l, u, nbd hold one value each: read as constants (bits 0-2); leg ub_off streams them"

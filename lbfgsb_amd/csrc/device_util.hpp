@@ -260,6 +260,26 @@ __device__ __forceinline__ void raw_issue(RawReg<BYTES> &r, const void *p) {
     r.v = (int)*reinterpret_cast<const signed char *>(p);
   }
 }
+// one 8-byte (fp64) / 4-byte (fp32) half of a two-element register image (the tile-local layout of W: a row
+// group's two rows are not neighbours in memory)
+template <bool NT>
+__device__ __forceinline__ void raw_issue_half(RawReg<16> &r, int half, const void *p) {
+  i32x2_t v;
+  if constexpr (NT)
+    v = __builtin_nontemporal_load(reinterpret_cast<const i32x2_t *>(p));
+  else
+    v = *reinterpret_cast<const i32x2_t *>(p);
+  if (half == 0)
+    r.v.xy = v;
+  else
+    r.v.zw = v;
+}
+// ... from a wave-uniform base pointer + a per-lane byte offset < 2^32 (scalar base + 32-bit vector offset: no
+// 64-bit address arithmetic per lane and load)
+template <bool NT>
+__device__ __forceinline__ void raw_issue_half_at(RawReg<16> &r, int half, const void *base, uint32_t byte_off) {
+  raw_issue_half<NT>(r, half, (const char *)base + byte_off);
+}
 // end of a run of raw_issue calls: nothing is scheduled across this point, so the whole run is
 // issued before the first use of any of it (N documents how many LATER loads/stores may still be
 // in flight when this trip is consumed; the compiler derives the s_waitcnt itself)
@@ -428,51 +448,203 @@ __device__ __forceinline__ void for_rows_raw(int64_t n, const Ctx &c, F &&f) {
 // contiguous run of the column with each instruction -- measured against the lane-pair form, which reads every other
 // element of the run twice: store pass 3.50 -> 2.80 ms, update pass 2.23 -> 1.95 ms at half of the rows free,
 // n = 1e8; profiles/round6_a_compact_shapes_ab.txt).  The slots of the tile's rows follow from its two mask words,
-// which are wave-uniform and fetched one trip ahead; a row's n-vector operands (x, g, ...) stay in natural order
-// (8-byte loads, 512 contiguous bytes per wave instruction).
-// TripCW (a one-row trip) provides
-//   void issue_cw(const Ctx &, int64_t i, int64_t slot, bool lf)   start every load of row i: its n-vector operands,
-//                                                    and its W entries from `slot` if lf (else the zero buffer)
-//   void land()
-// f(trip, i, WTag<1>) consumes one landed row; it is called for the tile's rows in the order l, l + 64.  Rows that
-// need their W entries although their layout bit is clear (the status changed since the layout was made) fetch
-// them inside f (TripCW::reload_cols): the layout decides how many bytes move, never a result.
-template <typename TripCW, typename Ctx, typename F>
+// which are wave-uniform (scalar loads, fetched one issue ahead); a row's n-vector operands (x, g, ...) stay in
+// natural order (8-byte loads, 512 contiguous bytes per wave instruction).
+// A trip's two rows are handed to the kernel body as ONE row group of width 2 (the register images of a 16-byte
+// load, filled by two 8-byte loads), so the body is the one the natural-order kernels run; what differs is where a
+// row group's rows live (CwPairRows, kernels_common.hpp).  Rows that need their W entries although their layout bit is clear (the status
+// changed since the layout was made) fetch them inside the body (Trip::reload_cols): the layout decides how many
+// bytes move, never a result.  The last, partial tile (n not a multiple of 128) is taken row by row (Trip1).
+// a full tile as its wave sees it: everything here is wave-uniform (scalar registers); a lane derives its two rows
+// (tb + lane, tb + lane + 64), their in-tile slots and layout bits from it where it needs them
+struct CwTile {
+  int64_t tb;       // first row of the tile
+  uint64_t m0, m1;  // layout bits of its rows [0, 64), [64, 128)
+};
+// in-tile slots (0 .. 127) and layout bits of the rows lane, lane + 64
+__device__ __forceinline__ void cw_slots(const CwTile &t, int (&sl)[2], bool (&lf)[2]) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int c0 = __popcll(t.m0), tf = c0 + __popcll(t.m1);
+  // layout-free rows of the tile in front of this lane's two rows
+  const int b0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(t.m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)t.m0, 0u));
+  const int b1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(t.m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)t.m1, 0u));
+  lf[0] = (t.m0 >> lane) & 1ull, lf[1] = (t.m1 >> lane) & 1ull;
+  sl[0] = lf[0] ? b0 : tf + (lane - b0);
+  sl[1] = lf[1] ? b1 : tf + (64 + lane - b1);
+}
+__device__ __forceinline__ int64_t wave_uniform(int64_t v) {
+  return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
+}
+// Trip2: issue_cw(const Ctx &, const CwTile &), land();  f(trip, first row of the tile, WTag<2>)
+// Trip1: issue_cw(const Ctx &, int64_t i, int64_t slot, bool lf, int64_t tile_first), land();  f(trip, i, WTag<1>)
+template <typename Trip2, typename Trip1, bool PIPE, typename Ctx, typename F>
 __device__ __forceinline__ void for_tiles_cw(int64_t n, const Ctx &c, const uint64_t *__restrict__ lmask, F &&f) {
   const int lane = threadIdx.x & 63;
-  const int64_t ntile = (n + 127) >> 7;
+  const int64_t nfull = n >> 7;
   const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
-  int64_t tr = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   // (wave-uniform, which the compiler cannot see: scalar registers for the tile arithmetic and the mask words)
-  tr = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tr >> 32)) << 32) |
-                 (uint32_t)__builtin_amdgcn_readfirstlane((int)tr));
-  if (tr >= ntile) return;
-  uint64_t m0 = lmask[2 * tr], m1 = lmask[2 * tr + 1];
-  for (;;) {
-    const int64_t nx = tr + stride;
-    const bool more = nx < ntile;
-    const int64_t nxc = more ? nx : tr;
-    const uint64_t m0n = lmask[2 * nxc], m1n = lmask[2 * nxc + 1];  // the next trip's words
-    const int c0 = __popcll(m0), tf = c0 + __popcll(m1);
-    // layout-free rows of the tile in front of this lane's two rows
-    const int b0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-    const int b1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-    const bool f0 = (m0 >> lane) & 1ull, f1 = (m1 >> lane) & 1ull;
-    const int64_t tb = tr << 7;
-    const int64_t s0 = tb + (f0 ? b0 : tf + (lane - b0));
-    const int64_t s1 = tb + (f1 ? b1 : tf + (64 + lane - b1));
-    const int64_t i0 = tb + lane, i1 = i0 + 64;
-    const bool v0 = i0 < n, v1 = i1 < n;  // (false only in the last tile; such rows have no layout bit)
-    TripCW A, B;
-    A.issue_cw(c, v0 ? i0 : n - 1, s0, f0);
-    B.issue_cw(c, v1 ? i1 : n - 1, s1, f1);
+  const int64_t t0 = wave_uniform((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (t0 < nfull) {
+    const int64_t last = nfull - 1;
+    if constexpr (!PIPE) {
+      uint64_t m0 = lmask[2 * t0], m1 = lmask[2 * t0 + 1];
+      for (int64_t tr = t0;;) {
+        const int64_t nx = tr + stride;
+        const bool more = nx < nfull;
+        const int64_t nxc = more ? nx : tr;
+        const uint64_t m0n = lmask[2 * nxc], m1n = lmask[2 * nxc + 1];  // the next trip's words
+        Trip2 A;
+        A.issue_cw(c, CwTile{tr << 7, m0, m1});
+        raw_wait<0>();
+        A.land();
+        f(A, tr << 7, WTag<2>{});
+        if (!more) break;
+        tr = nx, m0 = m0n, m1 = m1n;
+      }
+    } else {
+      // two trips in flight per wave, as for_rows_raw's PIPE; the mask words of the trip that is issued next are
+      // always one issue ahead (scalar loads: they do not queue behind the vector loads in flight)
+      auto cl = [&](int64_t t) { return t < nfull ? t : last; };
+      Trip2 A, B;
+      int64_t b = t0 + stride, nxt = b + stride;
+      {
+        const int64_t bc = cl(b);
+        const uint64_t a0 = lmask[2 * t0], a1 = lmask[2 * t0 + 1], b0 = lmask[2 * bc], b1 = lmask[2 * bc + 1];
+        A.issue_cw(c, CwTile{t0 << 7, a0, a1});
+        B.issue_cw(c, CwTile{bc << 7, b0, b1});
+      }
+      int64_t qc = cl(nxt);
+      uint64_t q0 = lmask[2 * qc], q1 = lmask[2 * qc + 1];
+      raw_wait<Trip2::NL>();
+      A.land();
+      f(A, t0 << 7, WTag<2>{});
+      while (b < nfull) {  // B holds trip b; (q0, q1) are the words of trip nxt
+        A.issue_cw(c, CwTile{qc << 7, q0, q1});
+        const int64_t nn = nxt + stride, nnc = cl(nn);
+        const uint64_t r0 = lmask[2 * nnc], r1 = lmask[2 * nnc + 1];
+        raw_wait<Trip2::NL>();
+        B.land();
+        f(B, b << 7, WTag<2>{});
+        if (nxt >= nfull) break;
+        B.issue_cw(c, CwTile{nnc << 7, r0, r1});
+        const int64_t n2 = nn + stride;
+        const int64_t a_tile = nxt;
+        qc = cl(n2), q0 = lmask[2 * qc], q1 = lmask[2 * qc + 1];
+        raw_wait<Trip2::NL>();
+        A.land();
+        f(A, a_tile << 7, WTag<2>{});
+        b = nn, nxt = n2;
+      }
+      raw_wait<0>();  // the last prefetch is unused: land it before its registers are reused
+      A.land();
+      B.land();
+    }
+  }
+  // the partial tile behind the full ones, row by row
+  if ((n & 127) != 0 && t0 == nfull % stride) {
+    const CwTile t{nfull << 7, lmask[2 * nfull], lmask[2 * nfull + 1]};
+    int sl[2];
+    bool lf[2];
+    cw_slots(t, sl, lf);
+    const int64_t i0 = t.tb + lane, i1 = i0 + 64;
+    const bool v0 = i0 < n, v1 = i1 < n;  // (rows beyond n have no layout bit)
+    Trip1 A, B;
+    A.issue_cw(c, v0 ? i0 : n - 1, t.tb + sl[0], lf[0], t.tb);
+    B.issue_cw(c, v1 ? i1 : n - 1, t.tb + sl[1], lf[1], t.tb);
     raw_wait<0>();
     A.land();
     B.land();
     if (v0) f(A, i0, WTag<1>{});
     if (v1) f(B, i1, WTag<1>{});
-    if (!more) break;
-    tr = nx, m0 = m0n, m1 = m1n;
+  }
+}
+
+// The same layout walked in HALF tiles: a wave takes 64 rows per trip, lane l owns row l of the half -- one row per
+// lane and trip, as the natural-order kernels with many accumulators run (RowsPerAcc), so that TWO trips fit the
+// register file and the next trip's loads are in flight while this one is computed (PIPE, as for_rows_raw).  The
+// update pass with formk's new-row sums needs that: 95 fp64 accumulators leave one wave per SIMD, and its arithmetic
+// (1.4 ms of VALU time at n = 1e8) has to overlap the loads.
+// Trip1 as above; f(trip, i, WTag<1>).  The partial half behind the full ones is taken by itself.
+template <typename Trip1, bool PIPE, typename Ctx, typename F>
+__device__ __forceinline__ void for_halves_cw(int64_t n, const Ctx &c, const uint64_t *__restrict__ lmask, F &&f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nh = n >> 6;  // full halves
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t t0 = wave_uniform((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  // start every load of half h (its tile's mask words m0, m1 are wave-uniform)
+  auto issue = [&](Trip1 &A, int64_t h, uint64_t m0, uint64_t m1, int64_t row_limit) {
+    const bool hi = (h & 1) != 0;  // (uniform)
+    const int c0 = __popcll(m0), tf = c0 + __popcll(m1);
+    const uint64_t mw = hi ? m1 : m0;
+    const int b = (hi ? c0 : 0) +
+                  (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
+    const bool lf = (mw >> lane) & 1ull;
+    const int r = (hi ? 64 : 0) + lane;
+    const int64_t tb = (h >> 1) << 7;
+    int64_t i = (h << 6) + lane;
+    if (i >= row_limit) i = row_limit - 1;
+    A.issue_cw(c, i, tb + (lf ? b : tf + (r - b)), lf, tb);
+  };
+  if (t0 < nh) {
+    const int64_t last = nh - 1;
+    auto cl = [&](int64_t h) { return h < nh ? h : last; };
+    if constexpr (!PIPE) {
+      uint64_t m0 = lmask[(t0 >> 1) * 2], m1 = lmask[(t0 >> 1) * 2 + 1];
+      for (int64_t h = t0;;) {
+        const int64_t nx = h + stride, nxc = cl(nx);
+        const uint64_t m0n = lmask[(nxc >> 1) * 2], m1n = lmask[(nxc >> 1) * 2 + 1];  // the next trip's words
+        Trip1 A;
+        issue(A, h, m0, m1, n);
+        raw_wait<0>();
+        A.land();
+        f(A, (h << 6) + lane, WTag<1>{});
+        if (nx >= nh) break;
+        h = nx, m0 = m0n, m1 = m1n;
+      }
+    } else {
+      Trip1 A, B;
+      int64_t b = t0 + stride, nxt = b + stride;
+      {
+        const int64_t bc = cl(b);
+        const uint64_t a0 = lmask[(t0 >> 1) * 2], a1 = lmask[(t0 >> 1) * 2 + 1];
+        const uint64_t b0 = lmask[(bc >> 1) * 2], b1 = lmask[(bc >> 1) * 2 + 1];
+        issue(A, t0, a0, a1, n);
+        issue(B, bc, b0, b1, n);
+      }
+      int64_t qc = cl(nxt);
+      uint64_t q0 = lmask[(qc >> 1) * 2], q1 = lmask[(qc >> 1) * 2 + 1];
+      raw_wait<Trip1::NL>();
+      A.land();
+      f(A, (t0 << 6) + lane, WTag<1>{});
+      while (b < nh) {  // B holds half b; (q0, q1) are the words of half nxt's tile
+        issue(A, qc, q0, q1, n);
+        const int64_t nn = nxt + stride, nnc = cl(nn);
+        const uint64_t r0 = lmask[(nnc >> 1) * 2], r1 = lmask[(nnc >> 1) * 2 + 1];
+        raw_wait<Trip1::NL>();
+        B.land();
+        f(B, (b << 6) + lane, WTag<1>{});
+        if (nxt >= nh) break;
+        issue(B, nnc, r0, r1, n);
+        const int64_t n2 = nn + stride, a_half = nxt;
+        qc = cl(n2), q0 = lmask[(qc >> 1) * 2], q1 = lmask[(qc >> 1) * 2 + 1];
+        raw_wait<Trip1::NL>();
+        A.land();
+        f(A, (a_half << 6) + lane, WTag<1>{});
+        b = nn, nxt = n2;
+      }
+      raw_wait<0>();  // the last prefetch is unused: land it before its registers are reused
+      A.land();
+      B.land();
+    }
+  }
+  if ((n & 63) != 0 && t0 == nh % stride) {  // the partial half
+    const uint64_t m0 = lmask[(nh >> 1) * 2], m1 = lmask[(nh >> 1) * 2 + 1];
+    Trip1 A;
+    issue(A, nh, m0, m1, n);
+    raw_wait<0>();
+    A.land();
+    if ((nh << 6) + lane < n) f(A, (nh << 6) + lane, WTag<1>{});
   }
 }
 

@@ -41,84 +41,177 @@ struct SubsmCtx {
   Pend pe;
   int ub;  // uniform bounds: bit 0 l, bit 1 u, bit 2 nbd are 64-byte constant buffers (see UpdScanCtx)
 };
-template <typename T, int MC, int W, bool NT, bool PSPEC>
-struct SubsmTrip {
-  static constexpr int NL = 6 + 2 * MC;
-  static constexpr bool CW = false;
-  __device__ __forceinline__ int64_t wrow(int64_t i) const { return i; }  // where row i sits in a W column
+template <typename T, int MC, int W>
+struct SubsmRegs {  // the register images of one row group
   RawOf<T, W> rl, ru, rx, rg, ra[MC], rb[MC];
   RawOf<nb_t, W> rnb;
   RawOf<iw_t, W> riw;
+};
+template <typename T, int MC, int W, bool NT, bool PSPEC>
+struct SubsmTrip : SubsmRegs<T, MC, W>, NaturalRows<W> {
+  static constexpr int NL = 6 + 2 * MC;
   __device__ __forceinline__ void issue(const SubsmCtx<T> &c, int64_t i) {
     constexpr int B = (int)sizeof(T) * W;
-    raw_issue<B, NT>(rl, (c.ub & 1) ? c.l : c.l + i);
-    raw_issue<B, NT>(ru, (c.ub & 2) ? c.u : c.u + i);
-    raw_issue<B, NT>(rx, c.xx + i);
-    raw_issue<B, NT>(rg, c.gg + i);
-    raw_issue<W, false>(rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
-    raw_issue<W, false>(riw, c.iwhere + i);
+    raw_issue<B, NT>(this->rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(this->ru, (c.ub & 2) ? c.u : c.u + i);
+    raw_issue<B, NT>(this->rx, c.xx + i);
+    raw_issue<B, NT>(this->rg, c.gg + i);
+    raw_issue<W, false>(this->rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
+    raw_issue<W, false>(this->riw, c.iwhere + i);
     // a pending pair is read from (r, d) -- or (r, t) when d is implicit -- which this pass
     // overwrites further down
     issue_cols<T, MC, W, NT, PSPEC>(c.wy, c.ws, c.r, c.pd, c.zero, i, c.col, c.head, c.m, c.ldw, c.pe,
-                                    ra, rb);
+                                    this->ra, this->rb);
   }
-  __device__ __forceinline__ void land() {
-    raw_land(rl);
-    raw_land(ru);
-    raw_land(rx);
-    raw_land(rg);
-    raw_land(rnb);
-    raw_land(riw);
-    land_cols<T, MC, W>(ra, rb);
-  }
+  __device__ __forceinline__ void land() {}
 };
-// One row under the tile-local free-row layout of W (for_tiles_cw): x, g, the bounds, iwhere and a pending
-// pair's vectors from row i, the stored columns from the row's slot if its layout bit is set -- only free rows
-// (iwhere <= 0) use them (cmprlb :1565-1583 and subsm :2770-2778 run over Index(1:nfree)); a free row whose bit is
-// clear fetches them in the kernel body (reload_cols).
-template <typename T, int MC, bool NT, bool PSPEC>
-struct SubsmTripCW : SubsmTrip<T, MC, 1, NT, PSPEC> {
-  static constexpr bool CW = true;
-  int64_t ws_;
-  bool lf_;
-  __device__ __forceinline__ int64_t wrow(int64_t) const { return ws_; }
-  template <bool NTL>
-  __device__ __forceinline__ void cols(const SubsmCtx<T> &c, int64_t i, bool lf) {
-    constexpr int B = (int)sizeof(T);
-    if constexpr (PSPEC) {
-#pragma unroll
-      for (int j = 0; j < MC - 1; ++j) {
-        const int64_t off = (int64_t)((c.head - 1 + j) % c.m) * c.ldw + ws_;
-        raw_issue<B, NTL>(this->ra[j], lf ? c.wy + off : c.zero);
-        raw_issue<B, NTL>(this->rb[j], lf ? c.ws + off : c.zero);
-      }
-      raw_issue<B, NTL>(this->ra[MC - 1], c.r + i);
-      raw_issue<B, NTL>(this->rb[MC - 1], c.pd + i);
+// The tile-local free-row layout of W (for_tiles_cw): x, g, the bounds, iwhere and a pending pair's vectors from
+// the row itself, the stored columns from the row's slot if its layout bit is set -- only free rows (iwhere <= 0)
+// use them (cmprlb :1565-1583 and subsm :2770-2778 run over Index(1:nfree)); a free row whose bit is clear fetches
+// them in the kernel body (reload_cols).
+// where logical column j of a row comes from: the stored column at the row's slot, or -- the pending pair -- the
+// vectors it is formed from at the row itself
+template <typename T, int MC, bool PSPEC>
+__device__ __forceinline__ void subsm_cw_col(const SubsmCtx<T> &c, int j, int64_t i, int64_t slot, bool want,
+                                             const T *&py, const T *&ps) {
+  if constexpr (PSPEC) {
+    if (j == MC - 1) {
+      py = c.r + i, ps = c.pd + i;
     } else {
+      const int64_t off = (int64_t)((c.head - 1 + j) % c.m) * c.ldw + slot;
+      py = want ? c.wy + off : c.zero, ps = want ? c.ws + off : c.zero;
+    }
+  } else {
+    const int64_t off = col_off(j, c.col, c.head, c.m, c.ldw) + slot;
+    const bool live = j < c.col, pj = c.pe.on && j == c.col - 1;
+    py = !live ? c.zero : (pj ? c.r + i : (want ? c.wy + off : c.zero));
+    ps = !live ? c.zero : (pj ? c.pd + i : (want ? c.ws + off : c.zero));
+  }
+}
+template <typename T, int MC, bool NT, bool PSPEC>
+struct SubsmTripCW1 : SubsmRegs<T, MC, 1>, CwOneRow {
+  static constexpr int NL = 6 + 2 * MC;
+  template <bool NTL>
+  __device__ __forceinline__ void cols(const SubsmCtx<T> &c, int64_t srow) {
+    constexpr int B = (int)sizeof(T);
 #pragma unroll
-      for (int j = 0; j < MC; ++j) {
-        const int64_t off = col_off(j, c.col, c.head, c.m, c.ldw) + ws_;
-        const bool live = j < c.col, pj = c.pe.on && j == c.col - 1;
-        const T *py = pj ? c.r + i : c.wy + off, *ps = pj ? c.pd + i : c.ws + off;
-        raw_issue<B, NTL>(this->ra[j], live && (lf || pj) ? py : c.zero);
-        raw_issue<B, NTL>(this->rb[j], live && (lf || pj) ? ps : c.zero);
-      }
+    for (int j = 0; j < MC; ++j) {
+      const T *py, *ps;
+      subsm_cw_col<T, MC, PSPEC>(c, j, this->ri_, srow, true, py, ps);
+      raw_issue<B, NTL>(this->ra[j], py);
+      raw_issue<B, NTL>(this->rb[j], ps);
     }
   }
-  __device__ __forceinline__ void issue_cw(const SubsmCtx<T> &c, int64_t i, int64_t slot, bool lf) {
+  // (`first`: a row whose layout bit is clear reads the first entry of its tile, see UpdScanTripCW1)
+  __device__ __forceinline__ void issue_cw(const SubsmCtx<T> &c, int64_t i, int64_t slot, bool lf, int64_t first) {
     constexpr int B = (int)sizeof(T);
-    ws_ = slot, lf_ = lf;
-    ri_ = i;
+    this->ri_ = i, this->ws_ = slot, this->lf_ = lf;
     raw_issue<B, NT>(this->rl, (c.ub & 1) ? c.l : c.l + i);
     raw_issue<B, NT>(this->ru, (c.ub & 2) ? c.u : c.u + i);
     raw_issue<B, NT>(this->rx, c.xx + i);
     raw_issue<B, NT>(this->rg, c.gg + i);
     raw_issue<1, false>(this->rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
     raw_issue<1, false>(this->riw, c.iwhere + i);
-    cols<NT>(c, i, lf);
+    cols<NT>(c, lf ? slot : first);
   }
-  int64_t ri_;
-  __device__ __forceinline__ void reload_cols(const SubsmCtx<T> &c) { cols<false>(c, ri_, true); }
+  __device__ __forceinline__ void land() {}
+  __device__ __forceinline__ void reload_cols(const SubsmCtx<T> &c, const bool (&miss)[1]) {
+    // (into registers of their own, merged afterwards: see UpdScanTripCW1, k_update.hip)
+    constexpr int B = (int)sizeof(T);
+    RawOf<T, 1> ty[MC], ts[MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const T *py, *ps;
+      subsm_cw_col<T, MC, PSPEC>(c, j, this->ri_, miss[0] ? this->ws_ : this->ri_ & ~(int64_t)127, true, py, ps);
+      raw_issue<B, false>(ty[j], py);
+      raw_issue<B, false>(ts[j], ps);
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      this->ra[j].v = miss[0] ? ty[j].v : this->ra[j].v;
+      this->rb[j].v = miss[0] ? ts[j].v : this->rb[j].v;
+    }
+  }
+};
+// ... the rows lane, lane + 64 of a full tile as one row group of width 2 (see UpdScanTripCW2, k_update.hip)
+template <typename T, int MC, bool NT, bool PSPEC>
+struct SubsmTripCW2 : SubsmRegs<T, MC, 2>, CwPairRows {
+  static_assert(sizeof(T) == 8, "compact W: fp64");
+  static constexpr int NL = 2 * (6 + 2 * MC);
+  RawReg<1> nb_[2], iw_[2];
+  // the stored columns of row k from its slot (the pending pair's vectors are loaded with the row's other vectors)
+  template <bool NTL>
+  __device__ __forceinline__ void cols_row(const SubsmCtx<T> &c, int k, int64_t srow) {
+#pragma unroll
+    for (int j = 0; j < (PSPEC ? MC - 1 : MC); ++j) {
+      const int64_t off = (PSPEC ? (int64_t)((c.head - 1 + j) % c.m) * c.ldw : col_off(j, c.col, c.head, c.m, c.ldw)) + srow;
+      const bool stored = PSPEC || (j < c.col && !(c.pe.on && j == c.col - 1));
+      if (PSPEC || stored || j >= c.col) {  // (not the pending column: it has been loaded from r / pd)
+        raw_issue_half<NTL>(this->ra[j], k, stored ? c.wy + off : c.zero);
+        raw_issue_half<NTL>(this->rb[j], k, stored ? c.ws + off : c.zero);
+      }
+    }
+  }
+  __device__ __forceinline__ void issue_cw(const SubsmCtx<T> &c, const CwTile &t) {
+    this->tile_ = t;
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t i = t.tb + (lane + 64 * k);
+      raw_issue_half<NT>(this->rl, k, (c.ub & 1) ? c.l : c.l + i);
+      raw_issue_half<NT>(this->ru, k, (c.ub & 2) ? c.u : c.u + i);
+      raw_issue_half<NT>(this->rx, k, c.xx + i);
+      raw_issue_half<NT>(this->rg, k, c.gg + i);
+      raw_issue<1, false>(nb_[k], (c.ub & 4) ? c.nbd : c.nbd + i);
+      raw_issue<1, false>(iw_[k], c.iwhere + i);
+      // the pending pair's y and s are formed from r and d / t of EVERY row (the pass commits the whole column)
+      if constexpr (PSPEC) {
+        raw_issue_half<NT>(this->ra[MC - 1], k, c.r + i);
+        raw_issue_half<NT>(this->rb[MC - 1], k, c.pd + i);
+      } else if (c.pe.on) {
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+          if (j == c.col - 1) {
+            raw_issue_half<NT>(this->ra[j], k, c.r + i);
+            raw_issue_half<NT>(this->rb[j], k, c.pd + i);
+          }
+      }
+    }
+    int sl[2];
+    bool lf[2];
+    cw_slots(t, sl, lf);
+    // (a row whose layout bit is clear reads the tile's first entry: see UpdScanTripCW2)
+    cols_row<NT>(c, 0, t.tb + (lf[0] ? sl[0] : 0));
+    cols_row<NT>(c, 1, t.tb + (lf[1] ? sl[1] : 0));
+  }
+  __device__ __forceinline__ void land() {
+    raw_join_bytes(this->rnb, nb_[0], nb_[1]);
+    raw_join_bytes(this->riw, iw_[0], iw_[1]);
+  }
+  __device__ __forceinline__ void reload_cols(const SubsmCtx<T> &c, const bool (&miss)[2]) {
+    int sl[2];
+    bool lf[2];
+    cw_slots(this->tile_, sl, lf);
+    // (into registers of their own, merged afterwards: see UpdScanTripCW1, k_update.hip)
+    RawReg<8> ty[MC][2], ts[MC][2];
+#pragma unroll
+    for (int j = 0; j < (PSPEC ? MC - 1 : MC); ++j) {
+      const int64_t off = (PSPEC ? (int64_t)((c.head - 1 + j) % c.m) * c.ldw : col_off(j, c.col, c.head, c.m, c.ldw)) +
+                          this->tile_.tb;
+      const bool stored = PSPEC || (j < c.col && !(c.pe.on && j == c.col - 1));
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        raw_issue<8, false>(ty[j][k], stored ? c.wy + off + (miss[k] ? sl[k] : 0) : c.zero);
+        raw_issue<8, false>(ts[j][k], stored ? c.ws + off + (miss[k] ? sl[k] : 0) : c.zero);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < (PSPEC ? MC - 1 : MC); ++j) {
+      const bool stored = PSPEC || (j < c.col && !(c.pe.on && j == c.col - 1));
+      if (stored && miss[0]) this->ra[j].v.xy = ty[j][0].v, this->rb[j].v.xy = ts[j][0].v;
+      if (stored && miss[1]) this->ra[j].v.zw = ty[j][1].v, this->rb[j].v.zw = ts[j][1].v;
+    }
+  }
 };
 // CW: W in the tile-local free-row layout `lmask` (fp64, MC <= 10; for_tiles_cw)
 template <typename T, int MC, bool NT, bool PSPEC, bool PIPE, bool CW = false>
@@ -130,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
     T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part, int pstride,
     const uint64_t *__restrict__ lmask = nullptr) {
-  static_assert(!CW || (!PIPE && sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10, one trip in flight");
+  static_assert(!CW || (sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10");
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
@@ -153,24 +246,19 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     dict_apply<T, W>(dict, ub, nb, lv, uv);
     if constexpr (std::remove_reference_t<decltype(tr)>::CW) {
       // a free row whose layout bit is clear (it became free after the layout was made)
-      const bool miss = !tr.lf_ && iw[0] <= 0;
-      if (__ballot(miss) != 0ull) {
-        if (miss) tr.reload_cols(ctx);
-      }
+      bool miss[W], any = false;
+#pragma unroll
+      for (int k = 0; k < W; ++k) miss[k] = !tr.lf(k) && iw[k] <= 0, any = any || miss[k];
+      if (__ballot(any) != 0ull) tr.reload_cols(ctx, miss);
     }
     get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     fix_pending<T, MC, W, PSPEC>(col, pe, gv, xv, a, b);
     if (PSPEC || pe.on) {
       double yn[W], sn[W];
       newest_cols<MC, W, PSPEC>(col, a, b, yn, sn);
-      const int64_t iw_ = tr.wrow(i);  // (the committed pair goes to the row's slot of the layout)
-      if (NT) {
-        stnt<W>(cwy + iw_, yn);
-        stnt<W>(cws + iw_, sn);
-      } else {
-        st<W>(cwy + iw_, yn);
-        st<W>(cws + iw_, sn);
-      }
+      // (the committed pair goes to the rows' slots of the layout)
+      tr.template st_w<NT>(cwy, i, yn);
+      tr.template st_w<NT>(cws, i, sn);
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) zv[k] = xcp_row<T>(xv[k], gv[k], iw[k], lv[k], uv[k], tsum);
@@ -222,24 +310,16 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     // r = g are not copies but a change of roles -- the trial point goes to the OTHER x buffer
     // (xout; it holds t of the previous line search, which pd reads above, row by row before this
     // store), the caller's next gradient to the other g buffer: 3 store streams instead of 5.
-    if (NT) {
-      if (zout) stnt<W>(zout + i, zv);
-      if (dvec) stnt<W>(dvec + i, dv);
-      if (tvec) stnt<W>(tvec + i, xv);
-      if (rout) stnt<W>(rout + i, gv);
-      if (xout) stnt<W>(xout + i, zv);
-    } else {
-      if (zout) st<W>(zout + i, zv);
-      if (dvec) st<W>(dvec + i, dv);
-      if (tvec) st<W>(tvec + i, xv);  // t = x (:2235)
-      if (rout) st<W>(rout + i, gv);  // r = g (:2236)
-      // first trial point of the line search when its step is known to be 1: x = z (:2265);
-      // xout may alias xx (each row is read above before it is written here)
-      if (xout) st<W>(xout + i, zv);
-    }
+    if (zout) tr.template st_rows<NT>(zout, i, zv);
+    if (dvec) tr.template st_rows<NT>(dvec, i, dv);
+    if (tvec) tr.template st_rows<NT>(tvec, i, xv);  // t = x (:2235)
+    if (rout) tr.template st_rows<NT>(rout, i, gv);  // r = g (:2236)
+    // first trial point of the line search when its step is known to be 1: x = z (:2265);
+    // xout may alias xx (each row is read above before it is written here)
+    if (xout) tr.template st_rows<NT>(xout, i, zv);
   };
   if constexpr (CW)
-    for_tiles_cw<SubsmTripCW<T, MC, NT, PSPEC>>(n, ctx, lmask, body);
+    for_tiles_cw<SubsmTripCW2<T, MC, NT, PSPEC>, SubsmTripCW1<T, MC, NT, PSPEC>, PIPE>(n, ctx, lmask, body);
   else
     for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(n, ctx, body);
   block_reduce_store<4>(acc, 3, 1, 0, part, pstride);

@@ -78,9 +78,12 @@ void launch_update_pairs(Queue &q, int64_t n, const T *g, const T *r, const T *d
 // the operands are fp32 values (after a unit step; s = stp d is a double otherwise), their product is exact in
 // fp64, so the fused form is the SAME number with one instruction less -- and the fp32 m = 20 instantiation of
 // this pass is issue-bound, not HBM-bound.
-template <typename T>
+// FUSED (the pair-shared pass on the tile-local layout of W): that pass is bound by what it issues next to its loads,
+// and its sums are added up in an order of their own anyway (compared at 1e-10, like every reduction): one rounding
+// per term instead of two.
+template <typename T, bool FUSED = false>
 __device__ __forceinline__ double dot_term(double acc, double a, double b) {
-  if constexpr (sizeof(T) == 4)
+  if constexpr (sizeof(T) == 4 || FUSED)
     return __builtin_fma(a, b, acc);
   else
     return acc + a * b;
@@ -99,53 +102,46 @@ struct UpdScanCtx {
   // PAIR: column pointers per lane parity, in LDS (see UpdScanPairTrip)
   const unsigned long long *ptab;
 };
-template <typename T, int MC, int W, bool NT>
-struct UpdScanTrip {
-  static constexpr int NL = 8 + 2 * MC;
-  static constexpr bool CW = false;
-  __device__ __forceinline__ int64_t wrow(int64_t i) const { return i; }  // where row i sits in a W column
+template <typename T, int MC, int W>
+struct UpdScanRegs {  // the register images of one row group
   RawOf<T, W> rx, rl, ru, rg, rr, rd, ra[MC], rb[MC];
   RawOf<nb_t, W> rnb;
   RawOf<iw_t, W> riw;
+};
+template <typename T, int MC, int W, bool NT>
+struct UpdScanTrip : UpdScanRegs<T, MC, W>, NaturalRows<W> {
+  static constexpr int NL = 8 + 2 * MC;
   __device__ __forceinline__ void issue(const UpdScanCtx<T> &c, int64_t i) {
     constexpr int B = (int)sizeof(T) * W;
-    raw_issue<B, NT>(rx, c.x + i);
-    raw_issue<B, NT>(rl, (c.ub & 1) ? c.l : c.l + i);
-    raw_issue<B, NT>(ru, (c.ub & 2) ? c.u : c.u + i);
-    raw_issue<B, NT>(rg, c.g + i);
-    raw_issue<B, NT>(rr, c.r + i);
-    raw_issue<B, NT>(rd, c.d + i);
-    raw_issue<W, false>(rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
-    raw_issue<W, false>(riw, c.iwhere + i);
+    raw_issue<B, NT>(this->rx, c.x + i);
+    raw_issue<B, NT>(this->rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(this->ru, (c.ub & 2) ? c.u : c.u + i);
+    raw_issue<B, NT>(this->rg, c.g + i);
+    raw_issue<B, NT>(this->rr, c.r + i);
+    raw_issue<B, NT>(this->rd, c.d + i);
+    raw_issue<W, false>(this->rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
+    raw_issue<W, false>(this->riw, c.iwhere + i);
     issue_cols<T, MC, W, NT>(c.wy, c.ws, (const T *)nullptr, (const T *)nullptr, c.zero, i, c.nold, c.head,
-                             c.m, c.ldw, Pend{0, 1.0}, ra, rb);
+                             c.m, c.ldw, Pend{0, 1.0}, this->ra, this->rb);
   }
-  __device__ __forceinline__ void land() {
-    raw_land(rx);
-    raw_land(rl);
-    raw_land(ru);
-    raw_land(rg);
-    raw_land(rr);
-    raw_land(rd);
-    raw_land(rnb);
-    raw_land(riw);
-    land_cols<T, MC, W>(ra, rb);
-  }
+  __device__ __forceinline__ void land() {}
 };
-// One row under the tile-local free-row layout of W (for_tiles_cw, device_util.hpp): the n-vector operands from
-// row i, the W entries from the row's slot -- if its layout bit is set; the rows behind the layout-free ones are
-// multiplied by exact zeros in nearly every case (s = 0: they sat at a bound, -g masked: they stay there) and
-// read the zero buffer instead; the few that changed status since the layout was made fetch their entries in
-// the kernel body (reload_cols), so the sums never depend on the layout.
+// The tile-local free-row layout of W (for_tiles_cw, device_util.hpp).  The n-vector operands of a row come from the
+// row itself, its W entries from its slot -- if its layout bit is set; the rows behind the layout-free ones are
+// multiplied by exact zeros in nearly every case (s = 0: they sat at a bound, -g masked: they stay there) and read
+// the zero buffer instead; the few that changed status since the layout was made fetch their entries in the kernel
+// body (reload_cols), so the sums never depend on the layout.
+// ... one row of the partial tile:
 template <typename T, int MC, bool NT>
-struct UpdScanTripCW : UpdScanTrip<T, MC, 1, NT> {
-  static constexpr bool CW = true;
-  int64_t ws_;
-  bool lf_;
-  __device__ __forceinline__ int64_t wrow(int64_t) const { return ws_; }
-  __device__ __forceinline__ void issue_cw(const UpdScanCtx<T> &c, int64_t i, int64_t slot, bool lf) {
+struct UpdScanTripCW1 : UpdScanRegs<T, MC, 1>, CwOneRow {
+  static constexpr int NL = 8 + 2 * MC;
+  // `first`: the first slot of the row's tile.  A row whose layout bit is clear reads THAT entry instead of its own
+  // (a line the tile's front run brings in anyway): no predicate, no second address.  Its value is never used where
+  // it could matter -- such a row either contributes products with exact zeros (it did not move, it is not free: any
+  // finite factor will do) or is caught as `miss` in the kernel body and fetches its own entries (reload_cols).
+  __device__ __forceinline__ void issue_cw(const UpdScanCtx<T> &c, int64_t i, int64_t slot, bool lf, int64_t first) {
     constexpr int B = (int)sizeof(T);
-    ws_ = slot, lf_ = lf;
+    this->ri_ = i, this->ws_ = slot, this->lf_ = lf;
     raw_issue<B, NT>(this->rx, c.x + i);
     raw_issue<B, NT>(this->rl, (c.ub & 1) ? c.l : c.l + i);
     raw_issue<B, NT>(this->ru, (c.ub & 2) ? c.u : c.u + i);
@@ -154,21 +150,108 @@ struct UpdScanTripCW : UpdScanTrip<T, MC, 1, NT> {
     raw_issue<B, NT>(this->rd, c.d + i);
     raw_issue<1, false>(this->rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
     raw_issue<1, false>(this->riw, c.iwhere + i);
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + slot;
-      const bool live = lf && j < c.nold;
-      raw_issue<B, NT>(this->ra[j], live ? c.wy + off : c.zero);
-      raw_issue<B, NT>(this->rb[j], live ? c.ws + off : c.zero);
-    }
+    cols<false>(c, lf ? slot : first);  // (plain loads: see UpdScanPairTripCW)
   }
-  __device__ __forceinline__ void reload_cols(const UpdScanCtx<T> &c) {
+  template <bool NTL>
+  __device__ __forceinline__ void cols(const UpdScanCtx<T> &c, int64_t srow) {
     constexpr int B = (int)sizeof(T);
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
-      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + ws_;
-      raw_issue<B, false>(this->ra[j], j < c.nold ? c.wy + off : c.zero);
-      raw_issue<B, false>(this->rb[j], j < c.nold ? c.ws + off : c.zero);
+      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + srow;
+      const bool live = j < c.nold;
+      raw_issue<B, NTL>(this->ra[j], live ? c.wy + off : c.zero);
+      raw_issue<B, NTL>(this->rb[j], live ? c.ws + off : c.zero);
+    }
+  }
+  __device__ __forceinline__ void land() {}
+  // Into registers of their own, merged afterwards: a load INTO ra / rb inside this (rare) branch would make every
+  // later use of them wait for whatever is in flight -- with two trips in flight, the next trip's loads.
+  __device__ __forceinline__ void reload_cols(const UpdScanCtx<T> &c, const bool (&miss)[1]) {
+    constexpr int B = (int)sizeof(T);
+    RawOf<T, 1> ty[MC], ts[MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + (miss[0] ? this->ws_ : this->ri_ & ~(int64_t)127);
+      const bool live = j < c.nold;
+      raw_issue<B, false>(ty[j], live ? c.wy + off : c.zero);
+      raw_issue<B, false>(ts[j], live ? c.ws + off : c.zero);
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      this->ra[j].v = miss[0] ? ty[j].v : this->ra[j].v;
+      this->rb[j].v = miss[0] ? ts[j].v : this->rb[j].v;
+    }
+  }
+};
+// ... the rows lane, lane + 64 of a full tile as one row group of width 2 (fp64: two 8-byte halves per register
+// image).  Addresses are a wave-uniform base (array + first row of the tile) + a 32-bit lane offset.  Unroll slots
+// beyond the stored pairs read the zero buffer (>= a tile long).
+template <typename T, int MC, bool NT>
+struct UpdScanTripCW2 : UpdScanRegs<T, MC, 2>, CwPairRows {
+  static_assert(sizeof(T) == 8, "compact W: fp64");
+  static constexpr int NL = 2 * (8 + 2 * MC);
+  RawReg<1> nb_[2], iw_[2];
+  // (addresses as the natural-order kernels form them: ONE 64-bit row offset per lane and row, the uniform column
+  //  offset added per load -- 40 uniform column bases would not fit the scalar registers)
+  template <bool NTL>
+  __device__ __forceinline__ void cols_row(const UpdScanCtx<T> &c, int k, int64_t srow) {
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + srow;
+      const bool live = j < c.nold;
+      raw_issue_half<NTL>(this->ra[j], k, live ? c.wy + off : c.zero);
+      raw_issue_half<NTL>(this->rb[j], k, live ? c.ws + off : c.zero);
+    }
+  }
+  __device__ __forceinline__ void issue_cw(const UpdScanCtx<T> &c, const CwTile &t) {
+    this->tile_ = t;
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t i = t.tb + (lane + 64 * k);
+      raw_issue_half<NT>(this->rx, k, c.x + i);
+      raw_issue_half<NT>(this->rl, k, (c.ub & 1) ? c.l : c.l + i);
+      raw_issue_half<NT>(this->ru, k, (c.ub & 2) ? c.u : c.u + i);
+      raw_issue_half<NT>(this->rg, k, c.g + i);
+      raw_issue_half<NT>(this->rr, k, c.r + i);
+      raw_issue_half<NT>(this->rd, k, c.d + i);
+      raw_issue<1, false>(nb_[k], (c.ub & 4) ? c.nbd : c.nbd + i);
+      raw_issue<1, false>(iw_[k], c.iwhere + i);
+    }
+    int sl[2];
+    bool lf[2];
+    cw_slots(t, sl, lf);
+    // A row whose layout bit is clear reads the tile's FIRST entry instead of its own (a line the tile's front run
+    // brings in anyway): no predicate, no second address.  Its value is never used where it could matter -- such a
+    // row either contributes products with exact zeros (it did not move, it is not free: any finite factor will do)
+    // or is caught as `miss` in the kernel body and fetches its own entries (reload_cols).
+    cols_row<NT>(c, 0, t.tb + (lf[0] ? sl[0] : 0));
+    cols_row<NT>(c, 1, t.tb + (lf[1] ? sl[1] : 0));
+  }
+  __device__ __forceinline__ void land() {
+    raw_join_bytes(this->rnb, nb_[0], nb_[1]);
+    raw_join_bytes(this->riw, iw_[0], iw_[1]);
+  }
+  __device__ __forceinline__ void reload_cols(const UpdScanCtx<T> &c, const bool (&miss)[2]) {
+    int sl[2];
+    bool lf[2];
+    cw_slots(this->tile_, sl, lf);
+    // (into registers of their own, merged afterwards: see UpdScanTripCW1)
+    RawReg<8> ty[MC][2], ts[MC][2];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      const int64_t off = col_off(j, c.nold, c.head, c.m, c.ldw) + this->tile_.tb;
+      const bool live = j < c.nold;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        raw_issue<8, false>(ty[j][k], live ? c.wy + off + (miss[k] ? sl[k] : 0) : c.zero);
+        raw_issue<8, false>(ts[j][k], live ? c.ws + off + (miss[k] ? sl[k] : 0) : c.zero);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+      if (miss[0]) this->ra[j].v.xy = ty[j][0].v, this->rb[j].v.xy = ts[j][0].v;
+      if (miss[1]) this->ra[j].v.zw = ty[j][1].v, this->rb[j].v.zw = ts[j][1].v;
     }
   }
 };
@@ -183,11 +266,9 @@ struct UpdScanTripCW : UpdScanTrip<T, MC, 1, NT> {
 // registers next to everything else -- the compiler kept them in VGPR lanes and fetched them back with ~90
 // v_readlane per trip (profiles/round5_u_pair_isa.md).
 template <typename T, int MC, int W, bool NT>
-struct UpdScanPairTrip {
+struct UpdScanPairTrip : NaturalRows<W> {
   static constexpr int H = MC / 2;
   static constexpr int NL = 8 + 2 * H;
-  static constexpr bool CW = false;
-  __device__ __forceinline__ int64_t wrow(int64_t i) const { return i; }
   RawOf<T, W> rx, rl, ru, rg, rr, rd;
   RawOf<T, 2 * W> ra[H], rb[H];
   RawOf<nb_t, W> rnb;
@@ -239,6 +320,84 @@ struct UpdScanPairTrip {
     }
   }
 };
+// The same sharing under the tile-local free-row layout of W (one row per lane and trip: for_halves_cw).  A pair's
+// two rows are not neighbours in a column any more: each lane reads its columns at its OWN row's slot and at its
+// partner's (two 8-byte loads into the halves of the register image; the partner's slot comes over by DPP).
+// What the sharing buys here is the register file: 8 x MC/2 column sums per lane instead of 8 x MC leave the 95 fp64
+// accumulators of the MC = 10 new-row pass in VGPRs (no accumulator lives in the AGPR file, which cost two moves per
+// update), and the pass is bound by its loads again instead of by what it issues.
+// TIGHT: the caller guarantees nold == MC - 1 (every iteration once the memory is full): the one dead unroll slot
+// is the odd lane's last, known at compile time -- no select in front of the other loads.
+template <typename T, int MC, bool NT, bool TIGHT>
+struct UpdScanPairTripCW : CwOneRow {
+  static_assert(sizeof(T) == 8, "compact W: fp64");
+  static constexpr int H = MC / 2;
+  static constexpr int NL = 8 + 4 * H;
+  RawOf<T, 1> rx, rl, ru, rg, rr, rd;
+  RawOf<T, 2> ra[H], rb[H];
+  RawOf<nb_t, 1> rnb;
+  RawOf<iw_t, 1> riw;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) T *gptr;
+  __device__ __forceinline__ static int64_t xchg64(int64_t v) {
+    const unsigned lo = (unsigned)pair_xchg((int)v), hi = (unsigned)pair_xchg((int)(v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+  }
+  // this lane's columns (H pairs from the LDS table) for the pair's rows at a0 (even lane's row), a1 (odd lane's)
+  template <bool NTL, typename R>
+  __device__ __forceinline__ void cols(const UpdScanCtx<T> &c, int64_t a0, int64_t a1, R (&qa)[H], R (&qb)[H]) {
+    const bool hi = threadIdx.x & 1;
+    int tb = hi ? 2 * H : 0;
+    asm volatile("" : "+v"(tb));
+    u64x2 p[H];
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) p[jj] = *reinterpret_cast<const u64x2 *>(c.ptab + tb + 2 * jj);
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      const bool dead = TIGHT ? (jj == H - 1 && hi) : (hi && H + jj >= c.nold);  // (that table entry is the zero buffer)
+      raw_issue_half<NTL>(qa[jj], 0, (const T *)((gptr)p[jj].x + (dead ? 0 : a0)));
+      raw_issue_half<NTL>(qa[jj], 1, (const T *)((gptr)p[jj].x + (dead ? 0 : a1)));
+      raw_issue_half<NTL>(qb[jj], 0, (const T *)((gptr)p[jj].y + (dead ? 0 : a0)));
+      raw_issue_half<NTL>(qb[jj], 1, (const T *)((gptr)p[jj].y + (dead ? 0 : a1)));
+    }
+  }
+  __device__ __forceinline__ void issue_cw(const UpdScanCtx<T> &c, int64_t i, int64_t slot, bool lf, int64_t first) {
+    constexpr int B = (int)sizeof(T);
+    this->ri_ = i, this->ws_ = slot, this->lf_ = lf;
+    raw_issue<B, NT>(rx, c.x + i);
+    raw_issue<B, NT>(rl, (c.ub & 1) ? c.l : c.l + i);
+    raw_issue<B, NT>(ru, (c.ub & 2) ? c.u : c.u + i);
+    raw_issue<B, NT>(rg, c.g + i);
+    raw_issue<B, NT>(rr, c.r + i);
+    raw_issue<B, NT>(rd, c.d + i);
+    raw_issue<1, false>(rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
+    raw_issue<1, false>(riw, c.iwhere + i);
+    // (a row whose layout bit is clear reads the first entry of its tile: see UpdScanTripCW1)
+    const int64_t mine = lf ? slot : first, other = xchg64(mine);
+    const bool hi = threadIdx.x & 1;
+    // (plain loads for the W entries, whatever NT says for the row vectors: the line in which this half's run of a
+    //  column ends is the one the other half's run begins in -- read by another wave at about the same time, and
+    //  a nontemporal line is fetched from HBM for each of them: 2.58 -> 2.39 ms at n = 1e8)
+    cols<false>(c, hi ? other : mine, hi ? mine : other, ra, rb);
+  }
+  __device__ __forceinline__ void land() {}
+  // miss[0]: THIS lane's row needs its own entries.  Both lanes of a pair fetch their columns of that row (into
+  // registers of their own, merged afterwards: see UpdScanTripCW1).
+  __device__ __forceinline__ void reload_cols(const UpdScanCtx<T> &c, const bool (&miss)[1]) {
+    const bool hi = threadIdx.x & 1;
+    const bool pm = pair_xchg((int)miss[0]) != 0;  // the partner's row
+    const int64_t first = this->ri_ & ~(int64_t)127;
+    const int64_t mine = (miss[0] || this->lf_) ? this->ws_ : first, other = xchg64(mine);
+    const bool m0 = hi ? pm : miss[0], m1 = hi ? miss[0] : pm;
+    RawOf<T, 2> ta[H], tb2[H];
+    cols<false>(c, hi ? other : mine, hi ? mine : other, ta, tb2);
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      if (m0) ra[jj].v.xy = ta[jj].v.xy, rb[jj].v.xy = tb2[jj].v.xy;
+      if (m1) ra[jj].v.zw = ta[jj].v.zw, rb[jj].v.zw = tb2[jj].v.zw;
+    }
+  }
+};
 // NEWROW: the pass also yields the new row/column of formk's WN1 (:1756-1793) for the pair being
 // formed here -- with the free/active split of the rows as cauchy's n-loop leaves it, i.e.
 // BEFORE the breakpoint walk (the host corrects the sums for the few rows the walk fixes, from
@@ -256,7 +415,7 @@ struct UpdScanPairTrip {
 // The caller passes a row count that is a multiple of 2 V (pairs are always complete) and runs the
 // plain instantiation on the few rows that remain.
 // CW: W in the tile-local free-row layout `lmask` (fp64, MC <= 10; for_tiles_cw)
-template <typename T, int MC, bool NT, bool PIPE, bool NEWROW, bool PAIR = false, bool CW = false>
+template <typename T, int MC, bool NT, bool PIPE, bool NEWROW, bool PAIR = false, bool CW = false, bool TIGHT = false>
 __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     int64_t n, const T *__restrict__ x, const T *__restrict__ l, const T *__restrict__ u,
     const nb_t *__restrict__ nbd, const T *__restrict__ g, const T *__restrict__ r,
@@ -264,14 +423,14 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
     int store_iw, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap, uint32_t *ccount,
     int ub, double *part, const uint64_t *__restrict__ lmask = nullptr) {
-  static_assert(!CW || (!PAIR && !PIPE && sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10, one trip in flight");
+  static_assert(!CW || (sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10");
   constexpr int NX = NEWROW ? 4 * MC + 4 : 0;  // extra sums
   constexpr int X = 4 * MC + 9;                // first extra slot
   constexpr int NA = 4 * MC + 11 + NX;
   constexpr int IMIN = X + NX, IMAX = X + NX + 1;  // bkmin, |proj g|
   // (fp32, MC = 10 with the new-row sums: 4 rows per lane after all -- the 16-byte loads are worth
   //  more than the second wave the 512 registers cost: 1.88 -> 1.65 ms at n = 1e8)
-  constexpr int V = (sizeof(T) == 4 && MC == 10 && NEWROW) ? 4 : RowsPerAcc<T, MC, NA>::V;
+  constexpr int V = CW ? 1 : ((sizeof(T) == 4 && MC == 10 && NEWROW) ? 4 : RowsPerAcc<T, MC, NA>::V);
   static_assert(!PAIR || (NEWROW && MC % 2 == 0), "PAIR: the new-row instantiation, even MC");
   constexpr int H = MC / 2;
   double acc[NA];
@@ -385,19 +544,19 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     }
     if constexpr (std::remove_reference_t<decltype(tr)>::CW) {
       // a row whose W entries are needed (it moved, or it is free at this point) although its layout bit is clear
-      const bool miss = !tr.lf_ && (dv[0] != 0.0 || iw[0] <= 0);
-      if (__ballot(miss) != 0ull) {
-        if (miss) tr.reload_cols(ctx);
-      }
+      bool miss[W], any = false;
+#pragma unroll
+      for (int k = 0; k < W; ++k) miss[k] = !tr.lf(k) && (dv[k] != 0.0 || iw[k] <= 0), any = any || miss[k];
+      if (__ballot(any) != 0ull) tr.reload_cols(ctx, miss);
     }
     auto row_stores = [&]() {
       if (store_pair) {  // else the pair stays pending (see Pend)
-        st<W>(ws + offn + tr.wrow(i), dv);
-        st<W>(wy + offn + tr.wrow(i), rv);
+        tr.template st_w<false>(ws + offn, i, dv);
+        tr.template st_w<false>(wy + offn, i, rv);
       }
       // iwhere settles after the first iterations: store only from waves that changed a row
-      if (store_iw && __ballot(iw_changed) != 0ull) sti<W>(iwhere + i, iw);
-      if (tbrk) st<W>(tbrk + i, tb);  // nullptr: the walk recomputes the times it needs
+      if (store_iw && __ballot(iw_changed) != 0ull) tr.sti_rows(iwhere, i, iw);
+      if (tbrk) tr.template st_rows<false>(tbrk, i, tb);  // nullptr: the walk recomputes the times it needs
     };
     // PAIR: in front of the column sums, so that nothing of the row part stays live across them (404 bytes
     // of scratch otherwise); the other instantiations hand breakpoints over below and keep them at the end
@@ -423,10 +582,10 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
         raw_get_col<2 * W, false>(tr.rb[jj], (const T *)nullptr, bj);
 #pragma unroll
         for (int k = 0; k < 2 * W; ++k) {
-          accp[0][jj] = dot_term<T>(accp[0][jj], qd[k], aj[k]);
-          accp[1][jj] = dot_term<T>(accp[1][jj], bj[k], qd[k]);
-          accp[2][jj] = dot_term<T>(accp[2][jj], aj[k], qn[k]);
-          accp[3][jj] = dot_term<T>(accp[3][jj], bj[k], qn[k]);
+          accp[0][jj] = dot_term<T, CW>(accp[0][jj], qd[k], aj[k]);
+          accp[1][jj] = dot_term<T, CW>(accp[1][jj], bj[k], qd[k]);
+          accp[2][jj] = dot_term<T, CW>(accp[2][jj], aj[k], qn[k]);
+          accp[3][jj] = dot_term<T, CW>(accp[3][jj], bj[k], qn[k]);
           accp[4][jj] = __builtin_fma(qy[k], aj[k], accp[4][jj]);
           accp[5][jj] = __builtin_fma(qs[k], bj[k], accp[5][jj]);
           accp[6][jj] = __builtin_fma(qs[k], aj[k], accp[6][jj]);
@@ -485,7 +644,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
             const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             if (pos < ccap) {
               ckeys[pos] = key_of((double)(T)tb[k]);
-              cidx[pos] = (uint32_t)(i + k);
+              cidx[pos] = (uint32_t)tr.row(i, k);
             }
           }
         }
@@ -493,8 +652,12 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     }
     if constexpr (!PAIR) row_stores();
   };
-  if constexpr (CW)
-    for_tiles_cw<UpdScanTripCW<T, MC, NT>>(n, ctx, lmask, body);
+  if constexpr (CW && PAIR)  // (the caller passes whole tiles)
+    for_halves_cw<UpdScanPairTripCW<T, MC, NT, TIGHT>, PIPE>(n, ctx, lmask, body);
+  else if constexpr (CW && NEWROW)  // (one row per lane and trip, two trips in flight: see for_halves_cw)
+    for_halves_cw<UpdScanTripCW1<T, MC, NT>, PIPE>(n, ctx, lmask, body);
+  else if constexpr (CW)
+    for_tiles_cw<UpdScanTripCW2<T, MC, NT>, UpdScanTripCW1<T, MC, NT>, PIPE>(n, ctx, lmask, body);
   else
     for_rows_raw<TripV, Trip1, V, PIPE, 0>(n, ctx, body);
   if constexpr (PAIR) {
@@ -602,13 +765,57 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
         const bool nrw = update_scan_extra(nold, newrow) != 0;
 #define LB_UPDSCAN_CW(MCV, NTV, NRV)                                                                   \
   {                                                                                                    \
-    gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, false, NRV, false, true>); \
-    hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, false, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,     \
-                       q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
-                       w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
-                       q.part(), w.lmask);                                                                       \
+    if (q.tune.pipe_cw && NRV) { /* (two trips in flight: the new-row instantiations, one wave per SIMD) */        \
+      gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, NRV, NRV, false, true>);   \
+      hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, NRV, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,       \
+                         q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
+                         w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
+                         q.part(), w.lmask);                                                                       \
+    } else {                                                                                                       \
+      gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, false, NRV, false, true>); \
+      hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, false, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,     \
+                         q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
+                         w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
+                         q.part(), w.lmask);                                                                       \
+    }                                                                                                              \
   }
-        if (nold <= 5) {
+        int nblocks = -1;
+        if (nold > 5 && nrw && q.tune.pair_cw && n >= CW_TILE) {
+          // MC = 10 with the new-row sums: lane pairs share the per-column accumulators (UpdScanPairTripCW) over
+          // the whole tiles; the rows behind them (< one tile) go to the plain instantiation as one more workgroup,
+          // whose partials land in column `gr` of the partial-sum matrix -- as the natural-order MC = 20 pass does
+          const int64_t n_main = n / CW_TILE * CW_TILE, n_rest = n - n_main;
+#define LB_PAIR_CW(NTV, PIPEV, TIGHTV)                                                                            \
+  {                                                                                                               \
+    gr = grid_for_w(q, n_main, VecOf<T>::V,                                                                       \
+                    (const void *)&update_scan_kernel<T, 10, NTV, PIPEV, true, true, true, TIGHTV>);              \
+    hipLaunchKernelGGL((update_scan_kernel<T, 10, NTV, PIPEV, true, true, true, TIGHTV>), dim3(gr), dim3(BLOCK), 0, \
+                       q.stream, n_main, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero,       \
+                       w.ld, w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,   \
+                       q.part(), w.lmask);                                                                          \
+  }
+          // (two trips in flight lost against two waves per SIMD: 3.2 vs 2.6 ms at n = 1e8 -- option "pipe_cw" = 2)
+          const bool pv = q.tune.pipe_cw >= 2;
+          if (nold == 9) {
+            if (q.nt) { if (pv) LB_PAIR_CW(true, true, true) else LB_PAIR_CW(true, false, true) }
+            else { if (pv) LB_PAIR_CW(false, true, true) else LB_PAIR_CW(false, false, true) }
+          } else {
+            if (q.nt) LB_PAIR_CW(true, false, false) else LB_PAIR_CW(false, false, false)
+          }
+#undef LB_PAIR_CW
+          nblocks = gr;
+          if (n_rest > 0) {
+            LB_LAUNCHED(q);
+            const int64_t o = n_main;
+            hipLaunchKernelGGL((update_scan_kernel<T, 10, false, false, true, false, true>), dim3(1), dim3(BLOCK), 0,
+                               q.stream, n_rest, x + o, (ub & 1) ? l : l + o, (ub & 2) ? u : u + o,
+                               (ub & 4) ? nbd : nbd + o, g + o, r + o, d + o, dimpl, stp, iwhere + o,
+                               tbrk ? tbrk + o : tbrk, w.ws + o, w.wy + o, w.zero, w.ld, w.m, head, nold, itail,
+                               store_pair, store_iw, -1.0, ckeys, cidx, ccap, ccount, ub, q.part() + gr,
+                               w.lmask + o / 64);
+            nblocks = gr + 1;
+          }
+        } else if (nold <= 5) {
           if (q.nt) { if (nrw) LB_UPDSCAN_CW(5, true, true) else LB_UPDSCAN_CW(5, true, false) }
           else { if (nrw) LB_UPDSCAN_CW(5, false, true) else LB_UPDSCAN_CW(5, false, false) }
         } else {
@@ -617,7 +824,7 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
         }
 #undef LB_UPDSCAN_CW
         LB_LAUNCHED(q);
-        launch_finalize(q, gr, 4 * maxc_for(nold) + 9 + update_scan_extra(nold, newrow), 1, 1);
+        launch_finalize(q, nblocks >= 0 ? nblocks : gr, 4 * maxc_for(nold) + 9 + update_scan_extra(nold, newrow), 1, 1);
         done = true;
       }
     }

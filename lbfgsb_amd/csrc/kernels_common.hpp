@@ -124,6 +124,76 @@ __device__ __forceinline__ int64_t wrow(const uint64_t *__restrict__ lmask, int6
   return (tile << 7) + (fr ? before : tf + (r - before));
 }
 
+// Where a trip's row group lives -- mixed into the trip types of the two passes over W, so that ONE kernel body
+// serves the natural order (W consecutive rows from i) and the tile-local layout (CwRows / one row and its slot).
+template <int W>
+struct NaturalRows {
+  static constexpr bool CW = false;
+  __device__ __forceinline__ int64_t row(int64_t i, int k) const { return i + k; }
+  template <bool NTS, typename E>
+  __device__ __forceinline__ void st_rows(E *p, int64_t i, const double (&v)[W]) const {  // p[row k] = v[k]
+    if constexpr (NTS) stnt<W>(p + i, v); else st<W>(p + i, v);
+  }
+  template <bool NTS, typename E>
+  __device__ __forceinline__ void st_w(E *col, int64_t i, const double (&v)[W]) const {  // into a W column
+    st_rows<NTS, E>(col, i, v);
+  }
+  __device__ __forceinline__ void sti_rows(iw_t *p, int64_t i, const int (&v)[W]) const { sti<W>(p + i, v); }
+};
+struct CwPairRows {  // the rows lane, lane + 64 of a full tile (for_tiles_cw): derived from the tile's scalars on demand
+  static constexpr bool CW = true;
+  CwTile tile_;
+  __device__ __forceinline__ int64_t row(int64_t, int k) const { return tile_.tb + (int64_t)((threadIdx.x & 63) + 64 * k); }
+  __device__ __forceinline__ bool lf(int k) const { return ((k ? tile_.m1 : tile_.m0) >> (threadIdx.x & 63)) & 1ull; }
+  template <bool NTS, typename E>
+  __device__ __forceinline__ void st_rows(E *p, int64_t, const double (&v)[2]) const {
+    E *q = p + tile_.tb;  // (uniform)
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double one[1] = {v[k]};
+      if constexpr (NTS) stnt<1>(q + (lane + 64 * k), one); else st<1>(q + (lane + 64 * k), one);
+    }
+  }
+  template <bool NTS, typename E>
+  __device__ __forceinline__ void st_w(E *col, int64_t, const double (&v)[2]) const {
+    int sl[2];
+    bool f[2];
+    cw_slots(tile_, sl, f);
+    E *q = col + tile_.tb;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double one[1] = {v[k]};
+      if constexpr (NTS) stnt<1>(q + sl[k], one); else st<1>(q + sl[k], one);
+    }
+  }
+  __device__ __forceinline__ void sti_rows(iw_t *p, int64_t, const int (&v)[2]) const {
+    iw_t *q = p + tile_.tb;
+    const int lane = (int)(threadIdx.x & 63);
+    q[lane] = (iw_t)v[0], q[lane + 64] = (iw_t)v[1];
+  }
+};
+struct CwOneRow {  // one row of the partial tile
+  static constexpr bool CW = true;
+  int64_t ri_, ws_;
+  bool lf_;
+  __device__ __forceinline__ int64_t row(int64_t, int) const { return ri_; }
+  __device__ __forceinline__ bool lf(int) const { return lf_; }
+  template <bool NTS, typename E>
+  __device__ __forceinline__ void st_rows(E *p, int64_t, const double (&v)[1]) const {
+    if constexpr (NTS) stnt<1>(p + ri_, v); else st<1>(p + ri_, v);
+  }
+  template <bool NTS, typename E>
+  __device__ __forceinline__ void st_w(E *col, int64_t, const double (&v)[1]) const {
+    if constexpr (NTS) stnt<1>(col + ws_, v); else st<1>(col + ws_, v);
+  }
+  __device__ __forceinline__ void sti_rows(iw_t *p, int64_t, const int (&v)[1]) const { p[ri_] = (iw_t)v[0]; }
+};
+// two single bytes -> the register image of a 2-byte load (raw_geti<2>)
+__device__ __forceinline__ void raw_join_bytes(RawReg<2> &r, const RawReg<1> &a, const RawReg<1> &b) {
+  r.v = (a.v & 0xff) | ((b.v & 0xff) << 8);
+}
+
 // ---- pending pair ----
 // Between matupd and the subspace pass of the same setulb call the newest pair (logical column
 // col-1) is not in W yet: update_scan_kernel only reduces, so that it stays a read-only pass

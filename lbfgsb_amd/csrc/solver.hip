@@ -211,8 +211,10 @@ class Solver final : public lbfgsb_hip_ctx {
       lbk::launch_lmask_ones(q, n, lmask);
     }
     HIPCHK(hipMalloc(&ub_buf, 192));
-    HIPCHK(hipMalloc(&zero_buf, 256));  // read by the unroll slots beyond the stored pairs
-    HIPCHK(hipMemsetAsync(zero_buf, 0, 256, stream));
+    // read by the unroll slots beyond the stored pairs (16 bytes per lane from its start; under the tile-local
+    // layout of W at a lane's in-tile slot: a tile of the widest kind long)
+    HIPCHK(hipMalloc(&zero_buf, 2048));
+    HIPCHK(hipMemsetAsync(zero_buf, 0, 2048, stream));
     const size_t vb = (size_t)(n + 32) * sizeof(T);
     for (T **p : {&z, &r_own, &d, &t_own, &xp, &tbrk}) {
       HIPCHK(hipMalloc(p, vb));
@@ -494,9 +496,11 @@ class Solver final : public lbfgsb_hip_ctx {
   }
   // Re-sort the tiles so that the rows that are free NOW (iwhere <= 0, after the walk) come first.  Called in front
   // of the storing pass, where iwhere is final for the iteration.  Automatic policy: pack once a tenth of the rows
-  // is not free and the free set has settled (this iteration changed < 2 % of the rows), re-pack when 3 % of the
-  // rows have changed status since (each costs one read + write of the live columns; a stale layout costs only
-  // the bytes of the stale rows).  The sums do not depend on any of this (for_tiles_cw).
+  // is not free and the free set has settled (this iteration changed < 2 % of the rows); from then on re-sort
+  // whenever a row has changed status since -- the kernel skips the tiles whose bits stand, so its cost is a scan
+  // of iwhere (1 byte per row) plus one read + write of the live columns of the DIRTY tiles (a changed row costs
+  // 128 rows x 2 col x 16 bytes once; left alone it costs a slow fetch in every pass).  The sums do not depend on
+  // any of this (for_tiles_cw).
   void cw_maybe_pack(int head, int col, int64_t changed_now) {
     live_head = head, live_col = col;
     if (!cw_eligible() || cw_policy == 0) return;
@@ -511,7 +515,7 @@ class Solver final : public lbfgsb_hip_ctx {
       if (!cw_packed)
         go = (double)(nglob - nfree_g) >= 0.10 * nn && (double)changed_now <= 0.02 * nn;
       else
-        go = (double)cw_stale >= 0.03 * nn;
+        go = cw_stale > 0;
     }
     if (!go) return;
     lbk::launch_w_relayout<T>(q, n, iwhere, lmask, Wraw(), head, col);

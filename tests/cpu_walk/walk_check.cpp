@@ -189,6 +189,23 @@ void launch_publish(Queue &q, const double *src, double *dst, int count, unsigne
   __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
   q.launches++;
 }
+// the tile-local free-row layout of W (k_layout.hip): this harness never turns the option on, so the bits stay "every
+// row of [0, n)" = natural order; a re-sort request would be a bug of the host code under test
+void launch_lmask_ones(Queue &q, int64_t n, uint64_t *lmask) {
+  const int64_t nwords = ((n + CW_TILE - 1) / CW_TILE) * (CW_TILE / 64);
+  for (int64_t w = 0; w < nwords; ++w) {
+    const int64_t r0 = w * 64;
+    lmask[w] = r0 + 64 <= n ? ~0ull : (r0 < n ? (1ull << (n - r0)) - 1ull : 0ull);
+  }
+  q.launches++;
+}
+template <typename T>
+void launch_w_relayout(Queue &, int64_t, const iw_t *, uint64_t *, WStore<T>, int, int) {
+  std::fprintf(stderr, "walk_check: launch_w_relayout called (the option is off in this harness)\n");
+  std::abort();
+}
+template void launch_w_relayout<double>(Queue &, int64_t, const iw_t *, uint64_t *, WStore<double>, int, int);
+template void launch_w_relayout<float>(Queue &, int64_t, const iw_t *, uint64_t *, WStore<float>, int, int);
 void launch_nbd_pack(Queue &q, int64_t n, const int32_t *nbd, nb_t *out) {
   for (int64_t i = 0; i < n; ++i) out[i] = (nb_t)nbd[i];
   q.launches++;

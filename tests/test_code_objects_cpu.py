@@ -37,6 +37,11 @@ def test_hot_kernels_of_the_headline_config_keep_their_occupancy():
     bare W'v kernel at 3 -- a register-count regression shows here before it shows in a bench line"""
     kr, rows = _resources()
     by = {kr.short(r["kernel"]): r for r in rows}
-    assert by["subsm_update_kernel<double, 10, true, true, false>"]["waves_per_simd"] >= 3
+    assert by["subsm_update_kernel<double, 10, true, true, false, false>"]["waves_per_simd"] >= 3
     assert by["wtv_kernel<double, 10, true>"]["waves_per_simd"] >= 3
-    assert by["update_scan_kernel<double, 10, true, true, true, false>"]["scratch"] == 0
+    assert by["update_scan_kernel<double, 10, true, true, true, false, false, false>"]["scratch"] == 0
+    # ... and on the tile-local free-row layout of W (option compact_w): the storing pass and the pair-shared
+    # update pass at two waves per SIMD, every accumulator of the latter in the VGPR file (no AGPR traffic)
+    assert by["subsm_update_kernel<double, 10, true, true, false, true>"]["waves_per_simd"] >= 2
+    up = by["update_scan_kernel<double, 10, true, false, true, true, true, true>"]
+    assert up["waves_per_simd"] >= 2 and up["agpr"] == 0 and up["scratch"] == 0
