@@ -329,6 +329,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the GPU parity tests use for the same fixture (tests/test_gpu_parity.py)
 GOLDEN_ROWS = {(100_000_000, 10, 0): ("quad_n1e8_m10_ref_rows.json", 1e-9),
                (10_000_000, 10, 1): ("rosenbrock_n1e7_anchors.json", 1e-7)}
+# REAL32 contexts against the REAL64 reference's rows of the same shape: tests/test_gpu_real32.py's rules (nfg exactly,
+# nseg / nfree within 1e-3 relative + 5, f to 1e-6)
+GOLDEN_ROWS_R32 = {(100_000_000, 20, 0): ("quad_n1e8_m20_ref_rows.json", 1e-6)}
 
 
 def parity_in_run(rows, n, m, real32, kind):
@@ -337,7 +340,7 @@ def parity_in_run(rows, n, m, real32, kind):
     workload at full size (tests/golden/*.json: data; generating scripts profiles/scripts/cpu_ref_full.py,
     tests/golden/make_anchors_n1e7.py).  Integers exactly, f within the fixture's tolerance.  Shapes without
     such rows report rows_checked = 0."""
-    fx = None if real32 else GOLDEN_ROWS.get((n, m, kind))
+    fx = (GOLDEN_ROWS_R32 if real32 else GOLDEN_ROWS).get((n, m, kind))
     if fx is None or not os.path.exists(os.path.join(GOLDEN, fx[0])):
         return {"rows_checked": 0, "ok": None, "why": "no reference rows on file for this shape"}
     by_iter = {r["iter"]: r for r in json.load(open(os.path.join(GOLDEN, fx[0])))["rows"]}
@@ -347,7 +350,11 @@ def parity_in_run(rows, n, m, real32, kind):
         if w is None:
             continue
         checked += 1
-        ok = (nfg, nseg, nfree) == (w["nfg"], w["nseg"], w["nfree"]) and abs(f - w["f"]) <= fx[1] * abs(w["f"])
+        if real32:
+            ok = (nfg == w["nfg"] and abs(nseg - w["nseg"]) <= 1e-3 * w["nseg"] + 5 and
+                  abs(nfree - w["nfree"]) <= 1e-3 * w["nfree"] + 5 and abs(f - w["f"]) <= fx[1] * abs(w["f"]))
+        else:
+            ok = (nfg, nseg, nfree) == (w["nfg"], w["nseg"], w["nfree"]) and abs(f - w["f"]) <= fx[1] * abs(w["f"])
         if not ok and len(bad) < 3:
             bad.append({"got": [it, nfg, nseg, nfree, f], "want": [w["iter"], w["nfg"], w["nseg"], w["nfree"], w["f"]]})
     out = {"rows_checked": checked, "ok": checked > 0 and not bad, "f_rel_tol": fx[1],

@@ -229,12 +229,12 @@ def test_real32_config5_full_shape_anchors(env):
     terms stagnate (measured with the real `-DREAL32 -fdefault-integer-8` build, DESIGN.md section 8:
     already at n = 2e5 its first walk has 180,423 segments where the REAL64 reference has 195,351).
     The meaningful reference for "fp32 storage, fp64 accumulation" is the REAL64 reference, and while
-    col < m an L-BFGS-B run does not depend on m: iterations 1..11 of this m = 20 run are iterations
-    1..11 of the m = 10 run the real reference printed at n = 1e8 (tests/golden/
-    quad_n1e8_m10_ref_rows.json).  Iterations 1-3: integer columns exactly (nseg(it1) = 97,671,921,
-    nfree(it2) = 49,999,496).  Iterations 4-11: nfg exactly, nseg / nfree within 1e-3 relative + 5 (the
-    walk's stopping point moves with the 6e-8 storage rounding of x and g: a handful of the 5e7 free
-    variables' breakpoints change sides), f to 1e-6.  Then: f monotone to the end, col = 20 reached,
+    its rows at this very shape are on file (tests/golden/quad_n1e8_m20_ref_rows.json: the REAL64 reference at
+    n = 1e8, m = 20, 26 iterations; its iterations 1..11 are those of the m = 10 run, col < 10 not depending
+    on m).  Iterations 1-3: integer columns exactly (nseg(it1) = 97,671,921, nfree(it2) = 49,999,496).
+    Iterations 4-26: nfg and col exactly, nseg / nfree within 1e-3 relative + 5 (the walk's stopping point
+    moves with the 6e-8 storage rounding of x and g: a handful of the 5e7 free variables' breakpoints change
+    sides), f to 1e-6.  Then: f monotone to the end, col = 20 reached,
     every subspace step from iteration 2 on through the closed form (two-pass iteration), and the whole
     trajectory -- f and |proj g| included -- bit for bit reproducible from run to run."""
     import json
@@ -273,15 +273,23 @@ def test_real32_config5_full_shape_anchors(env):
     assert task.startswith("NEW_X") and len(rows) == iters, (task, rows[-1])
     assert rows[0][2] == 97_671_921, rows[0]
     assert rows[1][3] == 49_999_496, rows[1]
-    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                      "quad_n1e8_m10_ref_rows.json")))["rows"]
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref10 = json.load(open(os.path.join(gold, "quad_n1e8_m10_ref_rows.json")))["rows"]
+    # the REAL64 reference's own rows at THIS shape (n = 1e8, m = 20; profiles/scripts/cpu_ref_full.py --m 20
+    # --iters 26, round 6): the steady state with 20 pairs stored -- iterations 12 to 26, the only ones in which
+    # update_scan_kernel<float, 20, ..., PAIR> at col = 20 runs -- has reference rows too
+    ref = json.load(open(os.path.join(gold, "quad_n1e8_m20_ref_rows.json")))["rows"]
+    assert len(ref) == iters and [r["col"] for r in ref][-6:] == [20] * 6
+    for a, b in zip(ref[:11], ref10[:11]):           # (col < 10: the two reference runs are the same run)
+        assert (a["nfg"], a["nseg"], a["nfree"], a["f"]) == (b["nfg"], b["nseg"], b["nfree"], b["f"])
     for got, want in zip(rows[:3], ref[:3]):
         assert got[:4] == (want["iter"], want["nfg"], want["nseg"], want["nfree"]), (got, want)
-    for got, want in zip(rows[:11], ref[:11]):       # col < 10: independent of m
+    for got, want in zip(rows, ref):                 # all 26 iterations, the REAL32 rules
         assert got[:2] == (want["iter"], want["nfg"]), (got, want)
         assert abs(got[2] - want["nseg"]) <= 1e-3 * want["nseg"] + 5, (got, want)
         assert abs(got[3] - want["nfree"]) <= 1e-3 * want["nfree"] + 5, (got, want)
         assert got[4] == pytest.approx(want["f"], rel=1e-6), (got, want)
+        assert got[6] == want["col"], (got, want)
     assert all(b[4] < a[4] for a, b in zip(rows, rows[1:])), [r[4] for r in rows]
     cols = [r[6] for r in rows]
     assert cols[-1] == m and cols[:11] == list(range(0, 11)) and all(b >= a for a, b in zip(cols, cols[1:])), cols
