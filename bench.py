@@ -393,15 +393,20 @@ class Run:
     """one solver context + its problem, advanced iteration by iteration"""
 
     def __init__(self, torch, dist, la, a, *, n, m, real32, kind, world, rank, local_rank, rccl_self, opts,
-                 parallel_gcp=False, defer=None, classic=None, arbitrary_box=False):
+                 parallel_gcp=False, defer=None, classic=None, arbitrary_box=False, torch_objective=False):
         self.torch, self.dist, self.world = torch, dist, world
         self.kind, self.n, self.m = kind, n, m
         dev = torch.device("cuda", local_rank)
         self.dev = dev
         row0, n_loc = la.block_partition(n, world, rank)
         self.n_loc = n_loc
+        # torch_objective: f, g by torch ops on torch's current stream, ordered against the solver's stream with events
+        # in both directions (stream_ordered: lbfgsb_hip_return_event / lbfgsb_hip_wait_stream), f handed over as a
+        # device scalar (lbfgsb_hip_f_device) -- what an ordinary PyTorch caller does, with no host sync of its own
+        self.torch_objective = bool(torch_objective)
         mk = lambda: la.DeviceSolver(n_loc, m, n_global=n, row0=row0, device=local_rank,   # noqa: E731
-                                     same_stream_objective=True, real32=real32, options=opts,
+                                     same_stream_objective=not torch_objective, stream_ordered=torch_objective,
+                                     real32=real32, options=opts,
                                      parallel_gcp=parallel_gcp,
                                      defer_lnsrch=(not a.no_defer) if defer is None else bool(defer))
         self.sol = mk()
@@ -437,6 +442,13 @@ class Run:
                 la.attach_rccl(self.sol, 0, 1, dev)
             self.collective = "RCCL all-gather on a 1-rank communicator (--rccl-self: latency floor)"
         x, self.l, self.u, self.nbd = problem_tensors(torch, dev, kind, n_loc, row0, real32, arbitrary_box)
+        if torch_objective:
+            assert kind == 0 and not real32
+            i = torch.arange(row0 + 1, row0 + n_loc + 1, dtype=torch.int64, device=dev)
+            self.a_ = 1.0 + 99.0 * ((7919 * i) % 10007).to(torch.float64) / 10006.0
+            self.c_ = -2.0 + 4.0 * ((104729 * i) % 100003).to(torch.float64) / 100002.0
+            del i
+            self.tmp_ = torch.empty_like(x)
         self.pp = not (a.classic if classic is None else classic)
         # ping-pong entry: two pairs of iterate / gradient buffers, the library tells which one is live
         self.xs = [x, torch.empty_like(x)] if self.pp else [x]
@@ -473,7 +485,13 @@ class Run:
             else:
                 task = sol.setulb(self.xs[0], self.l, self.u, self.nbd, self.gs[0], 0.0, 0.0)
             self.t_setulb += time.perf_counter() - t0
-            if task.startswith("FG"):
+            if task.startswith("FG") and self.torch_objective:
+                torch = self.torch
+                d = torch.sub(self.x, self.c_, out=self.tmp_)
+                torch.mul(self.a_, d, out=self.g)
+                f_dev = 0.5 * torch.dot(self.g, d)
+                sol.set_f_device(f_dev)          # (no .item(): this rank's part of f rides back with the next call's sums)
+            elif task.startswith("FG"):
                 sol.objective(self.kind, self.x, self.g, deferred=True)   # f rides back with the next call's sums
             elif task.startswith("NEW_X"):
                 done += 1
@@ -487,6 +505,7 @@ class Run:
         import gc
         self.sol.close()
         self.xs = self.gs = self.l = self.u = self.nbd = None
+        self.a_ = self.c_ = self.tmp_ = None
         # (release the 10+ GB of this leg NOW: a cyclic-garbage pass that frees them in the middle of the next
         #  leg's timed region costs that leg a 30-70 ms device-wide stall)
         gc.collect()
@@ -560,10 +579,11 @@ def pass_bytes(col, rbytes, pp, lean=True, ub=0, wfrac=1.0):
 
 
 def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, steps, warm_min, local_rank, opts,
-                 defer=None, classic=None, arbitrary_box=False):
+                 defer=None, classic=None, arbitrary_box=False, torch_objective=False):
     """a short leg for one of the other BASELINE.json configs: it/s and the two pass fractions"""
     run = Run(torch, dist, la, a, n=n, m=m, real32=real32, kind=kind, world=1, rank=0, local_rank=local_rank,
-              rccl_self=rccl_self, opts=opts, defer=defer, classic=classic, arbitrary_box=arbitrary_box)
+              rccl_self=rccl_self, opts=opts, defer=defer, classic=classic, arbitrary_box=arbitrary_box,
+              torch_objective=torch_objective)
     try:
         coll_us = run.sol.collective_time(1000) if rccl_self else None
         r = timed_leg(run, steps, warm_min, need_full_memory=(kind == 0))
@@ -1050,7 +1070,7 @@ def main():
         out["first_iteration_parallel_gcp_error"] = repr(e)
     # ---- the other BASELINE.json configs, short legs (N = 1 only; each a fresh context) ----
     if world == 1 and not a.no_other_configs and not a.real32 and n == 100_000_000 and m == 10:
-        leg_tags = ["ordinary_caller", "ub_off", "cfg1_n1e6", "cfg2_rosen_n1e7", "cfg4_r32_m20", "cfg3_rank_shape",
+        leg_tags = ["ordinary_caller", "torch_caller", "ub_off", "cfg1_n1e6", "cfg2_rosen_n1e7", "cfg4_r32_m20", "cfg3_rank_shape",
                     "cfg3_rank_shape_nodefer", "m32_n5e7", "m48_n2e7"]
         leg_defs = [
             ("ORDINARY CALLER, ARBITRARY BOX: the headline problem size with per-variable bounds (every l_i, u_i its own "
@@ -1058,6 +1078,12 @@ def main():
              "lbfgsb_hip_setulb_dev (t = x, r = g as copies) and no LBFGSB_F_DEFER_LNSRCH -- nothing the headline leans on",
              dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12, defer=False, classic=True,
                   arbitrary_box=True)),
+            ("TORCH-STREAM CALLER, ARBITRARY BOX: the same per-variable bounds, the objective evaluated by torch ops on "
+             "torch's current stream and ordered with events (stream_ordered: lbfgsb_hip_return_event / _wait_stream), "
+             "f handed over as a device scalar (lbfgsb_hip_f_device), ping-pong entry + LBFGSB_F_DEFER_LNSRCH -- the "
+             "deferred path for a caller that is NOT on the solver's stream",
+             dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12, defer=True, classic=False,
+                  arbitrary_box=True, torch_objective=True)),
             ("headline workload with the uniform-bounds detection OFF (l, u, nbd streamed per row)",
              dict(n=n, m=m, real32=False, kind=0, rccl_self=False, steps=20, warm_min=12,
                   opts=dict(opts, uniform_bounds=0))),

@@ -228,6 +228,21 @@ int lbfgsb_hip_setulb_dev_pp(lbfgsb_hip_ctx *ctx, void *x0, void *x1, const void
  * stream, so x may be read from any stream. */
 void *lbfgsb_hip_get_stream(lbfgsb_hip_ctx *ctx);
 int lbfgsb_hip_wait_stream(lbfgsb_hip_ctx *ctx, void *producer_stream);
+/* The mirror of lbfgsb_hip_wait_stream, for a caller whose objective runs on ANOTHER stream and who wants no host
+ * sync at an 'FG...' return (LBFGSB_F_NO_RETURN_SYNC, LBFGSB_F_DEFER_LNSRCH): an event is recorded on the context's
+ * stream behind everything the last call queued -- the storing pass that wrote the trial point included
+ * (src/lbfgsb.f90:2255-2272: the point the caller is asked to evaluate) -- and, with make_wait != 0,
+ * consumer_stream is made to wait for it (0 is the legacy default stream).  *event_out (may be NULL) receives the
+ * hipEvent_t, owned by the context and re-recorded by the next call of this function.  The round trip of such a
+ * caller:  setulb -> 'FG...' ; lbfgsb_hip_return_event(ctx, s, 1, NULL) ; f, g evaluated on s ;
+ * lbfgsb_hip_f_device / lbfgsb_hip_wait_stream(ctx, s) ; setulb.  Nothing in it blocks the host. */
+int lbfgsb_hip_return_event(lbfgsb_hip_ctx *ctx, void *consumer_stream, int make_wait, void **event_out);
+/* The caller's objective value as a device scalar (fp64; with several ranks: this rank's part of f, the library
+ * adds the parts up): it reaches the host with the next setulb call's first fetch, as the value of a built-in
+ * objective evaluated with h_f == NULL does (lbfgsb_hip_objective), and that call stores it in *f -- the 'f'
+ * argument of that call is ignored on entry.  order_after != 0: first order the context's stream behind
+ * producer_stream (lbfgsb_hip_wait_stream), on which *d_f and g were produced.  Only for an 'FG...' re-entry. */
+int lbfgsb_hip_f_device(lbfgsb_hip_ctx *ctx, const void *d_f, void *producer_stream, int order_after);
 
 /* -------------------------------------------------------------------------
  * setulb, host-pointer form: the exact reference signature (what the Fortran

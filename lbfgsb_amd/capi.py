@@ -37,6 +37,8 @@ PROTOTYPES = {
     "lbfgsb_hip_wait_stream": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_release_host": (C.c_int, [_vp]),
     "lbfgsb_hip_host_pinning": (C.c_int, [C.c_int]),
+    "lbfgsb_hip_return_event": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "lbfgsb_hip_f_device": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "lbfgsb_hip_tie_splits": (C.c_int, [_vp, _vp]),
     "lbfgsb_hip_defer_stats": (C.c_int, [_vp, _vp, _vp]),
     "lbfgsb_hip_host_gap": (C.c_int, [_vp, _vp, _vp]),

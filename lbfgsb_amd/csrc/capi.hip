@@ -129,6 +129,26 @@ int lbfgsb_hip_wait_stream(lbfgsb_hip_ctx *ctx, void *producer_stream) {
   return 0;
 }
 
+int lbfgsb_hip_return_event(lbfgsb_hip_ctx *ctx, void *consumer_stream, int make_wait, void **event_out) {
+  if (!ctx) return fail(LBFGSB_E_ARG, "ctx == NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->return_ev) HIPCHK(hipEventCreateWithFlags(&ctx->return_ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ctx->return_ev, ctx->q.stream));
+  if (make_wait && (hipStream_t)consumer_stream != ctx->q.stream)
+    HIPCHK(hipStreamWaitEvent((hipStream_t)consumer_stream, ctx->return_ev, 0));
+  if (event_out) *event_out = (void *)ctx->return_ev;
+  return 0;
+}
+
+int lbfgsb_hip_f_device(lbfgsb_hip_ctx *ctx, const void *d_f, void *producer_stream, int order_after) {
+  if (!ctx || !d_f) return fail(LBFGSB_E_ARG, "f_device: NULL argument");
+  if (order_after) {
+    const int rc = lbfgsb_hip_wait_stream(ctx, producer_stream);
+    if (rc) return rc;
+  }
+  return ctx->f_device((const double *)d_f);
+}
+
 int lbfgsb_hip_comm_init_host(lbfgsb_hip_ctx *ctx, lbfgsb_allreduce_fn ar, lbfgsb_allgather_fn ag,
                               void *user, int rank, int nranks) {
   if (!ctx || !ar || nranks < 1 || rank < 0 || rank >= nranks)

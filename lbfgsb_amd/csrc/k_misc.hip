@@ -953,6 +953,14 @@ void launch_obj_quadratic(Queue &q, int64_t n, int64_t row0, const T *x, T *g) {
   LB_LAUNCHED(q);
   launch_finalize(q, gr, 1, 0, 0);
 }
+// a caller's objective value that lives on the device: one "partial" for the fixed-order finalize, so that it travels
+// like the value of a built-in objective (slot 0 of the next fetch)
+__global__ void scalar_partial_kernel(const double *__restrict__ v, double *part) { part[0] = v[0]; }
+void launch_scalar_partial(Queue &q, const double *d_val) {
+  hipLaunchKernelGGL(scalar_partial_kernel, dim3(1), dim3(1), 0, q.stream, d_val, q.part());
+  LB_LAUNCHED(q);
+  launch_finalize(q, 1, 1, 0, 0);
+}
 // rows [row0, row0+n) of the chain; xl / xr = the neighbours' boundary elements x(row0-1),
 // x(row0+n) (1-element halo, exchanged by the caller; unused at the global ends)
 template <typename T>

@@ -509,6 +509,8 @@ void launch_obj_rosenbrock(Queue &q, int64_t n, int64_t row0, int64_t nglob, con
                            double xl, double xr);
 template <typename T>
 void launch_halo_pack(Queue &q, int64_t n, const T *x, double *out);
+// res sum [0] = *d_val (this rank's part of an objective value the caller computed on the device)
+void launch_scalar_partial(Queue &q, const double *d_val);
 
 // the stride of the update pass's result layout: the column capacity of the kernel that ran, or -- beyond 32
 // columns, where the pass is split into sub-launches and merged -- the next multiple of 32

@@ -167,6 +167,8 @@ class Solver final : public lbfgsb_hip_ctx {
     pf_ev = nullptr;
     if (order_ev) (void)hipEventDestroy(order_ev);
     order_ev = nullptr;
+    if (return_ev) (void)hipEventDestroy(return_ev);
+    return_ev = nullptr;
     for (auto &ring : clk_ev)
       for (auto &pair : ring)
         for (auto &e : pair) {
@@ -468,7 +470,13 @@ class Solver final : public lbfgsb_hip_ctx {
 
   // ---- tile-local free-row layout of W ("compact W": k_layout.hip; option "compact_w") ----
   uint64_t *lmask = nullptr;   // one bit per row (ceil128(n) bits): set = the row sits in the front run of its tile
-  bool cw_on = false;          // option: the two passes over W run on the layout (fp64, m <= 10, no mirroring)
+  // option "compact_w": 0 off; 1 the two passes over W run on the layout WHILE IT IS PACKED (natural-order kernels
+  // before the first pack and whenever something asked for natural order: a problem whose rows are all free never
+  // pays for the option); 2 they always do (the sums then do not depend on when the layout is made: the tests)
+  int cw_mode = 0;
+  bool cw_on = false;          // cw_mode != 0 (fp64, m <= 10, no mirroring: cw_eligible)
+  int64_t cw_min_rows = -1;    // option "compact_min_rows": automatic policy packs only from this many rows on
+                               // (-1: when W is much larger than the Infinity Cache, as the nontemporal loads)
   bool cw_packed = false;      // some bit is clear: the columns are NOT in natural order
   int cw_policy = 1;           // option "compact_policy": 0 never pack, 1 automatic, 2 re-pack in every iteration
   int64_t cw_stale = 0;        // rows (all ranks) that changed status since the layout was made
@@ -491,7 +499,7 @@ class Solver final : public lbfgsb_hip_ctx {
   // the layout as it is, for the kernels that take it into account
   lbk::WStore<T> Wc() {
     lbk::WStore<T> w = Wraw();
-    if (cw_eligible()) w.lmask = lmask;
+    if (cw_eligible() && (cw_mode == 2 || cw_packed)) w.lmask = lmask;
     return w;
   }
   // Re-sort the tiles so that the rows that are free NOW (iwhere <= 0, after the walk) come first.  Called in front
@@ -512,8 +520,10 @@ class Solver final : public lbfgsb_hip_ctx {
         return;
       }
       const double nn = (double)nglob;
+      // (a W that lives in the Infinity Cache gains nothing from fewer HBM bytes: n = 1e6, m = 10 lost 2.5 %)
+      const bool big = cw_min_rows >= 0 ? n >= cw_min_rows : (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
       if (!cw_packed)
-        go = (double)(nglob - nfree_g) >= 0.10 * nn && (double)changed_now <= 0.02 * nn;
+        go = big && (double)(nglob - nfree_g) >= 0.10 * nn && (double)changed_now <= 0.02 * nn;
       else
         go = cw_stale > 0;
     }

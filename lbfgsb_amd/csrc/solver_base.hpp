@@ -226,6 +226,8 @@ struct lbfgsb_hip_ctx {
                           const int32_t *nb1, double *ndiff) = 0;
   virtual int64_t freev_skipped() const = 0;
   virtual int collective_time(int reps, double *median_us, double *min_us) = 0;  // lbfgsb_hip_collective_time
+  virtual int f_device(const double *d_f) = 0;                                   // lbfgsb_hip_f_device
+  hipEvent_t return_ev = nullptr;                                                // lbfgsb_hip_return_event
   virtual void compact_stats(int64_t &packs, int64_t &unpacks, int &packed, int &eligible) const = 0;
   virtual int64_t skip_scans_reused() const = 0;
   virtual void defer_counts(int64_t &deferred, int64_t &reissued) const = 0;

@@ -261,6 +261,17 @@
     *f = f_scale * h_res[0];
     return 0;
   }
+  // the caller's own objective value, left on the device (this rank's part of f; fp64): it rides to the host with
+  // the next setulb call's first fetch exactly as a built-in objective's value does -- no host sync for f
+  int f_device(const double *d_f) override {
+    HIPCHK(hipSetDevice(device));
+    if (fold_fin) q.part_sel = 1, q.hold_fin = true;
+    lbk::launch_scalar_partial(q, d_f);
+    q.part_sel = 0, q.hold_fin = false;
+    f_scale = 1.0;
+    f_pending = true;
+    return 0;
+  }
   int sync() override {
     HIPCHK(hipStreamSynchronize(stream));
     return 0;

@@ -448,10 +448,16 @@
       return 0;
     };
     if (k == "compact_w") {  // the two passes over W on the tile-local free-row layout (fp64, m <= 10)
-      const bool was = cw_on;
-      const int rc = flag(cw_on);
-      if (rc == 0 && was && !cw_on) (void)W();  // (back to natural order for the kernels that will run now)
-      return rc;
+      const int rc = in_range(0, 2, cw_mode);
+      if (rc) return rc;
+      cw_on = cw_mode != 0;
+      if (!cw_on) (void)W();  // (back to natural order for the kernels that will run now)
+      return 0;
+    }
+    if (k == "compact_min_rows") {
+      if (!(v >= -1.0 && v <= 9.0e15) || v != std::floor(v)) return fail(LBFGSB_E_ARG, "set_option: compact_min_rows out of range");
+      cw_min_rows = (int64_t)v;
+      return 0;
     }
     if (k == "compact_policy") return in_range(0, 2, cw_policy);
     if (k == "two_pass") return flag(two_pass);

@@ -62,22 +62,29 @@ class DeviceSolver:
                  real32: bool = False, mirror_index: bool = False, device: int = 0, stream=None,
                  same_stream_objective: bool = False, parallel_gcp: bool = False,
                  exact_ties: bool = True, index_ties: bool = False, options: Optional[dict] = None,
-                 defer_lnsrch: bool = False):
+                 defer_lnsrch: bool = False, stream_ordered: bool = False):
         self.lib = load_library()
         # LBFGSB_F_DEFER_LNSRCH returns 'FG_LNSRCH' without waiting for the pass that writes the trial point
         # (it implies LBFGSB_F_NO_RETURN_SYNC): only a caller whose objective runs on the solver's OWN stream
         # may use it -- one that evaluates on torch's current stream would read x while it is being written
-        if defer_lnsrch and not same_stream_objective:
-            raise ValueError("defer_lnsrch=True needs same_stream_objective=True: the flag skips the host sync at "
-                             "every FG_LNSRCH return, so f,g must be evaluated on the solver's stream "
-                             "(DeviceSolver.objective / DeviceSolver.stream)")
+        # stream_ordered=True: the objective runs on torch's CURRENT stream and is ordered against the solver's stream
+        # with events in both directions -- after every 'FG...' return torch's stream is made to wait for the trial
+        # point (lbfgsb_hip_return_event), before every 'FG...' re-entry the solver's stream for g
+        # (lbfgsb_hip_wait_stream): no host sync at an FG return either, so such a caller may defer as well.
+        # f travels as a device scalar (set_f_device) or as a host float (sol.f[0] = float(...), which syncs torch).
+        if defer_lnsrch and not (same_stream_objective or stream_ordered):
+            raise ValueError("defer_lnsrch=True needs same_stream_objective=True or stream_ordered=True: the flag "
+                             "skips the host sync at every FG_LNSRCH return, so f,g must be evaluated on the "
+                             "solver's stream (DeviceSolver.objective / DeviceSolver.stream) or on a stream that is "
+                             "ordered behind it with events (stream_ordered)")
         self.same_stream_objective = bool(same_stream_objective)
+        self.stream_ordered = bool(stream_ordered) and not self.same_stream_objective
         self.n, self.m = int(n_local), int(m)
         self.n_global = int(n_global if n_global is not None else n_local)
         self.row0 = int(row0)
         self.real = np.float32 if real32 else np.float64
         flags = (capi.F_REAL32 if real32 else 0) | (capi.F_MIRROR_INDEX if mirror_index else 0)
-        flags |= capi.F_NO_RETURN_SYNC if same_stream_objective else 0
+        flags |= capi.F_NO_RETURN_SYNC if (same_stream_objective or stream_ordered) else 0
         flags |= capi.F_PARALLEL_GCP if parallel_gcp else 0  # opt-in, see include/lbfgsb_hip.h
         # a walk that ends inside a group of equal breakpoints is replayed in the reference's heap
         # order by default; index_ties=True (or exact_ties=False) opts out (include/lbfgsb_hip.h)
@@ -104,8 +111,9 @@ class DeviceSolver:
 
     def set_option(self, name: str, value: float):
         """measurement / test switch of this context (lbfgsb_hip_set_option)"""
-        if name == "defer_lnsrch" and float(value) != 0.0 and not self.same_stream_objective:
-            raise ValueError("option defer_lnsrch needs a context created with same_stream_objective=True")
+        if name == "defer_lnsrch" and float(value) != 0.0 and not (self.same_stream_objective or self.stream_ordered):
+            raise ValueError("option defer_lnsrch needs a context created with same_stream_objective=True or "
+                             "stream_ordered=True")
         check(self.lib.lbfgsb_hip_set_option(self.h, name.encode(), float(value)))
 
     def close(self):
@@ -178,6 +186,26 @@ class DeviceSolver:
             stream = torch.cuda.current_stream().cuda_stream
         check(self.lib.lbfgsb_hip_wait_stream(self.h, C.c_void_p(int(stream))))
 
+    def release_to_stream(self, stream=None):
+        """Make `stream` (default: torch's current stream) wait for everything the last call queued on the solver's
+        stream -- the trial point of an 'FG...' return included -- without blocking the host
+        (lbfgsb_hip_return_event)."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        check(self.lib.lbfgsb_hip_return_event(self.h, C.c_void_p(int(stream)), 1, None))
+
+    def set_f_device(self, f_dev, stream=None):
+        """The objective value as a 0-d / 1-element float64 CUDA tensor produced on `stream` (default: torch's current
+        stream): it reaches the host with the next setulb call's own fetch (lbfgsb_hip_f_device) -- no .item()."""
+        import torch
+        if not (f_dev.is_cuda and f_dev.dtype == torch.float64 and f_dev.numel() == 1):
+            raise TypeError("set_f_device needs a one-element float64 CUDA tensor")
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        self._keep_f = f_dev          # (alive until the next call has fetched it)
+        check(self.lib.lbfgsb_hip_f_device(self.h, C.c_void_p(f_dev.data_ptr()), C.c_void_p(int(stream)), 1))
+
     @property
     def stream(self) -> int:
         """the hipStream_t every kernel of this context runs on"""
@@ -230,6 +258,8 @@ class DeviceSolver:
         a = self._addr
         check(self.lib.lbfgsb_hip_setulb_dev(self.h, a(x), a(l), a(u), a(nbd), pf, a(g), float(factr),
                                              float(pgtol), pt, int(iprint), pc, pl, pi, pd))
+        if self.stream_ordered and bytes(self.task[:2]) == b"FG" and not isinstance(x, np.ndarray):
+            self.release_to_stream()   # (the caller's stream may read the trial point from here on)
         return self.task_s
 
     def setulb_pp(self, xs, l, u, nbd, gs, factr: float, pgtol: float, iprint: int = -1):
@@ -243,6 +273,8 @@ class DeviceSolver:
         check(self.lib.lbfgsb_hip_setulb_dev_pp(self.h, a(xs[0]), a(xs[1]), a(l), a(u), a(nbd), pf, a(gs[0]),
                                                 a(gs[1]), float(factr), float(pgtol), pt, int(iprint), pc, pl,
                                                 pi, pd, self._cur_ref))
+        if self.stream_ordered and bytes(self.task[:2]) == b"FG":
+            self.release_to_stream()   # (the caller's stream may read the trial point from here on)
         return self.task_s, cur.value
 
     def minimize(self, x, l, u, nbd, g, fg=None, builtin: int = 0, factr: float = 1e7,

@@ -233,3 +233,78 @@ def test_the_reach_of_the_first_window_changes_nothing(oracle_built, pp):
         a = _run(p, pp, True, 80, options={"win_slack": 0})
         b = _run(p, pp, True, 80, options={"win_slack": 0.25})
         assert a["rows"] == b["rows"] and a["wa"] == b["wa"], (p.name, p.n, p.m)
+
+
+def _run_torch_objective(p_data, pp, ordered, max_iter, side_stream):
+    """a separable quadratic whose f, g are evaluated by torch ops on torch's CURRENT stream (optionally a side
+    stream).  ordered=False: a default context (host sync at every FG return), f read back with .item();
+    ordered=True: stream_ordered + defer_lnsrch -- events in both directions (lbfgsb_hip_return_event /
+    lbfgsb_hip_wait_stream), f handed over as a device scalar (lbfgsb_hip_f_device): no host sync in the caller."""
+    import torch
+    import lbfgsb_amd as la
+    n, m, a_h, c_h, l_h, u_h, nbd_h, x0_h = p_data
+    sol = la.DeviceSolver(n, m, stream_ordered=ordered, defer_lnsrch=ordered)
+    st = torch.cuda.Stream() if side_stream else torch.cuda.current_stream()
+    try:
+        with torch.cuda.stream(st):
+            a, c = torch.from_numpy(a_h).cuda(), torch.from_numpy(c_h).cuda()
+            xs = [torch.from_numpy(x0_h.copy()).cuda(), torch.full((n,), 7.0, dtype=torch.float64, device="cuda")]
+            gs = [torch.zeros_like(xs[0]), torch.full_like(xs[0], -3.0)]
+            l, u = torch.from_numpy(l_h).cuda(), torch.from_numpy(u_h).cuda()
+            nbd = torch.from_numpy(nbd_h).cuda()
+            x, g = xs[0], gs[0]
+            rows, nfg_req = [], 0
+            t = ""
+            for _ in range(100000):
+                if pp:
+                    t, cur = sol.setulb_pp(xs, l, u, nbd, gs, 0.0, 0.0)
+                    x, g = xs[cur], gs[cur]
+                else:
+                    t = sol.setulb(x, l, u, nbd, g, 0.0, 0.0)
+                if t.startswith("FG"):
+                    nfg_req += 1
+                    d = x - c
+                    torch.mul(a, d, out=g)
+                    f = 0.5 * torch.dot(g, d)
+                    if ordered:
+                        sol.set_f_device(f)
+                    else:
+                        sol.f[0] = float(f.item())
+                else:
+                    sol.sync()
+                    rows.append((t, tuple(int(v) for v in sol.isave[21:44]), sol.f.tobytes(),
+                                 sol.dsave[[0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 15]].tobytes(), _digest(x), _digest(g)))
+                    if not t.startswith("NEW_X") or sol.isave[29] >= max_iter:
+                        break
+            st.synchronize()
+        return dict(rows=rows, nfg_req=nfg_req, defer=sol.defer_stats(), stats=sol.stats())
+    finally:
+        sol.close()
+
+
+@pytest.mark.parametrize("pp", [True, False])
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_torch_stream_objective_may_defer(oracle_built, pp, side_stream):
+    """An ordinary stream-ordered caller (objective = torch ops on torch's stream) with LBFGSB_F_DEFER_LNSRCH: events
+    instead of host syncs in both directions, f as a device scalar.  Every NEW_X return bit for bit that of the
+    default context driven by the same objective with f read back on the host; the library's own host syncs per
+    iteration drop by one, the caller adds none."""
+    rng = np.random.default_rng(42)
+    for n, m in ((20011, 7), (100003, 10)):
+        a = 1.0 + 99.0 * rng.random(n)
+        c = rng.normal(0, 2, n)
+        l = np.full(n, -1.0) - 1e-3 * rng.random(n)
+        u = np.full(n, 1.0) + 1e-3 * rng.random(n)
+        nbd = rng.integers(0, 4, n).astype(np.int32)
+        x0 = np.zeros(n)
+        data = (n, m, a, c, l, u, nbd, x0)
+        base = _run_torch_objective(data, pp, False, 40, side_stream)
+        got = _run_torch_objective(data, pp, True, 40, side_stream)
+        assert len(base["rows"]) == len(got["rows"]) >= 30
+        for k, (ra, rb) in enumerate(zip(base["rows"], got["rows"])):
+            assert ra == rb, (n, m, pp, side_stream, k, ra[:3], rb[:3])
+        deferred, reissued = got["defer"]
+        assert deferred >= 25 and got["nfg_req"] == base["nfg_req"] + reissued
+        iters = len(got["rows"])
+        assert got["stats"]["syncs"] <= base["stats"]["syncs"] - 0.8 * iters, (got["stats"]["syncs"],
+                                                                             base["stats"]["syncs"], iters)

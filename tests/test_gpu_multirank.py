@@ -285,14 +285,21 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) <= 4096                     # the compact line the driver parses (bench.LINE_CAP)
     out = json.loads(lines[0])
+    cfg = out["config"]
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
-    assert out["config"]["rows_per_gpu"] == 1000000 and "RCCL" in out["config"]["collective"]
-    assert out["collectives_per_iter"] == out["host_syncs_per_iter"] > 0     # one collective per host sync
-    assert out["first_iteration_nseg"] > 1900000     # ~0.977 n segments, walked across both ranks
+    assert cfg["rows_per_gpu"] == 1000000 and cfg["comm_kind"] == "rccl"
+    assert cfg["collectives_per_iter"] == cfg["host_syncs_per_iter"] > 0     # one collective per host sync
     assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
-    assert out["config"]["rccl_nranks"] == 2 and len(out["config"]["first_iteration_s_per_rank"]) == 2
-    assert out["config"]["parity_in_run"]["rows_checked"] == 0     # (no reference rows for this small shape)
+    # what a real scaling run needs to explain itself: the communicator's own rank count, the cost of
+    # one host sync on it, the syncs per iteration, the first iteration and the timed region per rank
+    assert cfg["rccl_nranks"] == 2 and len(cfg["first_iteration_s_per_rank"]) == 2
+    assert cfg["collective_us"] > 0 and cfg["ms_per_step_rank_min"] <= cfg["ms_per_step_rank_max"]
+    assert cfg["parity_in_run"]["rows_checked"] == 0     # (no reference rows for this small shape)
+    detail = json.load(open(os.path.join(root, "bench_detail.json")))
+    assert detail["first_iteration_nseg"] > 1900000     # ~0.977 n segments, walked across both ranks
+    assert "RCCL" in detail["config"]["collective"]
 
 
 @pytest.mark.parametrize("world,mode,n,m,iters,mixed", [
