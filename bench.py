@@ -591,7 +591,7 @@ def other_config(torch, dist, la, a, name, *, n, m, real32, kind, rccl_self, ste
         rb = 4 if real32 else 8
         ub = run.sol.uniform_bounds()
         cst = run.sol.compact_stats()
-        wfrac = (int(run.sol.isave[37]) / float(n)) if cst[3] else 1.0   # rows whose W entries the passes need
+        wfrac = (int(run.sol.isave[37]) / float(n)) if (cst[3] and cst[2]) else 1.0   # rows whose W entries the passes need
         upd_b, sub_b, _ = pass_bytes(max(col, 1), rb, run.pp, opts.get("lean", 1) != 0, ub, wfrac)
         passes = {}
         cw_b = (2 * max(col, 1) + 2) * rb + 1     # the third pass of col > 20: 2 col W columns + x, g + iwhere
@@ -854,7 +854,7 @@ def main():
     lean = opts.get("lean", 1) != 0
     ub = sol.uniform_bounds()
     cst = sol.compact_stats()          # (packs, unpacks, packed now, eligible)
-    wfrac = (nfree / float(n)) if cst[3] else 1.0
+    wfrac = (nfree / float(n)) if (cst[3] and cst[2]) else 1.0   # (packed: the passes read the free rows' entries)
     upd_bpr, sub_bpr, n_st = pass_bytes(col, rbytes, run.pp, lean, ub, wfrac)
     upd_masked, sub_masked, _ = pass_bytes(col, rbytes, run.pp, lean, ub, 1.0)
     ubs = "_ub%d" % ub if ub else ""
@@ -888,7 +888,7 @@ def main():
         return {"bound": "hbm", "kernel": label, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 # (the counts on file are of the kernels that stream every row: not those of the compact layout)
-                "traffic": None if cst[3] else static_traffic("w_pass_traffic.json", traffic_key, n_loc),
+                "traffic": None if (cst[3] and cst[2]) else static_traffic("w_pass_traffic.json", traffic_key, n_loc),
                 "traffic_source": "profiles/w_pass_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "over this bench at n=1e8, in-iteration launches of this kernel: bytes per "
                                   "row x rows; not re-measured in this run)",
@@ -916,10 +916,10 @@ def main():
                          % (tname, mc, nts, "; col - 1 > 20: two launches of the <20> kernel over half of the columns "
                             "each + a merge, timed together, priced at the bytes of ONE pass" if mc > 20 else
                             ("; compact_w: lane pairs share the column sums, W entries of the free rows only"
-                             if cst[3] else "")),
+                             if (cst[3] and cst[2]) else "")),
                          upd_bpr, "none", "update_scan" + ubs)
     entry = ("ping-pong entry" if run.pp else "classic entry") + (
-        ", W in the tile-local free-row layout: option compact_w" if cst[3] else "")
+        ", W in the tile-local free-row layout: option compact_w" if (cst[3] and cst[2]) else "")
     if run.pp:
         st_txt = "trial x + Ws/Wy column (3 of %d streams; t = x, r = g are a change of roles)" % (2 * col + 7)
     elif lean:

@@ -40,7 +40,7 @@ def run(rank, world, port, mode, n, m, iters, variant, out_path):
                                      options=({"exact_always": 1} if variant == "symx" else
                                               # the two passes over W on the tile-local free-row layout, re-sorted in
                                               # every iteration (tests/test_gpu_compact.py)
-                                              {"compact_w": 1, "compact_policy": 2}
+                                              {"compact_w": 2, "compact_policy": 2}
                                               if os.environ.get("LBFGSB_TEST_COMPACT") == "1" else None))
         if mode == "gloo":
             lbfgsb_amd.attach_host_group(s_, rank, world)

@@ -2,8 +2,10 @@
 reference's cmprlb / subsm / formk loops run over Index(1:nfree) (src/lbfgsb.f90:1565-1583, :2743-2778, :1756-1793,
 :2044-2054); streaming all n rows under a mask moves n / nfree times their bytes.
 
+compact_w = 1 (what bench.py sets): the passes run on the layout while it is packed, the natural-order kernels before
+the first pack (a problem whose rows are all free never pays for the option); compact_w = 2: always on the layout.
 What must hold:
-  * the LAYOUT never changes a result: with the option on, the sums are the same whatever the tiles look like --
+  * the LAYOUT never changes a result: with compact_w = 2 the sums are the same whatever the tiles look like --
     runs that never pack (policy 0), pack by the automatic rule (1) and re-sort the tiles in EVERY iteration (2)
     are bit for bit the same run (every return, x, g, the exported state);
   * against the run without the option only the order of the sums differs (another row-to-lane map): integer
@@ -93,10 +95,10 @@ def test_layout_never_changes_a_result(env, pp, defer):
     po = env["po"]
     packed_runs = 0
     for p in _problems(po):
-        base = _run(env, p, 60, pp=pp, defer=defer, compact_w=1, compact_policy=0)
+        base = _run(env, p, 60, pp=pp, defer=defer, compact_w=2, compact_policy=0)
         assert base["stats"][3] == 1 and base["stats"][0] == 0, (p.name, base["stats"])
         for pol in (2, 1):
-            r = _run(env, p, 60, pp=pp, defer=defer, compact_w=1, compact_policy=pol)
+            r = _run(env, p, 60, pp=pp, defer=defer, compact_w=2, compact_policy=pol, compact_min_rows=0)
             assert len(r["rows"]) == len(base["rows"]), (p.name, pol, len(r["rows"]), len(base["rows"]))
             for k, (a, b) in enumerate(zip(r["rows"], base["rows"])):
                 assert a == b, "%s (n=%d m=%d) policy %d: return %d differs: %s | %s" % (p.name, p.n, p.m, pol, k,
@@ -113,8 +115,14 @@ def test_option_on_follows_the_run_without_it(env):
     po = env["po"]
     for p in _problems(po)[:8]:
         a = _run(env, p, 14, export=False)
-        b = _run(env, p, 14, export=False, compact_w=1, compact_policy=2)
-        assert a["stats"][3] == 0 and b["stats"][3] == 1
+        b = _run(env, p, 14, export=False, compact_w=2, compact_policy=2)
+        c = _run(env, p, 14, export=False, compact_w=1, compact_min_rows=0)     # (what bench.py runs)
+        assert a["stats"][3] == 0 and b["stats"][3] == 1 and c["stats"][3] == 1
+        for rc in c["ints"][:8]:
+            ra = a["ints"][rc[0] - 1]
+            if rc[:4] != ra[:4]:
+                break
+            assert abs(ra[4] - rc[4]) <= 1e-9 * max(1.0, abs(ra[4])), (p.name, ra, rc)
         nsame = 0
         for ra, rb in zip(a["ints"], b["ints"]):
             if ra[:4] != rb[:4]:
@@ -147,7 +155,7 @@ def test_two_step_parity_with_the_tiles_resorted_inside_the_step(env, name, spec
             continue
         s = s0.copy()
         s.f[0] = p.fg(s.x, s.g)
-        sol = la.DeviceSolver(p.n, p.m, options={"compact_w": 1, "compact_policy": 2})
+        sol = la.DeviceSolver(p.n, p.m, options={"compact_w": 2, "compact_policy": 2})
         try:
             x, g = _dev(torch, s.x), _dev(torch, s.g)
             l, u, nbd = _dev(torch, p.l), _dev(torch, p.u), _dev(torch, p.nbd.astype(np.int32))
@@ -180,7 +188,7 @@ def test_checkpoint_resume_with_the_option_on(env):
     of the uninterrupted run, bit for bit -- the layouts of the two runs differ, the sums do not"""
     po, torch, la = env["po"], env["torch"], env["la"]
     p = po.problem_quadratic(20011, 6, mixed_nbd=True)
-    opts = {"compact_w": 1, "compact_policy": 1}
+    opts = {"compact_w": 2, "compact_policy": 1, "compact_min_rows": 0}
 
     def drive(sol, x, g, l, u, nbd, until, rows):
         while True:
@@ -227,7 +235,8 @@ def test_full_size_rows_with_the_option_on(env):
     problem -- integer columns exactly, f to 1e-9 -- and the layout packed by the automatic rule"""
     torch, la = env["torch"], env["la"]
     n, m = 1_000_000, 10
-    sol = la.DeviceSolver(n, m, defer_lnsrch=True, same_stream_objective=True, options={"compact_w": 1})
+    sol = la.DeviceSolver(n, m, defer_lnsrch=True, same_stream_objective=True,
+                          options={"compact_w": 1, "compact_min_rows": 0})
     try:
         xs = [torch.zeros(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")]
         gs = [torch.zeros_like(xs[0]), torch.empty_like(xs[0])]

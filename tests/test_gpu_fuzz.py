@@ -386,8 +386,8 @@ def drive_with_replay(po, p, max_iter, pp=False, final_check=True, replay_all=Fa
     (7200, 40, 1500, 1, 25, "lean=0"),
     # the two passes over W on the tile-local free-row layout (m <= 10), the tiles re-sorted in every iteration and
     # un-sorted by every export of the replay harness; and packed by the automatic rule
-    (9200, 60, 400, 1, 11, "compact_w=1,compact_policy=2"), (9300, 40, 3000, 1, 11, "pp,compact_w=1,compact_policy=2"),
-    (9400, 40, 3000, 3, 11, "pp,compact_w=1")])
+    (9200, 60, 400, 1, 11, "compact_w=2,compact_policy=2"), (9300, 40, 3000, 1, 11, "pp,compact_w=2,compact_policy=2"),
+    (9400, 40, 3000, 3, 11, "pp,compact_w=1,compact_min_rows=0")])
 def test_random_problems_against_oracle(oracle_built, first, count, nmax, mlo, mhi, switch):
     po = oracle_built
     words = switch.split(",") if switch else []
