@@ -503,27 +503,38 @@ class Solver final : public lbfgsb_hip_ctx {
     return w;
   }
   // Re-sort the tiles so that the rows that are free NOW (iwhere <= 0, after the walk) come first.  Called in front
-  // of the storing pass, where iwhere is final for the iteration.  Automatic policy: pack once a tenth of the rows
-  // is not free and the free set has settled (this iteration changed < 2 % of the rows); from then on re-sort
-  // whenever a row has changed status since -- the kernel skips the tiles whose bits stand, so its cost is a scan
-  // of iwhere (1 byte per row) plus one read + write of the live columns of the DIRTY tiles (a changed row costs
-  // 128 rows x 2 col x 16 bytes once; left alone it costs a slow fetch in every pass).  The sums do not depend on
-  // any of this (for_tiles_cw).
+  // of the storing pass, where iwhere is final for the iteration.  Automatic policy (compact_policy = 1):
+  //   * pack once a tenth of the rows is not free and the free set has SETTLED -- two iterations in a row that each
+  //     changed < 0.5 % of the rows -- and W is much larger than the Infinity Cache;
+  //   * from then on re-sort whenever a row has changed status since: the kernel skips the tiles whose bits stand,
+  //     so its cost is a scan of iwhere (1 byte per row) plus one read + write of the live columns of the DIRTY
+  //     tiles (a changed row costs 128 rows x 2 col x 16 bytes once; left alone it costs a slow fetch in every pass);
+  //   * an iteration that moves more than 2 % of the rows (driver3's Rosenbrock at n = 1e7 flips 5e6 rows in and out
+  //     of the free set every few iterations) ends the packing: back to natural order, and no new attempt for a while.
+  // The sums do not depend on any of this under compact_w = 2 (for_tiles_cw); under compact_w = 1 the kernels of the
+  // natural order run while the layout is not packed.
+  int cw_settled = 0;
   void cw_maybe_pack(int head, int col, int64_t changed_now) {
     live_head = head, live_col = col;
     if (!cw_eligible() || cw_policy == 0) return;
     cw_stale += changed_now;
     bool go = cw_policy == 2;
     if (cw_policy == 1) {
+      const double nn = (double)nglob;
+      cw_settled = (double)changed_now <= 0.005 * nn ? cw_settled + 1 : 0;
+      if (cw_packed && (double)changed_now > 0.02 * nn) {  // the free set is on the move
+        (void)W();
+        cw_hold = std::max(cw_hold, 8);
+        return;
+      }
       if (cw_hold > 0) {
         cw_hold--;
         return;
       }
-      const double nn = (double)nglob;
       // (a W that lives in the Infinity Cache gains nothing from fewer HBM bytes: n = 1e6, m = 10 lost 2.5 %)
       const bool big = cw_min_rows >= 0 ? n >= cw_min_rows : (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
       if (!cw_packed)
-        go = big && (double)(nglob - nfree_g) >= 0.10 * nn && (double)changed_now <= 0.02 * nn;
+        go = big && (double)(nglob - nfree_g) >= 0.10 * nn && cw_settled >= 2;
       else
         go = cw_stale > 0;
     }
@@ -656,7 +667,7 @@ class Solver final : public lbfgsb_hip_ctx {
     spec.valid = false, pend.on = 0, pend.impl = 0, d_impl = z_in_x = false, scan.ready = false;
     ls.deferred = false, defer_live = false, wl.pending = false;
     nrefresh = 0;
-    live_head = 1, live_col = 0, cw_stale = 0, cw_hold = 0;  // (no pair is stored: any layout bits may stay)
+    live_head = 1, live_col = 0, cw_stale = 0, cw_hold = 0, cw_settled = 0;  // (no pair is stored: any layout bits may stay)
     sfv.valid = false, sfv_hot = false, eager.valid = false, spec_live_len = 0;
     spcand.valid = false, last_tsum = 0.0, last_dtm0 = 0.0, iter_seen = 0, spec_factor = 2.0, last_walk_nseg = 0;
     epsmch = sizeof(T) == 4 ? (double)std::numeric_limits<float>::epsilon()
