@@ -190,11 +190,17 @@
                                     cf, lean ? (T *)nullptr : d, pp ? (T *)nullptr : t_own,
                                     lean ? z : (T *)nullptr, 1, lbk::Pend{1, 0.5, lean ? 1 : 0},
                                     lean ? t_own : d, ub_mask);
-      else             // as the evaluation of a trial point: reduces only
+      else {           // as the evaluation of a trial point: reduces only
+        // (on the packed layout the direction is taken as x - x = 0: a stale t_own would make EVERY row look as if
+        //  it had moved, and rows outside their tile's front run would all fetch their entries the slow way -- the
+        //  steady state this door is meant to time has a handful of such rows)
+        const bool pk = Wc().lmask != nullptr;
         lbk::launch_update_scan<T>(q, n, (const T *)x, lk(l), uk(u), nbk(), (const T *)g, r_own,
-                                   lean ? t_own : d, lean ? 1 : 0, 0.5, iwhere, (T *)nullptr, Wc(), head, col,
+                                   pk ? (const T *)x : (lean ? t_own : d), (pk || lean) ? 1 : 0, 0.5, iwhere,
+                                   (T *)nullptr, Wc(), head, col,
                                    (head + col - 2) % m + 1, 0, 0, nr_flag(col), -1.0, nullptr, nullptr, 0,
                                    nullptr, ub_mask);
+      }
     } else
       return fail(LBFGSB_E_ARG, "unknown kernel");
     return 0;
