@@ -115,23 +115,6 @@ struct SubsmTripCW1 : SubsmRegs<T, MC, 1>, CwOneRow {
     cols<NT>(c, lf ? slot : first);
   }
   __device__ __forceinline__ void land() {}
-  __device__ __forceinline__ void reload_cols(const SubsmCtx<T> &c, const bool (&miss)[1]) {
-    // (into registers of their own, merged afterwards: see UpdScanTripCW1, k_update.hip)
-    constexpr int B = (int)sizeof(T);
-    RawOf<T, 1> ty[MC], ts[MC];
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      const T *py, *ps;
-      subsm_cw_col<T, MC, PSPEC>(c, j, this->ri_, miss[0] ? this->ws_ : this->ri_ & ~(int64_t)127, true, py, ps);
-      raw_issue<B, false>(ty[j], py);
-      raw_issue<B, false>(ts[j], ps);
-    }
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-      this->ra[j].v = miss[0] ? ty[j].v : this->ra[j].v;
-      this->rb[j].v = miss[0] ? ts[j].v : this->rb[j].v;
-    }
-  }
 };
 // ... the rows lane, lane + 64 of a full tile as one row group of width 2 (see UpdScanTripCW2, k_update.hip)
 template <typename T, int MC, bool NT, bool PSPEC>
@@ -188,30 +171,6 @@ struct SubsmTripCW2 : SubsmRegs<T, MC, 2>, CwPairRows {
     raw_join_bytes(this->rnb, nb_[0], nb_[1]);
     raw_join_bytes(this->riw, iw_[0], iw_[1]);
   }
-  __device__ __forceinline__ void reload_cols(const SubsmCtx<T> &c, const bool (&miss)[2]) {
-    int sl[2];
-    bool lf[2];
-    cw_slots(this->tile_, sl, lf);
-    // (into registers of their own, merged afterwards: see UpdScanTripCW1, k_update.hip)
-    RawReg<8> ty[MC][2], ts[MC][2];
-#pragma unroll
-    for (int j = 0; j < (PSPEC ? MC - 1 : MC); ++j) {
-      const int64_t off = (PSPEC ? (int64_t)((c.head - 1 + j) % c.m) * c.ldw : col_off(j, c.col, c.head, c.m, c.ldw)) +
-                          this->tile_.tb;
-      const bool stored = PSPEC || (j < c.col && !(c.pe.on && j == c.col - 1));
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        raw_issue<8, false>(ty[j][k], stored ? c.wy + off + (miss[k] ? sl[k] : 0) : c.zero);
-        raw_issue<8, false>(ts[j][k], stored ? c.ws + off + (miss[k] ? sl[k] : 0) : c.zero);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < (PSPEC ? MC - 1 : MC); ++j) {
-      const bool stored = PSPEC || (j < c.col && !(c.pe.on && j == c.col - 1));
-      if (stored && miss[0]) this->ra[j].v.xy = ty[j][0].v, this->rb[j].v.xy = ts[j][0].v;
-      if (stored && miss[1]) this->ra[j].v.zw = ty[j][1].v, this->rb[j].v.zw = ts[j][1].v;
-    }
-  }
 };
 // CW: W in the tile-local free-row layout `lmask` (fp64, MC <= 10; for_tiles_cw)
 template <typename T, int MC, bool NT, bool PSPEC, bool PIPE, bool CW = false>
@@ -245,11 +204,14 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     raw_geti<W>(tr.riw, (const iw_t *)nullptr, iw);
     dict_apply<T, W>(dict, ub, nb, lv, uv);
     if constexpr (std::remove_reference_t<decltype(tr)>::CW) {
-      // a free row whose layout bit is clear (it became free after the layout was made)
-      bool miss[W], any = false;
+      // A free row whose layout bit is clear cannot exist HERE: the solver re-sorts the tiles in front of this pass
+      // whenever a row changed status (cw_maybe_pack), so the bits are the free set of this very iteration -- or all
+      // ones.  (Fetching such a row's entries in this kernel, as the update pass does, costs 88 registers and the
+      // third wave per SIMD.)  Should it happen all the same, the count of bound hits becomes absurd and the host
+      // refuses the result (subspace_land).
 #pragma unroll
-      for (int k = 0; k < W; ++k) miss[k] = !tr.lf(k) && iw[k] <= 0, any = any || miss[k];
-      if (__ballot(any) != 0ull) tr.reload_cols(ctx, miss);
+      for (int k = 0; k < W; ++k)
+        if (!tr.lf(k) && iw[k] <= 0) acc[0] += 1.0e30;
     }
     get_cols<T, MC, W>(tr.ra, tr.rb, a, b);
     fix_pending<T, MC, W, PSPEC>(col, pe, gv, xv, a, b);

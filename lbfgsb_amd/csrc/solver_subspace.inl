@@ -363,6 +363,8 @@
     const double theta = sub_theta;
     const int col = sub_col, head = sub_head;
     const lbk::Coef &cw = sub_cw;
+    if (R[0] >= 1.0e29)  // (k_subsm.hip: a free row outside its tile's front run -- the layout was not re-sorted)
+      return fail(LBFGSB_E_STATE, "storing pass: the tile-local layout of W is older than the free set");
     iword = R[0] > 0.0 ? 1 : 0;
     const double dd_p = R[1];
     ls.ready = true;
