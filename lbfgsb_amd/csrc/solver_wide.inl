@@ -318,6 +318,9 @@ int wide_subspace(const T *x, const T *l, const T *u, const int32_t *nbd, const 
         deferred = defer_on && ls_unit_step && !(flags & LBFGSB_F_PARALLEL_GCP);
         q.res_off = deferred ? DEFER_OFF : 0;
         if (deferred && fold_fin) q.part_sel = 2, q.hold_fin = true;
+        // (the host stretch between the landing of the trial point's sums and this launch: as subspace() counts it)
+        seg(4);
+        if (t_mid0 > 0.0) t_mid += now_s() - t_mid0, n_mid++, t_mid0 = 0.0;
         lbk::launch_wide_r_pass<T>(q, n, W(), head, col, cw, iwhere, nbk(), ub_mask, tail, pend, r, d_src());
         q.res_off = 0, q.part_sel = 0;
         pend.on = 0, pend.impl = 0;  // the pass stored the pair into its W slot
