@@ -52,7 +52,7 @@
       integer(c_int), parameter :: H2D = 1
 
       integer               :: n, m, maxit, warm, iprint, rc, cur, flags, k
-      logical               :: pp
+      logical               :: pp, compact
       real(wp), parameter   :: factr = 0.0_wp, pgtol = 0.0_wp
       character(len=60)     :: task, csave
       character(len=32)     :: arg
@@ -81,6 +81,10 @@
       end if
       if (command_argument_count() >= 5) then
          call get_command_argument(5, arg); pp = trim(arg) /= 'classic'
+      end if
+      compact = .false.
+      if (command_argument_count() >= 6) then
+         call get_command_argument(6, arg); compact = trim(arg) == 'compact'
       end if
 
       ! ---- device buffers (16 bytes of slack: the library asks for 16-byte aligned pointers, hipMalloc gives 256)
@@ -112,6 +116,15 @@
       if (rc /= 0) then
          write (output_unit, '(2a)') ' lbfgsb_create failed: ', lbfgsb_error_message()
          error stop 1
+      end if
+
+      ! the two passes over W on the free-rows-first layout (DESIGN.md 4g), as bench.py runs them
+      if (compact) then
+         call lbfgsb_set_option(ctx, 'compact_w', 1.0d0, rc)
+         if (rc /= 0) then
+            write (output_unit, '(2a)') ' lbfgsb_set_option failed: ', lbfgsb_error_message()
+            error stop 1
+         end if
       end if
 
       task = 'START'

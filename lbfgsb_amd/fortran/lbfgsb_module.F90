@@ -40,6 +40,7 @@
       public :: setulb_dev                             ! lbfgsb_hip_setulb_dev: x, g updated in place on the device
       public :: setulb_dev_pp                          ! lbfgsb_hip_setulb_dev_pp: ping-pong iterate buffers
       public :: lbfgsb_objective                       ! built-in device objectives (lbfgsb_hip_objective)
+      public :: lbfgsb_set_option                      ! per-context switches (lbfgsb_hip_set_option): 'compact_w', ...
       public :: lbfgsb_error_message                   ! text of the last failure (lbfgsb_hip_last_error)
       ! flags of lbfgsb_create (include/lbfgsb_hip.h)
       integer,parameter,public :: LBFGSB_F_REAL32 = 1, LBFGSB_F_MIRROR_INDEX = 2, LBFGSB_F_NO_RETURN_SYNC = 4, &
@@ -122,6 +123,13 @@
             integer(c_int),value :: kind
             integer(c_int) :: rc
          end function lbfgsb_hip_objective
+         function lbfgsb_hip_set_option(ctx,name,val) bind(C,name='lbfgsb_hip_set_option') result(rc)
+            import :: c_int, c_ptr, c_char, c_double
+            type(c_ptr),value :: ctx
+            character(kind=c_char) :: name(*)
+            real(c_double),value :: val
+            integer(c_int) :: rc
+         end function lbfgsb_hip_set_option
          function c_strlen(s) bind(C,name='strlen') result(k)
             import :: c_ptr, c_size_t
             type(c_ptr),value :: s
@@ -324,6 +332,23 @@
       cur = int(c32)
       if (rc /= 0) Task = 'ERROR: LBFGSB_HIP FAILURE'
       end subroutine setulb_dev_pp
+
+      ! A switch of this context (include/lbfgsb_hip.h, lbfgsb_hip_set_option), before 'START': e.g.
+      ! call lbfgsb_set_option(ctx, 'compact_w', 1.0d0, rc) -- the two passes over W read the W entries of the free
+      ! variables only (the reference's Index(1:nfree) loops, src/lbfgsb.f90:1565-1583, 2743-2778; DESIGN.md 4g)
+      subroutine lbfgsb_set_option(ctx, name, val, rc)
+      type(c_ptr),intent(in) :: ctx
+      character(len=*),intent(in) :: name
+      real(c_double),intent(in) :: val
+      integer,intent(out) :: rc
+      character(kind=c_char) :: cname(len_trim(name) + 1)
+      integer :: k
+      do k = 1, len_trim(name)
+         cname(k) = name(k:k)
+      end do
+      cname(len_trim(name) + 1) = c_null_char
+      rc = lbfgsb_hip_set_option(ctx, cname, val)
+      end subroutine lbfgsb_set_option
 
       ! Built-in objective on the context's stream: kind 0 = separable bounded quadratic (BASELINE.md 3),
       ! 1 = extended Rosenbrock (test/driver1.f90:274-289).  With f present the call waits for the value;
