@@ -478,67 +478,29 @@ __device__ __forceinline__ int64_t wave_uniform(int64_t v) {
 }
 // Trip2: issue_cw(const Ctx &, const CwTile &), land();  f(trip, first row of the tile, WTag<2>)
 // Trip1: issue_cw(const Ctx &, int64_t i, int64_t slot, bool lf, int64_t tile_first), land();  f(trip, i, WTag<1>)
-template <typename Trip2, typename Trip1, bool PIPE, typename Ctx, typename F>
+template <typename Trip2, typename Trip1, typename Ctx, typename F>
 __device__ __forceinline__ void for_tiles_cw(int64_t n, const Ctx &c, const uint64_t *__restrict__ lmask, F &&f) {
   const int lane = threadIdx.x & 63;
   const int64_t nfull = n >> 7;
   const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
   // (wave-uniform, which the compiler cannot see: scalar registers for the tile arithmetic and the mask words)
   const int64_t t0 = wave_uniform((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  // (one trip in flight per wave: two -- as for_rows_raw's PIPE -- lost against two or three waves per SIMD in every
+  //  kernel of the layout, 3.2 vs 2.55 ms for the update pass at n = 1e8: HISTORY round 6)
   if (t0 < nfull) {
-    const int64_t last = nfull - 1;
-    if constexpr (!PIPE) {
-      uint64_t m0 = lmask[2 * t0], m1 = lmask[2 * t0 + 1];
-      for (int64_t tr = t0;;) {
-        const int64_t nx = tr + stride;
-        const bool more = nx < nfull;
-        const int64_t nxc = more ? nx : tr;
-        const uint64_t m0n = lmask[2 * nxc], m1n = lmask[2 * nxc + 1];  // the next trip's words
-        Trip2 A;
-        A.issue_cw(c, CwTile{tr << 7, m0, m1});
-        raw_wait<0>();
-        A.land();
-        f(A, tr << 7, WTag<2>{});
-        if (!more) break;
-        tr = nx, m0 = m0n, m1 = m1n;
-      }
-    } else {
-      // two trips in flight per wave, as for_rows_raw's PIPE; the mask words of the trip that is issued next are
-      // always one issue ahead (scalar loads: they do not queue behind the vector loads in flight)
-      auto cl = [&](int64_t t) { return t < nfull ? t : last; };
-      Trip2 A, B;
-      int64_t b = t0 + stride, nxt = b + stride;
-      {
-        const int64_t bc = cl(b);
-        const uint64_t a0 = lmask[2 * t0], a1 = lmask[2 * t0 + 1], b0 = lmask[2 * bc], b1 = lmask[2 * bc + 1];
-        A.issue_cw(c, CwTile{t0 << 7, a0, a1});
-        B.issue_cw(c, CwTile{bc << 7, b0, b1});
-      }
-      int64_t qc = cl(nxt);
-      uint64_t q0 = lmask[2 * qc], q1 = lmask[2 * qc + 1];
-      raw_wait<Trip2::NL>();
+    uint64_t m0 = lmask[2 * t0], m1 = lmask[2 * t0 + 1];
+    for (int64_t tr = t0;;) {
+      const int64_t nx = tr + stride;
+      const bool more = nx < nfull;
+      const int64_t nxc = more ? nx : tr;
+      const uint64_t m0n = lmask[2 * nxc], m1n = lmask[2 * nxc + 1];  // the next trip's words
+      Trip2 A;
+      A.issue_cw(c, CwTile{tr << 7, m0, m1});
+      raw_wait<0>();
       A.land();
-      f(A, t0 << 7, WTag<2>{});
-      while (b < nfull) {  // B holds trip b; (q0, q1) are the words of trip nxt
-        A.issue_cw(c, CwTile{qc << 7, q0, q1});
-        const int64_t nn = nxt + stride, nnc = cl(nn);
-        const uint64_t r0 = lmask[2 * nnc], r1 = lmask[2 * nnc + 1];
-        raw_wait<Trip2::NL>();
-        B.land();
-        f(B, b << 7, WTag<2>{});
-        if (nxt >= nfull) break;
-        B.issue_cw(c, CwTile{nnc << 7, r0, r1});
-        const int64_t n2 = nn + stride;
-        const int64_t a_tile = nxt;
-        qc = cl(n2), q0 = lmask[2 * qc], q1 = lmask[2 * qc + 1];
-        raw_wait<Trip2::NL>();
-        A.land();
-        f(A, a_tile << 7, WTag<2>{});
-        b = nn, nxt = n2;
-      }
-      raw_wait<0>();  // the last prefetch is unused: land it before its registers are reused
-      A.land();
-      B.land();
+      f(A, tr << 7, WTag<2>{});
+      if (!more) break;
+      tr = nx, m0 = m0n, m1 = m1n;
     }
   }
   // the partial tile behind the full ones, row by row
@@ -561,12 +523,10 @@ __device__ __forceinline__ void for_tiles_cw(int64_t n, const Ctx &c, const uint
 }
 
 // The same layout walked in HALF tiles: a wave takes 64 rows per trip, lane l owns row l of the half -- one row per
-// lane and trip, as the natural-order kernels with many accumulators run (RowsPerAcc), so that TWO trips fit the
-// register file and the next trip's loads are in flight while this one is computed (PIPE, as for_rows_raw).  The
-// update pass with formk's new-row sums needs that: 95 fp64 accumulators leave one wave per SIMD, and its arithmetic
-// (1.4 ms of VALU time at n = 1e8) has to overlap the loads.
+// lane and trip, as the natural-order kernels with many accumulators run (RowsPerAcc): the update pass with formk's
+// new-row sums, whose lane pairs share the column accumulators (UpdScanPairTripCW) and so keep two waves per SIMD.
 // Trip1 as above; f(trip, i, WTag<1>).  The partial half behind the full ones is taken by itself.
-template <typename Trip1, bool PIPE, typename Ctx, typename F>
+template <typename Trip1, typename Ctx, typename F>
 __device__ __forceinline__ void for_halves_cw(int64_t n, const Ctx &c, const uint64_t *__restrict__ lmask, F &&f) {
   const int lane = threadIdx.x & 63;
   const int64_t nh = n >> 6;  // full halves
@@ -589,53 +549,17 @@ __device__ __forceinline__ void for_halves_cw(int64_t n, const Ctx &c, const uin
   if (t0 < nh) {
     const int64_t last = nh - 1;
     auto cl = [&](int64_t h) { return h < nh ? h : last; };
-    if constexpr (!PIPE) {
-      uint64_t m0 = lmask[(t0 >> 1) * 2], m1 = lmask[(t0 >> 1) * 2 + 1];
-      for (int64_t h = t0;;) {
-        const int64_t nx = h + stride, nxc = cl(nx);
-        const uint64_t m0n = lmask[(nxc >> 1) * 2], m1n = lmask[(nxc >> 1) * 2 + 1];  // the next trip's words
-        Trip1 A;
-        issue(A, h, m0, m1, n);
-        raw_wait<0>();
-        A.land();
-        f(A, (h << 6) + lane, WTag<1>{});
-        if (nx >= nh) break;
-        h = nx, m0 = m0n, m1 = m1n;
-      }
-    } else {
-      Trip1 A, B;
-      int64_t b = t0 + stride, nxt = b + stride;
-      {
-        const int64_t bc = cl(b);
-        const uint64_t a0 = lmask[(t0 >> 1) * 2], a1 = lmask[(t0 >> 1) * 2 + 1];
-        const uint64_t b0 = lmask[(bc >> 1) * 2], b1 = lmask[(bc >> 1) * 2 + 1];
-        issue(A, t0, a0, a1, n);
-        issue(B, bc, b0, b1, n);
-      }
-      int64_t qc = cl(nxt);
-      uint64_t q0 = lmask[(qc >> 1) * 2], q1 = lmask[(qc >> 1) * 2 + 1];
-      raw_wait<Trip1::NL>();
+    uint64_t m0 = lmask[(t0 >> 1) * 2], m1 = lmask[(t0 >> 1) * 2 + 1];
+    for (int64_t h = t0;;) {
+      const int64_t nx = h + stride, nxc = cl(nx);
+      const uint64_t m0n = lmask[(nxc >> 1) * 2], m1n = lmask[(nxc >> 1) * 2 + 1];  // the next trip's words
+      Trip1 A;
+      issue(A, h, m0, m1, n);
+      raw_wait<0>();
       A.land();
-      f(A, (t0 << 6) + lane, WTag<1>{});
-      while (b < nh) {  // B holds half b; (q0, q1) are the words of half nxt's tile
-        issue(A, qc, q0, q1, n);
-        const int64_t nn = nxt + stride, nnc = cl(nn);
-        const uint64_t r0 = lmask[(nnc >> 1) * 2], r1 = lmask[(nnc >> 1) * 2 + 1];
-        raw_wait<Trip1::NL>();
-        B.land();
-        f(B, (b << 6) + lane, WTag<1>{});
-        if (nxt >= nh) break;
-        issue(B, nnc, r0, r1, n);
-        const int64_t n2 = nn + stride, a_half = nxt;
-        qc = cl(n2), q0 = lmask[(qc >> 1) * 2], q1 = lmask[(qc >> 1) * 2 + 1];
-        raw_wait<Trip1::NL>();
-        A.land();
-        f(A, (a_half << 6) + lane, WTag<1>{});
-        b = nn, nxt = n2;
-      }
-      raw_wait<0>();  // the last prefetch is unused: land it before its registers are reused
-      A.land();
-      B.land();
+      f(A, (h << 6) + lane, WTag<1>{});
+      if (nx >= nh) break;
+      h = nx, m0 = m0n, m1 = m1n;
     }
   }
   if ((n & 63) != 0 && t0 == nh % stride) {  // the partial half

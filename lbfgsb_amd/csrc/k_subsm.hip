@@ -182,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     int m, int head, int col, double theta, Coef cf, Coef wv, T *dvec, T *tvec,
     T *xout, int do_stpmx, Pend pe, const T *pd, T *cwy, T *cws, int ub, double *part, int pstride,
     const uint64_t *__restrict__ lmask = nullptr) {
-  static_assert(!CW || (sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10");
+  static_assert(!CW || (sizeof(T) == 8 && MC <= 10 && !PIPE), "compact W: fp64, MC <= 10, one trip in flight");
   double acc[4] = {0.0, 0.0, 0.0, 1.0e10};
   const double rtheta = 1.0 / theta;
   constexpr int V = RowsPer<T, MC>::V;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void subsm_update_kernel(
     if (xout) tr.template st_rows<NT>(xout, i, zv);
   };
   if constexpr (CW)
-    for_tiles_cw<SubsmTripCW2<T, MC, NT, PSPEC>, SubsmTripCW1<T, MC, NT, PSPEC>, PIPE>(n, ctx, lmask, body);
+    for_tiles_cw<SubsmTripCW2<T, MC, NT, PSPEC>, SubsmTripCW1<T, MC, NT, PSPEC>>(n, ctx, lmask, body);
   else
     for_rows_raw<SubsmTrip<T, MC, V, NT, PSPEC>, SubsmTrip<T, MC, 1, NT, PSPEC>, V, PIPE, NS>(n, ctx, body);
   block_reduce_store<4>(acc, 3, 1, 0, part, pstride);

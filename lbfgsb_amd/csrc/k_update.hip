@@ -423,7 +423,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     const T *__restrict__ zero, int64_t ldw, int m, int head, int nold, int itail, int store_pair,
     int store_iw, double cand_hi, uint64_t *ckeys, uint32_t *cidx, uint32_t ccap, uint32_t *ccount,
     int ub, double *part, const uint64_t *__restrict__ lmask = nullptr) {
-  static_assert(!CW || (sizeof(T) == 8 && MC <= 10), "compact W: fp64, MC <= 10");
+  static_assert(!CW || (sizeof(T) == 8 && MC <= 10 && !PIPE), "compact W: fp64, MC <= 10, one trip in flight");
   constexpr int NX = NEWROW ? 4 * MC + 4 : 0;  // extra sums
   constexpr int X = 4 * MC + 9;                // first extra slot
   constexpr int NA = 4 * MC + 11 + NX;
@@ -653,11 +653,11 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
     if constexpr (!PAIR) row_stores();
   };
   if constexpr (CW && PAIR)  // (the caller passes whole tiles)
-    for_halves_cw<UpdScanPairTripCW<T, MC, NT, TIGHT>, PIPE>(n, ctx, lmask, body);
+    for_halves_cw<UpdScanPairTripCW<T, MC, NT, TIGHT>>(n, ctx, lmask, body);
   else if constexpr (CW && NEWROW)  // (one row per lane and trip, two trips in flight: see for_halves_cw)
-    for_halves_cw<UpdScanTripCW1<T, MC, NT>, PIPE>(n, ctx, lmask, body);
+    for_halves_cw<UpdScanTripCW1<T, MC, NT>>(n, ctx, lmask, body);
   else if constexpr (CW)
-    for_tiles_cw<UpdScanTripCW2<T, MC, NT>, UpdScanTripCW1<T, MC, NT>, PIPE>(n, ctx, lmask, body);
+    for_tiles_cw<UpdScanTripCW2<T, MC, NT>, UpdScanTripCW1<T, MC, NT>>(n, ctx, lmask, body);
   else
     for_rows_raw<TripV, Trip1, V, PIPE, 0>(n, ctx, body);
   if constexpr (PAIR) {
@@ -765,19 +765,11 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
         const bool nrw = update_scan_extra(nold, newrow) != 0;
 #define LB_UPDSCAN_CW(MCV, NTV, NRV)                                                                   \
   {                                                                                                    \
-    if (q.tune.pipe_cw && NRV) { /* (two trips in flight: the new-row instantiations, one wave per SIMD) */        \
-      gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, NRV, NRV, false, true>);   \
-      hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, NRV, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,       \
-                         q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
-                         w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
-                         q.part(), w.lmask);                                                                       \
-    } else {                                                                                                       \
-      gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, false, NRV, false, true>); \
-      hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, false, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,     \
-                         q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
-                         w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
-                         q.part(), w.lmask);                                                                       \
-    }                                                                                                              \
+    gr = grid_for_w(q, n, VecOf<T>::V, (const void *)&update_scan_kernel<T, MCV, NTV, false, NRV, false, true>); \
+    hipLaunchKernelGGL((update_scan_kernel<T, MCV, NTV, false, NRV, false, true>), dim3(gr), dim3(BLOCK), 0,     \
+                       q.stream, n, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero, w.ld,   \
+                       w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,     \
+                       q.part(), w.lmask);                                                                       \
   }
         int nblocks = -1;
         if (nold > 5 && nrw && q.tune.pair_cw && n >= CW_TILE) {
@@ -785,22 +777,19 @@ void launch_update_scan(Queue &q, int64_t n, const T *x, const T *l, const T *u,
           // the whole tiles; the rows behind them (< one tile) go to the plain instantiation as one more workgroup,
           // whose partials land in column `gr` of the partial-sum matrix -- as the natural-order MC = 20 pass does
           const int64_t n_main = n / CW_TILE * CW_TILE, n_rest = n - n_main;
-#define LB_PAIR_CW(NTV, PIPEV, TIGHTV)                                                                            \
+#define LB_PAIR_CW(NTV, TIGHTV)                                                                                   \
   {                                                                                                               \
     gr = grid_for_w(q, n_main, VecOf<T>::V,                                                                       \
-                    (const void *)&update_scan_kernel<T, 10, NTV, PIPEV, true, true, true, TIGHTV>);              \
-    hipLaunchKernelGGL((update_scan_kernel<T, 10, NTV, PIPEV, true, true, true, TIGHTV>), dim3(gr), dim3(BLOCK), 0, \
+                    (const void *)&update_scan_kernel<T, 10, NTV, false, true, true, true, TIGHTV>);              \
+    hipLaunchKernelGGL((update_scan_kernel<T, 10, NTV, false, true, true, true, TIGHTV>), dim3(gr), dim3(BLOCK), 0, \
                        q.stream, n_main, x, l, u, nbd, g, r, d, dimpl, stp, iwhere, tbrk, w.ws, w.wy, w.zero,       \
                        w.ld, w.m, head, nold, itail, store_pair, store_iw, cand_hi, ckeys, cidx, ccap, ccount, ub,   \
                        q.part(), w.lmask);                                                                          \
   }
-          // (two trips in flight lost against two waves per SIMD: 3.2 vs 2.6 ms at n = 1e8 -- option "pipe_cw" = 2)
-          const bool pv = q.tune.pipe_cw >= 2;
           if (nold == 9) {
-            if (q.nt) { if (pv) LB_PAIR_CW(true, true, true) else LB_PAIR_CW(true, false, true) }
-            else { if (pv) LB_PAIR_CW(false, true, true) else LB_PAIR_CW(false, false, true) }
+            if (q.nt) LB_PAIR_CW(true, true) else LB_PAIR_CW(false, true)
           } else {
-            if (q.nt) LB_PAIR_CW(true, false, false) else LB_PAIR_CW(false, false, false)
+            if (q.nt) LB_PAIR_CW(true, false) else LB_PAIR_CW(false, false)
           }
 #undef LB_PAIR_CW
           nblocks = gr;

@@ -31,7 +31,6 @@ struct Tune {
   int split_cols = 16;  // ... into parts of at most this many (experiment: 10 / 10 = two MC = 10 launches at m = 20)
   int gram_rows = 0;  // formk from scratch: 1 = the LDS-slab kernel instead of the quad kernel
   int pair_cw = 1;    // compact W, MC = 10 update pass with the new-row sums: lane pairs share the column accumulators
-  int pipe_cw = 1;    // compact W: the update pass with formk's new-row sums keeps two trips in flight per wave
 };
 
 // one reduction waiting to be finalized: `nblocks` partials per slot in part[slot * pstride + block],

@@ -508,7 +508,6 @@
     if (k == "pipe") return in_range(-1, 1, q.tune.pipe);
     if (k == "pair") return in_range(0, 2, q.tune.pair);
     if (k == "gram_rows") return in_range(0, 1, q.tune.gram_rows);
-    if (k == "pipe_cw") return in_range(0, 2, q.tune.pipe_cw);
     if (k == "pair_cw") return in_range(0, 1, q.tune.pair_cw);
     if (k == "split") {  // 20 (default: parts of <= 16 columns beyond 20 old pairs) or 10 (parts of <= 10 beyond 10)
       if (v != 10.0 && v != 20.0) return fail(LBFGSB_E_ARG, "set_option: split takes 10 or 20");
