@@ -121,6 +121,15 @@ def test_bench_parity_in_run_flags_what_it_should():
     bad = list(rows)
     bad[7] = bad[7][:4] + (bad[7][4] * (1 + 1e-8),)
     assert bench.parity_in_run(bad, 100_000_000, 10, False, 0)["ok"] is False
-    assert bench.parity_in_run(rows, 1_000_000, 10, False, 0)["ok"] is None          # no rows on file for this shape
+    assert bench.parity_in_run(rows, 3_000_000, 10, False, 0)["ok"] is None          # no rows on file for this shape
+    r6 = json.load(open(os.path.join(ROOT, "tests", "golden", "quad_n1e6_m10_ref_rows.json")))["rows"]
+    assert bench.parity_in_run([(r["iter"], r["nfg"], r["nseg"], r["nfree"], r["f"]) for r in r6], 1_000_000, 10,
+                               False, 0)["ok"] is True                                 # configs[1] has rows too
+    # REAL32 contexts are compared with the REAL64 reference's rows of the same shape under REAL32 rules
+    r20 = json.load(open(os.path.join(ROOT, "tests", "golden", "quad_n1e8_m20_ref_rows.json")))["rows"]
+    near = [(r["iter"], r["nfg"], r["nseg"] + 3, r["nfree"] - 4, r["f"] * (1 + 5e-7)) for r in r20]
+    assert bench.parity_in_run(near, 100_000_000, 20, True, 0)["ok"] is True
+    far = [(r["iter"], r["nfg"] + (r["iter"] == 20), r["nseg"], r["nfree"], r["f"]) for r in r20]
+    assert bench.parity_in_run(far, 100_000_000, 20, True, 0)["ok"] is False
     assert bench.parity_in_run(rows, 100_000_000, 10, True, 0)["ok"] is None          # REAL32: not the fixture's kind
     assert bench.parity_in_run([], 100_000_000, 10, False, 0)["ok"] is False         # nothing ran: not a pass
