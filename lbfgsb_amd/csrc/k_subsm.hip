@@ -163,9 +163,12 @@ struct SubsmTripCW2 : SubsmRegs<T, MC, 2>, CwPairRows {
     int sl[2];
     bool lf[2];
     cw_slots(t, sl, lf);
-    // (a row whose layout bit is clear reads the tile's first entry: see UpdScanTripCW2)
-    cols_row<NT>(c, 0, t.tb + (lf[0] ? sl[0] : 0));
-    cols_row<NT>(c, 1, t.tb + (lf[1] ? sl[1] : 0));
+    // (a row whose layout bit is clear reads the tile's first entry: see UpdScanTripCW2.  Plain loads for the W
+    //  entries whatever NT says for the row vectors: the two runs of a tile -- rows l and rows l + 64 -- meet in one
+    //  line, and a nontemporal line is fetched from HBM for each of the two instructions: 15.33 -> 13.51 GB per
+    //  launch = 1.05 x the algorithmic bytes, 2.84 -> 2.71 ms at n = 1e8, same box)
+    cols_row<false>(c, 0, t.tb + (lf[0] ? sl[0] : 0));
+    cols_row<false>(c, 1, t.tb + (lf[1] ? sl[1] : 0));
   }
   __device__ __forceinline__ void land() {
     raw_join_bytes(this->rnb, nb_[0], nb_[1]);

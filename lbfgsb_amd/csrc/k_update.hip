@@ -225,8 +225,8 @@ struct UpdScanTripCW2 : UpdScanRegs<T, MC, 2>, CwPairRows {
     // brings in anyway): no predicate, no second address.  Its value is never used where it could matter -- such a
     // row either contributes products with exact zeros (it did not move, it is not free: any finite factor will do)
     // or is caught as `miss` in the kernel body and fetches its own entries (reload_cols).
-    cols_row<NT>(c, 0, t.tb + (lf[0] ? sl[0] : 0));
-    cols_row<NT>(c, 1, t.tb + (lf[1] ? sl[1] : 0));
+    cols_row<false>(c, 0, t.tb + (lf[0] ? sl[0] : 0));  // (plain loads: see SubsmTripCW2)
+    cols_row<false>(c, 1, t.tb + (lf[1] ? sl[1] : 0));
   }
   __device__ __forceinline__ void land() {
     raw_join_bytes(this->rnb, nb_[0], nb_[1]);
