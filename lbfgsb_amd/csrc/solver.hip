@@ -504,8 +504,8 @@ class Solver final : public lbfgsb_hip_ctx {
   }
   // Re-sort the tiles so that the rows that are free NOW (iwhere <= 0, after the walk) come first.  Called in front
   // of the storing pass, where iwhere is final for the iteration.  Automatic policy (compact_policy = 1):
-  //   * pack once a tenth of the rows is not free and the free set has SETTLED -- two iterations in a row that each
-  //     changed < 0.5 % of the rows -- and W is much larger than the Infinity Cache;
+  //   * pack once a tenth of the rows is not free, the free set has SETTLED -- two iterations in a row that each
+  //     changed < 0.5 % of the rows --, the memory is full (col = m) and W is much larger than the Infinity Cache;
   //   * from then on re-sort whenever a row has changed status since: the kernel skips the tiles whose bits stand,
   //     so its cost is a scan of iwhere (1 byte per row) plus one read + write of the live columns of the DIRTY
   //     tiles (a changed row costs 128 rows x 2 col x 16 bytes once; left alone it costs a slow fetch in every pass);
@@ -533,8 +533,10 @@ class Solver final : public lbfgsb_hip_ctx {
       }
       // (a W that lives in the Infinity Cache gains nothing from fewer HBM bytes: n = 1e6, m = 10 lost 2.5 %)
       const bool big = cw_min_rows >= 0 ? n >= cw_min_rows : (size_t)2 * ld * m * sizeof(T) > ((size_t)192 << 20);
+      // (... and the memory is full: while it fills, the storing pass runs its general instantiation -- runtime
+      //  column count, pending pair by select -- which on the layout costs 5.2 ms against 3.4 in natural order)
       if (!cw_packed)
-        go = big && (double)(nglob - nfree_g) >= 0.10 * nn && cw_settled >= 2;
+        go = big && (double)(nglob - nfree_g) >= 0.10 * nn && cw_settled >= 2 && col >= m;
       else
         go = cw_stale > 0;
     }
