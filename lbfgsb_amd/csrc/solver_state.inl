@@ -94,7 +94,7 @@
     const int64_t mn = (int64_t)m * n;
     // (the imported columns are in natural row order)
     lbk::launch_lmask_ones(q, n, lmask);
-    cw_packed = false, cw_stale = 0, cw_hold = 0;
+    cw_packed = false, cw_stale = 0, cw_hold = 0, cw_settled = 0;
     live_head = std::min(std::max(isave_user[26], 1), m), live_col = std::min(std::max(isave_user[27], 0), m);
     HIPCHK(hipMemcpy2DAsync(ws, (size_t)ld * sizeof(T), wa, (size_t)n * sizeof(T),
                             (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, stream));
