@@ -397,6 +397,88 @@ __global__ __launch_bounds__(BLOCK) void upd_compact(int64_t n, const double *__
   }
   uacc_out(A, sums);
 }
+
+// ---- update pass, compact, lane PAIRS share the column sums over whole-tile trips (rows l, l + 64 per lane) ----
+// Each lane of a pair (2p, 2p + 1) owns HALF of the columns (even lane: [0, 5), odd lane: [5, 9)) and sums them over
+// the pair's FOUR rows; it loads its columns at the slots of all four rows (the partner's slots come over by
+// shuffle) and receives the partner's row scalars.  8 x 5 instead of 8 x 9 column accumulators per lane.
+__global__ __launch_bounds__(BLOCK) void upd_pair2(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
+    const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, double *sums) {
+  constexpr int H = 5;
+  const int64_t ntr = n / 128;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool hi = lane & 1;
+  double acc[8][H];
+  double misc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc[q][j] = 0.0;
+  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tr * 128;
+    const WaveTile wt = wave_tile(row0, L);
+    const int64_t i0 = row0 + lane, i1 = i0 + 64;
+    const double xv[2] = {ldnt1(x + i0), ldnt1(x + i1)}, gv[2] = {ldnt1(g + i0), ldnt1(g + i1)};
+    const double rv[2] = {ldnt1(r + i0), ldnt1(r + i1)}, tv[2] = {ldnt1(t + i0), ldnt1(t + i1)};
+    const int fw[2] = {iw[i0], iw[i1]};
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int b0 = __popcll(wt.m0 & below), b1 = __popcll(wt.m0) + __popcll(wt.m1 & below);
+    const int f0 = (int)((wt.m0 >> lane) & 1), f1 = (int)((wt.m1 >> lane) & 1);
+    const int fb0 = wt.gb + b0, fb1 = wt.gb + b1;
+    // slots relative to the tile base (T <= 4096: an int)
+    // (from the layout bits alone, as the library's kernels do: no load depends on iwhere; a row without a bit reads
+    //  the first entry of its group's run and multiplies it by exact zeros)
+    const int own0 = f0 ? fb0 : (int)wt.gb, own1 = f1 ? fb1 : (int)wt.gb;
+    const int oth0 = __shfl_xor(own0, 1), oth1 = __shfl_xor(own1, 1);
+    // order of the pair's four rows: (even lane row0, odd lane row0, even lane row1, odd lane row1)
+    const int sl[4] = {hi ? oth0 : own0, hi ? own0 : oth0, hi ? oth1 : own1, hi ? own1 : oth1};
+    double a[H][4], b[H][4];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const int c = (hi ? H : 0) + j;
+      const bool dead = c >= NC;
+      const double *pa = w + (int64_t)(dead ? 0 : c) * ld + wt.tbase, *pb = w + (int64_t)(NC + (dead ? 0 : c)) * ld + wt.tbase;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool z = dead;
+        a[j][k] = *(z ? zero : pa + sl[k]), b[j][k] = *(z ? zero : pb + sl[k]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double s4[4], ng4[4], yf4[4], sa4[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double s = xv[k] - tv[k], y = gv[k] - rv[k];
+      const bool fr = fw[k] <= 0;
+      const double ng = fr ? -gv[k] : 0.0, yf = fr ? y : 0.0, sa = fr ? 0.0 : s;
+      misc[0] += gv[k] * s, misc[1] += y * y, misc[2] -= ng * ng;
+      const double os = __shfl_xor(s, 1), ong = __shfl_xor(ng, 1), oyf = __shfl_xor(yf, 1), osa = __shfl_xor(sa, 1);
+      s4[2 * k] = hi ? os : s, s4[2 * k + 1] = hi ? s : os;
+      ng4[2 * k] = hi ? ong : ng, ng4[2 * k + 1] = hi ? ng : ong;
+      yf4[2 * k] = hi ? oyf : yf, yf4[2 * k + 1] = hi ? yf : oyf;
+      sa4[2 * k] = hi ? osa : sa, sa4[2 * k + 1] = hi ? sa : osa;
+    }
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[0][j] = __builtin_fma(s4[k], a[j][k], acc[0][j]), acc[1][j] = __builtin_fma(b[j][k], s4[k], acc[1][j]);
+        acc[2][j] = __builtin_fma(a[j][k], ng4[k], acc[2][j]), acc[3][j] = __builtin_fma(b[j][k], ng4[k], acc[3][j]);
+        acc[4][j] = __builtin_fma(yf4[k], a[j][k], acc[4][j]), acc[5][j] = __builtin_fma(sa4[k], b[j][k], acc[5][j]);
+        acc[6][j] = __builtin_fma(sa4[k], a[j][k], acc[6][j]), acc[7][j] = __builtin_fma(b[j][k], yf4[k], acc[7][j]);
+      }
+  }
+  double tot = misc[0] + misc[1] + misc[2];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const int c = (hi ? H : 0) + j;
+      if (c < NC) tot += acc[q][j] * (1.0 + 0.01 * (q * NC + c));
+    }
+  wave_sum_store(tot, sums);
+}
 // for the check: the masked update kernel sees s = 0 on rows that are not free (as the real pass does: rows at a
 // bound do not move) -- k_settle makes t = x there
 __global__ void k_settle(int64_t n, const int8_t *iw, const double *x, double *t) {
@@ -457,6 +539,8 @@ int main(int argc, char **argv) {
   for (int j = 0; j < 2 * NC; ++j) cf.c[j] = 0.01 * (j + 1), cf.w[j] = -0.02 * (j + 2);
   const int g_sm = resident_grid(store_masked), g_sp = resident_grid(store_cpair), g_ss = resident_grid(store_csplit);
   const int g_um = resident_grid(upd_masked), g_up = resident_grid(upd_compact<false>), g_us = resident_grid(upd_compact<true>);
+  const int g_u2 = resident_grid(upd_pair2);
+  printf("upd_pair2 resident grid %d\n", g_u2);
   printf("n = %lld rows, fp64, %d stored pairs + pending; resident grids: store %d / %d / %d, update %d / %d / %d\n",
          (long long)n, NC, g_sm, g_sp, g_ss, g_um, g_up, g_us);
   printf("%-5s %-6s %-6s | %-44s | %-44s\n", "free", "tile", "stale", "STORE pass ms (masked | c_pair | c_split)  B/row alg",
@@ -506,6 +590,12 @@ int main(int argc, char **argv) {
         const double t_um = time_ms([&] { upd_masked<<<g_um, BLOCK>>>(n, x, g, r, t, iw, wn, ld, sums); }, reps);
         const double t_up = time_ms([&] { upd_compact<false><<<g_up, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
         const double t_us = time_ms([&] { upd_compact<true><<<g_us, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
+        CK(hipMemset(sums, 0, 64));
+        upd_pair2<<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
+        const double cs_p2 = get();
+        const double t_u2 = time_ms([&] { upd_pair2<<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
+        printf("      upd_pair2 (lane pairs share the column sums, tile trips): %6.3f ms  checksum %s\n", t_u2,
+               std::fabs(cs_p2 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
         const double nf = frac;  // (stale: +- 0.5 %)
         const double b_sm = 4 * 8 + 1 + 2 * NC * 8 + 3 * 8, b_sc = 4 * 8 + 1 + 2 * NC * 8 * nf + 3 * 8 + 0.19;
         const double b_um = 4 * 8 + 1 + 2 * NC * 8, b_uc = 4 * 8 + 1 + 2 * NC * 8 * nf + 0.19;
