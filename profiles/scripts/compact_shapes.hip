@@ -276,6 +276,64 @@ __global__ __launch_bounds__(BLOCK) void store_csplit(int64_t n, const double *_
   wave_sum_store(acc, sums);
 }
 
+
+// ---- storing pass, compact, SLOT order (T = 128 only): see upd_dense ----
+__global__ __launch_bounds__(BLOCK) void store_dense(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
+    const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, Coefs cf, double *xout, double *py, double *ps, double *sums) {
+  __shared__ uint8_t perm[BLOCK / 64][128];
+  const int64_t ntr = n / 128;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tr * 128;
+    const WaveTile wt = wave_tile(row0, L);
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int c0 = __popcll(wt.m0), tf = c0 + __popcll(wt.m1);
+    const int b0 = __popcll(wt.m0 & below), b1 = c0 + __popcll(wt.m1 & below);
+    const int s0 = ((wt.m0 >> lane) & 1) ? b0 : tf + (lane - b0);
+    const int s1 = ((wt.m1 >> lane) & 1) ? b1 : tf + (64 + lane - b1);
+    perm[wv][s0] = (uint8_t)lane, perm[wv][s1] = (uint8_t)(64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t i0 = row0 + perm[wv][lane], i1 = row0 + perm[wv][64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const double xv[2] = {ldnt1(x + i0), ldnt1(x + i1)}, gv[2] = {ldnt1(g + i0), ldnt1(g + i1)};
+    const double rv[2] = {ldnt1(r + i0), ldnt1(r + i1)}, tv[2] = {ldnt1(t + i0), ldnt1(t + i1)};
+    const bool need[2] = {lane < tf, 64 + lane < tf};   // (the layout was made from this iwhere: bit = free)
+    double a[NC][2], b[NC][2];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const double *pa = w + (int64_t)j * ld + row0, *pb = w + (int64_t)(NC + j) * ld + row0;
+      a[j][0] = *(need[0] ? pa + lane : zero), b[j][0] = *(need[0] ? pb + lane : zero);
+      a[j][1] = 0.0, b[j][1] = 0.0;
+    }
+    if (tf > 64) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const double *pa = w + (int64_t)j * ld + row0, *pb = w + (int64_t)(NC + j) * ld + row0;
+        a[j][1] = *(need[1] ? pa + 64 + lane : zero), b[j][1] = *(need[1] ? pb + 64 + lane : zero);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double z[2] = {xv[0], xv[1]};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (need[k]) {
+        double ak[NC], bk[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) ak[j] = a[j][k], bk[j] = b[j][k];
+        z[k] = fmin(1.0, fmax(-1.0, xv[k] + newton_row(xv[k], gv[k], ak, bk, cf)));
+      }
+      const double dv = z[k] - xv[k];
+      acc = acc + dv * gv[k];
+    }
+    stnt1(xout + i0, z[0]), stnt1(xout + i1, z[1]);
+    stnt1(py + row0 + lane, gv[0] - rv[0]), stnt1(py + row0 + 64 + lane, gv[1] - rv[1]);
+    stnt1(ps + row0 + lane, xv[0] - tv[0]), stnt1(ps + row0 + 64 + lane, xv[1] - tv[1]);
+  }
+  wave_sum_store(acc, sums);
+}
 // ============================ update pass ============================
 // 8 sums per column (matupd 2, cauchy p 2, formk's new row 4) + a few row sums
 struct UAcc {
@@ -479,6 +537,62 @@ __global__ __launch_bounds__(BLOCK) void upd_pair2(int64_t n, const double *__re
     }
   wave_sum_store(tot, sums);
 }
+
+// ---- update pass, compact, SLOT order: lane l works on the rows in slots l and l + 64 of the tile (T = 128 only) ----
+// The W loads are dense: lanes [0, tf) of the first half read consecutive entries of the run, the second half is
+// loaded only by tiles with more than 64 free rows (wave-uniform).  The row vectors are gathered through the slot ->
+// row map of the tile (built per trip in LDS: one byte per slot).  Sums run in slot order.
+__global__ __launch_bounds__(BLOCK) void upd_dense(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
+    const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, double *sums) {
+  __shared__ uint8_t perm[BLOCK / 64][128];
+  const int64_t ntr = n / 128;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  UAcc A;
+  uacc_zero(A);
+  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tr * 128;
+    const WaveTile wt = wave_tile(row0, L);
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int c0 = __popcll(wt.m0), tf = c0 + __popcll(wt.m1);
+    const int b0 = __popcll(wt.m0 & below), b1 = c0 + __popcll(wt.m1 & below);
+    const int s0 = ((wt.m0 >> lane) & 1) ? b0 : tf + (lane - b0);
+    const int s1 = ((wt.m1 >> lane) & 1) ? b1 : tf + (64 + lane - b1);
+    perm[wv][s0] = (uint8_t)lane, perm[wv][s1] = (uint8_t)(64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t i0 = row0 + perm[wv][lane], i1 = row0 + perm[wv][64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const double xv[2] = {ldnt1(x + i0), ldnt1(x + i1)}, gv[2] = {ldnt1(g + i0), ldnt1(g + i1)};
+    const double rv[2] = {ldnt1(r + i0), ldnt1(r + i1)}, tv[2] = {ldnt1(t + i0), ldnt1(t + i1)};
+    const int fw[2] = {iw[i0], iw[i1]};
+    double a[NC][2], b[NC][2];
+    const bool n0 = lane < tf;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const double *pa = w + (int64_t)j * ld + row0, *pb = w + (int64_t)(NC + j) * ld + row0;
+      a[j][0] = *(n0 ? pa + lane : zero), b[j][0] = *(n0 ? pb + lane : zero);
+      a[j][1] = 0.0, b[j][1] = 0.0;
+    }
+    if (tf > 64) {  // (wave-uniform)
+      const bool n1 = 64 + lane < tf;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const double *pa = w + (int64_t)j * ld + row0, *pb = w + (int64_t)(NC + j) * ld + row0;
+        a[j][1] = *(n1 ? pa + 64 + lane : zero), b[j][1] = *(n1 ? pb + 64 + lane : zero);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double ak[NC], bk[NC];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) ak[j] = a[j][k], bk[j] = b[j][k];
+      urow(A, xv[k], gv[k], rv[k], tv[k], fw[k], ak, bk);
+    }
+  }
+  uacc_out(A, sums);
+}
 // for the check: the masked update kernel sees s = 0 on rows that are not free (as the real pass does: rows at a
 // bound do not move) -- k_settle makes t = x there
 __global__ void k_settle(int64_t n, const int8_t *iw, const double *x, double *t) {
@@ -539,7 +653,8 @@ int main(int argc, char **argv) {
   for (int j = 0; j < 2 * NC; ++j) cf.c[j] = 0.01 * (j + 1), cf.w[j] = -0.02 * (j + 2);
   const int g_sm = resident_grid(store_masked), g_sp = resident_grid(store_cpair), g_ss = resident_grid(store_csplit);
   const int g_um = resident_grid(upd_masked), g_up = resident_grid(upd_compact<false>), g_us = resident_grid(upd_compact<true>);
-  const int g_u2 = resident_grid(upd_pair2);
+  const int g_u2 = resident_grid(upd_pair2), g_ud = resident_grid(upd_dense);
+  printf("upd_dense resident grid %d\n", g_ud);
   printf("upd_pair2 resident grid %d\n", g_u2);
   printf("n = %lld rows, fp64, %d stored pairs + pending; resident grids: store %d / %d / %d, update %d / %d / %d\n",
          (long long)n, NC, g_sm, g_sp, g_ss, g_um, g_up, g_us);
@@ -550,7 +665,7 @@ int main(int argc, char **argv) {
     for (int T : {128, 1024, 4096}) {
       for (int stale : {0, 1}) {
         if (stale && T != 1024) continue;
-        if (frac == 1.0 && T != 1024) continue;
+        if (frac == 1.0 && T == 4096) continue;
         int tshift = 0;
         while ((1 << tshift) < T) ++tshift;
         const uint32_t thresh = frac >= 1.0 ? 0xffffffffu : (uint32_t)(frac * 4294967296.0);
@@ -596,6 +711,21 @@ int main(int argc, char **argv) {
         const double t_u2 = time_ms([&] { upd_pair2<<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
         printf("      upd_pair2 (lane pairs share the column sums, tile trips): %6.3f ms  checksum %s\n", t_u2,
                std::fabs(cs_p2 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
+        if (T == 128) {
+          static const int g_sd = resident_grid(store_dense);
+          CK(hipMemset(sums, 0, 64));
+          store_dense<<<g_sd, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
+          const double cs_sd = get();
+          const double t_sd = time_ms([&] { store_dense<<<g_sd, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
+          printf("      store_dense (slot order, dense W loads, grid %d): %6.3f ms  checksum %s\n", g_sd, t_sd,
+                 std::fabs(cs_sd - cs[0]) <= 1e-9 * std::fabs(cs[0]) ? "ok" : "DIFFERS");
+          CK(hipMemset(sums, 0, 64));
+          upd_dense<<<g_ud, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
+          const double cs_d = get();
+          const double t_ud = time_ms([&] { upd_dense<<<g_ud, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
+          printf("      upd_dense (slot order, dense W loads): %6.3f ms  checksum %s\n", t_ud,
+                 std::fabs(cs_d - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
+        }
         const double nf = frac;  // (stale: +- 0.5 %)
         const double b_sm = 4 * 8 + 1 + 2 * NC * 8 + 3 * 8, b_sc = 4 * 8 + 1 + 2 * NC * 8 * nf + 3 * 8 + 0.19;
         const double b_um = 4 * 8 + 1 + 2 * NC * 8, b_uc = 4 * 8 + 1 + 2 * NC * 8 * nf + 0.19;
