@@ -593,6 +593,166 @@ __global__ __launch_bounds__(BLOCK) void upd_dense(int64_t n, const double *__re
   }
   uacc_out(A, sums);
 }
+
+// ---- SLOT order with 16-byte loads: tiles of 256 rows, lane l works on slots (2l, 2l + 1) and (128 + 2l, 129 + 2l) ----
+// The free rows' W entries are the front of the tile: one dense 16-byte load per column and lane, the back pair only
+// in tiles with more than 128 free rows (wave-uniform).  Row vectors: 8-byte gathers through the slot -> row map.
+struct Tile256 {
+  int tf;
+  int rr[4];  // row (inside the tile) of this lane's four slots
+};
+__device__ __forceinline__ Tile256 tile256(const uint64_t *lmask, int64_t tr, uint8_t *perm, int lane) {
+  uint64_t m[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) m[q] = lmask[4 * tr + q];
+  int c[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = __popcll(m[q]);
+  Tile256 t;
+  t.tf = c[0] + c[1] + c[2] + c[3];
+  const uint64_t below = (1ull << lane) - 1ull;
+  int run = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = run + __popcll(m[q] & below);
+    const int row = 64 * q + lane;
+    const int slot = ((m[q] >> lane) & 1) ? b : t.tf + (row - b);
+    perm[slot] = (uint8_t)row;
+    run += c[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uchar2 f = *reinterpret_cast<const uchar2 *>(perm + 2 * lane), bk = *reinterpret_cast<const uchar2 *>(perm + 128 + 2 * lane);
+  __builtin_amdgcn_wave_barrier();
+  t.rr[0] = f.x, t.rr[1] = f.y, t.rr[2] = bk.x, t.rr[3] = bk.y;
+  return t;
+}
+__global__ __launch_bounds__(BLOCK) void upd_dense16(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
+    const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, double *sums) {
+  __shared__ uint8_t perm[BLOCK / 64][256];
+  const int64_t ntr = n / 256;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  UAcc A;
+  uacc_zero(A);
+  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tr * 256;
+    const Tile256 T = tile256(L.lmask, tr, perm[wv], lane);
+    double xv[4], gv[4], rv[4], tv[4];
+    int fw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = row0 + T.rr[k];
+      xv[k] = ldnt1(x + i), gv[k] = ldnt1(g + i), rv[k] = ldnt1(r + i), tv[k] = ldnt1(t + i), fw[k] = iw[i];
+    }
+    d2 a[NC][2], b[NC][2];
+    const bool n0 = 2 * lane < T.tf;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const double *pa = w + (int64_t)j * ld + row0 + 2 * lane, *pb = w + (int64_t)(NC + j) * ld + row0 + 2 * lane;
+      a[j][0] = *reinterpret_cast<const d2 *>(n0 ? pa : zero), b[j][0] = *reinterpret_cast<const d2 *>(n0 ? pb : zero);
+      a[j][1] = d2{0.0, 0.0}, b[j][1] = d2{0.0, 0.0};
+    }
+    if (T.tf > 128) {  // (wave-uniform)
+      const bool n1 = 128 + 2 * lane < T.tf;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const double *pa = w + (int64_t)j * ld + row0 + 128 + 2 * lane, *pb = w + (int64_t)(NC + j) * ld + row0 + 128 + 2 * lane;
+        a[j][1] = *reinterpret_cast<const d2 *>(n1 ? pa : zero), b[j][1] = *reinterpret_cast<const d2 *>(n1 ? pb : zero);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double ak[NC], bk[NC];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) ak[j] = a[j][k >> 1][k & 1], bk[j] = b[j][k >> 1][k & 1];
+      urow(A, xv[k], gv[k], rv[k], tv[k], fw[k], ak, bk);
+    }
+  }
+  uacc_out(A, sums);
+}
+__global__ __launch_bounds__(BLOCK) void store_dense16(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
+    const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, Coefs cf, double *xout, double *py, double *ps, double *sums) {
+  __shared__ uint8_t perm[BLOCK / 64][256];
+  const int64_t ntr = n / 256;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tr * 256;
+    const Tile256 T = tile256(L.lmask, tr, perm[wv], lane);
+    double xv[4], gv[4], rv[4], tv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = row0 + T.rr[k];
+      xv[k] = ldnt1(x + i), gv[k] = ldnt1(g + i), rv[k] = ldnt1(r + i), tv[k] = ldnt1(t + i);
+    }
+    d2 a[NC][2], b[NC][2];
+    const bool n0 = 2 * lane < T.tf;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const double *pa = w + (int64_t)j * ld + row0 + 2 * lane, *pb = w + (int64_t)(NC + j) * ld + row0 + 2 * lane;
+      a[j][0] = *reinterpret_cast<const d2 *>(n0 ? pa : zero), b[j][0] = *reinterpret_cast<const d2 *>(n0 ? pb : zero);
+      a[j][1] = d2{0.0, 0.0}, b[j][1] = d2{0.0, 0.0};
+    }
+    if (T.tf > 128) {
+      const bool n1 = 128 + 2 * lane < T.tf;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const double *pa = w + (int64_t)j * ld + row0 + 128 + 2 * lane, *pb = w + (int64_t)(NC + j) * ld + row0 + 128 + 2 * lane;
+        a[j][1] = *reinterpret_cast<const d2 *>(n1 ? pa : zero), b[j][1] = *reinterpret_cast<const d2 *>(n1 ? pb : zero);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int slot = (k >> 1) * 128 + 2 * lane + (k & 1);
+      z[k] = xv[k];
+      if (slot < T.tf) {
+        double ak[NC], bk[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) ak[j] = a[j][k >> 1][k & 1], bk[j] = b[j][k >> 1][k & 1];
+        z[k] = fmin(1.0, fmax(-1.0, xv[k] + newton_row(xv[k], gv[k], ak, bk, cf)));
+      }
+      const double dv = z[k] - xv[k];
+      acc = acc + dv * gv[k];
+      stnt1(xout + row0 + T.rr[k], z[k]);
+    }
+    stnt2(py + row0 + 2 * lane, d2{gv[0] - rv[0], gv[1] - rv[1]}), stnt2(py + row0 + 128 + 2 * lane, d2{gv[2] - rv[2], gv[3] - rv[3]});
+    stnt2(ps + row0 + 2 * lane, d2{xv[0] - tv[0], xv[1] - tv[1]}), stnt2(ps + row0 + 128 + 2 * lane, d2{xv[2] - tv[2], xv[3] - tv[3]});
+  }
+  wave_sum_store(acc, sums);
+}
+
+// ---- ceiling of the access pattern: the update pass's bytes (tiles of 256: the front tf entries of 2 NC columns, all of
+// x, g, r, t, iwhere) with 16-byte loads, one add per value, few registers (many waves) ----
+__global__ __launch_bounds__(BLOCK) void ceil_pattern(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
+    const double *__restrict__ w, int64_t ld, Layout L, double *sums) {
+  const int64_t ntr = n / 256;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  d2 acc = {0.0, 0.0};
+  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = tr * 256;
+    int tf = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tf += __popcll(L.lmask[4 * tr + q]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t i = row0 + 128 * h + 2 * lane;
+      acc += ldnt2(x + i) + ldnt2(g + i) + ldnt2(r + i) + ldnt2(t + i);
+      const char2 c = *reinterpret_cast<const char2 *>(iw + i);
+      acc[0] += c.x + c.y;
+      if (128 * h + 2 * lane < tf) {
+#pragma unroll
+        for (int j = 0; j < 2 * NC; ++j) acc += *reinterpret_cast<const d2 *>(w + (int64_t)j * ld + i);
+      }
+    }
+  }
+  wave_sum_store(acc[0] + acc[1], sums);
+}
 // for the check: the masked update kernel sees s = 0 on rows that are not free (as the real pass does: rows at a
 // bound do not move) -- k_settle makes t = x there
 __global__ void k_settle(int64_t n, const int8_t *iw, const double *x, double *t) {
@@ -662,9 +822,10 @@ int main(int argc, char **argv) {
          "UPDATE pass ms (masked | c_pair | c_split)  B/row alg");
   auto get = [&]() { double h; CK(hipMemcpy(&h, sums, 8, hipMemcpyDeviceToHost)); return h; };
   for (double frac : {1.0, 0.5, 0.1}) {
-    for (int T : {128, 1024, 4096}) {
+    for (int T : {128, 256, 1024, 4096}) {
       for (int stale : {0, 1}) {
         if (stale && T != 1024) continue;
+        if (T == 256 && frac == 0.1) continue;
         if (frac == 1.0 && T == 4096) continue;
         int tshift = 0;
         while ((1 << tshift) < T) ++tshift;
@@ -724,6 +885,27 @@ int main(int argc, char **argv) {
           const double cs_d = get();
           const double t_ud = time_ms([&] { upd_dense<<<g_ud, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
           printf("      upd_dense (slot order, dense W loads): %6.3f ms  checksum %s\n", t_ud,
+                 std::fabs(cs_d - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
+        }
+        if (T == 256) {
+          static const int g_cp = resident_grid(ceil_pattern);
+          for (int mult : {1, 2}) {
+            const double t_cp = time_ms([&] { ceil_pattern<<<g_cp * mult / 2, BLOCK>>>(n, x, g, r, t, iw, wc, ld, L, sums); }, reps);
+            printf("      ceil_pattern (the update pass's bytes, 16-byte loads, one add per value; grid %d): %6.3f ms = %4.2f TB/s\n", g_cp * mult / 2, t_cp,
+                   (4 * 8 + 1 + 2 * NC * 8 * frac) * n / t_cp * 1e-9);
+          }
+          static const int g_s16 = resident_grid(store_dense16), g_u16 = resident_grid(upd_dense16);
+          CK(hipMemset(sums, 0, 64));
+          store_dense16<<<g_s16, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
+          const double cs_sd = get();
+          const double t_sd = time_ms([&] { store_dense16<<<g_s16, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
+          printf("      store_dense16 (slot order, 16-byte W loads, tiles of 256, grid %d): %6.3f ms  checksum %s\n", g_s16, t_sd,
+                 std::fabs(cs_sd - cs[0]) <= 1e-9 * std::fabs(cs[0]) ? "ok" : "DIFFERS");
+          CK(hipMemset(sums, 0, 64));
+          upd_dense16<<<g_u16, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
+          const double cs_d = get();
+          const double t_ud = time_ms([&] { upd_dense16<<<g_u16, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
+          printf("      upd_dense16 (slot order, 16-byte W loads, tiles of 256, grid %d): %6.3f ms  checksum %s\n", g_u16, t_ud,
                  std::fabs(cs_d - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
         }
         const double nf = frac;  // (stale: +- 0.5 %)
