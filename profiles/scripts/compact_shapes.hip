@@ -51,6 +51,18 @@ struct Layout {
   int tshift;             // log2(T)
 };
 
+
+// trip -> wave assignment: round k of the grid-stride loop is rotated by k * g_rot waves (0: the plain grid-stride
+// loop, every wave marching through memory in lock-step with the same stride)
+__device__ int g_rot;
+#define TRIPS(tr, ntr)                                                                                              \
+  for (int64_t k_ = 0, nw_ = (int64_t)gridDim.x * 4, wid_ = (int64_t)blockIdx.x * 4 + wv, tr = wid_; k_ * nw_ < (ntr); \
+       ++k_, tr = k_ * nw_ + (wid_ + k_ * g_rot) % nw_)                                                              \
+    if (tr < (ntr))
+#define LANES(iv, nv)                                                                                                 \
+  for (int64_t k_ = 0, nt_ = (int64_t)gridDim.x * BLOCK, tid_ = (int64_t)blockIdx.x * BLOCK + threadIdx.x, iv = tid_;  \
+       k_ * nt_ < (nv); ++k_, iv = k_ * nt_ + (tid_ + k_ * g_rot * 64) % nt_)                                          \
+    if (iv < (nv))
 // ---- set-up ----
 __global__ void k_fill_vec(int64_t n, double *x, double *g, double *r, double *t) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void store_masked(int64_t n, const double *_
     const double *__restrict__ w, int64_t ld, Coefs cf, double *xout, double *cwy, double *cws, double *sums) {
   const int64_t nv = n / 2, stride = (int64_t)gridDim.x * BLOCK;
   double acc = 0.0;
-  for (int64_t iv = (int64_t)blockIdx.x * BLOCK + threadIdx.x; iv < nv; iv += stride) {
+  LANES(iv, nv) {
     const int64_t i = iv * 2;
     const d2 xv = ldnt2(x + i), gv = ldnt2(g + i), rv = ldnt2(r + i), tv = ldnt2(t + i);
     const char2 iv2 = *reinterpret_cast<const char2 *>(iw + i);
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(BLOCK) void store_cpair(int64_t n, const double *__
   const int64_t ntr = n / 128;  // (n a multiple of 128 here)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 128, i = row0 + 2 * lane;
     const WaveTile wt = wave_tile(row0, L);
     const d2 xv = ldnt2(x + i), gv = ldnt2(g + i), rv = ldnt2(r + i), tv = ldnt2(t + i);
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(BLOCK) void store_csplit(int64_t n, const double *_
   const int64_t ntr = n / 128;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 128;
     const WaveTile wt = wave_tile(row0, L);
     const int64_t i0 = row0 + lane, i1 = i0 + 64;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void store_dense(int64_t n, const double *__
   const int64_t ntr = n / 128;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 128;
     const WaveTile wt = wave_tile(row0, L);
     const uint64_t below = (1ull << lane) - 1ull;
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void upd_masked(int64_t n, const double *__r
   const int64_t nv = n / 2, stride = (int64_t)gridDim.x * BLOCK;
   UAcc A;
   uacc_zero(A);
-  for (int64_t iv = (int64_t)blockIdx.x * BLOCK + threadIdx.x; iv < nv; iv += stride) {
+  LANES(iv, nv) {
     const int64_t i = iv * 2;
     const d2 xv = ldnt2(x + i), gv = ldnt2(g + i), rv = ldnt2(r + i), tv = ldnt2(t + i);
     const char2 iv2 = *reinterpret_cast<const char2 *>(iw + i);
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void upd_compact(int64_t n, const double *__
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   UAcc A;
   uacc_zero(A);
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 128;
     const WaveTile wt = wave_tile(row0, L);
     double xv[2], gv[2], rv[2], tv[2];
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void upd_pair2(int64_t n, const double *__re
   for (int q = 0; q < 8; ++q)
 #pragma unroll
     for (int j = 0; j < H; ++j) acc[q][j] = 0.0;
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 128;
     const WaveTile wt = wave_tile(row0, L);
     const int64_t i0 = row0 + lane, i1 = i0 + 64;
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(BLOCK) void upd_dense(int64_t n, const double *__re
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   UAcc A;
   uacc_zero(A);
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 128;
     const WaveTile wt = wave_tile(row0, L);
     const uint64_t below = (1ull << lane) - 1ull;
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(BLOCK) void upd_dense16(int64_t n, const double *__
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   UAcc A;
   uacc_zero(A);
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 256;
     const Tile256 T = tile256(L.lmask, tr, perm[wv], lane);
     double xv[4], gv[4], rv[4], tv[4];
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(BLOCK) void store_dense16(int64_t n, const double *
   const int64_t ntr = n / 256;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
     const int64_t row0 = tr * 256;
     const Tile256 T = tile256(L.lmask, tr, perm[wv], lane);
     double xv[4], gv[4], rv[4], tv[4];
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) void ceil_pattern(int64_t n, const double *_
   const int64_t ntr = n / 256;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   d2 acc = {0.0, 0.0};
-  for (int64_t tr = (int64_t)blockIdx.x * 4 + wv; tr < ntr; tr += (int64_t)gridDim.x * 4) {
+  TRIPS(tr, ntr) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int64_t grp = 2 * tr + h, row0 = grp * 128;
@@ -793,6 +805,9 @@ static double time_ms(F &&launch, int reps) {
 int main(int argc, char **argv) {
   const int64_t n = ((argc > 1 ? atoll(argv[1]) : 100000000ll) / 4096) * 4096;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
+  const int rot = argc > 3 ? atoi(argv[3]) : 0;
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_rot), &rot, sizeof rot));
+  printf("trip rotation %d\n", rot);
   const int64_t ld = n;
   double *x, *g, *r, *t, *xout, *wn, *wc, *zero, *sums;
   int8_t *iw;
@@ -821,11 +836,11 @@ int main(int argc, char **argv) {
          "UPDATE pass ms (masked | c_pair | c_split)  B/row alg");
   auto get = [&]() { double h; CK(hipMemcpy(&h, sums, 8, hipMemcpyDeviceToHost)); return h; };
   for (double frac : {1.0, 0.5, 0.1}) {
-    for (int T : {128, 256, 1024, 4096}) {
+    for (int T : {128, 256, 1024, 4096, 32768}) {
       for (int stale : {0, 1}) {
         if (stale && T != 1024) continue;
         if (T == 256 && frac == 0.1) continue;
-        if (frac == 1.0 && T == 4096) continue;
+        if (frac == 1.0 && T >= 4096) continue;
         int tshift = 0;
         while ((1 << tshift) < T) ++tshift;
         const uint32_t thresh = frac >= 1.0 ? 0xffffffffu : (uint32_t)(frac * 4294967296.0);
