@@ -348,6 +348,29 @@ __device__ __forceinline__ double pair_xchg(double v) {
 __device__ __forceinline__ float pair_xchg(float v) {
   return __builtin_bit_cast(float, pair_xchg(__builtin_bit_cast(int, v)));
 }
+// The lanes l and l + 32 of a wave as a pair (gfx950: v_permlane32_swap): lo = the value of the pair's lane below
+// 32, hi = the value of the one above, in BOTH lanes -- one instruction per 32 bits, no select behind it.
+__device__ __forceinline__ void half_pair(int v, int &lo, int &hi) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  lo = (int)r[0], hi = (int)r[1];
+}
+__device__ __forceinline__ void half_pair(int64_t v, int64_t &lo, int64_t &hi) {
+  int l0, h0, l1, h1;
+  half_pair((int)v, l0, h0);
+  half_pair((int)(v >> 32), l1, h1);
+  lo = (int64_t)(((unsigned long long)(unsigned)l1 << 32) | (unsigned)l0);
+  hi = (int64_t)(((unsigned long long)(unsigned)h1 << 32) | (unsigned)h0);
+}
+__device__ __forceinline__ void half_pair(double v, double &lo, double &hi) {
+  int64_t l, h;
+  half_pair(__builtin_bit_cast(int64_t, v), l, h);
+  lo = __builtin_bit_cast(double, l), hi = __builtin_bit_cast(double, h);
+}
+__device__ __forceinline__ void half_pair(float v, float &lo, float &hi) {
+  int l, h;
+  half_pair(__builtin_bit_cast(int, v), l, h);
+  lo = __builtin_bit_cast(float, l), hi = __builtin_bit_cast(float, h);
+}
 // rows per lane for kernels unrolled to MC column pairs: 16 B per lane per array, halved
 // for MC >= 20 so that the 2*MC operand values of a row group still fit the register file
 template <typename T, int MC>

@@ -322,7 +322,10 @@ struct UpdScanPairTrip : NaturalRows<W> {
 };
 // The same sharing under the tile-local free-row layout of W (one row per lane and trip: for_halves_cw).  A pair's
 // two rows are not neighbours in a column any more: each lane reads its columns at its OWN row's slot and at its
-// partner's (two 8-byte loads into the halves of the register image; the partner's slot comes over by DPP).
+// partner's (two 8-byte loads into the halves of the register image).  The pair is (l, l + 32), not (2p, 2p + 1):
+// a load instruction then reads the slots of 32 CONSECUTIVE rows of two columns -- two contiguous pieces -- instead
+// of every other slot of 64 rows, whose lines the partner instruction has to touch again (bare kernels: - 10 % at
+// nfree/n = 0.5, profiles/round6_g_compact_shapes_pair32.txt); slots and row scalars cross by v_permlane32_swap.
 // What the sharing buys here is the register file: 8 x MC/2 column sums per lane instead of 8 x MC leave the 95 fp64
 // accumulators of the MC = 10 new-row pass in VGPRs (no accumulator lives in the AGPR file, which cost two moves per
 // update), and the pass is bound by its loads again instead of by what it issues.
@@ -339,14 +342,10 @@ struct UpdScanPairTripCW : CwOneRow {
   RawOf<iw_t, 1> riw;
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) T *gptr;
-  __device__ __forceinline__ static int64_t xchg64(int64_t v) {
-    const unsigned lo = (unsigned)pair_xchg((int)v), hi = (unsigned)pair_xchg((int)(v >> 32));
-    return (int64_t)(((unsigned long long)hi << 32) | lo);
-  }
   // this lane's columns (H pairs from the LDS table) for the pair's rows at a0 (even lane's row), a1 (odd lane's)
   template <bool NTL, typename R>
   __device__ __forceinline__ void cols(const UpdScanCtx<T> &c, int64_t a0, int64_t a1, R (&qa)[H], R (&qb)[H]) {
-    const bool hi = threadIdx.x & 1;
+    const bool hi = threadIdx.x & 32;
     int tb = hi ? 2 * H : 0;
     asm volatile("" : "+v"(tb));
     u64x2 p[H];
@@ -373,24 +372,25 @@ struct UpdScanPairTripCW : CwOneRow {
     raw_issue<1, false>(rnb, (c.ub & 4) ? c.nbd : c.nbd + i);
     raw_issue<1, false>(riw, c.iwhere + i);
     // (a row whose layout bit is clear reads the first entry of its tile: see UpdScanTripCW1)
-    const int64_t mine = lf ? slot : first, other = xchg64(mine);
-    const bool hi = threadIdx.x & 1;
+    int64_t a0, a1;  // the slots of the pair's rows: the lane below 32, the lane above
+    half_pair(lf ? slot : first, a0, a1);
     // (plain loads for the W entries, whatever NT says for the row vectors: the line in which this half's run of a
     //  column ends is the one the other half's run begins in -- read by another wave at about the same time, and
     //  a nontemporal line is fetched from HBM for each of them: 2.58 -> 2.39 ms at n = 1e8)
-    cols<false>(c, hi ? other : mine, hi ? mine : other, ra, rb);
+    cols<false>(c, a0, a1, ra, rb);
   }
   __device__ __forceinline__ void land() {}
   // miss[0]: THIS lane's row needs its own entries.  Both lanes of a pair fetch their columns of that row (into
   // registers of their own, merged afterwards: see UpdScanTripCW1).
   __device__ __forceinline__ void reload_cols(const UpdScanCtx<T> &c, const bool (&miss)[1]) {
-    const bool hi = threadIdx.x & 1;
-    const bool pm = pair_xchg((int)miss[0]) != 0;  // the partner's row
+    int mi0, mi1;
+    half_pair((int)miss[0], mi0, mi1);
+    const bool m0 = mi0 != 0, m1 = mi1 != 0;
     const int64_t first = this->ri_ & ~(int64_t)127;
-    const int64_t mine = (miss[0] || this->lf_) ? this->ws_ : first, other = xchg64(mine);
-    const bool m0 = hi ? pm : miss[0], m1 = hi ? miss[0] : pm;
+    int64_t a0, a1;
+    half_pair((miss[0] || this->lf_) ? this->ws_ : first, a0, a1);
     RawOf<T, 2> ta[H], tb2[H];
-    cols<false>(c, hi ? other : mine, hi ? mine : other, ta, tb2);
+    cols<false>(c, a0, a1, ta, tb2);
 #pragma unroll
     for (int jj = 0; jj < H; ++jj) {
       if (m0) ra[jj].v.xy = ta[jj].v.xy, rb[jj].v.xy = tb2[jj].v.xy;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
   for (int a = 0; a < (PAIR ? 8 : 1); ++a)
 #pragma unroll
     for (int b = 0; b < (PAIR ? H : 1); ++b) accp[a][b] = 0.0;
-  const bool hi = threadIdx.x & 1;
+  const bool hi = threadIdx.x & ((PAIR && CW) ? 32 : 1);  // (which half of the columns: see the two pair trips)
   const int64_t offn = (int64_t)(itail - 1) * ldw;
   __shared__ unsigned long long ptab[PAIR ? 2 * MC : 1];  // [lane parity][column of the half][Wy, Ws]
   if constexpr (PAIR) {
@@ -567,13 +567,24 @@ __global__ __launch_bounds__(BLOCK) void update_scan_kernel(
       double qd[2 * W], qn[2 * W], qy[2 * W], qs[2 * W];
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        const double od = pair_xchg(dv[k]);
-        qd[k] = hi ? od : dv[k], qd[W + k] = hi ? dv[k] : od;
         const T n_ = (T)ng[k], y_ = (T)yf[k], s_ = (T)sa[k];
-        const T on = pair_xchg(n_), oy = pair_xchg(y_), os = pair_xchg(s_);
-        qn[k] = (double)(hi ? on : n_), qn[W + k] = (double)(hi ? n_ : on);
-        qy[k] = (double)(hi ? oy : y_), qy[W + k] = (double)(hi ? y_ : oy);
-        qs[k] = (double)(hi ? os : s_), qs[W + k] = (double)(hi ? s_ : os);
+        if constexpr (CW) {  // (W = 1; the pair is (l, l + 32): both values in both lanes, no select)
+          T n0, n1, y0, y1, s0, s1;
+          half_pair(dv[k], qd[k], qd[W + k]);
+          half_pair(n_, n0, n1);
+          half_pair(y_, y0, y1);
+          half_pair(s_, s0, s1);
+          qn[k] = (double)n0, qn[W + k] = (double)n1;
+          qy[k] = (double)y0, qy[W + k] = (double)y1;
+          qs[k] = (double)s0, qs[W + k] = (double)s1;
+        } else {
+          const double od = pair_xchg(dv[k]);
+          qd[k] = hi ? od : dv[k], qd[W + k] = hi ? dv[k] : od;
+          const T on = pair_xchg(n_), oy = pair_xchg(y_), os = pair_xchg(s_);
+          qn[k] = (double)(hi ? on : n_), qn[W + k] = (double)(hi ? n_ : on);
+          qy[k] = (double)(hi ? oy : y_), qy[W + k] = (double)(hi ? y_ : oy);
+          qs[k] = (double)(hi ? os : s_), qs[W + k] = (double)(hi ? s_ : os);
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < H; ++jj) {

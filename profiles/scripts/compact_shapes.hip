@@ -472,13 +472,14 @@ __global__ __launch_bounds__(BLOCK) void upd_compact(int64_t n, const double *__
 // Each lane of a pair (2p, 2p + 1) owns HALF of the columns (even lane: [0, 5), odd lane: [5, 9)) and sums them over
 // the pair's FOUR rows; it loads its columns at the slots of all four rows (the partner's slots come over by
 // shuffle) and receives the partner's row scalars.  8 x 5 instead of 8 x 9 column accumulators per lane.
+template <int X>
 __global__ __launch_bounds__(BLOCK) void upd_pair2(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
     const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
     const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, double *sums) {
   constexpr int H = 5;
   const int64_t ntr = n / 128;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const bool hi = lane & 1;
+  const bool hi = lane & X;
   double acc[8][H];
   double misc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void upd_pair2(int64_t n, const double *__re
     // (from the layout bits alone, as the library's kernels do: no load depends on iwhere; a row without a bit reads
     //  the first entry of its group's run and multiplies it by exact zeros)
     const int own0 = f0 ? fb0 : (int)wt.gb, own1 = f1 ? fb1 : (int)wt.gb;
-    const int oth0 = __shfl_xor(own0, 1), oth1 = __shfl_xor(own1, 1);
+    const int oth0 = __shfl_xor(own0, X), oth1 = __shfl_xor(own1, X);
     // order of the pair's four rows: (even lane row0, odd lane row0, even lane row1, odd lane row1)
     const int sl[4] = {hi ? oth0 : own0, hi ? own0 : oth0, hi ? oth1 : own1, hi ? own1 : oth1};
     double a[H][4], b[H][4];
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(BLOCK) void upd_pair2(int64_t n, const double *__re
       const bool fr = fw[k] <= 0;
       const double ng = fr ? -gv[k] : 0.0, yf = fr ? y : 0.0, sa = fr ? 0.0 : s;
       misc[0] += gv[k] * s, misc[1] += y * y, misc[2] -= ng * ng;
-      const double os = __shfl_xor(s, 1), ong = __shfl_xor(ng, 1), oyf = __shfl_xor(yf, 1), osa = __shfl_xor(sa, 1);
+      const double os = __shfl_xor(s, X), ong = __shfl_xor(ng, X), oyf = __shfl_xor(yf, X), osa = __shfl_xor(sa, X);
       s4[2 * k] = hi ? os : s, s4[2 * k + 1] = hi ? s : os;
       ng4[2 * k] = hi ? ong : ng, ng4[2 * k + 1] = hi ? ng : ong;
       yf4[2 * k] = hi ? oyf : yf, yf4[2 * k + 1] = hi ? yf : oyf;
@@ -827,7 +828,7 @@ int main(int argc, char **argv) {
   for (int j = 0; j < 2 * NC; ++j) cf.c[j] = 0.01 * (j + 1), cf.w[j] = -0.02 * (j + 2);
   const int g_sm = resident_grid(store_masked), g_sp = resident_grid(store_cpair), g_ss = resident_grid(store_csplit);
   const int g_um = resident_grid(upd_masked), g_up = resident_grid(upd_compact<false>), g_us = resident_grid(upd_compact<true>);
-  const int g_u2 = resident_grid(upd_pair2), g_ud = resident_grid(upd_dense);
+  const int g_u2 = resident_grid(upd_pair2<1>), g_ud = resident_grid(upd_dense);
   printf("upd_dense resident grid %d\n", g_ud);
   printf("upd_pair2 resident grid %d\n", g_u2);
   printf("n = %lld rows, fp64, %d stored pairs + pending; resident grids: store %d / %d / %d, update %d / %d / %d\n",
@@ -881,11 +882,16 @@ int main(int argc, char **argv) {
         const double t_up = time_ms([&] { upd_compact<false><<<g_up, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
         const double t_us = time_ms([&] { upd_compact<true><<<g_us, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
         CK(hipMemset(sums, 0, 64));
-        upd_pair2<<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
+        upd_pair2<1><<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
         const double cs_p2 = get();
-        const double t_u2 = time_ms([&] { upd_pair2<<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
-        printf("      upd_pair2 (lane pairs share the column sums, tile trips): %6.3f ms  checksum %s\n", t_u2,
-               std::fabs(cs_p2 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
+        const double t_u2 = time_ms([&] { upd_pair2<1><<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
+        CK(hipMemset(sums, 0, 64));
+        upd_pair2<32><<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
+        const double cs_p32 = get();
+        const double t_u32 = time_ms([&] { upd_pair2<32><<<g_u2, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
+        printf("      upd_pair2 (lane pairs share the column sums, tile trips): lanes (2p, 2p + 1) %6.3f ms  checksum %s | lanes (l, l + 32) %6.3f ms  checksum %s\n", t_u2,
+               std::fabs(cs_p2 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS", t_u32,
+               std::fabs(cs_p32 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
         if (T == 128) {
           static const int g_sd = resident_grid(store_dense);
           CK(hipMemset(sums, 0, 64));
