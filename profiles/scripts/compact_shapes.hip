@@ -241,6 +241,9 @@ __global__ __launch_bounds__(BLOCK) void store_cpair(int64_t n, const double *__
 }
 
 // compact, lane = rows (l, l + 64) of the wave's 128
+// LIB: as the library's pass does it -- the W loads go by the layout bits alone (no load waits for iwhere; a row
+// without a bit reads the first entry of its group's run) and are plain, not nontemporal
+template <bool LIB>
 __global__ __launch_bounds__(BLOCK) void store_csplit(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
     const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
     const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, Coefs cf, double *xout, double *py, double *ps, double *sums) {
@@ -265,8 +268,13 @@ __global__ __launch_bounds__(BLOCK) void store_csplit(int64_t n, const double *_
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const double *pa = w + (int64_t)j * ld, *pb = w + (int64_t)(NC + j) * ld;
-      a[j][0] = ldnt1(need[0] ? pa + s0 : zero), a[j][1] = ldnt1(need[1] ? pa + s1 : zero);
-      b[j][0] = ldnt1(need[0] ? pb + s0 : zero), b[j][1] = ldnt1(need[1] ? pb + s1 : zero);
+      if constexpr (LIB) {
+        const int64_t d0 = f0 ? s0 : wt.tbase + wt.gb, d1 = f1 ? s1 : wt.tbase + wt.gb;
+        a[j][0] = pa[d0], a[j][1] = pa[d1], b[j][0] = pb[d0], b[j][1] = pb[d1];
+      } else {
+        a[j][0] = ldnt1(need[0] ? pa + s0 : zero), a[j][1] = ldnt1(need[1] ? pa + s1 : zero);
+        b[j][0] = ldnt1(need[0] ? pb + s0 : zero), b[j][1] = ldnt1(need[1] ? pb + s1 : zero);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     double z[2] = {xv[0], xv[1]};
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(BLOCK) void store_csplit(int64_t n, const double *_
 
 
 // ---- storing pass, compact, SLOT order (T = 128 only): see upd_dense ----
+template <bool PLAIN>
 __global__ __launch_bounds__(BLOCK) void store_dense(int64_t n, const double *__restrict__ x, const double *__restrict__ g,
     const double *__restrict__ r, const double *__restrict__ t, const int8_t *__restrict__ iw,
     const double *__restrict__ w, const double *__restrict__ zero, int64_t ld, Layout L, Coefs cf, double *xout, double *py, double *ps, double *sums) {
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void store_dense(int64_t n, const double *__
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const double *pa = w + (int64_t)j * ld + row0, *pb = w + (int64_t)(NC + j) * ld + row0;
-      a[j][0] = *(need[0] ? pa + lane : zero), b[j][0] = *(need[0] ? pb + lane : zero);
+      a[j][0] = PLAIN ? *(need[0] ? pa + lane : zero) : ldnt1(need[0] ? pa + lane : zero), b[j][0] = PLAIN ? *(need[0] ? pb + lane : zero) : ldnt1(need[0] ? pb + lane : zero);
       a[j][1] = 0.0, b[j][1] = 0.0;
     }
     if (tf > 64) {
@@ -826,7 +835,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&ginfo, (size_t)(n / 128 + 2) * sizeof(uint2)));
   Coefs cf;
   for (int j = 0; j < 2 * NC; ++j) cf.c[j] = 0.01 * (j + 1), cf.w[j] = -0.02 * (j + 2);
-  const int g_sm = resident_grid(store_masked), g_sp = resident_grid(store_cpair), g_ss = resident_grid(store_csplit);
+  const int g_sm = resident_grid(store_masked), g_sp = resident_grid(store_cpair), g_ss = resident_grid(store_csplit<false>);
   const int g_um = resident_grid(upd_masked), g_up = resident_grid(upd_compact<false>), g_us = resident_grid(upd_compact<true>);
   const int g_u2 = resident_grid(upd_pair2<1>), g_ud = resident_grid(upd_dense);
   printf("upd_dense resident grid %d\n", g_ud);
@@ -861,7 +870,7 @@ int main(int argc, char **argv) {
         store_cpair<<<g_sp, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
         cs[1] = get();
         CK(hipMemset(sums, 0, 64));
-        store_csplit<<<g_ss, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
+        store_csplit<false><<<g_ss, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
         cs[2] = get();
         CK(hipMemset(sums, 0, 64));
         upd_masked<<<g_um, BLOCK>>>(n, x, g, r, t, iw, wn, ld, sums);
@@ -877,7 +886,7 @@ int main(int argc, char **argv) {
         // timings
         const double t_sm = time_ms([&] { store_masked<<<g_sm, BLOCK>>>(n, x, g, r, t, iw, wn, ld, cf, xout, wn + (int64_t)2 * NC * ld, wn + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
         const double t_sp = time_ms([&] { store_cpair<<<g_sp, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
-        const double t_ss = time_ms([&] { store_csplit<<<g_ss, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
+        const double t_ss = time_ms([&] { store_csplit<false><<<g_ss, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
         const double t_um = time_ms([&] { upd_masked<<<g_um, BLOCK>>>(n, x, g, r, t, iw, wn, ld, sums); }, reps);
         const double t_up = time_ms([&] { upd_compact<false><<<g_up, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
         const double t_us = time_ms([&] { upd_compact<true><<<g_us, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums); }, reps);
@@ -893,13 +902,23 @@ int main(int argc, char **argv) {
                std::fabs(cs_p2 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS", t_u32,
                std::fabs(cs_p32 - cs[3]) <= 1e-9 * std::fabs(cs[3]) ? "ok" : "DIFFERS");
         if (T == 128) {
-          static const int g_sd = resident_grid(store_dense);
+          static const int g_sd = resident_grid(store_dense<false>);
           CK(hipMemset(sums, 0, 64));
-          store_dense<<<g_sd, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
+          store_dense<false><<<g_sd, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
           const double cs_sd = get();
-          const double t_sd = time_ms([&] { store_dense<<<g_sd, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
+          const double t_sd = time_ms([&] { store_dense<false><<<g_sd, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
           printf("      store_dense (slot order, dense W loads, grid %d): %6.3f ms  checksum %s\n", g_sd, t_sd,
                  std::fabs(cs_sd - cs[0]) <= 1e-9 * std::fabs(cs[0]) ? "ok" : "DIFFERS");
+          {
+            static const int g_sl = resident_grid(store_csplit<true>), g_sdp = resident_grid(store_dense<true>);
+            CK(hipMemset(sums, 0, 64));
+            store_csplit<true><<<g_sl, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums);
+            const double cs_l = get();
+            const double t_l = time_ms([&] { store_csplit<true><<<g_sl, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
+            const double t_dp = time_ms([&] { store_dense<true><<<g_sdp, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, cf, xout, wc + (int64_t)2 * NC * ld, wc + (int64_t)(2 * NC + 1) * ld, sums); }, reps);
+            printf("      as the library loads W (by the bits, plain loads): c_split %6.3f ms (grid %d) checksum %s | slot order, dense %6.3f ms (grid %d)\n", t_l, g_sl,
+                   std::fabs(cs_l - cs[0]) <= 1e-9 * std::fabs(cs[0]) ? "ok" : "DIFFERS", t_dp, g_sdp);
+          }
           CK(hipMemset(sums, 0, 64));
           upd_dense<<<g_ud, BLOCK>>>(n, x, g, r, t, iw, wc, zero, ld, L, sums);
           const double cs_d = get();
